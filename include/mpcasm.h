@@ -1,0 +1,140 @@
+/*
+ * mpcasm.h -- C ABI of libmpcasm.so, the MI355X (gfx950) batched QP-assembly
+ * engine behind the mpc_interface problem-description API.
+ *
+ * The reference (Gepetto/mpc-interface) has no native boundary on this path:
+ * everything is numpy inside one Python process.  Each entry point below
+ * replaces the reference function cited next to it (paths relative to the
+ * reference checkout); INTEGRATION.md shows the ctypes stubs a maintainer of
+ * the reference would add to call them.
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; every pointer named d_* is a DEVICE pointer
+ *     (hipMalloc'ed or a torch-ROCm tensor's data_ptr()), h_* is a HOST pointer;
+ *   - the caller owns every buffer; the library allocates only the device copy
+ *     of a plan's tables, released by mpcasm_plan_destroy;
+ *   - all launches are asynchronous on `stream` (a hipStream_t passed as
+ *     void*, NULL = default stream); no call synchronises the device;
+ *   - every function returns MPCASM_OK (0) or a negative mpcasm_status; no
+ *     exception crosses the boundary;
+ *   - all floating point data is IEEE binary64, row-major, densely packed.
+ */
+#ifndef MPCASM_H
+#define MPCASM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum mpcasm_status {
+  MPCASM_OK = 0,
+  MPCASM_ERR_ARG = -1,      /* null pointer, non-positive size, bad flag        */
+  MPCASM_ERR_PLAN = -2,     /* malformed plan tables (magic/version/bounds)     */
+  MPCASM_ERR_HIP = -3,      /* a HIP runtime call failed (see mpcasm_last_hip)  */
+  MPCASM_ERR_NODEVICE = -4, /* no HIP device visible                            */
+  MPCASM_ERR_LIMIT = -5     /* problem exceeds a kernel limit (LDS, sources)    */
+} mpcasm_status;
+
+typedef struct mpcasm_plan mpcasm_plan; /* opaque, immutable after creation */
+
+/* library / device ------------------------------------------------------- */
+
+/* ABI version of this header (major*1000 + minor). */
+int mpcasm_abi_version(void);
+/* Number of visible HIP devices (0 when none; never fails). */
+int mpcasm_device_count(void);
+/* Last hipError_t seen by the calling thread inside the library (0 = none). */
+int mpcasm_last_hip(void);
+/* Static string for a status code. */
+const char* mpcasm_status_string(int status);
+
+/* K1  horizon extension ---------------------------------------------------
+ * Replaces tools.extend_matrices(N, A, B)      python/mpc_interface/tools.py:14-33
+ * (C++ twin gecko::tools::extend_matrices      cpp/src/tools.cc:83-144),
+ * batched over `batch` independent systems.
+ *
+ *   ltv == 0:  d_A [batch][n][n],     d_B [batch][n][m]      x+ = A x + B u
+ *   ltv == 1:  d_A [batch][N][n][n],  d_B [batch][N][n][m]   x_{k+1} = A_k x_k + B_k u_k
+ *   d_S [batch][N][n][n]      S[b][k][j][i]    = (A^{k+1})[i][j]          (A_k...A_0 when ltv)
+ *   d_U [batch][m][N][N][n]   U[b][j][k][l][i] = (A^{k-l} B)[i][j], l<=k  (A_k..A_{l+1} B_l when ltv)
+ *                                              = 0,                 l>k
+ * i.e. U[b][j] is the reference's list element U[j] (shape N x N x n).
+ * Every byte of S and U is written (zeros included).
+ */
+int mpcasm_fill_su(const double* d_A, const double* d_B, double* d_S, double* d_U,
+                   int batch, int N, int n, int m, int ltv, void* stream);
+
+/* plans -------------------------------------------------------------------
+ * A plan is the compiled *structure* of one Formulation (index maps, flattened
+ * definition graph, cost and constraint tables): what the reference re-derives
+ * from dicts on every call of
+ *   Formulation.make_preview_matrices          python/mpc_interface/body.py:149-193
+ *   Formulation.generate_all_qp_constraints    body.py:304-320
+ *   Formulation.generate_all_qp_costs          body.py:322-329
+ * The tables are produced by the host plan compiler (mpcasm/plan.py); their
+ * layout is documented in csrc/plan_tables.h.  h_itab / h_dtab are copied.
+ */
+int mpcasm_plan_create(const int32_t* h_itab, size_t n_itab,
+                       const double* h_dtab, size_t n_dtab,
+                       mpcasm_plan** out_plan);
+int mpcasm_plan_destroy(mpcasm_plan* plan);
+
+/* Sizes of a plan: out[0]=given_len ng, out[1]=optim_len no, out[2]=rows of
+ * the stacked G (nc), out[3]=params per instance, out[4]=number of sources,
+ * out[5]=row-set rows, out[6]=leading dimension of the workspace rows,
+ * out[7]=preview rows (sum over definitions). */
+int mpcasm_plan_sizes(const mpcasm_plan* plan, int64_t out[8]);
+
+/* Bytes of scratch the assembly of `batch` instances needs (device memory,
+ * caller-allocated, 16-byte aligned). */
+int mpcasm_workspace_bytes(const mpcasm_plan* plan, int batch, size_t* out_bytes);
+
+/* K2+K3+K4  batched QP assembly --------------------------------------------
+ * Replaces, for `batch` instances of one structure,
+ *   Formulation.generate_all_qp_matrices(given)  body.py:333-348
+ * on top of the preview matrices of make_preview_matrices (body.py:149-193):
+ *
+ *   h_src        host array of plan.n_sources DEVICE pointers: the horizon
+ *                matrices ExtendedSystem.matrices[k] ([N][p][n] each,
+ *                dynamics.py:199) the definitions read
+ *   h_src_stride host array, elements between consecutive instances of each
+ *                source (0 = one copy shared by the whole batch)
+ *   d_params     [batch][n_params]  per-instance Cost / Constraint numbers
+ *                (weight, aim, cross_aim; arrow, center, extreme)
+ *   d_given      [batch][ng]        the 'given' vector (body.py:195-207)
+ *   d_P [batch][no][no]  d_q [batch][no]  d_G [batch][nc][no]  d_h [batch][nc]
+ *                qpsolvers layout: minimise 1/2 x'Px + q'x  s.t.  Gx <= h
+ *                (the reference returns them as A=G, h, Q=P, q).
+ *   d_work       scratch of mpcasm_workspace_bytes(plan, batch)
+ *
+ * Any of d_P/d_q (both) or d_G/d_h (both) may be NULL to skip that half.
+ */
+int mpcasm_assemble(const mpcasm_plan* plan, const double* const* h_src,
+                    const int64_t* h_src_stride, const double* d_params,
+                    const double* d_given, double* d_P, double* d_q, double* d_G,
+                    double* d_h, void* d_work, int batch, void* stream);
+
+/* K2 alone  preview matrices ------------------------------------------------
+ * Replaces Formulation.make_preview_matrices   body.py:149-193
+ * d_PM [batch][preview_rows][ng+no]: for every definition, in definition
+ * order, the rows of [Mg | Mo] (Formulation.PM[var] = (Mg, Mo)).
+ */
+int mpcasm_preview_matrices(const mpcasm_plan* plan, const double* const* h_src,
+                            const int64_t* h_src_stride, double* d_PM, int batch,
+                            void* stream);
+
+/* f2  batched preview --------------------------------------------------------
+ * Replaces Formulation.preview(given, optim, variable)   body.py:209-219
+ * for every definition at once: d_out[batch][preview_rows] =
+ *   Mg @ given + Mo @ optim  with d_PM as written by mpcasm_preview_matrices.
+ */
+int mpcasm_preview(const double* d_PM, const double* d_given, const double* d_optim,
+                   double* d_out, int batch, int rows, int ng, int no, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPCASM_H */

@@ -1,0 +1,303 @@
+// assemble.hip -- K2 (preview composition), K3 (Hessian / gradient, fp64 MFMA)
+// and K4 (constraint stack) for gfx950: the staged pipeline that works for any
+// problem size (workspace in HBM).  Small problems take the fused single-launch
+// path of fused.hip instead.
+//
+// Reference semantics (python/mpc_interface/body.py):
+//   K2  make_preview_matrices / get_matrices_from_dynamics / _from_definition  :149-193
+//   K3  generate_qp_cost :266-302, generate_all_qp_costs :322-329
+//   K4  generate_qp_constraint :236-264, generate_all_qp_constraints :304-320
+//       with Constraint.matrices()/bound() (restrictions.py:175-199) folded in.
+//
+// Workspace per instance: V[rtot][ldv] doubles.  Row r of V holds, for one row
+// of a row-set, the optim part Mo (columns 0..no-1) and in column `no` the dot
+// product d = Mg . given -- the given part itself is never stored.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_common.h"
+#include "kernels.h"
+
+namespace mpcasm {
+
+namespace {
+
+constexpr int BLOCK = 256;
+constexpr int WAVES = BLOCK / 64;
+
+// ---------------------------------------------------------------------------
+// K2: one wavefront per row, lanes over columns
+// ---------------------------------------------------------------------------
+constexpr int K2_ROWS_PER_WAVE = 4;
+
+__global__ __launch_bounds__(BLOCK) void compose_rowsets_kernel(PlanDev p, SrcTable src,
+                                                                const double* __restrict__ given,
+                                                                double* __restrict__ V, int nrb) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long inst = blockIdx.x / nrb;
+  const int rb = blockIdx.x - inst * nrb;
+  const int W = p.ng + p.no;
+  const int32_t* rowptr = p.itab + p.off_rowptr;
+  const int32_t* entbase = p.itab + p.off_entbase;
+  const int32_t* entk = p.itab + p.off_entk;
+  const double* coef = p.dtab + p.doff_entcoef;
+  const double* g = given + inst * p.ng;
+  double* Vb = V + (size_t)inst * p.rtot * p.ldv;
+
+  const int r0 = (rb * WAVES + wave) * K2_ROWS_PER_WAVE;
+  for (int r = r0; r < min(r0 + K2_ROWS_PER_WAVE, p.rtot); ++r) {
+    const int e0 = rowptr[r], e1 = rowptr[r + 1];
+    double dpart = 0.0;
+    for (int c = lane; c < W; c += 64) {
+      const double v = compose_element(p, src, inst, W, c, e0, e1, entbase, entk, coef);
+      if (c < p.ng)
+        dpart = fma(v, g[c], dpart);
+      else
+        Vb[(size_t)r * p.ldv + (c - p.ng)] = v;
+    }
+    dpart = wave_sum(dpart);
+    if (lane == 0) Vb[(size_t)r * p.ldv + p.no] = dpart;
+  }
+}
+
+// all definitions, full [Mg | Mo] rows (Formulation.PM)
+__global__ __launch_bounds__(BLOCK) void compose_preview_kernel(PlanDev p, SrcTable src,
+                                                                double* __restrict__ PM, int nrb) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long inst = blockIdx.x / nrb;
+  const int rb = blockIdx.x - inst * nrb;
+  const int W = p.ng + p.no;
+  const int32_t* rowptr = p.itab + p.off_pm_rowptr;
+  const int32_t* entbase = p.itab + p.off_pm_entbase;
+  const int32_t* entk = p.itab + p.off_pm_entk;
+  const double* coef = p.dtab + p.doff_pm_entcoef;
+  double* out = PM + (size_t)inst * p.pmrows * W;
+
+  const int r0 = (rb * WAVES + wave) * K2_ROWS_PER_WAVE;
+  for (int r = r0; r < min(r0 + K2_ROWS_PER_WAVE, p.pmrows); ++r) {
+    const int e0 = rowptr[r], e1 = rowptr[r + 1];
+    for (int c = lane; c < W; c += 64)
+      out[(size_t)r * W + c] = compose_element(p, src, inst, W, c, e0, e1, entbase, entk, coef);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K3: [P | q] = sum_gterms  (w A)^T [B | r]   with v_mfma_f64_16x16x4_f64.
+// One wavefront owns a 32x32 block of [P | q] (2x2 MFMA tiles) and walks every
+// gterm, four workspace rows per MFMA.  Operand lane map (cdna guide section 3):
+// A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15];
+// D: col = lane&15, row = (lane>>4) + 4*reg.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void hessian_kernel(PlanDev p,
+                                                        const double* __restrict__ params,
+                                                        const double* __restrict__ V,
+                                                        double* __restrict__ P,
+                                                        double* __restrict__ q, int nrb) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long inst = blockIdx.x / nrb;
+  const int rb = blockIdx.x - inst * nrb;
+  const int no = p.no;
+  const int nbr = (no + 31) / 32;      // block rows
+  const int nbc = (no + 1 + 31) / 32;  // block columns (q is column `no`)
+  const int blk = rb * WAVES + wave;
+  if (blk >= nbr * nbc) return;
+  const int bi = blk / nbc, bj = blk - bi * nbc;
+  const bool has_qcol = (bj == no / 32);
+  const double* Vb = V + (size_t)inst * p.rtot * p.ldv;
+  const double* pb = params + (size_t)inst * p.nparams;
+  const int32_t* gt = p.itab + p.off_gterm;
+  const int li = lane & 15, lk = lane >> 4;
+  const int ldv = p.ldv;
+
+  f64x4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
+
+  const int arow0 = bi * 32 + li, arow1 = arow0 + 16;  // rows of P == columns of A's source
+  const int bcol0 = bj * 32 + li, bcol1 = bcol0 + 16;
+
+  for (int g = 0; g < p.ngterm; ++g) {
+    const int32_t* rec = gt + g * GT_WORDS;
+    const int flags = rec[GT_FLAGS];
+    const bool hasP = flags & GT_FLAG_P;
+    if (!hasP && !has_qcol) continue;
+    const int aoff = rec[GT_AOFF], boff = rec[GT_BOFF], doff = rec[GT_DOFF];
+    const int nrows = rec[GT_NROWS];
+    const double w = pb[rec[GT_WPARAM]];
+    const double aim = pb[rec[GT_AIMPARAM]];
+    const double scale = (flags & GT_FLAG_HALF) ? 0.5 : 1.0;
+    for (int k0 = 0; k0 < nrows; k0 += 4) {
+      const int k = k0 + lk;
+      const bool valid = k < nrows;
+      const double* arow = Vb + (size_t)(aoff + k) * ldv;
+      const double* brow = Vb + (size_t)(boff + k) * ldv;
+      double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+      if (valid) {
+        if (arow0 < no) a0 = w * arow[arow0];
+        if (arow1 < no) a1 = w * arow[arow1];
+        if (hasP) {
+          if (bcol0 < no) b0 = brow[bcol0];
+          if (bcol1 < no) b1 = brow[bcol1];
+        }
+        if (has_qcol) {
+          const double r = scale * (Vb[(size_t)(doff + k) * ldv + no] - aim);
+          if (bcol0 == no) b0 = r;
+          if (bcol1 == no) b1 = r;
+        }
+      }
+      acc[0][0] = mfma_f64_16x16x4(a0, b0, acc[0][0]);
+      acc[0][1] = mfma_f64_16x16x4(a0, b1, acc[0][1]);
+      acc[1][0] = mfma_f64_16x16x4(a1, b0, acc[1][0]);
+      acc[1][1] = mfma_f64_16x16x4(a1, b1, acc[1][1]);
+    }
+  }
+
+  double* Pb = P + (size_t)inst * no * no;
+  double* qb = q + (size_t)inst * no;
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int row = bi * 32 + ti * 16 + lk + 4 * reg;
+        const int col = bj * 32 + tj * 16 + li;
+        if (row < no) {
+          if (col < no)
+            Pb[(size_t)row * no + col] = acc[ti][tj][reg];
+          else if (col == no)
+            qb[row] = acc[ti][tj][reg];
+        }
+      }
+}
+
+// ---------------------------------------------------------------------------
+// K4: rows of the stacked G and h; one wavefront per output row
+// ---------------------------------------------------------------------------
+constexpr int K4_ROWS_PER_WAVE = 4;
+
+__global__ __launch_bounds__(BLOCK) void constraints_kernel(PlanDev p,
+                                                            const double* __restrict__ params,
+                                                            const double* __restrict__ V,
+                                                            double* __restrict__ G,
+                                                            double* __restrict__ h, int nrb) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long inst = blockIdx.x / nrb;
+  const int rb = blockIdx.x - inst * nrb;
+  const int no = p.no, ldv = p.ldv;
+  const double* Vb = V + (size_t)inst * p.rtot * ldv;
+  const double* pb = params + (size_t)inst * p.nparams;
+  double* Gb = G + (size_t)inst * p.nc * no;
+  double* hb = h + (size_t)inst * p.nc;
+  const int32_t* rowlimit = p.itab + p.off_rowlimit;
+  const int32_t* limits = p.itab + p.off_limit;
+  const int32_t* lax = p.itab + p.off_lax;
+
+  const int R0 = (rb * WAVES + wave) * K4_ROWS_PER_WAVE;
+  for (int R = R0; R < min(R0 + K4_ROWS_PER_WAVE, p.nc); ++R) {
+    const int32_t* lm = limits + rowlimit[R] * LM_WORDS;
+    const int r = R - lm[LM_OUT0];
+    const int naxes = lm[LM_NAXES];
+    const int32_t* lx = lax + lm[LM_LAX0] * LX_WORDS;
+    const double* arrow = pb + lm[LM_ARROW_P] + (lm[LM_ARROW_ROWS] == 1 ? 0 : r) * naxes;
+    for (int c = lane; c < no; c += 64) {
+      double acc = 0.0;
+      for (int ax = 0; ax < naxes; ++ax) {
+        const int rr = lx[ax * LX_WORDS + LX_ROWS] == 1 ? 0 : r;
+        acc = fma(arrow[ax], Vb[(size_t)(lx[ax * LX_WORDS + LX_ROWOFF] + rr) * ldv + c], acc);
+      }
+      Gb[(size_t)R * no + c] = acc;
+    }
+    if (lane == 0) {
+      const double* center = pb + lm[LM_CENTER_P] + (lm[LM_CENTER_ROWS] == 1 ? 0 : r) * naxes;
+      const double extreme = pb[lm[LM_EXTREME_P] + (lm[LM_EXTREME_ROWS] == 1 ? 0 : r)];
+      double ac = 0.0, ad = 0.0;
+      for (int ax = 0; ax < naxes; ++ax) {
+        const int rr = lx[ax * LX_WORDS + LX_ROWS] == 1 ? 0 : r;
+        ac += arrow[ax] * center[ax];
+        ad = fma(arrow[ax], Vb[(size_t)(lx[ax * LX_WORDS + LX_ROWOFF] + rr) * ldv + no], ad);
+      }
+      hb[R] = (extreme + ac) - ad;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// f2: out[b][r] = PM[b][r][:] . [given ; optim]    (body.py:209-219)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void preview_kernel(const double* __restrict__ PM,
+                                                        const double* __restrict__ given,
+                                                        const double* __restrict__ optim,
+                                                        double* __restrict__ out, int rows, int ng,
+                                                        int no, int nrb) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long inst = blockIdx.x / nrb;
+  const int rb = blockIdx.x - inst * nrb;
+  const int W = ng + no;
+  const int r = rb * WAVES + wave;
+  if (r >= rows) return;
+  const double* row = PM + ((size_t)inst * rows + r) * W;
+  const double* g = given + (size_t)inst * ng;
+  const double* x = optim + (size_t)inst * no;
+  double s = 0.0;
+  for (int c = lane; c < W; c += 64) s = fma(row[c], c < ng ? g[c] : x[c - ng], s);
+  s = wave_sum(s);
+  if (lane == 0) out[(size_t)inst * rows + r] = s;
+}
+
+inline unsigned ceil_div(unsigned a, unsigned b) { return (a + b - 1) / b; }
+
+}  // namespace
+
+size_t assemble_workspace_bytes(const PlanDev& p, int batch) {
+  return (size_t)batch * p.rtot * p.ldv * sizeof(double);
+}
+
+int launch_assemble_staged(const PlanDev& p, const SrcTable& src, const double* params,
+                           const double* given, double* P, double* q, double* G, double* h,
+                           void* work, int batch, hipStream_t stream, hipError_t* err) {
+  double* V = static_cast<double*>(work);
+  if (p.rtot > 0) {
+    const unsigned nrb = ceil_div(p.rtot, WAVES * K2_ROWS_PER_WAVE);
+    hipLaunchKernelGGL(compose_rowsets_kernel, dim3(nrb * batch), dim3(BLOCK), 0, stream, p, src,
+                       given, V, (int)nrb);
+  }
+  if (P && p.no > 0) {
+    const unsigned nblk = ceil_div(p.no, 32) * ceil_div(p.no + 1, 32);
+    const unsigned nrb = ceil_div(nblk, WAVES);
+    hipLaunchKernelGGL(hessian_kernel, dim3(nrb * batch), dim3(BLOCK), 0, stream, p, params, V, P,
+                       q, (int)nrb);
+  }
+  if (G && p.nc > 0) {
+    const unsigned nrb = ceil_div(p.nc, WAVES * K4_ROWS_PER_WAVE);
+    hipLaunchKernelGGL(constraints_kernel, dim3(nrb * batch), dim3(BLOCK), 0, stream, p, params, V,
+                       G, h, (int)nrb);
+  }
+  *err = hipGetLastError();
+  return *err == hipSuccess ? MPCASM_OK : MPCASM_ERR_HIP;
+}
+
+int launch_preview_matrices(const PlanDev& p, const SrcTable& src, double* PM, int batch,
+                            hipStream_t stream, hipError_t* err) {
+  *err = hipSuccess;
+  if (p.pmrows > 0) {
+    const unsigned nrb = ceil_div(p.pmrows, WAVES * K2_ROWS_PER_WAVE);
+    hipLaunchKernelGGL(compose_preview_kernel, dim3(nrb * batch), dim3(BLOCK), 0, stream, p, src,
+                       PM, (int)nrb);
+    *err = hipGetLastError();
+  }
+  return *err == hipSuccess ? MPCASM_OK : MPCASM_ERR_HIP;
+}
+
+int launch_preview(const double* PM, const double* given, const double* optim, double* out,
+                   int batch, int rows, int ng, int no, hipStream_t stream, hipError_t* err) {
+  const unsigned nrb = ceil_div(rows, WAVES);
+  hipLaunchKernelGGL(preview_kernel, dim3(nrb * batch), dim3(BLOCK), 0, stream, PM, given, optim,
+                     out, rows, ng, no, (int)nrb);
+  *err = hipGetLastError();
+  return *err == hipSuccess ? MPCASM_OK : MPCASM_ERR_HIP;
+}
+
+}  // namespace mpcasm

@@ -1,0 +1,304 @@
+// capi.hip -- extern "C" boundary of libmpcasm.so (declared in include/mpcasm.h).
+// Argument checking, plan validation / upload and kernel dispatch; no kernel code.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <new>
+
+#include "kernels.h"
+
+using namespace mpcasm;
+
+struct mpcasm_plan {
+  PlanDev dev;
+  int32_t* d_itab;
+  double* d_dtab;
+  int device;
+};
+
+namespace {
+
+thread_local int g_last_hip = 0;
+
+int hip_fail(hipError_t e) {
+  g_last_hip = (int)e;
+  return MPCASM_ERR_HIP;
+}
+
+// section [off, off + len) must lie inside [H_WORDS, n)
+bool in_range(int64_t off, int64_t len, int64_t n, int64_t lo) {
+  return off >= lo && len >= 0 && off + len <= n;
+}
+
+int validate_plan(const int32_t* it, size_t n_itab, size_t n_dtab) {
+  if (n_itab < (size_t)H_WORDS) return MPCASM_ERR_PLAN;
+  if (it[H_MAGIC] != PLAN_MAGIC || it[H_VERSION] != PLAN_VERSION) return MPCASM_ERR_PLAN;
+  if ((size_t)it[H_NITAB] != n_itab || (size_t)it[H_NDTAB] != n_dtab) return MPCASM_ERR_PLAN;
+  const int64_t n = (int64_t)n_itab, nd = (int64_t)n_dtab;
+  const int64_t ng = it[H_NG], no = it[H_NO], nc = it[H_NC];
+  if (ng < 0 || no < 0 || nc < 0 || it[H_NPARAMS] < 0) return MPCASM_ERR_PLAN;
+  if (it[H_NSRC] < 0 || it[H_NSRC] > MAX_SOURCES) return MPCASM_ERR_LIMIT;
+  if (it[H_LDV] < no + 1 || (it[H_LDV] & 1)) return MPCASM_ERR_PLAN;
+  const int64_t W = ng + no;
+  bool ok = true;
+  ok = ok && in_range(it[H_OFF_SEG], (int64_t)it[H_NSEG] * SEG_WORDS, n, H_WORDS);
+  ok = ok && in_range(it[H_OFF_COLSEG], (int64_t)it[H_NBASE] * W, n, H_WORDS);
+  ok = ok && in_range(it[H_OFF_ROWPTR], (int64_t)it[H_RTOT] + 1, n, H_WORDS);
+  ok = ok && in_range(it[H_OFF_ENTBASE], it[H_NENT], n, H_WORDS);
+  ok = ok && in_range(it[H_OFF_ENTK], it[H_NENT], n, H_WORDS);
+  ok = ok && in_range(it[H_OFF_GTERM], (int64_t)it[H_NGTERM] * GT_WORDS, n, H_WORDS);
+  ok = ok && in_range(it[H_OFF_LIMIT], (int64_t)it[H_NLIMIT] * LM_WORDS, n, H_WORDS);
+  ok = ok && in_range(it[H_OFF_LAX], (int64_t)it[H_NLAX] * LX_WORDS, n, H_WORDS);
+  ok = ok && in_range(it[H_OFF_ROWLIMIT], nc, n, H_WORDS);
+  ok = ok && in_range(it[H_OFF_PM_ROWPTR], (int64_t)it[H_PMROWS] + 1, n, H_WORDS);
+  ok = ok && in_range(it[H_OFF_PM_ENTBASE], it[H_PM_NENT], n, H_WORDS);
+  ok = ok && in_range(it[H_OFF_PM_ENTK], it[H_PM_NENT], n, H_WORDS);
+  ok = ok && in_range(it[H_DOFF_ENTCOEF], it[H_NENT], nd, 0);
+  ok = ok && in_range(it[H_DOFF_PM_ENTCOEF], it[H_PM_NENT], nd, 0);
+  if (!ok) return MPCASM_ERR_PLAN;
+
+  // content checks: every index a kernel dereferences stays inside its table
+  const int32_t* seg = it + it[H_OFF_SEG];
+  for (int s = 0; s < it[H_NSEG]; ++s) {
+    const int32_t* r = seg + s * SEG_WORDS;
+    if (r[SEG_KIND] != SEG_KIND_GATHER && r[SEG_KIND] != SEG_KIND_IDENTITY) return MPCASM_ERR_PLAN;
+    if (r[SEG_KIND] == SEG_KIND_GATHER && (r[SEG_SRC] < 0 || r[SEG_SRC] >= it[H_NSRC]))
+      return MPCASM_ERR_PLAN;
+    if (r[SEG_DST0] < 0 || r[SEG_LEN] < 0 || r[SEG_DST0] + r[SEG_LEN] > W) return MPCASM_ERR_PLAN;
+  }
+  const int32_t* colseg = it + it[H_OFF_COLSEG];
+  for (int64_t i = 0; i < (int64_t)it[H_NBASE] * W; ++i)
+    if (colseg[i] < -1 || colseg[i] >= it[H_NSEG]) return MPCASM_ERR_PLAN;
+  auto check_csr = [&](int off_ptr, int rows, int off_base, int nent) {
+    const int32_t* rp = it + off_ptr;
+    if (rp[0] != 0 || rp[rows] != nent) return false;
+    for (int r = 0; r < rows; ++r)
+      if (rp[r + 1] < rp[r]) return false;
+    const int32_t* eb = it + off_base;
+    for (int e = 0; e < nent; ++e)
+      if (eb[e] < 0 || eb[e] >= it[H_NBASE]) return false;
+    return true;
+  };
+  if (!check_csr(it[H_OFF_ROWPTR], it[H_RTOT], it[H_OFF_ENTBASE], it[H_NENT])) return MPCASM_ERR_PLAN;
+  if (!check_csr(it[H_OFF_PM_ROWPTR], it[H_PMROWS], it[H_OFF_PM_ENTBASE], it[H_PM_NENT]))
+    return MPCASM_ERR_PLAN;
+  const int32_t* gt = it + it[H_OFF_GTERM];
+  for (int g = 0; g < it[H_NGTERM]; ++g) {
+    const int32_t* r = gt + g * GT_WORDS;
+    const int nr = r[GT_NROWS];
+    if (nr < 0 || r[GT_AOFF] < 0 || r[GT_AOFF] + nr > it[H_RTOT]) return MPCASM_ERR_PLAN;
+    if (r[GT_DOFF] < 0 || r[GT_DOFF] + nr > it[H_RTOT]) return MPCASM_ERR_PLAN;
+    if ((r[GT_FLAGS] & GT_FLAG_P) && (r[GT_BOFF] < 0 || r[GT_BOFF] + nr > it[H_RTOT]))
+      return MPCASM_ERR_PLAN;
+    if (r[GT_WPARAM] < 0 || r[GT_WPARAM] >= it[H_NPARAMS]) return MPCASM_ERR_PLAN;
+    if (r[GT_AIMPARAM] < 0 || r[GT_AIMPARAM] >= it[H_NPARAMS]) return MPCASM_ERR_PLAN;
+  }
+  const int32_t* lim = it + it[H_OFF_LIMIT];
+  const int32_t* lax = it + it[H_OFF_LAX];
+  const int32_t* rowlimit = it + it[H_OFF_ROWLIMIT];
+  for (int l = 0; l < it[H_NLIMIT]; ++l) {
+    const int32_t* r = lim + l * LM_WORDS;
+    const int nr = r[LM_NROWS], na = r[LM_NAXES];
+    if (nr < 0 || na < 0 || r[LM_OUT0] < 0 || r[LM_OUT0] + nr > nc) return MPCASM_ERR_PLAN;
+    if (r[LM_LAX0] < 0 || r[LM_LAX0] + na > it[H_NLAX]) return MPCASM_ERR_PLAN;
+    const int ar = r[LM_ARROW_ROWS], cr = r[LM_CENTER_ROWS], er = r[LM_EXTREME_ROWS];
+    if ((ar != 1 && ar != nr) || (cr != 1 && cr != nr) || (er != 1 && er != nr))
+      return MPCASM_ERR_PLAN;
+    if (r[LM_ARROW_P] < 0 || r[LM_ARROW_P] + ar * na > it[H_NPARAMS]) return MPCASM_ERR_PLAN;
+    if (r[LM_CENTER_P] < 0 || r[LM_CENTER_P] + cr * na > it[H_NPARAMS]) return MPCASM_ERR_PLAN;
+    if (r[LM_EXTREME_P] < 0 || r[LM_EXTREME_P] + er > it[H_NPARAMS]) return MPCASM_ERR_PLAN;
+    for (int a = 0; a < na; ++a) {
+      const int32_t* x = lax + (r[LM_LAX0] + a) * LX_WORDS;
+      if ((x[LX_ROWS] != 1 && x[LX_ROWS] != nr) || x[LX_ROWOFF] < 0 ||
+          x[LX_ROWOFF] + x[LX_ROWS] > it[H_RTOT])
+        return MPCASM_ERR_PLAN;
+    }
+    for (int k = 0; k < nr; ++k)
+      if (rowlimit[r[LM_OUT0] + k] != l) return MPCASM_ERR_PLAN;
+  }
+  return MPCASM_OK;
+}
+
+int make_src_table(const mpcasm_plan* plan, const double* const* h_src,
+                   const int64_t* h_src_stride, SrcTable* out) {
+  memset(out, 0, sizeof(*out));
+  for (int s = 0; s < plan->dev.nsrc; ++s) {
+    if (!h_src[s] || h_src_stride[s] < 0) return MPCASM_ERR_ARG;
+    out->ptr[s] = h_src[s];
+    out->stride[s] = h_src_stride[s];
+  }
+  return MPCASM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mpcasm_abi_version(void) { return 1000; }
+
+int mpcasm_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int mpcasm_last_hip(void) { return g_last_hip; }
+
+const char* mpcasm_status_string(int status) {
+  switch (status) {
+    case MPCASM_OK: return "ok";
+    case MPCASM_ERR_ARG: return "invalid argument";
+    case MPCASM_ERR_PLAN: return "malformed plan tables";
+    case MPCASM_ERR_HIP: return "HIP runtime error";
+    case MPCASM_ERR_NODEVICE: return "no HIP device";
+    case MPCASM_ERR_LIMIT: return "problem exceeds a kernel limit";
+    default: return "unknown status";
+  }
+}
+
+int mpcasm_fill_su(const double* d_A, const double* d_B, double* d_S, double* d_U, int batch,
+                   int N, int n, int m, int ltv, void* stream) {
+  if (!d_A || !d_B || !d_S || !d_U) return MPCASM_ERR_ARG;
+  if (batch < 0 || N < 1 || n < 1 || m < 1 || (ltv != 0 && ltv != 1)) return MPCASM_ERR_ARG;
+  if (batch == 0) return MPCASM_OK;
+  if (mpcasm_device_count() == 0) return MPCASM_ERR_NODEVICE;
+  hipError_t err;
+  const int rc = launch_fill_su(d_A, d_B, d_S, d_U, batch, N, n, m, ltv,
+                                static_cast<hipStream_t>(stream), &err);
+  if (rc == MPCASM_ERR_HIP) g_last_hip = (int)err;
+  return rc;
+}
+
+int mpcasm_plan_create(const int32_t* h_itab, size_t n_itab, const double* h_dtab, size_t n_dtab,
+                       mpcasm_plan** out_plan) {
+  if (!h_itab || !out_plan || (n_dtab && !h_dtab)) return MPCASM_ERR_ARG;
+  *out_plan = nullptr;
+  const int rc = validate_plan(h_itab, n_itab, n_dtab);
+  if (rc != MPCASM_OK) return rc;
+  if (mpcasm_device_count() == 0) return MPCASM_ERR_NODEVICE;
+
+  mpcasm_plan* plan = new (std::nothrow) mpcasm_plan();
+  if (!plan) return MPCASM_ERR_ARG;
+  hipError_t e;
+  if ((e = hipGetDevice(&plan->device)) != hipSuccess) {
+    delete plan;
+    return hip_fail(e);
+  }
+  plan->d_itab = nullptr;
+  plan->d_dtab = nullptr;
+  const size_t dbytes = (n_dtab ? n_dtab : 1) * sizeof(double);
+  if ((e = hipMalloc(&plan->d_itab, n_itab * sizeof(int32_t))) != hipSuccess ||
+      (e = hipMalloc(&plan->d_dtab, dbytes)) != hipSuccess ||
+      (e = hipMemcpy(plan->d_itab, h_itab, n_itab * sizeof(int32_t), hipMemcpyHostToDevice)) !=
+          hipSuccess ||
+      (n_dtab && (e = hipMemcpy(plan->d_dtab, h_dtab, n_dtab * sizeof(double),
+                                hipMemcpyHostToDevice)) != hipSuccess)) {
+    if (plan->d_itab) (void)hipFree(plan->d_itab);
+    if (plan->d_dtab) (void)hipFree(plan->d_dtab);
+    delete plan;
+    return hip_fail(e);
+  }
+  PlanDev& d = plan->dev;
+  const int32_t* it = h_itab;
+  d.itab = plan->d_itab;
+  d.dtab = plan->d_dtab;
+  d.ng = it[H_NG]; d.no = it[H_NO]; d.nc = it[H_NC]; d.nparams = it[H_NPARAMS];
+  d.nsrc = it[H_NSRC]; d.nbase = it[H_NBASE]; d.nseg = it[H_NSEG]; d.rtot = it[H_RTOT];
+  d.nent = it[H_NENT]; d.ngterm = it[H_NGTERM]; d.nlimit = it[H_NLIMIT]; d.nlax = it[H_NLAX];
+  d.pmrows = it[H_PMROWS]; d.pm_nent = it[H_PM_NENT]; d.ldv = it[H_LDV];
+  d.off_seg = it[H_OFF_SEG]; d.off_colseg = it[H_OFF_COLSEG]; d.off_rowptr = it[H_OFF_ROWPTR];
+  d.off_entbase = it[H_OFF_ENTBASE]; d.off_entk = it[H_OFF_ENTK]; d.off_gterm = it[H_OFF_GTERM];
+  d.off_limit = it[H_OFF_LIMIT]; d.off_lax = it[H_OFF_LAX]; d.off_rowlimit = it[H_OFF_ROWLIMIT];
+  d.off_pm_rowptr = it[H_OFF_PM_ROWPTR]; d.off_pm_entbase = it[H_OFF_PM_ENTBASE];
+  d.off_pm_entk = it[H_OFF_PM_ENTK];
+  d.doff_entcoef = it[H_DOFF_ENTCOEF]; d.doff_pm_entcoef = it[H_DOFF_PM_ENTCOEF];
+  *out_plan = plan;
+  return MPCASM_OK;
+}
+
+int mpcasm_plan_destroy(mpcasm_plan* plan) {
+  if (!plan) return MPCASM_OK;
+  hipError_t e1 = hipFree(plan->d_itab);
+  hipError_t e2 = hipFree(plan->d_dtab);
+  delete plan;
+  if (e1 != hipSuccess) return hip_fail(e1);
+  if (e2 != hipSuccess) return hip_fail(e2);
+  return MPCASM_OK;
+}
+
+int mpcasm_plan_sizes(const mpcasm_plan* plan, int64_t out[8]) {
+  if (!plan || !out) return MPCASM_ERR_ARG;
+  const PlanDev& d = plan->dev;
+  out[0] = d.ng; out[1] = d.no; out[2] = d.nc; out[3] = d.nparams;
+  out[4] = d.nsrc; out[5] = d.rtot; out[6] = d.ldv; out[7] = d.pmrows;
+  return MPCASM_OK;
+}
+
+int mpcasm_workspace_bytes(const mpcasm_plan* plan, int batch, size_t* out_bytes) {
+  if (!plan || !out_bytes || batch < 0) return MPCASM_ERR_ARG;
+  *out_bytes = assemble_workspace_bytes(plan->dev, batch);
+  return MPCASM_OK;
+}
+
+int mpcasm_assemble(const mpcasm_plan* plan, const double* const* h_src,
+                    const int64_t* h_src_stride, const double* d_params, const double* d_given,
+                    double* d_P, double* d_q, double* d_G, double* d_h, void* d_work, int batch,
+                    void* stream) {
+  if (!plan || batch < 0) return MPCASM_ERR_ARG;
+  const PlanDev& d = plan->dev;
+  if ((d.nsrc && (!h_src || !h_src_stride)) || (d.nparams && !d_params) || (d.ng && !d_given))
+    return MPCASM_ERR_ARG;
+  if ((d_P == nullptr) != (d_q == nullptr) || (d_G == nullptr) != (d_h == nullptr))
+    return MPCASM_ERR_ARG;
+  if (d.rtot && !d_work) return MPCASM_ERR_ARG;
+  if (batch == 0) return MPCASM_OK;
+  SrcTable src;
+  int rc = make_src_table(plan, h_src, h_src_stride, &src);
+  if (rc != MPCASM_OK) return rc;
+  hipError_t err;
+  rc = launch_assemble(d, src, d_params, d_given, d_P, d_q, d_G, d_h, d_work, batch,
+                       static_cast<hipStream_t>(stream), &err);
+  if (rc == MPCASM_ERR_HIP) g_last_hip = (int)err;
+  return rc;
+}
+
+int mpcasm_preview_matrices(const mpcasm_plan* plan, const double* const* h_src,
+                            const int64_t* h_src_stride, double* d_PM, int batch, void* stream) {
+  if (!plan || !d_PM || batch < 0) return MPCASM_ERR_ARG;
+  if (plan->dev.nsrc && (!h_src || !h_src_stride)) return MPCASM_ERR_ARG;
+  if (batch == 0) return MPCASM_OK;
+  SrcTable src;
+  int rc = make_src_table(plan, h_src, h_src_stride, &src);
+  if (rc != MPCASM_OK) return rc;
+  hipError_t err;
+  rc = launch_preview_matrices(plan->dev, src, d_PM, batch, static_cast<hipStream_t>(stream), &err);
+  if (rc == MPCASM_ERR_HIP) g_last_hip = (int)err;
+  return rc;
+}
+
+int mpcasm_preview(const double* d_PM, const double* d_given, const double* d_optim, double* d_out,
+                   int batch, int rows, int ng, int no, void* stream) {
+  if (!d_PM || !d_out || batch < 0 || rows < 0 || ng < 0 || no < 0) return MPCASM_ERR_ARG;
+  if ((ng && !d_given) || (no && !d_optim)) return MPCASM_ERR_ARG;
+  if (batch == 0 || rows == 0) return MPCASM_OK;
+  hipError_t err;
+  const int rc = launch_preview(d_PM, d_given, d_optim, d_out, batch, rows, ng, no,
+                                static_cast<hipStream_t>(stream), &err);
+  if (rc == MPCASM_ERR_HIP) g_last_hip = (int)err;
+  return rc;
+}
+
+}  // extern "C"
+
+namespace mpcasm {
+
+// dispatch: fused single launch when the problem fits on chip, else staged
+int launch_assemble(const PlanDev& p, const SrcTable& src, const double* params,
+                    const double* given, double* P, double* q, double* G, double* h, void* work,
+                    int batch, hipStream_t stream, hipError_t* err) {
+  return launch_assemble_staged(p, src, params, given, P, q, G, h, work, batch, stream, err);
+}
+
+}  // namespace mpcasm

@@ -1,0 +1,59 @@
+// device_common.h -- device helpers shared by the assembly kernels (gfx950).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.h"
+
+namespace mpcasm {
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+// D = A(16x4) * B(4x16) + C on the fp64 matrix core.
+// Lane l supplies A[l & 15][l >> 4] and B[l >> 4][l & 15]; D register r of lane l
+// is element (row = (l >> 4) + 4 r, col = l & 15).
+__device__ __forceinline__ f64x4 mfma_f64_16x16x4(double a, double b, f64x4 c) {
+  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+// sum over the 64 lanes of a wavefront, result in every lane
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// One element of a composed row: sum_e coef[e] * base_row(entbase[e], entk[e])[c]
+// (flattened definition graph, body.py:158-193).  Column c belongs to at most
+// one segment of each base variable (colseg); a segment is either an identity
+// block (domain variable, dynamics.py:277-281) or a strided slice of a source
+// (state of an ExtendedSystem: matrices[dID][k, :, sID], dynamics.py:283-295).
+__device__ __forceinline__ double compose_element(const PlanDev& p, const SrcTable& src, long inst,
+                                                  int W, int c, int e0, int e1,
+                                                  const int32_t* __restrict__ entbase,
+                                                  const int32_t* __restrict__ entk,
+                                                  const double* __restrict__ coef) {
+  const int32_t* colseg = p.itab + p.off_colseg;
+  const int32_t* segs = p.itab + p.off_seg;
+  double acc = 0.0;
+  for (int e = e0; e < e1; ++e) {
+    const int sg = colseg[entbase[e] * W + c];
+    if (sg >= 0) {
+      const int32_t* s = segs + sg * SEG_WORDS;
+      const int k = entk[e];
+      const int j = c - s[SEG_DST0];
+      double val;
+      if (s[SEG_KIND] == SEG_KIND_IDENTITY) {
+        val = (j == k) ? 1.0 : 0.0;
+      } else {
+        const int sid = s[SEG_SRC];
+        val = src.ptr[sid][inst * src.stride[sid] + s[SEG_OFF0] + (long)k * s[SEG_ROWSTRIDE] +
+                           (long)j * s[SEG_ELEMSTRIDE]];
+      }
+      acc = fma(coef[e], val, acc);
+    }
+  }
+  return acc;
+}
+
+}  // namespace mpcasm

@@ -1,0 +1,45 @@
+// kernels.h -- internal launch interface between capi.hip and the kernel files.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/mpcasm.h"
+#include "plan_tables.h"
+
+namespace mpcasm {
+
+// device-side view of a plan (pointers into the device copies of the tables)
+struct PlanDev {
+  const int32_t* itab;
+  const double* dtab;
+  int ng, no, nc, nparams, nsrc, nbase, nseg, rtot, nent, ngterm, nlimit, nlax, pmrows, pm_nent, ldv;
+  int off_seg, off_colseg, off_rowptr, off_entbase, off_entk, off_gterm, off_limit, off_lax, off_rowlimit;
+  int off_pm_rowptr, off_pm_entbase, off_pm_entk;
+  int doff_entcoef, doff_pm_entcoef;
+};
+
+// sources of one launch (device pointers + per-instance strides, by value)
+struct SrcTable {
+  const double* ptr[MAX_SOURCES];
+  long long stride[MAX_SOURCES];
+};
+
+// fill.hip
+int launch_fill_su(const double* A, const double* B, double* S, double* U, int batch, int N, int n,
+                   int m, int ltv, hipStream_t stream, hipError_t* err);
+
+// assemble.hip
+size_t assemble_workspace_bytes(const PlanDev& p, int batch);
+int launch_assemble_staged(const PlanDev& p, const SrcTable& src, const double* params,
+                           const double* given, double* P, double* q, double* G, double* h,
+                           void* work, int batch, hipStream_t stream, hipError_t* err);
+int launch_assemble(const PlanDev& p, const SrcTable& src, const double* params,
+                    const double* given, double* P, double* q, double* G, double* h, void* work,
+                    int batch, hipStream_t stream, hipError_t* err);
+int launch_preview_matrices(const PlanDev& p, const SrcTable& src, double* PM, int batch,
+                            hipStream_t stream, hipError_t* err);
+int launch_preview(const double* PM, const double* given, const double* optim, double* out,
+                   int batch, int rows, int ng, int no, hipStream_t stream, hipError_t* err);
+
+}  // namespace mpcasm

@@ -1,0 +1,88 @@
+// plan_tables.h -- layout of the flat plan tables shared by the host plan
+// compiler (mpcasm/plan.py, which mirrors these constants) and the kernels.
+//
+// A plan is two arrays: int32 `itab` (structure) and double `dtab` (numbers
+// that are the same for every instance of the batch: definition coefficients
+// with L matrices folded in).  itab starts with a header of H_WORDS words; all
+// H_OFF_* are word offsets into itab, all H_DOFF_* element offsets into dtab.
+//
+// Vocabulary (reference python/mpc_interface/body.py):
+//   column   one entry of [given | optim]: c < ng is given c, else optim c-ng
+//   source   one horizon matrix ExtendedSystem.matrices[k], shape [N][p][n]
+//            (dynamics.py:199), shared by the batch or one per instance
+//   base     a variable defined directly by a dynamics object (a key of
+//            Formulation.of): a domain variable (identity rows) or a state of
+//            an ExtendedSystem (rows gathered from sources), body.py:158-177
+//   segment  a run of columns of one base variable fed by one source slice
+//   row      one row of [Mg | Mo] of some definition, stored as a CSR list of
+//            (base, base_row, coefficient): the flattened definition graph of
+//            body.py:179-193
+//   row-set  consecutive rows consumed by a cost or a constraint (a variable
+//            restricted to a schedule, L folded in)
+//   gterm    one accumulation  P += w A^T B,  q += w A^T r  of body.py:292-300
+//   limit    one Constraint (restrictions.py:15) -> rows of G, h
+#pragma once
+#include <stdint.h>
+
+namespace mpcasm {
+
+constexpr int32_t PLAN_MAGIC = 0x4D504341;  // 'MPCA'
+constexpr int32_t PLAN_VERSION = 3;
+
+enum HeaderWord : int {
+  H_MAGIC = 0,
+  H_VERSION,
+  H_NG,            // given_len
+  H_NO,            // optim_len
+  H_NC,            // rows of stacked G
+  H_NPARAMS,       // doubles per instance in d_params
+  H_NSRC,          // number of sources
+  H_NBASE,         // number of base variables
+  H_NSEG,          // number of segments
+  H_RTOT,          // rows of all row-sets (workspace rows per instance)
+  H_NENT,          // CSR entries of the row-set program
+  H_NGTERM,
+  H_NLIMIT,
+  H_NLAX,          // limit-axis records
+  H_PMROWS,        // rows of the preview program (all definitions)
+  H_PM_NENT,
+  H_LDV,           // workspace leading dimension (>= no + 1, even)
+  H_OFF_SEG,
+  H_OFF_COLSEG,    // [nbase][ng+no] segment id or -1
+  H_OFF_ROWPTR,    // [RTOT+1]
+  H_OFF_ENTBASE,   // [NENT]
+  H_OFF_ENTK,      // [NENT]
+  H_OFF_GTERM,
+  H_OFF_LIMIT,
+  H_OFF_LAX,
+  H_OFF_ROWLIMIT,  // [NC] limit index of every row of the stacked G
+  H_OFF_PM_ROWPTR, // [PMROWS+1]
+  H_OFF_PM_ENTBASE,
+  H_OFF_PM_ENTK,
+  H_DOFF_ENTCOEF,    // [NENT]
+  H_DOFF_PM_ENTCOEF, // [PM_NENT]
+  H_NITAB,         // total words of itab (self check)
+  H_NDTAB,         // total elements of dtab
+  H_WORDS = 40
+};
+
+// segment record
+enum { SEG_SRC = 0, SEG_OFF0, SEG_ROWSTRIDE, SEG_ELEMSTRIDE, SEG_DST0, SEG_LEN, SEG_KIND, SEG_PAD, SEG_WORDS = 8 };
+enum { SEG_KIND_GATHER = 0, SEG_KIND_IDENTITY = 1 };
+
+// gterm record:  P[:, :] += w * A^T B   (when GT_FLAG_P),   q += s * w * A^T (d[D_OFF + k] - aim)
+enum { GT_AOFF = 0, GT_BOFF, GT_NROWS, GT_WPARAM, GT_DOFF, GT_AIMPARAM, GT_FLAGS, GT_PAD, GT_WORDS = 8 };
+enum { GT_FLAG_P = 1, GT_FLAG_HALF = 2 };
+
+// limit record
+enum {
+  LM_OUT0 = 0, LM_NROWS, LM_NAXES, LM_LAX0,
+  LM_ARROW_P, LM_ARROW_ROWS, LM_CENTER_P, LM_CENTER_ROWS, LM_EXTREME_P, LM_EXTREME_ROWS,
+  LM_PAD0, LM_PAD1, LM_WORDS = 12
+};
+// limit-axis record
+enum { LX_ROWOFF = 0, LX_ROWS, LX_WORDS = 2 };
+
+constexpr int MAX_SOURCES = 32;
+
+}  // namespace mpcasm

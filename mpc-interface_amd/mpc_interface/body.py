@@ -1,0 +1,288 @@
+"""QP formulation: the drop-in ``Formulation`` whose numeric work runs on the GPU.
+
+Same public surface as /root/reference/python/mpc_interface/body.py (incorporate_*,
+identify_qp_domain, update, make_preview_matrices, arrange_given, preview,
+generate_qp_constraint / _cost, generate_all_qp_matrices ...), same return layout
+(numpy float64, 2-D column vectors).  The bookkeeping (domain order, sizes, index
+ranges) is host Python as in the reference; every matrix is produced by the HIP
+kernels of ``mpcasm`` with a batch of one, so this class is the B=1 view of the
+batched engine (``mpcasm.engine.Assembler`` is the B>1 view of the same kernels).
+There is no numpy fallback: without libmpcasm.so or without a HIP device the
+numeric methods raise ``RuntimeError``.
+"""
+from collections.abc import Mapping
+
+import numpy as np
+
+from . import tools as use
+
+
+class _PreviewMatrices(Mapping):
+    """``Formulation.PM``: ``{definition: (Mg, Mo)}`` computed by the K2 kernel
+    on first access and cached until the next ``make_preview_matrices``."""
+
+    def __init__(self, form):
+        self._form = form
+        self._names = list(form.definitions.keys())
+        self._data = None
+
+    def _materialize(self):
+        if self._data is None:
+            asm = self._form._assembler()
+            PM = asm.preview_matrices()[0].cpu().numpy()
+            ng = asm.ng
+            self._data = {}
+            for var in self._names:
+                r0, rows = asm.plan.pm_rows[var]
+                block = PM[r0:r0 + rows]
+                self._data[var] = (np.ascontiguousarray(block[:, :ng]),
+                                   np.ascontiguousarray(block[:, ng:]))
+        return self._data
+
+    def __getitem__(self, variable):
+        return self._materialize()[variable]
+
+    def __iter__(self):
+        return iter(self._names)
+
+    def __len__(self):
+        return len(self._names)
+
+    def update(self, other):
+        self._materialize().update(other)
+        for name in other:
+            if name not in self._names:
+                self._names.append(name)
+
+
+class Formulation:
+    def __init__(self):
+        self.domain = {}            # variable -> size, in incorporation order
+        self.optim_variables = []
+        self.given_variables = []
+        self.optim_sizes = []
+        self.given_sizes = []
+        self.optim_len = 0          # unknowns of the QP
+        self.given_len = 0          # entries of the 'given' vector
+        self.optim_ID = {}          # variable -> range in the QP solution
+        self.given_ID = {}          # variable -> range in the given vector
+        self.domain_ID = {"optim_ID": self.optim_ID, "given_ID": self.given_ID}
+
+        self.definitions = {}       # variable -> LineCombo
+        self.dynamics = {}          # name -> ExtendedSystem / DomainVariable
+        self.of = {}                # variable -> name of its dynamics
+
+        self.constraint_boxes = {}
+        self.constraints = {}       # name -> list of Constraint
+        self.goals = {}             # name -> Cost
+
+        self.update_incorporations = use.do_not_update
+        self._asm = None            # full-problem assembler of the current structure
+        self._device = None
+
+    # ---- incorporations (body.py:38-94) ------------------------------------
+    def incorporate_dynamics(self, name, new_dynamics):
+        self.domain.update(new_dynamics.domain)
+        self.dynamics[name] = new_dynamics
+        for variable in new_dynamics.all_variables.keys():
+            self.of[variable] = name
+        self.definitions.update(new_dynamics.definitions)
+
+    def incorporate_definition(self, name, new_definition):
+        for variable in new_definition.keys():
+            assert variable in self.definitions.keys(), (
+                "The definition must depend only on defined variables, but the "
+                "this definition depends on " + variable
+            )
+        self.definitions[name] = new_definition
+
+    def incorporate_definitions(self, dict_of_defs):
+        for name, combination in dict_of_defs.items():
+            self.incorporate_definition(name, combination)
+
+    def _assert_defined(self, variable, axes):
+        for axis in axes:
+            assert variable + axis in self.definitions.keys(), (
+                "All constrained variables must be previously defined, "
+                "but '{}' was not defined.".format(variable + axis)
+            )
+
+    def incorporate_constraint(self, name, new_limits):
+        if not isinstance(new_limits, list):
+            new_limits = [new_limits]
+        for limit in new_limits:
+            self._assert_defined(limit.variable, limit.axes)
+        self.constraints[name] = new_limits
+
+    def incorporate_box(self, name, new_box):
+        for limit in new_box.constraints:
+            self._assert_defined(limit.variable, limit.axes)
+        self.constraint_boxes[name] = new_box
+
+    def incorporate_goal(self, name, new_goal):
+        self._assert_defined(new_goal.variable, new_goal.axes)
+        self.goals[name] = new_goal
+
+    # ---- QP domain bookkeeping (body.py:97-136) -------------------------------
+    def identify_qp_domain(self, optimization_domain):
+        """``optimization_domain``: names of the unknowns, in QP order; every
+        other domain variable is 'given', in domain order."""
+        self.optim_variables = optimization_domain
+        self.given_variables = [
+            v for v in self.domain.keys() if v not in optimization_domain
+        ]
+        self.update_qp_sizes()
+        self.update_qp_IDs()
+
+    def update_qp_domain(self):
+        for behavior in self.dynamics.values():
+            if behavior.time_variant:
+                self.domain.update(behavior.domain)
+
+    def update_qp_sizes(self):
+        self.optim_sizes = [self.domain[v] for v in self.optim_variables]
+        self.given_sizes = [self.domain[v] for v in self.given_variables]
+        self.optim_len = sum(self.optim_sizes)
+        self.given_len = sum(self.given_sizes)
+
+    @staticmethod
+    def _prefix_ranges(names, sizes):
+        ranges, start = {}, 0
+        for name, size in zip(names, sizes):
+            ranges[name] = range(start, start + size)
+            start += size
+        return ranges
+
+    def update_qp_IDs(self):
+        # dict.update only: keys of variables that left the domain persist, as in
+        # the reference (body.py:135-136)
+        self.optim_ID.update(self._prefix_ranges(self.optim_variables, self.optim_sizes))
+        self.given_ID.update(self._prefix_ranges(self.given_variables, self.given_sizes))
+
+    def set_updating_rule(self, how_to_update=None):
+        self.update_incorporations = how_to_update
+
+    def update(self, **kargs):
+        """Per-tick refresh (body.py:142-147)."""
+        self.update_incorporations(self, **kargs)
+        self.update_qp_domain()
+        self.update_qp_sizes()
+        self.update_qp_IDs()
+        self.make_preview_matrices()
+
+    # ---- device plumbing -----------------------------------------------------------
+    def _all_limits(self):
+        limits = [l for group in self.constraints.values() for l in group]
+        limits += [l for box in self.constraint_boxes.values() for l in box.constraints]
+        return limits
+
+    def _assembler(self, costs=None, limits=None):
+        """Assembler (batch 1) carrying the current numbers.  The full-problem one
+        is kept until the next ``make_preview_matrices`` (the preview matrices are
+        frozen in between, as ``self.PM`` is in the reference); the Cost /
+        Constraint numbers are re-read on every call and a change of their
+        structure (schedule, L, shapes, membership) recompiles the plan."""
+        from mpcasm.engine import Assembler
+        from mpcasm.plan import structure_fingerprint
+
+        if costs is None and limits is None:
+            asm = self._asm
+            if asm is not None and (
+                    asm.plan.fingerprint != structure_fingerprint(self.goals, self._all_limits())
+                    or not asm.refresh_params()):
+                asm = None
+            if asm is None:
+                asm = self._asm = Assembler(self, batch=1, device=self._device)
+            return asm
+        return Assembler(self, batch=1, device=self._device,
+                         costs={} if costs is None else costs,
+                         limits=[] if limits is None else limits)
+
+    def make_preview_matrices(self):
+        """``self.PM[var] = (Mg, Mo)`` for every definition (body.py:149-193),
+        produced by the K2 kernel when first read."""
+        self._asm = None
+        self.PM = _PreviewMatrices(self)
+
+    def get_matrices_from_dynamics(self, variable):
+        return self.PM[variable]
+
+    def get_matrices_from_definition(self, variable):
+        return self.PM[variable]
+
+    def arrange_given(self, collector):
+        """Column vector of all given values, ordered by ``given_ID``
+        (body.py:195-207); ``collector`` maps variable -> one-column ndarray."""
+        if not self.given_len:
+            return np.array([])
+        given = np.zeros([self.given_len, 1])
+        for variable, indices in self.given_ID.items():
+            given[indices] = collector[variable]
+        return given
+
+    def _pm_rows(self, variable):
+        asm = self._assembler()
+        return asm.plan.pm_rows[variable]
+
+    def preview(self, given, optim, variable, axes=None):
+        """``Mg @ given + Mo @ optim`` (body.py:209-219), on the device."""
+        asm = self._assembler()
+        if not hasattr(self, "_pm_dev") or self._pm_dev[0] is not asm:
+            self._pm_dev = (asm, asm.preview_matrices())
+        values = asm.preview(self._pm_dev[1], np.asarray(given, dtype=float).reshape(1, -1),
+                             np.asarray(optim, dtype=float).reshape(1, -1))[0].cpu().numpy()
+
+        def rows_of(name):
+            r0, rows = asm.plan.pm_rows[name]
+            return values[r0:r0 + rows].reshape(-1, 1)
+
+        if axes is None:
+            return rows_of(variable)
+        return np.hstack([rows_of(variable + axis) for axis in axes])
+
+    def goal_distance(self, given, optim, goal_name):
+        """Squared distance of a goal's variable to its aim (body.py:221-228)."""
+        goal = self.goals[goal_name]
+        value = 0
+        for i, axis in enumerate(goal.axes):
+            v = self.preview(given, optim, goal.variable + axis) - goal.aim[:, i]
+            value += v.T @ v
+        return float(value)
+
+    def full_goal_distance(self, given, optim):
+        return sum(self.goal_distance(given, optim, name) for name in self.goals.keys())
+
+    # ---- QP blocks (body.py:236-348) ----------------------------------------------
+    @staticmethod
+    def _host(t):
+        return t[0].cpu().numpy()
+
+    def generate_qp_constraint(self, limit, given):
+        """``(A, h)`` of one Constraint; ``limit`` must be up to date."""
+        asm = self._assembler(limits=[limit])
+        _, _, G, h = asm.assemble(np.asarray(given, dtype=float).reshape(1, -1), want_cost=False)
+        return self._host(G), self._host(h).reshape(-1, 1)
+
+    def generate_qp_cost(self, cost, given):
+        """``(Q, q)`` of one Cost."""
+        asm = self._assembler(costs={"cost": cost})
+        P, q, _, _ = asm.assemble(np.asarray(given, dtype=float).reshape(1, -1),
+                                  want_constraints=False)
+        return self._host(P), self._host(q).reshape(-1, 1)
+
+    def generate_all_qp_constraints(self, given):
+        _, _, G, h = self._assembler().assemble(
+            np.asarray(given, dtype=float).reshape(1, -1), want_cost=False)
+        return self._host(G), self._host(h).reshape(-1, 1)
+
+    def generate_all_qp_costs(self, given):
+        P, q, _, _ = self._assembler().assemble(
+            np.asarray(given, dtype=float).reshape(1, -1), want_constraints=False)
+        return self._host(P), self._host(q).reshape(-1, 1)
+
+    def generate_all_qp_matrices(self, given):
+        """``A, h, Q, q`` for ``A x < h`` and ``1/2 x' Q x + q' x`` (body.py:333-348):
+        qpsolvers' ``G, h, P, q``; there are no equality constraints."""
+        P, q, G, h = self._assembler().assemble(np.asarray(given, dtype=float).reshape(1, -1))
+        return (self._host(G), self._host(h).reshape(-1, 1),
+                self._host(P), self._host(q).reshape(-1, 1))

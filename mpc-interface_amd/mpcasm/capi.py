@@ -1,0 +1,86 @@
+"""ctypes binding of libmpcasm.so (C ABI declared in include/mpcasm.h).
+
+The library is built in-tree by ``make -C mpc-interface_amd`` (or
+``__graft_entry__.build()``) into this directory.  Loading fails loudly when it
+is missing: there is no Python or CPU fallback for the kernels.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmpcasm.so")
+
+OK = 0
+STATUS = {
+    0: "MPCASM_OK",
+    -1: "MPCASM_ERR_ARG",
+    -2: "MPCASM_ERR_PLAN",
+    -3: "MPCASM_ERR_HIP",
+    -4: "MPCASM_ERR_NODEVICE",
+    -5: "MPCASM_ERR_LIMIT",
+}
+
+# every symbol include/mpcasm.h declares: name -> (restype, argtypes)
+_c_double_p = ctypes.POINTER(ctypes.c_double)
+_void_p = ctypes.c_void_p
+SIGNATURES = {
+    "mpcasm_abi_version": (ctypes.c_int, []),
+    "mpcasm_device_count": (ctypes.c_int, []),
+    "mpcasm_last_hip": (ctypes.c_int, []),
+    "mpcasm_status_string": (ctypes.c_char_p, [ctypes.c_int]),
+    "mpcasm_fill_su": (ctypes.c_int, [_void_p, _void_p, _void_p, _void_p, ctypes.c_int,
+                                      ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                      _void_p]),
+    "mpcasm_plan_create": (ctypes.c_int, [_void_p, ctypes.c_size_t, _void_p, ctypes.c_size_t,
+                                          ctypes.POINTER(_void_p)]),
+    "mpcasm_plan_destroy": (ctypes.c_int, [_void_p]),
+    "mpcasm_plan_sizes": (ctypes.c_int, [_void_p, ctypes.POINTER(ctypes.c_int64)]),
+    "mpcasm_workspace_bytes": (ctypes.c_int, [_void_p, ctypes.c_int,
+                                              ctypes.POINTER(ctypes.c_size_t)]),
+    "mpcasm_assemble": (ctypes.c_int, [_void_p, ctypes.POINTER(_void_p),
+                                       ctypes.POINTER(ctypes.c_int64), _void_p, _void_p, _void_p,
+                                       _void_p, _void_p, _void_p, _void_p, ctypes.c_int, _void_p]),
+    "mpcasm_preview_matrices": (ctypes.c_int, [_void_p, ctypes.POINTER(_void_p),
+                                               ctypes.POINTER(ctypes.c_int64), _void_p,
+                                               ctypes.c_int, _void_p]),
+    "mpcasm_preview": (ctypes.c_int, [_void_p, _void_p, _void_p, _void_p, ctypes.c_int,
+                                      ctypes.c_int, ctypes.c_int, ctypes.c_int, _void_p]),
+}
+
+
+class MpcasmError(RuntimeError):
+    """A C-ABI call returned a negative status."""
+
+    def __init__(self, status, where, hip=0):
+        self.status = status
+        self.hip = hip
+        msg = "%s failed: %s" % (where, STATUS.get(status, str(status)))
+        if hip:
+            msg += " (hipError_t %d)" % hip
+        super().__init__(msg)
+
+
+_lib = None
+
+
+def load():
+    """The loaded library (cached); raises RuntimeError when it was not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libmpcasm.so is missing (%s): build it with `make -C mpc-interface_amd` "
+                "or __graft_entry__.build(); the assembly kernels have no fallback" % LIB_PATH
+            )
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in SIGNATURES.items():
+            fn = getattr(lib, name)       # AttributeError = symbol not exported
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = lib
+    return _lib
+
+
+def check(status, where):
+    if status != OK:
+        raise MpcasmError(status, where, load().mpcasm_last_hip())

@@ -1,0 +1,278 @@
+"""Batched QP assembly on one MI355X: torch-ROCm tensors as device buffers, the
+kernels of libmpcasm.so through the C ABI (``mpcasm.capi``).
+
+* :func:`fill_su` -- K1, batched ``tools.extend_matrices`` (tools.py:14-33)
+* :class:`Assembler` -- K2+K3+K4 for a batch of instances of one Formulation
+  structure: ``assemble(given)`` returns the qpsolvers blocks
+  ``P (B,no,no), q (B,no), G (B,nc,no), h (B,nc)`` (body.py:333-348) and
+  ``preview_matrices()`` the stacked ``[Mg | Mo]`` of every definition
+  (body.py:149-193).
+
+torch is used for memory, streams and ``data_ptr()`` only; nothing here
+computes on the host and nothing falls back to the CPU.
+"""
+import ctypes
+
+import numpy as np
+
+from . import capi
+from .plan import compile_plan
+
+
+def _torch():
+    import torch
+
+    return torch
+
+
+def require_device():
+    """The torch module, after checking that a HIP device is usable."""
+    torch = _torch()
+    if not torch.cuda.is_available():
+        raise RuntimeError(
+            "mpcasm: no HIP device is visible; the QP-assembly path runs only on the GPU "
+            "(there is no CPU fallback)")
+    capi.load()
+    return torch
+
+
+def _stream_handle(torch, stream):
+    s = torch.cuda.current_stream() if stream is None else stream
+    return ctypes.c_void_p(s.cuda_stream)
+
+
+def _as_device(torch, x, device):
+    """float64 contiguous device tensor from a tensor or array."""
+    if isinstance(x, torch.Tensor):
+        return x.to(device=device, dtype=torch.float64).contiguous()
+    return torch.as_tensor(np.ascontiguousarray(x, dtype=np.float64), device=device)
+
+
+# --------------------------------------------------------------------------
+# K1
+# --------------------------------------------------------------------------
+def fill_su(A, B, N, ltv=False, out=None, stream=None, device=None):
+    """Horizon matrices of a batch of systems (``mpcasm_fill_su``).
+
+    ``A``: ``(B, n, n)`` and ``B``: ``(B, n, m)`` (or ``(B, N, n, n)`` /
+    ``(B, N, n, m)`` when ``ltv``).  Returns device tensors ``S (B, N, n, n)``
+    and ``U (B, m, N, N, n)`` with ``U[b, j]`` = the reference's ``U[j]``.
+    """
+    torch = require_device()
+    if device is None:
+        device = A.device if isinstance(A, torch.Tensor) and A.is_cuda else torch.device(
+            "cuda", torch.cuda.current_device())
+    A = _as_device(torch, A, device)
+    Bm = _as_device(torch, B, device)
+    N = int(N)
+    if ltv:
+        if A.dim() != 4 or Bm.dim() != 4 or A.shape[1] != N or Bm.shape[1] != N:
+            raise ValueError("ltv fill needs A (B,N,n,n) and B (B,N,n,m)")
+        batch, _, n, m = Bm.shape
+    else:
+        if A.dim() != 3 or Bm.dim() != 3:
+            raise ValueError("fill needs A (B,n,n) and B (B,n,m)")
+        batch, n, m = Bm.shape
+    if A.shape[-2:] != (n, n) or A.shape[0] != batch:
+        raise ValueError("A %s does not match B %s" % (tuple(A.shape), tuple(Bm.shape)))
+    if out is None:
+        S = torch.empty((batch, N, n, n), dtype=torch.float64, device=device)
+        U = torch.empty((batch, m, N, N, n), dtype=torch.float64, device=device)
+    else:
+        S, U = out
+    with torch.cuda.device(device):
+        rc = capi.load().mpcasm_fill_su(
+            A.data_ptr(), Bm.data_ptr(), S.data_ptr(), U.data_ptr(), batch, N, n, m,
+            1 if ltv else 0, _stream_handle(torch, stream))
+    capi.check(rc, "mpcasm_fill_su")
+    return S, U
+
+
+def fill_su_numpy(A, B, N, ltv=False):
+    """:func:`fill_su` with numpy in / numpy out (single-instance drop-in path)."""
+    S, U = fill_su(A, B, N, ltv=ltv)
+    return S.cpu().numpy(), U.cpu().numpy()
+
+
+# --------------------------------------------------------------------------
+# K2 + K3 + K4
+# --------------------------------------------------------------------------
+class Assembler:
+    """Batched assembly of one Formulation structure on one device.
+
+    Per-instance numbers:
+      * ``given``  ``(B, ng)``  -- argument of :meth:`assemble`;
+      * parameters (weight / aim / cross_aim of every Cost, arrow / center /
+        extreme of every Constraint) -- start as the Formulation's current
+        values broadcast over the batch, override with :meth:`set_param`;
+      * horizon matrices -- shared by default (the Formulation's own arrays),
+        bind a ``(B, N, p, n)`` tensor with :meth:`bind_source` for per-instance
+        dynamics (e.g. the output of :func:`fill_su`).
+    """
+
+    def __init__(self, form, batch=1, device=None, costs=None, limits=None):
+        torch = require_device()
+        self._torch = torch
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None \
+            else torch.device(device)
+        self.batch = int(batch)
+        self.plan = compile_plan(form, costs=costs, limits=limits)
+        p = self.plan
+        self.ng, self.no, self.nc = p.ng, p.no, p.nc
+
+        lib = capi.load()
+        self._handle = ctypes.c_void_p()
+        itab = np.ascontiguousarray(p.itab)
+        dtab = np.ascontiguousarray(p.dtab)
+        with torch.cuda.device(self.device):
+            rc = lib.mpcasm_plan_create(
+                itab.ctypes.data, itab.size, dtab.ctypes.data if dtab.size else None, dtab.size,
+                ctypes.byref(self._handle))
+        capi.check(rc, "mpcasm_plan_create")
+
+        # sources: shared copies of the formulation's horizon matrices
+        self._src = [_as_device(torch, s.array, self.device) for s in p.sources]
+        self._src_stride = [0] * len(p.sources)
+        self._src_index = {s.key: i for i, s in enumerate(p.sources)}
+
+        base = torch.as_tensor(p.params, dtype=torch.float64, device=self.device)
+        self.params = base.unsqueeze(0).repeat(self.batch, 1).contiguous()
+
+        nbytes = ctypes.c_size_t()
+        capi.check(lib.mpcasm_workspace_bytes(self._handle, self.batch, ctypes.byref(nbytes)),
+                   "mpcasm_workspace_bytes")
+        self._work = torch.empty(max(nbytes.value // 8, 1), dtype=torch.float64,
+                                 device=self.device)
+        self._out = None
+
+    def __del__(self):
+        handle = getattr(self, "_handle", None)
+        if handle:
+            try:
+                capi.load().mpcasm_plan_destroy(handle)
+            except Exception:
+                pass
+            self._handle = None
+
+    # ---- per-instance numbers -------------------------------------------------
+    def refresh_params(self):
+        """Re-read weights / aims / arrows / centres / extremes from the Cost and
+        Constraint objects the plan was compiled from and broadcast them over the
+        batch.  Returns False when a field changed shape (recompile needed)."""
+        values = self.plan.current_params()
+        if values is None:
+            return False
+        base = self._torch.as_tensor(values, dtype=self._torch.float64, device=self.device)
+        self.params[:] = base.unsqueeze(0)
+        return True
+
+    def source_keys(self):
+        return list(self._src_index.keys())
+
+    def bind_source(self, key, tensor):
+        """Use ``tensor`` for the horizon matrix ``key = (dynamics name, k)``:
+        shape ``(N, p, n)`` (shared) or ``(B, N, p, n)`` (one per instance)."""
+        torch = self._torch
+        i = self._src_index[key]
+        shape = tuple(self.plan.sources[i].array.shape)
+        t = _as_device(torch, tensor, self.device)
+        if tuple(t.shape) == shape:
+            self._src[i], self._src_stride[i] = t, 0
+        elif tuple(t.shape) == (self.batch,) + shape:
+            self._src[i], self._src_stride[i] = t, int(np.prod(shape))
+        else:
+            raise ValueError("source %r expects %s or %s, got %s"
+                             % (key, shape, (self.batch,) + shape, tuple(t.shape)))
+
+    def param_slice(self, kind, name, field):
+        """Columns of :attr:`params` holding one field, e.g.
+        ``("cost", "track vel_x", "aim")`` or ``("limit", 3, "center")``."""
+        start, rows, cols = self.plan.param_slots[(kind, name, field)]
+        return slice(start, start + rows * cols), (rows, cols)
+
+    def set_param(self, kind, name, field, values):
+        """``values``: shape ``(rows, cols)`` (all instances) or ``(B, rows, cols)``."""
+        torch = self._torch
+        sl, (rows, cols) = self.param_slice(kind, name, field)
+        v = _as_device(torch, values, self.device).reshape(-1, rows * cols)
+        if v.shape[0] not in (1, self.batch):
+            raise ValueError("expected 1 or %d instances, got %d" % (self.batch, v.shape[0]))
+        self.params[:, sl] = v
+
+    # ---- launches ---------------------------------------------------------------
+    def _src_args(self):
+        n = len(self._src)
+        ptrs = (ctypes.c_void_p * max(n, 1))(*[t.data_ptr() for t in self._src])
+        strides = (ctypes.c_int64 * max(n, 1))(*self._src_stride)
+        return ptrs, strides
+
+    def assemble(self, given=None, out=None, stream=None, want_cost=True, want_constraints=True):
+        """Assemble the whole batch; returns ``(P, q, G, h)`` device tensors
+        (``None`` for a skipped half).  ``given``: ``(B, ng)`` or ``(ng,)``."""
+        torch = self._torch
+        B, ng, no, nc = self.batch, self.ng, self.no, self.nc
+        if ng:
+            g = _as_device(torch, given, self.device).reshape(-1, ng)
+            if g.shape[0] == 1 and B > 1:
+                g = g.repeat(B, 1)
+            if g.shape[0] != B:
+                raise ValueError("given must have %d rows, got %d" % (B, g.shape[0]))
+        else:
+            g = None
+        if out is None:
+            if self._out is None:
+                f = dict(dtype=torch.float64, device=self.device)
+                self._out = (torch.empty((B, no, no), **f), torch.empty((B, no), **f),
+                             torch.empty((B, nc, no), **f), torch.empty((B, nc), **f))
+            out = self._out
+        P, q, G, h = out
+        if not want_cost:
+            P = q = None
+        if not want_constraints or nc == 0:
+            G = h = None
+        ptrs, strides = self._src_args()
+        ptr = lambda t: t.data_ptr() if t is not None else None
+        with torch.cuda.device(self.device):
+            rc = capi.load().mpcasm_assemble(
+                self._handle, ptrs, strides, self.params.data_ptr(), ptr(g), ptr(P), ptr(q),
+                ptr(G), ptr(h), self._work.data_ptr(), B, _stream_handle(torch, stream))
+        capi.check(rc, "mpcasm_assemble")
+        return P, q, G, h
+
+    def preview_matrices(self, stream=None):
+        """``(B, preview_rows, ng+no)`` device tensor; rows of definition ``v`` are
+        ``plan.pm_rows[v]``, columns ``[:ng]`` = Mg, ``[ng:]`` = Mo."""
+        torch = self._torch
+        W = self.ng + self.no
+        PM = torch.empty((self.batch, self.plan.pmrows, W), dtype=torch.float64,
+                         device=self.device)
+        ptrs, strides = self._src_args()
+        with torch.cuda.device(self.device):
+            rc = capi.load().mpcasm_preview_matrices(
+                self._handle, ptrs, strides, PM.data_ptr(), self.batch,
+                _stream_handle(torch, stream))
+        capi.check(rc, "mpcasm_preview_matrices")
+        return PM
+
+    def preview(self, PM, given, optim, stream=None):
+        """``Mg @ given + Mo @ optim`` for every definition row (body.py:209-219):
+        ``(B, preview_rows)``."""
+        torch = self._torch
+        g = _as_device(torch, given, self.device).reshape(self.batch, self.ng) if self.ng else None
+        x = _as_device(torch, optim, self.device).reshape(self.batch, self.no) if self.no else None
+        out = torch.empty((self.batch, self.plan.pmrows), dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = capi.load().mpcasm_preview(
+                PM.data_ptr(), g.data_ptr() if g is not None else None,
+                x.data_ptr() if x is not None else None, out.data_ptr(), self.batch,
+                self.plan.pmrows, self.ng, self.no, _stream_handle(torch, stream))
+        capi.check(rc, "mpcasm_preview")
+        return out
+
+
+def shard_bounds(batch, world_size, rank):
+    """Contiguous slice ``[lo, hi)`` of a batch owned by ``rank`` (instances are
+    independent: no collective on the data path)."""
+    base, extra = divmod(int(batch), int(world_size))
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)

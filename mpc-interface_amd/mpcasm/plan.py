@@ -1,0 +1,429 @@
+"""Plan compiler: Formulation structure -> flat device tables.
+
+The reference re-interprets its dict-of-dicts problem description on every tick
+(body.py:149-193 for the preview matrices, :236-329 for the QP blocks).  Here
+the *structure* -- index maps, the flattened definition graph, which rows every
+cost / constraint consumes -- is compiled once into two flat arrays (``itab``
+int32, ``dtab`` float64, layout in csrc/plan_tables.h) and the *numbers* that
+differ between instances of a batch (given vector, weights, aims, arrows,
+centres, extremes, horizon matrices) stay outside, as device buffers.
+
+This module is host logic only (numpy / scipy.sparse); it never evaluates a
+preview matrix or a QP block -- that is the kernels' job.
+"""
+import numpy as np
+import scipy.sparse as sp
+
+PLAN_MAGIC = 0x4D504341
+PLAN_VERSION = 3
+
+# header words (csrc/plan_tables.h, enum HeaderWord)
+_H = {name: i for i, name in enumerate([
+    "MAGIC", "VERSION", "NG", "NO", "NC", "NPARAMS", "NSRC", "NBASE", "NSEG", "RTOT", "NENT",
+    "NGTERM", "NLIMIT", "NLAX", "PMROWS", "PM_NENT", "LDV",
+    "OFF_SEG", "OFF_COLSEG", "OFF_ROWPTR", "OFF_ENTBASE", "OFF_ENTK", "OFF_GTERM", "OFF_LIMIT",
+    "OFF_LAX", "OFF_ROWLIMIT", "OFF_PM_ROWPTR", "OFF_PM_ENTBASE", "OFF_PM_ENTK",
+    "DOFF_ENTCOEF", "DOFF_PM_ENTCOEF", "NITAB", "NDTAB",
+])}
+H_WORDS = 40
+SEG_WORDS, GT_WORDS, LM_WORDS, LX_WORDS = 8, 8, 12, 2
+SEG_GATHER, SEG_IDENTITY = 0, 1
+GT_FLAG_P, GT_FLAG_HALF = 1, 2
+MAX_SOURCES = 32
+
+
+class Source:
+    """One horizon matrix read by the definitions: ``ExtendedSystem.matrices[k]``
+    (key ``(dynamics name, k)``) or an anonymous constant coefficient block."""
+
+    def __init__(self, key, array):
+        self.key = key
+        self.array = np.ascontiguousarray(array, dtype=np.float64)
+
+
+class Plan:
+    """Compiled structure of one Formulation (see module docstring)."""
+
+    def __init__(self):
+        self.itab = None
+        self.dtab = None
+        self.ng = self.no = self.nc = 0
+        self.sources = []          # list[Source]
+        self.params = None         # base parameter vector (current numbers of the form)
+        self.param_slots = {}      # (kind, name, field) -> (start, rows, cols)
+        self.pm_rows = {}          # definition -> (row0, rows) in the preview program
+        self.pmrows = 0
+        self.rtot = 0
+        self.ldv = 0
+        self.limit_rows = []       # (out_row0, nrows) of every limit, stacking order
+        self.optim_ID = {}
+        self.given_ID = {}
+        self.param_getters = []    # (start, size, callable) -> current numbers of the objects
+        self.fingerprint = None    # structure of the costs / limits this plan was built from
+
+    def current_params(self):
+        """Parameter vector re-read from the Cost / Constraint objects, or ``None``
+        when a field no longer has the shape it was compiled with."""
+        out = np.empty_like(self.params)
+        for start, size, getter in self.param_getters:
+            values = np.asarray(getter(), dtype=np.float64).ravel()
+            if values.size != size:
+                return None
+            out[start:start + size] = values
+        return out
+
+    def signature(self):
+        """Bytes identifying the structure (cache key)."""
+        return self.itab.tobytes() + self.dtab.tobytes()
+
+
+# --------------------------------------------------------------------------
+def _columns(form):
+    """Column offset of every domain variable in [given | optim] (body.py:164-169)."""
+    ng = form.given_len
+    cols = {}
+    for var in form.given_variables:
+        cols[var] = (form.given_ID[var].start, len(form.given_ID[var]))
+    for var in form.optim_variables:
+        cols[var] = (ng + form.optim_ID[var].start, len(form.optim_ID[var]))
+    return cols
+
+
+class _Builder:
+    def __init__(self, form):
+        self.form = form
+        self.ng, self.no = form.given_len, form.optim_len
+        self.W = self.ng + self.no
+        self.cols = _columns(form)
+        self.sources = []
+        self._source_ids = {}
+        self.segments = []            # SEG_WORDS ints each
+        self.base_ids = {}            # base variable -> id
+        self.base_rows = []           # rows of every base variable
+        self.base_row0 = []           # offset in the global base-row space
+        self.colseg = []              # per base: array [W] of segment ids
+        self.var_matrix = {}          # definition -> sparse (rows x total_base_rows)
+        self.rowset_rows = []         # list of sparse row blocks
+        self.rowset_keys = {}
+        self.rtot = 0
+        self.params = []
+        self.param_slots = {}
+        self.param_getters = []
+
+    # ---- sources ---------------------------------------------------------
+    def source_id(self, key, array):
+        if key not in self._source_ids:
+            if len(self.sources) >= MAX_SOURCES:
+                raise ValueError("more than %d horizon matrices in one formulation" % MAX_SOURCES)
+            self._source_ids[key] = len(self.sources)
+            self.sources.append(Source(key, array))
+        return self._source_ids[key]
+
+    # ---- base variables (body.py:158-177) ----------------------------------
+    def add_base(self, var):
+        form = self.form
+        dyn_name = form.of[var]
+        dyn = form.dynamics[dyn_name]
+        rows = int(dyn.all_variables[var])
+        bid = len(self.base_rows)
+        self.base_ids[var] = bid
+        self.base_row0.append(sum(self.base_rows))
+        self.base_rows.append(rows)
+        colseg = -np.ones(self.W, dtype=np.int32)
+
+        state_ID = getattr(dyn, "state_ID", {})
+        for pos, (dep, matrix) in enumerate(form.definitions[var].items()):
+            if dep not in self.cols:
+                raise ValueError(
+                    "The variable {} in the definition of {} seems to not be given nor "
+                    "optimal.".format(dep, var))
+            dst0, length = self.cols[dep]
+            matrix = np.asarray(matrix, dtype=np.float64)
+            seg = None
+            if var in state_ID and dep in dyn.domain_ID:
+                dID, sID = dyn.domain_ID[dep], state_ID[var]
+                src = dyn.matrices[dID]
+                if (src.ndim == 3 and sID < src.shape[2]
+                        and matrix.shape == src.shape[:2]
+                        and np.array_equal(matrix, src[..., sID])):
+                    sid = self.source_id((dyn_name, dID), src)
+                    n = src.shape[2]
+                    seg = [sid, sID, src.shape[1] * n, n, dst0, length, SEG_GATHER, 0]
+            if seg is None:
+                block = np.broadcast_to(matrix, (rows, length)) if matrix.ndim < 2 else matrix
+                if block.shape != (rows, length):
+                    raise ValueError(
+                        "coefficient of {} in the definition of {} has shape {} instead of "
+                        "{}".format(dep, var, block.shape, (rows, length)))
+                if rows == length and np.array_equal(block, np.eye(rows)):
+                    seg = [0, 0, 0, 0, dst0, length, SEG_IDENTITY, 0]
+                else:
+                    sid = self.source_id(("const", var, pos), np.array(block))
+                    seg = [sid, 0, length, 1, dst0, length, SEG_GATHER, 0]
+            colseg[dst0:dst0 + length] = len(self.segments)
+            self.segments.append(seg)
+        self.colseg.append(colseg)
+
+    # ---- flattened definition graph (body.py:179-193) ----------------------
+    def flatten_definitions(self):
+        form = self.form
+        for var in form.definitions.keys():
+            if var in form.of:
+                self.add_base(var)
+        total = sum(self.base_rows)
+        for var, combo in form.definitions.items():
+            if var in form.of:
+                bid = self.base_ids[var]
+                rows, r0 = self.base_rows[bid], self.base_row0[bid]
+                M = sp.csr_matrix(
+                    (np.ones(rows), (np.arange(rows), r0 + np.arange(rows))), shape=(rows, total))
+            else:
+                M = None
+                for dep, coef in combo.items():
+                    D = self.var_matrix[dep]
+                    c = np.array(coef, dtype=np.float64)
+                    if c.ndim == 0:
+                        term = D * float(c)
+                    elif c.ndim == 1:
+                        term = sp.csr_matrix(c[None, :]) @ D
+                    else:
+                        term = sp.csr_matrix(c) @ D
+                    M = term if M is None else M + term
+                M = sp.csr_matrix(M)
+            M.sum_duplicates()
+            M.sort_indices()
+            self.var_matrix[var] = M
+        self.total_base_rows = total
+
+    # ---- row-sets -----------------------------------------------------------
+    def rowset(self, var, schedule, L):
+        """Rows of ``L @ M_var[schedule]`` (or ``M_var[schedule]``); returns
+        ``(offset, nrows)`` in the workspace.  ``schedule`` falsy = all rows."""
+        M = self.var_matrix[var]
+        if schedule:
+            pick = list(schedule)
+            key_s = (schedule.start, schedule.stop, schedule.step)
+        else:
+            pick, key_s = None, None
+        if L is not None:
+            Lm = np.atleast_2d(np.asarray(L, dtype=np.float64))
+            key_l = (Lm.shape, Lm.tobytes())
+        else:
+            Lm, key_l = None, None
+        key = (var, key_s, key_l)
+        if key in self.rowset_keys:
+            return self.rowset_keys[key]
+        block = M[pick] if pick is not None else M
+        if Lm is not None:
+            if Lm.shape[1] != block.shape[0]:
+                raise ValueError(
+                    "L with {} columns applied to {} rows of {}".format(
+                        Lm.shape[1], block.shape[0], var))
+            block = sp.csr_matrix(sp.csr_matrix(Lm) @ block)
+        block = sp.csr_matrix(block)
+        block.sum_duplicates()
+        block.sort_indices()
+        out = (self.rtot, block.shape[0])
+        self.rowset_rows.append(block)
+        self.rtot += block.shape[0]
+        self.rowset_keys[key] = out
+        return out
+
+    # ---- parameters -----------------------------------------------------------
+    def param(self, key, getter):
+        values = np.atleast_2d(np.asarray(getter(), dtype=np.float64))
+        start = len(self.params)
+        self.params.extend(values.ravel().tolist())
+        self.param_slots[key] = (start, values.shape[0], values.shape[1])
+        self.param_getters.append((start, values.size, getter))
+        return start
+
+
+def _ids(seq):
+    return tuple(id(x) for x in seq) if seq else ()
+
+
+def _sched(schedule):
+    return (schedule.start, schedule.stop, schedule.step) if schedule else None
+
+
+def structure_fingerprint(costs, limits):
+    """Cheap key of everything in the costs / limits that is *structure* for a
+    plan (objects, variables, schedules, L identities, field shapes)."""
+    key = []
+    for name, c in costs.items():
+        key.append(("c", name, id(c), c.variable, c.cross, tuple(c.axes), _sched(c.schedule),
+                    _ids(c.L), _ids(c.cross_L), np.shape(c.aim), np.shape(c.cross_aim)))
+    for l in limits:
+        key.append(("l", id(l), l.variable, tuple(l.axes), _sched(l.schedule), _ids(l.L),
+                    np.shape(l.arrow), np.shape(l.center), np.shape(l.extreme)))
+    return tuple(key)
+
+
+def _csr_tables(blocks, base_row0, base_rows, total):
+    """Stack sparse row blocks and split the global base-row index into
+    (base id, row within base)."""
+    if blocks:
+        M = sp.vstack(blocks, format="csr")
+    else:
+        M = sp.csr_matrix((0, max(total, 1)))
+    starts = np.asarray(base_row0, dtype=np.int64)
+    idx = M.indices.astype(np.int64)
+    base = np.searchsorted(starts, idx, side="right") - 1 if idx.size else idx
+    k = idx - starts[base] if idx.size else idx
+    return (M.indptr.astype(np.int32), base.astype(np.int32), k.astype(np.int32),
+            M.data.astype(np.float64), M.shape[0])
+
+
+def compile_plan(form, costs=None, limits=None):
+    """Compile ``form`` (an up-to-date Formulation: sizes and IDs current).
+
+    ``costs``: dict name -> Cost to include (default ``form.goals``);
+    ``limits``: list of Constraint in stacking order (default: every limit of
+    ``form.constraints`` then of ``form.constraint_boxes``, body.py:306-315).
+    """
+    b = _Builder(form)
+    b.flatten_definitions()
+    no = b.no
+
+    if costs is None:
+        costs = form.goals
+    if limits is None:
+        limits = [l for group in form.constraints.values() for l in group]
+        limits += [l for box in form.constraint_boxes.values() for l in box.constraints]
+
+    # ---- costs -> gterms (body.py:266-302) -------------------------------------
+    gterms = []
+    for name, cost in costs.items():
+        p_w = b.param(("cost", name, "weight"), lambda c=cost: [[float(c.weight)]])
+        aim = np.asarray(cost.aim, dtype=np.float64)
+        caim = np.asarray(cost.cross_aim, dtype=np.float64)
+        if aim.ndim != 2 or aim.shape[0] != 1 or np.atleast_2d(caim).shape[0] != 1:
+            # the reference fails to broadcast (no,1) += (no,r) for r > 1 (body.py:293-300)
+            raise ValueError(
+                "cost '{}': aim and cross_aim must hold one value per axis".format(name))
+        p_aim = b.param(("cost", name, "aim"),
+                        lambda c=cost: np.asarray(c.aim, dtype=np.float64).reshape(1, -1))
+        crossed = bool(getattr(cost, "crossed", cost.cross != cost.variable))
+        p_caim = (b.param(("cost", name, "cross_aim"),
+                          lambda c=cost: np.asarray(c.cross_aim, dtype=np.float64).reshape(1, -1))
+                  if crossed else p_aim)
+        for i, axis in enumerate(cost.axes):
+            va, nv = b.rowset(cost.variable + axis, cost.schedule, cost.L[i] if cost.L else None)
+            ca, ncr = b.rowset(cost.cross + axis, cost.schedule,
+                               cost.cross_L[i] if cost.cross_L else None)
+            if nv != ncr:
+                raise ValueError(
+                    "cost '{}': {} rows of '{}' against {} rows of '{}'".format(
+                        name, nv, cost.variable + axis, ncr, cost.cross + axis))
+            if not crossed and va == ca:
+                #  q += w V^T (Vg g - aim)
+                gterms.append([va, va, nv, p_w, va, p_aim + i, GT_FLAG_P, 0])
+            else:
+                #  P += w V^T C ;  q += w/2 V^T (Cg g - cross_aim) + w/2 C^T (Vg g - aim)
+                gterms.append([va, ca, nv, p_w, ca, p_caim + i, GT_FLAG_P | GT_FLAG_HALF, 0])
+                gterms.append([ca, -1, nv, p_w, va, p_aim + i, GT_FLAG_HALF, 0])
+
+    # ---- limits (body.py:236-264, restrictions.py:147-199) -----------------------
+    limit_recs, lax_recs, rowlimit, limit_rows = [], [], [], []
+    out0 = 0
+    for idx, limit in enumerate(limits):
+        naxes = len(limit.axes)
+        first = limit.variable + limit.axes[0]
+        var_rows = b.var_matrix[first].shape[0]
+        nlines = limit.nlines
+        nrows = int(var_rows if nlines is None else nlines)
+        lax0 = len(lax_recs)
+        for i, axis in enumerate(limit.axes):
+            off, rs = b.rowset(limit.variable + axis, limit.schedule,
+                               limit.L[i] if limit.L else None)
+            if rs not in (1, nrows):
+                raise ValueError(
+                    "constraint on '{}': {} rows cannot fill {} lines".format(
+                        limit.variable + axis, rs, nrows))
+            lax_recs.append([off, rs])
+        arrow = np.asarray(limit.arrow, dtype=np.float64).reshape(-1, naxes)
+        center = np.asarray(limit.center, dtype=np.float64).reshape(-1, naxes)
+        extreme = np.asarray(limit.extreme, dtype=np.float64).reshape(-1, 1)
+        for label, field in (("arrow", arrow), ("center", center), ("extreme", extreme)):
+            if field.shape[0] not in (1, nrows):
+                raise ValueError(
+                    "constraint on '{}': '{}' has {} rows for {} lines".format(
+                        limit.variable, label, field.shape[0], nrows))
+        p_a = b.param(("limit", idx, "arrow"), lambda l=limit, k=naxes: np.asarray(
+            l.arrow, dtype=np.float64).reshape(-1, k))
+        p_c = b.param(("limit", idx, "center"), lambda l=limit, k=naxes: np.asarray(
+            l.center, dtype=np.float64).reshape(-1, k))
+        p_e = b.param(("limit", idx, "extreme"), lambda l=limit: np.asarray(
+            l.extreme, dtype=np.float64).reshape(-1, 1))
+        limit_recs.append([out0, nrows, naxes, lax0, p_a, arrow.shape[0], p_c, center.shape[0],
+                           p_e, extreme.shape[0], 0, 0])
+        rowlimit.extend([idx] * nrows)
+        limit_rows.append((out0, nrows))
+        out0 += nrows
+    nc = out0
+
+    # ---- tables ---------------------------------------------------------------------
+    rowptr, entbase, entk, entcoef, rtot = _csr_tables(
+        b.rowset_rows, b.base_row0, b.base_rows, b.total_base_rows)
+    assert rtot == b.rtot
+    pm_blocks, pm_rows, r0 = [], {}, 0
+    for var in form.definitions.keys():
+        M = b.var_matrix[var]
+        pm_blocks.append(M)
+        pm_rows[var] = (r0, M.shape[0])
+        r0 += M.shape[0]
+    pm_rowptr, pm_entbase, pm_entk, pm_entcoef, pmrows = _csr_tables(
+        pm_blocks, b.base_row0, b.base_rows, b.total_base_rows)
+
+    sections = [
+        ("OFF_SEG", np.asarray(b.segments, dtype=np.int32).reshape(-1)),
+        ("OFF_COLSEG", (np.concatenate(b.colseg) if b.colseg else np.zeros(0)).astype(np.int32)),
+        ("OFF_ROWPTR", rowptr),
+        ("OFF_ENTBASE", entbase),
+        ("OFF_ENTK", entk),
+        ("OFF_GTERM", np.asarray(gterms, dtype=np.int32).reshape(-1)),
+        ("OFF_LIMIT", np.asarray(limit_recs, dtype=np.int32).reshape(-1)),
+        ("OFF_LAX", np.asarray(lax_recs, dtype=np.int32).reshape(-1)),
+        ("OFF_ROWLIMIT", np.asarray(rowlimit, dtype=np.int32)),
+        ("OFF_PM_ROWPTR", pm_rowptr),
+        ("OFF_PM_ENTBASE", pm_entbase),
+        ("OFF_PM_ENTK", pm_entk),
+    ]
+    header = np.zeros(H_WORDS, dtype=np.int32)
+    parts, off = [header], H_WORDS
+    for name, arr in sections:
+        header[_H[name]] = off
+        parts.append(arr)
+        off += arr.size
+    dtab = np.concatenate([entcoef, pm_entcoef]).astype(np.float64)
+
+    ldv = no + 1 + ((no + 1) & 1)
+    params = np.asarray(b.params, dtype=np.float64)
+    header[_H["MAGIC"]], header[_H["VERSION"]] = PLAN_MAGIC, PLAN_VERSION
+    header[_H["NG"]], header[_H["NO"]], header[_H["NC"]] = b.ng, no, nc
+    header[_H["NPARAMS"]] = params.size
+    header[_H["NSRC"]], header[_H["NBASE"]] = len(b.sources), len(b.base_rows)
+    header[_H["NSEG"]], header[_H["RTOT"]], header[_H["NENT"]] = len(b.segments), rtot, entcoef.size
+    header[_H["NGTERM"]], header[_H["NLIMIT"]] = len(gterms), len(limit_recs)
+    header[_H["NLAX"]], header[_H["PMROWS"]] = len(lax_recs), pmrows
+    header[_H["PM_NENT"]], header[_H["LDV"]] = pm_entcoef.size, ldv
+    header[_H["DOFF_ENTCOEF"]], header[_H["DOFF_PM_ENTCOEF"]] = 0, entcoef.size
+    header[_H["NITAB"]], header[_H["NDTAB"]] = off, dtab.size
+
+    plan = Plan()
+    plan.itab = np.concatenate(parts).astype(np.int32)
+    plan.dtab = dtab
+    plan.ng, plan.no, plan.nc = b.ng, no, nc
+    plan.sources = b.sources
+    plan.params = params
+    plan.param_slots = b.param_slots
+    plan.param_getters = b.param_getters
+    plan.fingerprint = structure_fingerprint(costs, limits)
+    plan.pm_rows, plan.pmrows = pm_rows, pmrows
+    plan.rtot, plan.ldv = rtot, ldv
+    plan.limit_rows = limit_rows
+    plan.optim_ID = {v: form.optim_ID[v] for v in form.optim_variables}
+    plan.given_ID = {v: form.given_ID[v] for v in form.given_variables}
+    plan.n_gterms = len(gterms)
+    return plan

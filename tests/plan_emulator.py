@@ -1,0 +1,96 @@
+"""numpy interpreter of the plan tables  --  TEST INFRASTRUCTURE ONLY.
+
+Executes ``itab`` / ``dtab`` exactly as csrc/plan_tables.h documents them, one
+instance at a time, so that the host plan compiler (``mpcasm.plan``) can be
+checked against the oracle on a machine without a GPU.  It is not a fallback:
+nothing under ``mpc-interface_amd/`` imports it.
+"""
+import numpy as np
+
+from mpcasm import plan as P
+
+H = P._H
+
+
+def _section(itab, name, count):
+    off = itab[H[name]]
+    return itab[off:off + count]
+
+
+def _row(plan, srcs, rowptr, entbase, entk, coef, r, W):
+    it = plan.itab
+    W_ = W
+    segs = _section(it, "OFF_SEG", it[H["NSEG"]] * P.SEG_WORDS).reshape(-1, P.SEG_WORDS)
+    colseg = _section(it, "OFF_COLSEG", it[H["NBASE"]] * W_).reshape(-1, W_) if W_ else None
+    out = np.zeros(W_)
+    for e in range(rowptr[r], rowptr[r + 1]):
+        u, k, cf = entbase[e], entk[e], coef[e]
+        for c in range(W_):
+            sg = colseg[u, c]
+            if sg < 0:
+                continue
+            s = segs[sg]
+            j = c - s[4]
+            if s[6] == P.SEG_IDENTITY:
+                val = 1.0 if j == k else 0.0
+            else:
+                val = srcs[s[0]].ravel()[s[1] + k * s[2] + j * s[3]]
+            out[c] += cf * val
+    return out
+
+
+def run(plan, given, params=None, sources=None):
+    """Returns dict with V, P, q, G, h, PM for one instance."""
+    it, dt = plan.itab, plan.dtab
+    ng, no, nc = plan.ng, plan.no, plan.nc
+    W = ng + no
+    srcs = [s.array for s in plan.sources] if sources is None else sources
+    params = plan.params if params is None else params
+    g = np.asarray(given, dtype=float).ravel()
+
+    rtot, nent = it[H["RTOT"]], it[H["NENT"]]
+    rowptr = _section(it, "OFF_ROWPTR", rtot + 1)
+    entbase, entk = _section(it, "OFF_ENTBASE", nent), _section(it, "OFF_ENTK", nent)
+    coef = dt[it[H["DOFF_ENTCOEF"]]:it[H["DOFF_ENTCOEF"]] + nent]
+    V = np.zeros((rtot, no + 1))
+    for r in range(rtot):
+        row = _row(plan, srcs, rowptr, entbase, entk, coef, r, W)
+        V[r, :no] = row[ng:]
+        V[r, no] = row[:ng] @ g if ng else 0.0
+
+    Pm, q = np.zeros((no, no)), np.zeros(no)
+    gt = _section(it, "OFF_GTERM", it[H["NGTERM"]] * P.GT_WORDS).reshape(-1, P.GT_WORDS)
+    for a, b, n, pw, d, pa, flags, _ in gt:
+        w, aim = params[pw], params[pa]
+        scale = 0.5 if flags & P.GT_FLAG_HALF else 1.0
+        A = w * V[a:a + n, :no]
+        if flags & P.GT_FLAG_P:
+            Pm += A.T @ V[b:b + n, :no]
+        q += A.T @ (scale * (V[d:d + n, no] - aim))
+
+    G, h = np.zeros((nc, no)), np.zeros(nc)
+    lims = _section(it, "OFF_LIMIT", it[H["NLIMIT"]] * P.LM_WORDS).reshape(-1, P.LM_WORDS)
+    lax = _section(it, "OFF_LAX", it[H["NLAX"]] * P.LX_WORDS).reshape(-1, P.LX_WORDS)
+    rowlimit = _section(it, "OFF_ROWLIMIT", nc)
+    for R in range(nc):
+        lm = lims[rowlimit[R]]
+        r, na = R - lm[0], lm[2]
+        pick = lambda p0, rows, width: params[p0 + (0 if rows == 1 else r) * width:][:width]
+        arrow, center = pick(lm[4], lm[5], na), pick(lm[6], lm[7], na)
+        extreme = params[lm[8] + (0 if lm[9] == 1 else r)]
+        ac = ad = 0.0
+        for ax in range(na):
+            off, rows = lax[lm[3] + ax]
+            src_row = V[off + (0 if rows == 1 else r)]
+            G[R] += arrow[ax] * src_row[:no]
+            ac += arrow[ax] * center[ax]
+            ad += arrow[ax] * src_row[no]
+        h[R] = (extreme + ac) - ad
+
+    pmrows, pm_nent = it[H["PMROWS"]], it[H["PM_NENT"]]
+    prp = _section(it, "OFF_PM_ROWPTR", pmrows + 1)
+    peb, pek = _section(it, "OFF_PM_ENTBASE", pm_nent), _section(it, "OFF_PM_ENTK", pm_nent)
+    pcoef = dt[it[H["DOFF_PM_ENTCOEF"]]:it[H["DOFF_PM_ENTCOEF"]] + pm_nent]
+    PM = np.stack([_row(plan, srcs, prp, peb, pek, pcoef, r, W) for r in range(pmrows)]) \
+        if pmrows else np.zeros((0, W))
+    return {"V": V, "P": Pm, "q": q, "G": G, "h": h, "PM": PM}

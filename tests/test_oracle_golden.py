@@ -1,0 +1,145 @@
+"""CPU: the oracle and this repository's host classes against the golden vectors
+captured from the real reference (tests/golden/make_golden.py).
+
+Every problem is rebuilt with the repository's own ``mpc_interface`` API (host
+logic; ``extend_matrices`` served by the oracle through the ``cpu_api`` fixture),
+then the oracle runs on those objects and must reproduce the reference's numbers:
+index maps bit-exact, floating point within 1e-10 relative.
+"""
+import json
+
+import numpy as np
+import pytest
+
+from helpers import RTOL, assert_close, golden, ranges_from_json
+from mpcasm import problems
+from oracle import qp_oracle as orc
+
+
+# --------------------------------------------------------------------------- G1
+def test_extend_matrices_reference_fixture():
+    """The reference's own known-answer test (test_dynamics.py:139-152): J->CCC,
+    tau=0.1, omega=3.3445, N=36 against python/tests/LIP_matrices."""
+    g = golden("g1_extend")
+    S, U = orc.extend_matrices(36, g["lip36/A"], g["lip36/B"])
+    assert S.shape == (36, 3, 3) and len(U) == 1 and U[0].shape == (36, 36, 3)
+    assert_close(S, g["lip36/S"], what="S")
+    assert_close(U[0], g["lip36/U0"], what="U")
+
+
+@pytest.mark.parametrize("n,m,N", [(3, 1, 16), (3, 1, 32), (3, 1, 100), (8, 6, 20),
+                                   (12, 6, 64), (1, 1, 5), (2, 3, 1)])
+def test_extend_matrices_random_lti(n, m, N):
+    g = golden("g1_extend")
+    key = "lti_n%d_m%d_N%d/" % (n, m, N)
+    A, B = g[key + "A"], g[key + "B"]
+    S, U = orc.extend_matrices(N, A, B)
+    # shape contract of the reference's test_tools.py:19-33
+    assert S.shape == (N, n, n) and isinstance(U, list) and len(U) == m
+    assert U[0].shape == (N, N, n)
+    assert_close(S, g[key + "S"], what="S")
+    if key + "U" in g:
+        assert_close(np.stack(U), g[key + "U"], what="U")
+    else:
+        rows = g[key + "U_rows"]
+        assert_close(U[0][rows], g[key + "U_first"], what="U first")
+        assert_close(U[m - 1][rows], g[key + "U_last"], what="U last")
+        assert_close(np.array([u.sum() for u in U]), g[key + "U_sums"], what="U sums")
+    # LTV generalisation degenerates to the LTI result
+    Sl, Ul = orc.extend_matrices_ltv(N, np.stack([A] * N), np.stack([B] * N))
+    assert_close(Sl, S, 1e-13, "ltv S")
+    assert_close(np.stack(Ul), np.stack(U), 1e-13, "ltv U")
+
+
+def test_extend_matrices_structure():
+    """Layout identities of SURVEY.md section 3.3: block-lower-triangular Toeplitz."""
+    rng = np.random.default_rng(5)
+    A, B = rng.standard_normal((4, 4)) / 2, rng.standard_normal((4, 2))
+    S, U = orc.extend_matrices(7, A, B)
+    for k in range(7):
+        assert_close(S[k], np.linalg.matrix_power(A, k + 1).T, 1e-12)
+        for l in range(7):
+            for j in range(2):
+                want = (np.linalg.matrix_power(A, k - l) @ B)[:, j] if l <= k else np.zeros(4)
+                assert_close(U[j][k, l], want, 1e-12)
+
+
+# ---------------------------------------------------------------------- G2 .. G6
+def check_snapshot(form, g, prefix):
+    """Index maps bit-exact; PM, per-part blocks and stacked blocks within RTOL."""
+    maps = orc.qp_index_maps(form.domain, form.optim_variables)
+    assert {k: form.optim_ID[k] for k in form.optim_variables} == \
+        ranges_from_json(g[prefix + "optim_ID"])
+    assert {k: form.given_ID[k] for k in form.given_variables} == \
+        ranges_from_json(g[prefix + "given_ID"])
+    assert list(maps["optim_ID"].items()) == list(ranges_from_json(g[prefix + "optim_ID"]).items())
+    assert list(maps["given_ID"].items()) == list(ranges_from_json(g[prefix + "given_ID"]).items())
+    assert list(form.definitions.keys()) == json.loads(str(g[prefix + "definitions"]))
+
+    given = g[prefix + "given"]
+    PM = orc.preview_matrices(form, maps)
+    for var in form.definitions:
+        if prefix + "PM/" + var + "/Mg" in g:
+            assert_close(PM[var][0], g[prefix + "PM/" + var + "/Mg"], what=var + " Mg")
+            assert_close(PM[var][1], g[prefix + "PM/" + var + "/Mo"], what=var + " Mo")
+    for k, limit in enumerate(orc.all_limits(form)):
+        if prefix + "limit%d/A" % k in g:
+            A, h = orc.qp_constraint(PM, limit, given)
+            assert_close(A, g[prefix + "limit%d/A" % k], what="limit A")
+            assert_close(h, g[prefix + "limit%d/h" % k], what="limit h")
+    for name, cost in form.goals.items():
+        if prefix + "cost/" + name + "/Q" in g:
+            Q, q = orc.qp_cost(PM, cost, given)
+            assert_close(Q, g[prefix + "cost/" + name + "/Q"], what="cost Q")
+            assert_close(q, g[prefix + "cost/" + name + "/q"], what="cost q")
+    A, h, Q, q = orc.assemble(form, given, PM, maps)
+    for mine, nm in ((A, "A"), (h, "h"), (Q, "Q"), (q, "q")):
+        assert_close(mine, g[prefix + nm], RTOL, prefix + nm)
+    return A, h, Q, q
+
+
+def test_body_case(cpu_api):
+    g = golden("g2_body")
+    form = problems.body_case(cpu_api)
+    A, h, Q, q = check_snapshot(form, g, "arange/")
+    # shapes the reference's test_body.py:140-162 asserts
+    assert A.shape == (54, form.optim_len) and h.shape == (54, 1)
+    assert Q.shape == (form.optim_len,) * 2 and q.shape == (form.optim_len, 1)
+    check_snapshot(form, g, "random/")
+    # crossed cost gives a non-symmetric Hessian (SURVEY.md section 8a quirk i)
+    assert np.abs(Q - Q.T).max() > 1e-6
+
+
+@pytest.mark.parametrize("step_samples", [8, 12])
+def test_biped_ticks(cpu_api, step_samples):
+    """Walking ticks: the QP width alternates (34/36 at N=16, 50/52 at N=24)."""
+    conf = problems.BipedConfig(step_samples=step_samples)
+    g = golden("g3_biped_N%d" % conf.horizon_lenght)
+    form = problems.biped(cpu_api, conf)
+    clock = problems.StepClock(conf.step_samples, form.domain["Ds_x"])
+    keep = set(int(t) for t in g["ticks"])
+    shapes = []
+    for tick in range(18):
+        form.update(step_times=clock.step_times, step_count=clock.step_count)
+        if tick in keep:
+            p = "tick%02d/" % tick
+            assert np.array_equal(clock.step_times, g[p + "step_times"])
+            assert clock.step_count == int(g[p + "step_count"])
+            box = form.constraint_boxes["stepping area"]
+            assert_close(np.stack([l.center for l in box.constraints]),
+                         g[p + "stepping_centers"], 1e-15, "centers")
+            check_snapshot(form, g, p)
+        nc = orc.assemble(form, np.zeros([form.given_len, 1]))[0].shape[0]
+        shapes.append([tick, clock.step_count, form.optim_len, nc])
+        clock.tick()
+    assert np.array_equal(np.array(shapes), g["shapes"])
+
+
+def test_lipm3d_and_lti_configs(cpu_api):
+    g = golden("g6_configs")
+    form = problems.lipm3d(cpu_api, N=32)
+    A, h, Q, q = check_snapshot(form, g, "lipm3d_N32/")
+    assert Q.shape == (96, 96) and A.shape == (196, 96)
+    form = problems.random_lti(cpu_api, np.random.default_rng(20262), nx=12, nu=6, N=8)
+    A, h, Q, q = check_snapshot(form, g, "lti_nx12_nu6_N8/")
+    assert Q.shape == (48, 48) and A.shape == (2 * 12 * 8, 48)

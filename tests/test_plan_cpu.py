@@ -1,0 +1,164 @@
+"""CPU: the host plan compiler (mpcasm.plan) against the oracle.
+
+The plan tables are executed by tests/plan_emulator.py, a numpy interpreter of
+csrc/plan_tables.h, so that the compiler's flattening of the definition graph,
+row-set bookkeeping, gterm / limit records and parameter layout are verified
+without a GPU.  The same tables drive the HIP kernels (tests/test_gpu_*.py).
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+import plan_emulator
+from helpers import assert_close
+from mpcasm import capi, problems
+from mpcasm.plan import _H, compile_plan, structure_fingerprint
+from oracle import qp_oracle as orc
+
+
+def check_plan(form, given, tol=1e-12):
+    plan = compile_plan(form)
+    out = plan_emulator.run(plan, given)
+    PM = orc.preview_matrices(form)
+    A, h, Q, q = orc.assemble(form, given, PM)
+    assert (plan.ng, plan.no, plan.nc) == (form.given_len, form.optim_len, A.shape[0])
+    assert_close(out["P"], Q, tol, "P")
+    assert_close(out["q"], q.ravel(), tol, "q")
+    assert_close(out["G"], A, tol, "G")
+    assert_close(out["h"], h.ravel(), tol, "h")
+    for var, (r0, rows) in plan.pm_rows.items():
+        block = out["PM"][r0:r0 + rows]
+        assert_close(block[:, :plan.ng], PM[var][0], tol, var + " Mg")
+        assert_close(block[:, plan.ng:], PM[var][1], tol, var + " Mo")
+    return plan
+
+
+def test_body_case_plan(cpu_api):
+    form = problems.body_case(cpu_api)
+    rng = np.random.default_rng(3)
+    plan = check_plan(form, rng.standard_normal([form.given_len, 1]))
+    # the crossed cost expands into two gterms, the others into one per axis
+    assert plan.n_gterms == 2 + 1 + 2 + 2
+    # index maps are carried bit-exact
+    assert plan.optim_ID == {v: form.optim_ID[v] for v in form.optim_variables}
+
+
+@pytest.mark.parametrize("step_samples", [8, 12])
+def test_biped_plan_over_ticks(cpu_api, step_samples):
+    conf = problems.BipedConfig(step_samples=step_samples)
+    form = problems.biped(cpu_api, conf)
+    clock = problems.StepClock(conf.step_samples, form.domain["Ds_x"])
+    rng = np.random.default_rng(11)
+    widths = set()
+    for tick in range(10):
+        form.update(step_times=clock.step_times, step_count=clock.step_count)
+        given = form.arrange_given(problems.biped_given_collector(form, rng, 0.01))
+        if tick in (0, 1, 7, 8, 9):
+            check_plan(form, given)
+        widths.add(form.optim_len)
+        clock.tick()
+    assert len(widths) == 2      # ragged QP width across walking phases
+
+
+def test_lipm3d_and_lti_plans(cpu_api):
+    form = problems.lipm3d(cpu_api, N=12)
+    check_plan(form, np.random.default_rng(0).normal(0, 0.05, [form.given_len, 1]))
+    form = problems.random_lti(cpu_api, np.random.default_rng(1), nx=5, nu=2, N=6)
+    check_plan(form, np.random.default_rng(2).standard_normal([form.given_len, 1]))
+
+
+def test_constraint_with_L_and_per_row_fields(cpu_api):
+    """Rows from L, per-row arrow / center / extreme, 1-D and 2-D definition
+    coefficients, a state-space box."""
+    api = cpu_api
+    rng = np.random.default_rng(8)
+    N = 6
+    A, B = problems.random_lti_matrices(rng, 3, 2)
+    ext = api.ExtendedSystem.from_cotrol_system(
+        api.ControlSystem(["u0", "u1"], ["p", "v", "a"], A, B, axes=["_x", "_y"]), "x", N)
+    form = api.Formulation()
+    form.incorporate_dynamics("plant", ext)
+    form.incorporate_definitions({
+        "mix_x": api.LineCombo({"p_x": rng.standard_normal((4, N)), "v_x": rng.standard_normal((4, N))}),
+        "mix_y": api.LineCombo({"p_y": rng.standard_normal((4, N)), "v_y": 2.0 * np.eye(4, N)}),
+        "avg_x": api.LineCombo({"p_x": np.ones(N) / N}),
+    })
+    form.incorporate_constraint("rows", [
+        api.Constraint("mix", rng.uniform(1, 2, 4), axes=["_x", "_y"],
+                       arrow=rng.standard_normal((4, 2)), center=rng.standard_normal((4, 2))),
+        api.Constraint("p", 3.0, axes=["_x", "_y"], arrow=[1.0, -0.5],
+                       L=[rng.standard_normal((3, 2)), rng.standard_normal((3, 2))],
+                       schedule=range(2, 4)),
+        api.Constraint("avg_x", 1.5),
+    ])
+    form.incorporate_box("ss", api.Box.state_space(
+        "v_x", np.array([[0.0, 1], [1, 0.5], [0.2, -1], [-1, 0]]), schedule=range(0, 2)))
+    form.incorporate_goal("g1", api.Cost("mix", 2.0, aim=[0.3, -0.2], axes=["_x", "_y"],
+                                         L=rng.standard_normal((2, 4))))
+    form.incorporate_goal("g2", api.Cost("a", 0.5, aim=[1.0], axes=["_x"], schedule=range(1, 5),
+                                         cross="v", cross_aim=[0.25]))
+    form.incorporate_goal("g3", api.Cost("avg_x", 4.0, aim=0.1))
+    form.identify_qp_domain(["u0_x", "u1_x", "u0_y", "u1_y"])
+    form.make_preview_matrices()
+    check_plan(form, rng.standard_normal([form.given_len, 1]))
+
+
+def test_param_refresh_and_fingerprint(cpu_api):
+    form = problems.body_case(cpu_api)
+    plan = compile_plan(form)
+    limits = orc.all_limits(form)
+    fp = structure_fingerprint(form.goals, limits)
+    assert plan.fingerprint == fp
+    form.goals["velocity"].update(aim=[3.0, -1.0], weight=7.0)
+    limits[0].update(extreme=2.5)
+    assert structure_fingerprint(form.goals, limits) == fp      # numbers only
+    params = plan.current_params()
+    s, r, c = plan.param_slots[("cost", "velocity", "aim")]
+    assert list(params[s:s + r * c]) == [3.0, -1.0]
+    given = np.random.default_rng(0).standard_normal([form.given_len, 1])
+    out = plan_emulator.run(plan, given, params=params)
+    A, h, Q, q = orc.assemble(form, given)
+    assert_close(out["q"], q.ravel(), 1e-12)
+    assert_close(out["h"], h.ravel(), 1e-12)
+    form.goals["terminal"].update(schedule=range(7, 9))
+    assert structure_fingerprint(form.goals, limits) != fp      # structure changed
+
+
+def test_invalid_problems_raise(cpu_api):
+    api = cpu_api
+    form = problems.body_case(api)
+    form.goals["velocity"].aim = np.zeros([2, 2])                # two rows: the reference cannot
+    with pytest.raises(ValueError):                              # broadcast them either
+        compile_plan(form)
+    form = problems.body_case(api)
+    form.definitions["DCM_x"].variables[0] = "unknown"
+    with pytest.raises(KeyError):
+        compile_plan(form)
+
+
+def test_plan_tables_rejected_or_accepted_by_the_library(cpu_api):
+    """mpcasm_plan_create validates the tables on the host before touching the
+    device: a corrupted plan is MPCASM_ERR_PLAN everywhere, a good one reaches the
+    device step (MPCASM_ERR_NODEVICE on this CPU-only machine, OK on a GPU box)."""
+    lib = capi.load()
+    plan = compile_plan(problems.body_case(cpu_api))
+    handle = ctypes.c_void_p()
+
+    def create(itab, dtab):
+        return lib.mpcasm_plan_create(itab.ctypes.data, itab.size, dtab.ctypes.data, dtab.size,
+                                      ctypes.byref(handle))
+
+    rc = create(plan.itab, plan.dtab)
+    assert rc in (0, -4), rc
+    if rc == 0:
+        assert lib.mpcasm_plan_destroy(handle) == 0
+    for word, value in (("MAGIC", 0), ("VERSION", 99), ("OFF_ROWPTR", 10 ** 6), ("NC", -1),
+                        ("LDV", 3)):
+        bad = plan.itab.copy()
+        bad[_H[word]] = value
+        assert create(bad, plan.dtab) == -2, word
+    bad = plan.itab.copy()
+    bad[bad[_H["OFF_ENTBASE"]]] = 10 ** 6          # base id out of range
+    assert create(bad, plan.dtab) == -2
+    assert create(plan.itab[:-1].copy(), plan.dtab) == -2
