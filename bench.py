@@ -1,0 +1,241 @@
+#!/usr/bin/env python3
+"""Benchmark of the QP-assembly hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1], SURVEY.md section 8d "C2"): the biped-LIPM walking
+formulation, N=16, 2 axes, 6 costs, 3 boxes (36 unknowns, 76 inequality rows in
+the headline phase), B independent instances per GPU in fp64, synthetic inputs
+resident in HBM.  One *step* is one pass of the hot path over one batch:
+
+    K1  mpcasm_fill_su     per-instance (A, B) -> horizon matrices S, U
+    K2-K4 mpcasm_assemble  S, U, given, parameters -> P, q, G, h  for every instance
+
+Prints ONE JSON line (rank 0): whole-job assemblies/s, the roofline object of the
+dominant kernel (hipEvent-timed inside the timed region) and, at N=1, the CPU
+baseline (the numpy oracle -- a port of the reference algorithm -- timed on this
+box's host cores for a bounded sample of the same workload).
+
+Multi-GPU: one process per GPU (torch.distributed, backend nccl = RCCL); the batch
+is sharded with no collective on the data path (weak scaling: B per GPU is fixed);
+the only collectives are the barriers around the timed region and the MAX of the
+elapsed time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+# the CPU baseline is quoted for one core: keep BLAS single-threaded
+os.environ.setdefault("OMP_NUM_THREADS", "1")
+os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
+
+import numpy as np  # noqa: E402
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for path in (os.path.join(ROOT, "mpc-interface_amd"), ROOT):
+    if path not in sys.path:
+        sys.path.insert(0, path)
+
+HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def build_workload(batch, seed):
+    """The biped formulation in its 36-wide phase + per-instance synthetic inputs."""
+    from mpcasm import engine, problems
+
+    api = problems.load_api("mpc_interface")
+    conf = problems.BipedConfig(step_samples=8)               # N = 16
+    form = problems.biped(api, conf)
+    form.update(step_times=np.array([6, 14]), step_count=0)   # phase phi=1: no=36, nc=76
+    N = conf.horizon_lenght
+
+    rng = np.random.default_rng(seed)
+    given = np.zeros([batch, form.given_len])
+    for var, ids in form.given_ID.items():
+        if var.startswith("x0"):
+            given[:, ids] = rng.normal(0, 0.05, [batch, len(ids)])
+        elif var.startswith("s0"):
+            given[:, ids] = rng.uniform(-0.1, 0.1, [batch, len(ids)])
+        else:
+            given[:, ids] = rng.normal(0, 0.01, [batch, len(ids)])
+    # per-instance dynamics: jerk-input LIPM sampled at a per-instance period
+    get_A, get_B, _ = api.tools.get_system_matrices("J->CCC")
+    taus = rng.uniform(0.09, 0.11, batch)
+    A = np.stack([get_A(tau=t) for t in taus])
+    B = np.stack([get_B(tau=t) for t in taus])
+    aims = rng.uniform(0, 0.6, [batch, 1, 1])
+    return dict(api=api, conf=conf, form=form, N=N, given=given, A=A, B=B, aims=aims,
+                engine=engine, problems=problems)
+
+
+def cpu_baseline(work, budget_s=12.0):
+    """The oracle (numpy port of the reference path) on one host core: per
+    instance extend_matrices + preview matrices + all QP blocks."""
+    from oracle import qp_oracle as orc
+
+    form, N = work["form"], work["N"]
+    lip = form.dynamics["LIP"]
+    saved = list(lip.matrices)
+    done, t0 = 0, time.perf_counter()
+    while True:
+        b = done % work["given"].shape[0]
+        S, U = orc.extend_matrices(N, work["A"][b], work["B"][b])
+        lip.matrices = U + [S]
+        lip.update_definitions()
+        form.goals["track vel_x"].update(aim=work["aims"][b, 0])
+        maps = orc.qp_index_maps(form.domain, form.optim_variables)
+        PM = orc.preview_matrices(form, maps)
+        orc.assemble(form, work["given"][b].reshape(-1, 1), PM, maps)
+        done += 1
+        elapsed = time.perf_counter() - t0
+        if elapsed >= budget_s:
+            break
+    lip.matrices = saved
+    lip.update_definitions()
+    return done / elapsed, done, elapsed
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=4096, help="instances per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the assembly path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    if args.gpus != world and rank == 0 and world > 1:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+
+    B = args.batch
+    work = build_workload(B, 20260 + rank)          # each rank owns its own shard of instances
+    engine, form, N = work["engine"], work["form"], work["N"]
+    dev = torch.device("cuda", local_rank)
+    A = torch.as_tensor(work["A"], device=dev)
+    Bm = torch.as_tensor(work["B"], device=dev)
+    given = torch.as_tensor(work["given"], device=dev)
+    S = torch.empty((B, N, 3, 3), dtype=torch.float64, device=dev)
+    U = torch.empty((B, 1, N, N, 3), dtype=torch.float64, device=dev)
+    asm = engine.Assembler(form, batch=B, device=dev)
+    asm.set_param("cost", "track vel_x", "aim", work["aims"])
+    asm.bind_source(("LIP", 0), U[:, 0])
+    asm.bind_source(("LIP", 1), S)
+
+    def step():
+        engine.fill_su(A, Bm, N, out=(S, U))
+        return asm.assemble(given)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+
+    # timed region: exactly K steps; hipEvents (on the launch stream) bracket each
+    # C-ABI call so that the kernels' own durations come from the same run
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record()
+        engine.fill_su(A, Bm, N, out=(S, U))
+        ev[k][1].record()
+        asm.assemble(given)
+        ev[k][2].record()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    fill_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+    asm_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
+
+    no, ng, nc = asm.no, asm.ng, asm.nc
+    nparams = int(asm.params.shape[1])
+    bytes_fill = 8 * (N * 9 + N * N * 3) + 8 * (9 + 3)                    # written + read
+    bytes_asm = 8 * (no * no + no + nc * no + nc) + 8 * (ng + nparams) + 8 * (N * 9 + N * N * 3)
+    total = world * B * args.steps
+    value = total / elapsed
+
+    # dominant kernel = the assembly (K2-K4); HBM-bound
+    achieved = bytes_asm * B / (asm_ms * 1e-3) / 1e9
+    record = {
+        "metric": "QP assemblies/sec (P,q,G,h), biped N=16 batched",
+        "value": value,
+        "unit": "assemblies/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": "C2: biped LIPM (J->CCC) N=16, 2 axes, 6 costs, 3 boxes; no=%d nc=%d ng=%d; "
+                        "per-instance (A,B), given, velocity aim; B=%d per GPU" % (no, nc, ng, B),
+            "batch_per_gpu": B,
+            "global_batch": B * world,
+            "horizon": N,
+            "step": "mpcasm_fill_su + mpcasm_assemble",
+        },
+        "roofline": {
+            "kernel": "mpcasm_assemble (K2 compose + K3 hessian_mfma + K4 constraint_stack)",
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBPS,
+            "traffic": None,
+            "algorithmic_bytes_per_assembly": bytes_asm,
+            "avg_launch_ms": asm_ms,
+        },
+        "fill": {
+            "kernel": "mpcasm_fill_su (K1 toeplitz_fill)",
+            "algorithmic_bytes_per_system": bytes_fill,
+            "avg_launch_ms": fill_ms,
+            "achieved_GBps": bytes_fill * B / (fill_ms * 1e-3) / 1e9,
+        },
+        "hbm_GBps_end_to_end": (bytes_asm + bytes_fill) * value / 1e9,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        rate, count, secs = cpu_baseline(work)
+        record["cpu_baseline"] = {
+            "value": rate,
+            "unit": "assemblies/s",
+            "cores": 1,
+            "kind": "port",
+            "sample": "%d assemblies of the same workload in %.1f s: oracle/qp_oracle.py "
+                      "(extend_matrices + preview matrices + all QP blocks per instance), "
+                      "single process, host has %d cores" % (count, secs, os.cpu_count() or 0),
+        }
+    if rank == 0:
+        print(json.dumps(record))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -39,7 +39,7 @@ __host__ __device__ inline size_t lti_lds_doubles(int N, int n, int m) {
   return even_up((size_t)m * N * n) + 2 * even_up((size_t)n * (m + n)) + even_up((size_t)n * n);
 }
 
-template <int TPI>
+template <int TPI, bool GENERIC>
 __global__ __launch_bounds__(BLOCK) void fill_lti_kernel(const double* __restrict__ A,
                                                          const double* __restrict__ B,
                                                          double* __restrict__ S,
@@ -65,7 +65,9 @@ __global__ __launch_bounds__(BLOCK) void fill_lti_kernel(const double* __restric
   double* Sb = S + (size_t)inst * N * n * n;
   double* Ub = U + (size_t)inst * m * N * rl;
 
-  // element e of X: column c = e / n (c < m: input c, else state column c-m), row i = e % n
+  // element e of X: column c = e / n (c < m: input c, else state column c-m), row i = e % n.
+  // Each thread owns the same few elements in every step, so (c, i) are divided out once;
+  // GENERIC (n (m+n) > TPI * EPT) falls back to a strided loop with the division inside.
   int ec[EPT], ei[EPT];
 #pragma unroll
   for (int u = 0; u < EPT; ++u) {
@@ -73,25 +75,34 @@ __global__ __launch_bounds__(BLOCK) void fill_lti_kernel(const double* __restric
     ec[u] = e / n;
     ei[u] = e - ec[u] * n;
   }
+  auto for_each_element = [&](auto&& body) {
+    if constexpr (!GENERIC) {
+#pragma unroll
+      for (int u = 0; u < EPT; ++u) {
+        const int e = tid + u * TPI;
+        if (e < xsz) body(e, ec[u], ei[u]);
+      }
+    } else {
+      for (int e = tid; e < xsz; e += TPI) {
+        const int c = e / n;
+        body(e, c, e - c * n);
+      }
+    }
+  };
 
   if (live) {
     for (int e = tid; e < n * n; e += TPI) Am[e] = Ab[e];
-#pragma unroll
-    for (int u = 0; u < EPT; ++u) {
-      const int e = tid + u * TPI;
-      if (e < xsz) {
-        const int c = ec[u], i = ei[u];
-        if (c < m) {
-          const double v = Bb[i * m + c];
-          X[e] = v;
-          R[(size_t)c * rl + (size_t)(N - 1) * n + i] = v;  // d = 0
-        } else {
-          const double v = Ab[i * n + (c - m)];
-          X[e] = v;
-          Sb[e - n * m] = v;  // S[0][j][i], (j, i) order == e order
-        }
+    for_each_element([&](int e, int c, int i) {
+      if (c < m) {
+        const double v = Bb[i * m + c];
+        X[e] = v;
+        R[(size_t)c * rl + (size_t)(N - 1) * n + i] = v;  // d = 0
+      } else {
+        const double v = Ab[i * n + (c - m)];
+        X[e] = v;
+        Sb[e - n * m] = v;  // S[0][j][i], (j, i) order == e order
       }
-    }
+    });
   }
   __syncthreads();
 
@@ -100,20 +111,15 @@ __global__ __launch_bounds__(BLOCK) void fill_lti_kernel(const double* __restric
     const double* Xp = X + ((d - 1) & 1) * xstep;
     double* Xc = X + (d & 1) * xstep;
     if (live) {
-#pragma unroll
-      for (int u = 0; u < EPT; ++u) {
-        const int e = tid + u * TPI;
-        if (e < xsz) {
-          const int c = ec[u], i = ei[u];
-          double v = 0.0;
-          for (int t = 0; t < n; ++t) v = fma(Am[i * n + t], Xp[c * n + t], v);
-          Xc[e] = v;
-          if (c < m)
-            R[(size_t)c * rl + (size_t)(N - 1 - d) * n + i] = v;
-          else
-            Sb[(size_t)d * n * n + (e - n * m)] = v;
-        }
-      }
+      for_each_element([&](int e, int c, int i) {
+        double v = 0.0;
+        for (int t = 0; t < n; ++t) v = fma(Am[i * n + t], Xp[c * n + t], v);
+        Xc[e] = v;
+        if (c < m)
+          R[(size_t)c * rl + (size_t)(N - 1 - d) * n + i] = v;
+        else
+          Sb[(size_t)d * n * n + (e - n * m)] = v;
+      });
     }
     __syncthreads();
   }
@@ -282,13 +288,20 @@ int launch_fill_su(const double* A, const double* B, double* S, double* U, int b
     if (small) {
       const size_t bytes = per * 4;
       const int blocks = (batch + 3) / 4;
-      hipLaunchKernelGGL(fill_lti_kernel<64>, dim3(blocks), dim3(BLOCK), bytes, stream, A, B, S, U,
-                         batch, N, n, m);
+      hipLaunchKernelGGL((fill_lti_kernel<64, false>), dim3(blocks), dim3(BLOCK), bytes, stream, A,
+                         B, S, U, batch, N, n, m);
+    } else if (per > LDS_MAX) {
+      return MPCASM_ERR_LIMIT;  // the A^d B table of one system must fit in LDS
+    } else if (xsz <= BLOCK * EPT) {
+      if ((*err = allow_lds(fill_lti_kernel<BLOCK, false>, per)) != hipSuccess)
+        return MPCASM_ERR_HIP;
+      hipLaunchKernelGGL((fill_lti_kernel<BLOCK, false>), dim3(batch), dim3(BLOCK), per, stream, A,
+                         B, S, U, batch, N, n, m);
     } else {
-      if (xsz > BLOCK * EPT || per > LDS_MAX) return MPCASM_ERR_LIMIT;
-      if ((*err = allow_lds(fill_lti_kernel<BLOCK>, per)) != hipSuccess) return MPCASM_ERR_HIP;
-      hipLaunchKernelGGL(fill_lti_kernel<BLOCK>, dim3(batch), dim3(BLOCK), per, stream, A, B, S, U,
-                         batch, N, n, m);
+      if ((*err = allow_lds(fill_lti_kernel<BLOCK, true>, per)) != hipSuccess)
+        return MPCASM_ERR_HIP;
+      hipLaunchKernelGGL((fill_lti_kernel<BLOCK, true>), dim3(batch), dim3(BLOCK), per, stream, A,
+                         B, S, U, batch, N, n, m);
     }
   } else {
     const size_t per = ltv_lds_doubles(N, n, m) * sizeof(double);

@@ -246,7 +246,7 @@ class Formulation:
         value = 0
         for i, axis in enumerate(goal.axes):
             v = self.preview(given, optim, goal.variable + axis) - goal.aim[:, i]
-            value += v.T @ v
+            value += (v.T @ v).item()
         return float(value)
 
     def full_goal_distance(self, given, optim):

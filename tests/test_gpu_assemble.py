@@ -1,0 +1,312 @@
+"""GPU: the assembly kernels (K2 + K3 + K4 through mpcasm_assemble /
+mpcasm_preview_matrices) against the golden vectors of the real reference and the
+oracle.  Index maps bit-exact; P, q, G, h and the preview matrices within 1e-10
+relative (north star), observed ~1e-15.
+"""
+import json
+
+import numpy as np
+import pytest
+
+from helpers import RTOL, RTOL_TIGHT, assert_close, golden, ranges_from_json
+from mpcasm import problems
+from oracle import qp_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def check_drop_in(form, g, prefix, parts=True):
+    """The reference's call sequence on this repository's Formulation (B=1 path)."""
+    assert {k: form.optim_ID[k] for k in form.optim_variables} == \
+        ranges_from_json(g[prefix + "optim_ID"])
+    assert {k: form.given_ID[k] for k in form.given_variables} == \
+        ranges_from_json(g[prefix + "given_ID"])
+    given = g[prefix + "given"]
+    names = json.loads(str(g[prefix + "definitions"]))
+    assert list(form.PM.keys()) == names and len(form.PM) == len(form.definitions)
+    for var in names:
+        if prefix + "PM/" + var + "/Mg" in g:
+            Mg, Mo = form.PM[var]
+            assert_close(Mg, g[prefix + "PM/" + var + "/Mg"], RTOL_TIGHT, var + " Mg")
+            assert_close(Mo, g[prefix + "PM/" + var + "/Mo"], RTOL_TIGHT, var + " Mo")
+    if parts:
+        for k, limit in enumerate(orc.all_limits(form)):
+            if prefix + "limit%d/A" % k in g:
+                A, h = form.generate_qp_constraint(limit, given)
+                assert_close(A, g[prefix + "limit%d/A" % k], RTOL_TIGHT, "limit A")
+                assert_close(h, g[prefix + "limit%d/h" % k], RTOL_TIGHT, "limit h")
+        for name, cost in form.goals.items():
+            if prefix + "cost/" + name + "/Q" in g:
+                Q, q = form.generate_qp_cost(cost, given)
+                assert_close(Q, g[prefix + "cost/" + name + "/Q"], RTOL_TIGHT, "cost Q " + name)
+                assert_close(q, g[prefix + "cost/" + name + "/q"], RTOL_TIGHT, "cost q " + name)
+    A, h, Q, q = form.generate_all_qp_matrices(given)
+    assert h.ndim == 2 and h.shape[1] == 1 and q.shape == (form.optim_len, 1)
+    for mine, nm in ((A, "A"), (h, "h"), (Q, "Q"), (q, "q")):
+        assert mine.dtype == np.float64 and mine.flags["C_CONTIGUOUS"]
+        assert_close(mine, g[prefix + nm], RTOL_TIGHT, prefix + nm)
+    A2, h2 = form.generate_all_qp_constraints(given)
+    Q2, q2 = form.generate_all_qp_costs(given)
+    assert np.array_equal(A2, A) and np.array_equal(h2, h)
+    assert np.array_equal(Q2, Q) and np.array_equal(q2, q)
+    return A, h, Q, q
+
+
+def test_body_case_drop_in(gpu_api):
+    """The problem of the reference's test_body.py: shapes it asserts (:140-162)
+    plus the values captured from the reference."""
+    g = golden("g2_body")
+    form = problems.body_case(gpu_api)
+    A, h, Q, q = check_drop_in(form, g, "arange/")
+    assert A.shape == (54, form.optim_len) and h.shape == (54, 1)
+    limit = form.constraints["kinematics"][0]
+    A1, h1 = form.generate_qp_constraint(limit, g["arange/given"])
+    assert A1.shape == (9, form.optim_len) and (h1 == limit.bound()).all()   # test_body.py:142
+    check_drop_in(form, g, "random/")
+    assert np.abs(Q - Q.T).max() > 1e-6          # crossed cost: non-symmetric Hessian
+
+
+@pytest.mark.parametrize("step_samples", [8, 12])
+def test_biped_ticks_drop_in(gpu_api, step_samples):
+    """C1: single instance, the walking loop's update -> arrange_given ->
+    generate_all_qp_matrices sequence (biped_mpc_loop.py:51-56), both QP widths."""
+    conf = problems.BipedConfig(step_samples=step_samples)
+    g = golden("g3_biped_N%d" % conf.horizon_lenght)
+    form = problems.biped(gpu_api, conf)
+    clock = problems.StepClock(conf.step_samples, form.domain["Ds_x"])
+    keep = [int(t) for t in g["ticks"]]
+    for tick in range(18):
+        form.update(step_times=clock.step_times, step_count=clock.step_count)
+        if tick in keep:
+            A, h, Q, q = check_drop_in(form, g, "tick%02d/" % tick, parts=(tick == keep[0]))
+            row = g["shapes"][tick]
+            assert (Q.shape[0], A.shape[0]) == (row[2], row[3])
+        clock.tick()
+
+
+def test_numbers_changed_between_calls_are_picked_up(gpu_api):
+    """Cost / Constraint objects are mutated in place between calls in the
+    reference's usage; the cached plan must re-read them."""
+    form = problems.body_case(gpu_api)
+    given = np.random.default_rng(0).standard_normal([form.given_len, 1])
+    form.generate_all_qp_matrices(given)
+    form.goals["velocity"].update(aim=[3.0, -1.0], weight=7.0)
+    form.constraints["kinematics"][0].update(extreme=2.5)
+    form.goals["terminal"].update(schedule=range(6, 9))          # structure change
+    A, h, Q, q = form.generate_all_qp_matrices(given)
+    Ao, ho, Qo, qo = orc.assemble(form, given)
+    for mine, ref in ((A, Ao), (h, ho), (Q, Qo), (q, qo)):
+        assert_close(mine, ref, RTOL_TIGHT)
+
+
+def test_preview_and_goal_distance(gpu_api):
+    form = problems.body_case(gpu_api)
+    rng = np.random.default_rng(1)
+    given = rng.standard_normal([form.given_len, 1])
+    optim = rng.standard_normal([form.optim_len, 1])
+    PM = orc.preview_matrices(form)
+    for var in ("CoM_x", "DCM_y", "s_x"):
+        assert_close(form.preview(given, optim, var), orc.preview(PM, given, optim, var),
+                     RTOL_TIGHT, var)
+    both = form.preview(given, optim, "CoM", ["_x", "_y"])
+    assert both.shape == (9, 2)
+    assert_close(both, orc.preview(PM, given, optim, "CoM", ["_x", "_y"]), RTOL_TIGHT)
+    v = orc.preview(PM, given, optim, "DCM_x") - form.goals["stability"].aim[:, 0]
+    assert abs(form.goal_distance(given, optim, "stability") - float(v.T @ v)) < 1e-9
+
+
+def batched_case(form, batch, seed, vary):
+    """Assemble `batch` instances with per-instance given and parameters; check a
+    sample of instances one by one against the oracle run on a mutated copy of
+    the description."""
+    import torch
+    from mpcasm.engine import Assembler
+
+    rng = np.random.default_rng(seed)
+    asm = Assembler(form, batch=batch)
+    given = rng.normal(0, 0.1, [batch, form.given_len])
+    overrides = vary(asm, rng, batch)
+    P, q, G, h = asm.assemble(torch.as_tensor(given, device="cuda"))
+    torch.cuda.synchronize()
+    P, q, G, h = (t.cpu().numpy() for t in (P, q, G, h))
+    assert P.shape == (batch, form.optim_len, form.optim_len) and h.shape[0] == batch
+    return asm, given, overrides, (P, q, G, h)
+
+
+def test_biped_batch_c2(gpu_api):
+    """C2: B=4096 instances of the biped (36-wide phase), per-instance given
+    vector, velocity aim and stepping-area centres."""
+    conf = problems.BipedConfig(step_samples=8)
+    form = problems.biped(gpu_api, conf)
+    form.update(step_times=np.array([6, 14]), step_count=0)      # phi = 1: 36-wide
+    assert form.optim_len == 36
+    limits = orc.all_limits(form)
+    batch = 4096
+
+    def vary(asm, rng, B):
+        aims = rng.uniform(0, 0.6, [B, 1, 1])
+        asm.set_param("cost", "track vel_x", "aim", aims)
+        centers = {}
+        for k in range(4):                                      # facets of the stepping area
+            c = np.asarray(limits[k].center, dtype=float)[None] + rng.normal(0, 0.01, [B, 2, 2])
+            asm.set_param("limit", k, "center", c)
+            centers[k] = c
+        return aims, centers
+
+    asm, given, (aims, centers), (P, q, G, h) = batched_case(form, batch, 20260, vary)
+    assert G.shape == (batch, 76, 36)
+    for b in (0, 1, 1777, batch - 1):
+        form.goals["track vel_x"].update(aim=aims[b, 0])
+        for k in range(4):
+            limits[k].update(center=centers[k][b])
+        A, hh, Q, qq = orc.assemble(form, given[b].reshape(-1, 1))
+        assert_close(P[b], Q, RTOL_TIGHT, "P")
+        assert_close(q[b], qq.ravel(), RTOL_TIGHT, "q")
+        assert_close(G[b], A, RTOL_TIGHT, "G")
+        assert_close(h[b], hh.ravel(), RTOL_TIGHT, "h")
+    # size-independent property over the whole batch: P does not depend on given /
+    # aims here, so it is the same matrix for every instance, and symmetric
+    assert np.abs(P - P[0]).max() == 0.0
+    assert np.abs(P[0] - P[0].T).max() <= 1e-12 * np.abs(P[0]).max()
+
+
+def test_biped_batch_per_instance_dynamics(gpu_api):
+    """Per-instance horizon matrices: K1's output bound as a source of K2."""
+    import torch
+    from mpcasm import engine
+
+    conf = problems.BipedConfig(step_samples=8)
+    form = problems.biped(gpu_api, conf)
+    form.update(step_times=np.array([7, 15]), step_count=0)      # phi = 0: 34-wide
+    assert form.optim_len == 34
+    batch = 33
+    rng = np.random.default_rng(5)
+    get_A, get_B, _ = gpu_api.tools.get_system_matrices("J->CCC")
+    taus = rng.uniform(0.08, 0.12, batch)
+    A = np.stack([get_A(tau=t) for t in taus])
+    B = np.stack([get_B(tau=t) for t in taus])
+    S, U = engine.fill_su(A, B, conf.horizon_lenght)
+    asm = engine.Assembler(form, batch=batch)
+    assert ("LIP", 0) in asm.source_keys() and ("LIP", 1) in asm.source_keys()
+    asm.bind_source(("LIP", 0), U[:, 0])
+    asm.bind_source(("LIP", 1), S)
+    given = rng.normal(0, 0.1, [batch, form.given_len])
+    P, q, G, h = (t.cpu().numpy() for t in asm.assemble(given))
+    lip = form.dynamics["LIP"]
+    for b in (0, 7, batch - 1):
+        Sb, Ub = orc.extend_matrices(conf.horizon_lenght, A[b], B[b])
+        lip.matrices = Ub + [Sb]
+        lip.update_definitions()
+        Ao, ho, Qo, qo = orc.assemble(form, given[b].reshape(-1, 1))
+        assert_close(P[b], Qo, RTOL_TIGHT)
+        assert_close(q[b], qo.ravel(), RTOL_TIGHT)
+        assert_close(G[b], Ao, RTOL_TIGHT)
+        assert_close(h[b], ho.ravel(), RTOL_TIGHT)
+
+
+def test_lipm3d_c3(gpu_api):
+    """C3: N=32, 3 axes, 96 unknowns, 196 inequality rows; golden at B=1, oracle
+    on sampled instances of a batch."""
+    g = golden("g6_configs")
+    form = problems.lipm3d(gpu_api, N=32)
+    A, h, Q, q = check_drop_in(form, g, "lipm3d_N32/", parts=False)
+    assert Q.shape == (96, 96) and A.shape == (196, 96)
+    asm, given, _, (P, qq, G, hh) = batched_case(form, 512, 20261, lambda *a: None)
+    for b in (0, 100, 511):
+        Ao, ho, Qo, qo = orc.assemble(form, given[b].reshape(-1, 1))
+        assert_close(P[b], Qo, RTOL_TIGHT)
+        assert_close(qq[b], qo.ravel(), RTOL_TIGHT)
+        assert_close(G[b], Ao, RTOL_TIGHT)
+        assert_close(hh[b], ho.ravel(), RTOL_TIGHT)
+
+
+def test_random_lti_c4(gpu_api):
+    """C4 shape (nx=12, nu=6): golden at N=8, the full N=64 size (384 unknowns,
+    1536 rows) against the oracle."""
+    g = golden("g6_configs")
+    form = problems.random_lti(gpu_api, np.random.default_rng(20262), nx=12, nu=6, N=8)
+    check_drop_in(form, g, "lti_nx12_nu6_N8/", parts=False)
+    form = problems.random_lti(gpu_api, np.random.default_rng(20262), nx=12, nu=6, N=64)
+    assert form.optim_len == 384
+    asm, given, _, (P, q, G, h) = batched_case(form, 4, 1, lambda *a: None)
+    assert G.shape == (4, 1536, 384)
+    for b in (0, 3):
+        Ao, ho, Qo, qo = orc.assemble(form, given[b].reshape(-1, 1))
+        assert_close(P[b], Qo, RTOL_TIGHT)
+        assert_close(q[b], qo.ravel(), RTOL_TIGHT)
+        assert_close(G[b], Ao, RTOL_TIGHT)
+        assert_close(h[b], ho.ravel(), RTOL_TIGHT)
+
+
+def test_l_matrices_and_per_row_fields(gpu_api):
+    """Every structural branch at once (L on costs and constraints, schedules,
+    1-D / 2-D definition coefficients, cross terms, state-space box)."""
+    api = gpu_api
+    rng = np.random.default_rng(8)
+    N = 6
+    A, B = problems.random_lti_matrices(rng, 3, 2)
+    ext = api.ExtendedSystem.from_cotrol_system(
+        api.ControlSystem(["u0", "u1"], ["p", "v", "a"], A, B, axes=["_x", "_y"]), "x", N)
+    form = api.Formulation()
+    form.incorporate_dynamics("plant", ext)
+    form.incorporate_definitions({
+        "mix_x": api.LineCombo({"p_x": rng.standard_normal((4, N)),
+                                "v_x": rng.standard_normal((4, N))}),
+        "mix_y": api.LineCombo({"p_y": rng.standard_normal((4, N)), "v_y": 2.0 * np.eye(4, N)}),
+        "avg_x": api.LineCombo({"p_x": np.ones(N) / N}),
+    })
+    form.incorporate_constraint("rows", [
+        api.Constraint("mix", rng.uniform(1, 2, 4), axes=["_x", "_y"],
+                       arrow=rng.standard_normal((4, 2)), center=rng.standard_normal((4, 2))),
+        api.Constraint("p", 3.0, axes=["_x", "_y"], arrow=[1.0, -0.5],
+                       L=[rng.standard_normal((3, 2)), rng.standard_normal((3, 2))],
+                       schedule=range(2, 4)),
+        api.Constraint("avg_x", 1.5),
+    ])
+    form.incorporate_box("ss", api.Box.state_space(
+        "v_x", np.array([[0.0, 1], [1, 0.5], [0.2, -1], [-1, 0]]), schedule=range(0, 2)))
+    form.incorporate_goal("g1", api.Cost("mix", 2.0, aim=[0.3, -0.2], axes=["_x", "_y"],
+                                         L=rng.standard_normal((2, 4))))
+    form.incorporate_goal("g2", api.Cost("a", 0.5, aim=[1.0], axes=["_x"], schedule=range(1, 5),
+                                         cross="v", cross_aim=[0.25]))
+    form.incorporate_goal("g3", api.Cost("avg_x", 4.0, aim=0.1))
+    form.identify_qp_domain(["u0_x", "u1_x", "u0_y", "u1_y"])
+    form.make_preview_matrices()
+    given = rng.standard_normal([form.given_len, 1])
+    A_, h_, Q_, q_ = form.generate_all_qp_matrices(given)
+    PMo = orc.preview_matrices(form)
+    Ao, ho, Qo, qo = orc.assemble(form, given, PMo)
+    for mine, ref in ((A_, Ao), (h_, ho), (Q_, Qo), (q_, qo)):
+        assert_close(mine, ref, RTOL_TIGHT)
+    for var in form.definitions:
+        assert_close(form.PM[var][0], PMo[var][0], RTOL_TIGHT)
+        assert_close(form.PM[var][1], PMo[var][1], RTOL_TIGHT)
+
+
+def test_errors_and_edges(gpu_api):
+    from mpcasm import capi
+    from mpcasm.engine import Assembler
+
+    form = problems.body_case(gpu_api)
+    asm = Assembler(form, batch=3)
+    with pytest.raises(ValueError):
+        asm.assemble(np.zeros([2, form.given_len]))              # wrong batch
+    with pytest.raises(KeyError):
+        asm.set_param("cost", "nope", "aim", [[0.0]])
+    with pytest.raises(KeyError):
+        asm.bind_source(("LIP", 9), np.zeros(3))
+    with pytest.raises(ValueError):
+        asm.bind_source(("LIP", 0), np.zeros((2, 2, 2)))
+    lib = capi.load()
+    assert lib.mpcasm_assemble(None, None, None, None, None, None, None, None, None, None,
+                               1, None) == -1
+    # P without q is refused
+    P, q, G, h = asm.assemble(np.zeros([3, form.given_len]))
+    ptrs, strides = asm._src_args()
+    rc = lib.mpcasm_assemble(asm._handle, ptrs, strides, asm.params.data_ptr(), P.data_ptr(),
+                             P.data_ptr(), None, G.data_ptr(), h.data_ptr(),
+                             asm._work.data_ptr(), 3, None)
+    assert rc == -1
+    # a definition that depends on an undefined variable is refused at incorporation
+    with pytest.raises(AssertionError):
+        form.incorporate_definition("bad", gpu_api.LineCombo({"nope_x": 1}))
