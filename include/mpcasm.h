@@ -50,6 +50,11 @@ int mpcasm_device_count(void);
 int mpcasm_last_hip(void);
 /* Static string for a status code. */
 const char* mpcasm_status_string(int status);
+/* Process-wide options.  MPCASM_OPT_FORCE_STAGED (value 0/1): always take the
+ * staged K2 -> K3 -> K4 pipeline (workspace in HBM) instead of the fused
+ * single-launch kernel; used by the parity tests to exercise both paths. */
+enum { MPCASM_OPT_FORCE_STAGED = 1 };
+int mpcasm_set_option(int option, int value);
 
 /* K1  horizon extension ---------------------------------------------------
  * Replaces tools.extend_matrices(N, A, B)      python/mpc_interface/tools.py:14-33

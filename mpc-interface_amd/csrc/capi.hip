@@ -11,6 +11,10 @@
 
 using namespace mpcasm;
 
+namespace mpcasm {
+extern bool g_force_staged;
+}
+
 struct mpcasm_plan {
   PlanDev dev;
   int32_t* d_itab;
@@ -57,7 +61,35 @@ int validate_plan(const int32_t* it, size_t n_itab, size_t n_dtab) {
   ok = ok && in_range(it[H_OFF_PM_ENTK], it[H_PM_NENT], n, H_WORDS);
   ok = ok && in_range(it[H_DOFF_ENTCOEF], it[H_NENT], nd, 0);
   ok = ok && in_range(it[H_DOFF_PM_ENTCOEF], it[H_PM_NENT], nd, 0);
+  if (it[H_FUSED_OK] != 0 && it[H_FUSED_OK] != 1) return MPCASM_ERR_PLAN;
+  if (it[H_FUSED_OK]) {
+    ok = ok && it[H_ARENA_TOTAL] >= 1 && it[H_NFD] >= 0 && it[H_NOPS] >= 0 && it[H_NCOEF] >= 0;
+    ok = ok && in_range(it[H_OFF_ARENA], (int64_t)it[H_NSRC] * 2, n, H_WORDS);
+    ok = ok && in_range(it[H_OFF_FD_IDX], it[H_NFD], n, H_WORDS);
+    ok = ok && in_range(it[H_OFF_FD_PTR], (int64_t)it[H_NFD] + 1, n, H_WORDS);
+    ok = ok && in_range(it[H_OFF_OP], (int64_t)it[H_NOPS] * 2, n, H_WORDS);
+      ok = ok && in_range(it[H_DOFF_COEFPOOL], it[H_NCOEF], nd, 0);
+  }
   if (!ok) return MPCASM_ERR_PLAN;
+  if (it[H_FUSED_OK]) {
+    const int32_t* ar = it + it[H_OFF_ARENA];
+    for (int s = 0; s < it[H_NSRC]; ++s)
+      if (ar[2 * s] < 1 || ar[2 * s + 1] < 0 ||
+          (int64_t)ar[2 * s] + ar[2 * s + 1] > it[H_ARENA_TOTAL])
+        return MPCASM_ERR_PLAN;
+    const int64_t vsize = (int64_t)it[H_RTOT] * it[H_LDV];
+    const int32_t* fi = it + it[H_OFF_FD_IDX];
+    const int32_t* fp = it + it[H_OFF_FD_PTR];
+    if (fp[0] != 0 || fp[it[H_NFD]] != it[H_NOPS]) return MPCASM_ERR_PLAN;
+    for (int i = 0; i < it[H_NFD]; ++i)
+      if (fi[i] < 0 || fi[i] >= vsize || fp[i + 1] < fp[i]) return MPCASM_ERR_PLAN;
+    const uint32_t* op = reinterpret_cast<const uint32_t*>(it + it[H_OFF_OP]);
+    for (int o = 0; o < it[H_NOPS]; ++o) {
+      if (op[2 * o] >= (uint32_t)it[H_ARENA_TOTAL]) return MPCASM_ERR_PLAN;
+      if ((op[2 * o + 1] >> 16) > (uint32_t)ng || (op[2 * o + 1] & 0xFFFFu) >= (uint32_t)it[H_NCOEF])
+        return MPCASM_ERR_PLAN;
+    }
+  }
 
   // content checks: every index a kernel dereferences stays inside its table
   const int32_t* seg = it + it[H_OFF_SEG];
@@ -146,6 +178,14 @@ int mpcasm_device_count(void) {
 
 int mpcasm_last_hip(void) { return g_last_hip; }
 
+int mpcasm_set_option(int option, int value) {
+  if (option == MPCASM_OPT_FORCE_STAGED) {
+    g_force_staged = value != 0;
+    return MPCASM_OK;
+  }
+  return MPCASM_ERR_ARG;
+}
+
 const char* mpcasm_status_string(int status) {
   switch (status) {
     case MPCASM_OK: return "ok";
@@ -214,6 +254,17 @@ int mpcasm_plan_create(const int32_t* h_itab, size_t n_itab, const double* h_dta
   d.off_pm_rowptr = it[H_OFF_PM_ROWPTR]; d.off_pm_entbase = it[H_OFF_PM_ENTBASE];
   d.off_pm_entk = it[H_OFF_PM_ENTK];
   d.doff_entcoef = it[H_DOFF_ENTCOEF]; d.doff_pm_entcoef = it[H_DOFF_PM_ENTCOEF];
+  d.fused_ok = it[H_FUSED_OK]; d.arena_total = it[H_ARENA_TOTAL]; d.off_arena = it[H_OFF_ARENA];
+  d.nfd = it[H_NFD]; d.off_fd_idx = it[H_OFF_FD_IDX]; d.off_fd_ptr = it[H_OFF_FD_PTR];
+  d.nops = it[H_NOPS]; d.off_op = it[H_OFF_OP]; d.ncoef = it[H_NCOEF];
+  d.doff_coefpool = it[H_DOFF_COEFPOOL];
+  d.max_axes = 0;
+  for (int l = 0; l < it[H_NLIMIT]; ++l) {
+    const int na = it[it[H_OFF_LIMIT] + l * LM_WORDS + LM_NAXES];
+    if (na > d.max_axes) d.max_axes = na;
+  }
+  // the op table is read as int2: keep its word offset even (the compiler pads it)
+  if (d.fused_ok && (d.off_op & 1)) d.fused_ok = 0;
   *out_plan = plan;
   return MPCASM_OK;
 }
@@ -294,10 +345,17 @@ int mpcasm_preview(const double* d_PM, const double* d_given, const double* d_op
 
 namespace mpcasm {
 
+bool g_force_staged = false;  // test hook: mpcasm_set_option(MPCASM_OPT_FORCE_STAGED, 1)
+
 // dispatch: fused single launch when the problem fits on chip, else staged
 int launch_assemble(const PlanDev& p, const SrcTable& src, const double* params,
                     const double* given, double* P, double* q, double* G, double* h, void* work,
                     int batch, hipStream_t stream, hipError_t* err) {
+  // LDS budget that still leaves two workgroups per CU (160 KiB each)
+  constexpr size_t FUSED_LDS_LIMIT = 80 * 1024;
+  const size_t lds = fused_lds_bytes(p, 4);
+  if (lds != 0 && lds <= FUSED_LDS_LIMIT && !g_force_staged)
+    return launch_assemble_fused(p, src, params, given, P, q, G, h, batch, lds, stream, err);
   return launch_assemble_staged(p, src, params, given, P, q, G, h, work, batch, stream, err);
 }
 

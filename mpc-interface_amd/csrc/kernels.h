@@ -17,6 +17,9 @@ struct PlanDev {
   int off_seg, off_colseg, off_rowptr, off_entbase, off_entk, off_gterm, off_limit, off_lax, off_rowlimit;
   int off_pm_rowptr, off_pm_entbase, off_pm_entk;
   int doff_entcoef, doff_pm_entcoef;
+  // fused program
+  int fused_ok, arena_total, off_arena, nfd, off_fd_idx, off_fd_ptr, nops, off_op, ncoef,
+      doff_coefpool, max_axes;
 };
 
 // sources of one launch (device pointers + per-instance strides, by value)
@@ -34,6 +37,11 @@ size_t assemble_workspace_bytes(const PlanDev& p, int batch);
 int launch_assemble_staged(const PlanDev& p, const SrcTable& src, const double* params,
                            const double* given, double* P, double* q, double* G, double* h,
                            void* work, int batch, hipStream_t stream, hipError_t* err);
+// fused.hip
+size_t fused_lds_bytes(const PlanDev& p, int nw);
+int launch_assemble_fused(const PlanDev& p, const SrcTable& src, const double* params,
+                          const double* given, double* P, double* q, double* G, double* h,
+                          int batch, size_t lds_bytes, hipStream_t stream, hipError_t* err);
 int launch_assemble(const PlanDev& p, const SrcTable& src, const double* params,
                     const double* given, double* P, double* q, double* G, double* h, void* work,
                     int batch, hipStream_t stream, hipError_t* err);

@@ -27,7 +27,7 @@
 namespace mpcasm {
 
 constexpr int32_t PLAN_MAGIC = 0x4D504341;  // 'MPCA'
-constexpr int32_t PLAN_VERSION = 3;
+constexpr int32_t PLAN_VERSION = 4;
 
 enum HeaderWord : int {
   H_MAGIC = 0,
@@ -63,7 +63,18 @@ enum HeaderWord : int {
   H_DOFF_PM_ENTCOEF, // [PM_NENT]
   H_NITAB,         // total words of itab (self check)
   H_NDTAB,         // total elements of dtab
-  H_WORDS = 40
+  // ---- fused program (small problems: everything of one instance on chip) ----
+  H_FUSED_OK,      // 1 when the sections below are present
+  H_ARENA_TOTAL,   // doubles of the on-chip source arena (slot 0 holds the constant 1.0)
+  H_OFF_ARENA,     // [NSRC][2] arena offset, size of every source
+  H_NFD,           // composed elements of the workspace that are structurally non-zero
+  H_OFF_FD_IDX,    // [NFD] workspace index r*ldv + c  (c == no: the d column)
+  H_OFF_FD_PTR,    // [NFD+1] op range of every element
+  H_NOPS,
+  H_OFF_OP,        // [NOPS][2]: arena offset of the source value; (given index + 1) << 16 | coef id
+  H_NCOEF,
+  H_DOFF_COEFPOOL, // [NCOEF] distinct coefficients
+  H_WORDS = 48
 };
 
 // segment record
@@ -71,7 +82,9 @@ enum { SEG_SRC = 0, SEG_OFF0, SEG_ROWSTRIDE, SEG_ELEMSTRIDE, SEG_DST0, SEG_LEN, 
 enum { SEG_KIND_GATHER = 0, SEG_KIND_IDENTITY = 1 };
 
 // gterm record:  P[:, :] += w * A^T B   (when GT_FLAG_P),   q += s * w * A^T (d[D_OFF + k] - aim)
-enum { GT_AOFF = 0, GT_BOFF, GT_NROWS, GT_WPARAM, GT_DOFF, GT_AIMPARAM, GT_FLAGS, GT_PAD, GT_WORDS = 8 };
+// GT_MASKA / GT_MASKB: bit t set when 16-column tile t of the optim columns holds a
+// structural non-zero in the A / B rows (tiles >= 30 fold onto bit 30)
+enum { GT_AOFF = 0, GT_BOFF, GT_NROWS, GT_WPARAM, GT_DOFF, GT_AIMPARAM, GT_FLAGS, GT_MASKA, GT_MASKB, GT_PAD, GT_WORDS = 10 };
 enum { GT_FLAG_P = 1, GT_FLAG_HALF = 2 };
 
 // limit record

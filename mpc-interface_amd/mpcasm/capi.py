@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmpcasm.so")
 
 OK = 0
+OPT_FORCE_STAGED = 1
 STATUS = {
     0: "MPCASM_OK",
     -1: "MPCASM_ERR_ARG",
@@ -28,6 +29,7 @@ SIGNATURES = {
     "mpcasm_device_count": (ctypes.c_int, []),
     "mpcasm_last_hip": (ctypes.c_int, []),
     "mpcasm_status_string": (ctypes.c_char_p, [ctypes.c_int]),
+    "mpcasm_set_option": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     "mpcasm_fill_su": (ctypes.c_int, [_void_p, _void_p, _void_p, _void_p, ctypes.c_int,
                                       ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                       _void_p]),

@@ -15,7 +15,7 @@ import numpy as np
 import scipy.sparse as sp
 
 PLAN_MAGIC = 0x4D504341
-PLAN_VERSION = 3
+PLAN_VERSION = 4
 
 # header words (csrc/plan_tables.h, enum HeaderWord)
 _H = {name: i for i, name in enumerate([
@@ -24,9 +24,13 @@ _H = {name: i for i, name in enumerate([
     "OFF_SEG", "OFF_COLSEG", "OFF_ROWPTR", "OFF_ENTBASE", "OFF_ENTK", "OFF_GTERM", "OFF_LIMIT",
     "OFF_LAX", "OFF_ROWLIMIT", "OFF_PM_ROWPTR", "OFF_PM_ENTBASE", "OFF_PM_ENTK",
     "DOFF_ENTCOEF", "DOFF_PM_ENTCOEF", "NITAB", "NDTAB",
+    "FUSED_OK", "ARENA_TOTAL", "OFF_ARENA", "NFD", "OFF_FD_IDX", "OFF_FD_PTR", "NOPS", "OFF_OP",
+    "NCOEF", "DOFF_COEFPOOL",
 ])}
-H_WORDS = 40
-SEG_WORDS, GT_WORDS, LM_WORDS, LX_WORDS = 8, 8, 12, 2
+H_WORDS = 48
+SEG_WORDS, GT_WORDS, LM_WORDS, LX_WORDS = 8, 10, 12, 2
+FUSED_MAX_OPS = 1 << 18           # beyond this the staged pipeline is used
+FUSED_MAX_ARENA = 1 << 14         # doubles
 SEG_GATHER, SEG_IDENTITY = 0, 1
 GT_FLAG_P, GT_FLAG_HALF = 1, 2
 MAX_SOURCES = 32
@@ -275,6 +279,70 @@ def _csr_tables(blocks, base_row0, base_rows, total):
             M.data.astype(np.float64), M.shape[0])
 
 
+def _fused_program(b, rowptr, entbase, entk, entcoef, rtot, ldv):
+    """Flatten the row-set program one level further, down to single workspace
+    elements: every structurally non-zero element of V (and every d = Mg . given)
+    becomes a short list of ops ``coef * arena[src] (* given[g])``, with all
+    sources of one instance laid out in one on-chip arena (slot 0 = constant 1)."""
+    ng, no = b.ng, b.no
+    arena_off, total = [], 1
+    for s in b.sources:
+        arena_off.append(total)
+        total += s.array.size
+    arena = np.asarray([[o, s.array.size] for o, s in zip(arena_off, b.sources)],
+                       dtype=np.int32).reshape(-1)
+    row_tiles = np.zeros(max(rtot, 1), dtype=np.int64)
+    empty = dict(ok=0, arena_total=total, arena=arena, fd_idx=np.zeros(0, np.int32),
+                 fd_ptr=np.zeros(1, np.int32), ops=np.zeros(0, np.int32),
+                 coefpool=np.zeros(0), row_tiles=row_tiles)
+
+    segs_of_base = [[] for _ in b.base_rows]
+    for bid, colseg in enumerate(b.colseg):
+        for sg in sorted(set(int(x) for x in colseg if x >= 0)):
+            segs_of_base[bid].append(b.segments[sg])
+
+    dst, src, gidx, coef = [], [], [], []
+    for r in range(rtot):
+        for e in range(rowptr[r], rowptr[r + 1]):
+            u, k, cf = int(entbase[e]), int(entk[e]), float(entcoef[e])
+            for sid, off0, rs, es, dst0, length, kind, _ in segs_of_base[u]:
+                if kind == SEG_IDENTITY:
+                    if k >= length:
+                        continue
+                    cols = np.array([dst0 + k])
+                    srcs = np.zeros(1, dtype=np.int64)              # the constant 1.0
+                else:
+                    cols = dst0 + np.arange(length)
+                    srcs = arena_off[sid] + off0 + k * rs + np.arange(length) * es
+                given = cols < ng
+                dst.append(np.where(given, r * ldv + no, r * ldv + (cols - ng)))
+                gidx.append(np.where(given, cols, -1))
+                src.append(srcs)
+                coef.append(np.full(cols.size, cf))
+                opt = cols[~given] - ng
+                for t in np.unique(opt // 16):
+                    row_tiles[r] |= 1 << min(int(t), 30)
+        if sum(a.size for a in dst) > FUSED_MAX_OPS:
+            empty["row_tiles"] = np.full(max(rtot, 1), 0x7FFFFFFF, dtype=np.int64)
+            return empty
+    if not dst:
+        empty["ok"] = int(total <= FUSED_MAX_ARENA)
+        return empty
+    dst, src = np.concatenate(dst), np.concatenate(src)
+    gidx, coef = np.concatenate(gidx), np.concatenate(coef)
+    order = np.argsort(dst, kind="stable")          # keeps the entry order inside an element
+    dst, src, gidx, coef = dst[order], src[order], gidx[order], coef[order]
+    fd_idx, first = np.unique(dst, return_index=True)
+    fd_ptr = np.append(first, dst.size)
+    pool, cid = np.unique(coef, return_inverse=True)
+    ok = int(total <= FUSED_MAX_ARENA and pool.size < 65536 and ng < 65535)
+    packed = (((gidx.astype(np.int64) + 1) << 16) | cid.astype(np.int64)).astype(np.uint32)
+    ops = np.stack([src.astype(np.uint32), packed], axis=1).view(np.int32).reshape(-1)
+    return dict(ok=ok, arena_total=total, arena=arena, fd_idx=fd_idx.astype(np.int32),
+                fd_ptr=fd_ptr.astype(np.int32), ops=ops, coefpool=pool.astype(np.float64),
+                row_tiles=row_tiles)
+
+
 def compile_plan(form, costs=None, limits=None):
     """Compile ``form`` (an up-to-date Formulation: sizes and IDs current).
 
@@ -318,11 +386,11 @@ def compile_plan(form, costs=None, limits=None):
                         name, nv, cost.variable + axis, ncr, cost.cross + axis))
             if not crossed and va == ca:
                 #  q += w V^T (Vg g - aim)
-                gterms.append([va, va, nv, p_w, va, p_aim + i, GT_FLAG_P, 0])
+                gterms.append([va, va, nv, p_w, va, p_aim + i, GT_FLAG_P, 0, 0, 0])
             else:
                 #  P += w V^T C ;  q += w/2 V^T (Cg g - cross_aim) + w/2 C^T (Vg g - aim)
-                gterms.append([va, ca, nv, p_w, ca, p_caim + i, GT_FLAG_P | GT_FLAG_HALF, 0])
-                gterms.append([ca, -1, nv, p_w, va, p_aim + i, GT_FLAG_HALF, 0])
+                gterms.append([va, ca, nv, p_w, ca, p_caim + i, GT_FLAG_P | GT_FLAG_HALF, 0, 0, 0])
+                gterms.append([ca, -1, nv, p_w, va, p_aim + i, GT_FLAG_HALF, 0, 0, 0])
 
     # ---- limits (body.py:236-264, restrictions.py:147-199) -----------------------
     limit_recs, lax_recs, rowlimit, limit_rows = [], [], [], []
@@ -367,6 +435,18 @@ def compile_plan(form, costs=None, limits=None):
     rowptr, entbase, entk, entcoef, rtot = _csr_tables(
         b.rowset_rows, b.base_row0, b.base_rows, b.total_base_rows)
     assert rtot == b.rtot
+    ldv = no + 1 + ((no + 1) & 1)
+    fused = _fused_program(b, rowptr, entbase, entk, entcoef, rtot, ldv)
+    # structural tile masks of the gterm operands (exact zeros of the workspace)
+    tiles = fused["row_tiles"]
+    for rec in gterms:
+        def mask(off, n):
+            m = 0
+            for r in range(off, off + n):
+                m |= int(tiles[r])
+            return m
+        rec[7] = mask(rec[0], rec[2])
+        rec[8] = mask(rec[1], rec[2]) if rec[1] >= 0 else 0
     pm_blocks, pm_rows, r0 = [], {}, 0
     for var in form.definitions.keys():
         M = b.var_matrix[var]
@@ -389,16 +469,21 @@ def compile_plan(form, costs=None, limits=None):
         ("OFF_PM_ROWPTR", pm_rowptr),
         ("OFF_PM_ENTBASE", pm_entbase),
         ("OFF_PM_ENTK", pm_entk),
+        ("OFF_ARENA", fused["arena"]),
+        ("OFF_FD_IDX", fused["fd_idx"]),
+        ("OFF_FD_PTR", fused["fd_ptr"]),
+        ("OFF_OP", fused["ops"]),
     ]
     header = np.zeros(H_WORDS, dtype=np.int32)
     parts, off = [header], H_WORDS
     for name, arr in sections:
+        if name == "OFF_OP" and off & 1:          # the kernels read ops as 8-byte pairs
+            parts.append(np.zeros(1, dtype=np.int32))
+            off += 1
         header[_H[name]] = off
         parts.append(arr)
         off += arr.size
-    dtab = np.concatenate([entcoef, pm_entcoef]).astype(np.float64)
-
-    ldv = no + 1 + ((no + 1) & 1)
+    dtab = np.concatenate([entcoef, pm_entcoef, fused["coefpool"]]).astype(np.float64)
     params = np.asarray(b.params, dtype=np.float64)
     header[_H["MAGIC"]], header[_H["VERSION"]] = PLAN_MAGIC, PLAN_VERSION
     header[_H["NG"]], header[_H["NO"]], header[_H["NC"]] = b.ng, no, nc
@@ -409,6 +494,10 @@ def compile_plan(form, costs=None, limits=None):
     header[_H["NLAX"]], header[_H["PMROWS"]] = len(lax_recs), pmrows
     header[_H["PM_NENT"]], header[_H["LDV"]] = pm_entcoef.size, ldv
     header[_H["DOFF_ENTCOEF"]], header[_H["DOFF_PM_ENTCOEF"]] = 0, entcoef.size
+    header[_H["FUSED_OK"]], header[_H["ARENA_TOTAL"]] = fused["ok"], fused["arena_total"]
+    header[_H["NFD"]], header[_H["NOPS"]] = fused["fd_idx"].size, fused["ops"].size // 2
+    header[_H["NCOEF"]] = fused["coefpool"].size
+    header[_H["DOFF_COEFPOOL"]] = entcoef.size + pm_entcoef.size
     header[_H["NITAB"]], header[_H["NDTAB"]] = off, dtab.size
 
     plan = Plan()

@@ -60,7 +60,7 @@ def run(plan, given, params=None, sources=None):
 
     Pm, q = np.zeros((no, no)), np.zeros(no)
     gt = _section(it, "OFF_GTERM", it[H["NGTERM"]] * P.GT_WORDS).reshape(-1, P.GT_WORDS)
-    for a, b, n, pw, d, pa, flags, _ in gt:
+    for a, b, n, pw, d, pa, flags, _ma, _mb, _pad in gt:
         w, aim = params[pw], params[pa]
         scale = 0.5 if flags & P.GT_FLAG_HALF else 1.0
         A = w * V[a:a + n, :no]
@@ -94,3 +94,43 @@ def run(plan, given, params=None, sources=None):
     PM = np.stack([_row(plan, srcs, prp, peb, pek, pcoef, r, W) for r in range(pmrows)]) \
         if pmrows else np.zeros((0, W))
     return {"V": V, "P": Pm, "q": q, "G": G, "h": h, "PM": PM}
+
+
+def run_fused_workspace(plan, given, sources=None):
+    """Workspace V built by the *fused program* (per-element op lists over the
+    on-chip source arena), for comparison with the row-set program's V."""
+    it, dt = plan.itab, plan.dtab
+    no, ldv = plan.no, plan.ldv
+    srcs = [s.array for s in plan.sources] if sources is None else sources
+    g = np.asarray(given, dtype=float).ravel()
+    assert it[H["FUSED_OK"]] == 1
+    arena = np.zeros(it[H["ARENA_TOTAL"]])
+    arena[0] = 1.0
+    rec = _section(it, "OFF_ARENA", 2 * it[H["NSRC"]]).reshape(-1, 2)
+    for (off, size), a in zip(rec, srcs):
+        assert a.size == size
+        arena[off:off + size] = a.ravel()
+    nfd, nops = it[H["NFD"]], it[H["NOPS"]]
+    fd_idx = _section(it, "OFF_FD_IDX", nfd)
+    fd_ptr = _section(it, "OFF_FD_PTR", nfd + 1)
+    ops = _section(it, "OFF_OP", 2 * nops).view(np.uint32).reshape(-1, 2)
+    pool = dt[it[H["DOFF_COEFPOOL"]]:it[H["DOFF_COEFPOOL"]] + it[H["NCOEF"]]]
+    V = np.zeros(plan.rtot * ldv)
+    for i in range(nfd):
+        acc = 0.0
+        for o in range(fd_ptr[i], fd_ptr[i + 1]):
+            src, packed = int(ops[o, 0]), int(ops[o, 1])
+            gi, cid = (packed >> 16) - 1, packed & 0xFFFF
+            acc += pool[cid] * arena[src] * (g[gi] if gi >= 0 else 1.0)
+        V[fd_idx[i]] = acc
+    V = V.reshape(plan.rtot, ldv)[:, :no + 1]
+    # tile masks promise exact zeros outside the marked 16-column tiles
+    gt = _section(it, "OFF_GTERM", it[H["NGTERM"]] * P.GT_WORDS).reshape(-1, P.GT_WORDS)
+    for a, b, n, pw, d, pa, flags, ma, mb, _pad in gt:
+        for off, mask in ((a, ma), (b, mb)):
+            if off < 0:
+                continue
+            for t in range((no + 15) // 16):
+                if not (mask >> min(t, 30)) & 1:
+                    assert not V[off:off + n, 16 * t:min(16 * t + 16, no)].any()
+    return V

@@ -15,6 +15,22 @@ from oracle import qp_oracle as orc
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["fused", "staged"])
+def kernel_path(request):
+    """Every test runs twice: on the fused single-launch kernel (taken when one
+    instance fits on chip) and on the staged K2 -> K3 -> K4 pipeline."""
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    from mpcasm import capi
+
+    lib = capi.load()
+    assert lib.mpcasm_set_option(capi.OPT_FORCE_STAGED, int(request.param == "staged")) == 0
+    yield request.param
+    lib.mpcasm_set_option(capi.OPT_FORCE_STAGED, 0)
+
+
 def check_drop_in(form, g, prefix, parts=True):
     """The reference's call sequence on this repository's Formulation (B=1 path)."""
     assert {k: form.optim_ID[k] for k in form.optim_variables} == \

@@ -27,6 +27,8 @@ def check_plan(form, given, tol=1e-12):
     assert_close(out["q"], q.ravel(), tol, "q")
     assert_close(out["G"], A, tol, "G")
     assert_close(out["h"], h.ravel(), tol, "h")
+    # the fused program (per-element op lists) builds the same workspace
+    assert_close(plan_emulator.run_fused_workspace(plan, given), out["V"], tol, "fused V")
     for var, (r0, rows) in plan.pm_rows.items():
         block = out["PM"][r0:r0 + rows]
         assert_close(block[:, :plan.ng], PM[var][0], tol, var + " Mg")
