@@ -50,10 +50,16 @@ int mpcasm_device_count(void);
 int mpcasm_last_hip(void);
 /* Static string for a status code. */
 const char* mpcasm_status_string(int status);
-/* Process-wide options.  MPCASM_OPT_FORCE_STAGED (value 0/1): always take the
- * staged K2 -> K3 -> K4 pipeline (workspace in HBM) instead of the fused
- * single-launch kernel; used by the parity tests to exercise both paths. */
-enum { MPCASM_OPT_FORCE_STAGED = 1 };
+/* Process-wide options.  MPCASM_OPT_PATH selects the assembly kernels: 0 = best
+ * available (persistent fused kernel when one instance fits on chip), 1 = never
+ * the persistent kernel (per-instance fused kernel if it fits), 2 = always the
+ * staged K2 -> K3 -> K4 pipeline with the workspace in HBM.  The parity tests use
+ * it to exercise every path; all paths give the same results. */
+enum { MPCASM_OPT_PATH = 1, MPCASM_OPT_PHASE_MASK = 2 };
+/* MPCASM_OPT_PHASE_MASK is a profiling aid (timing-only ablation of the fused
+ * kernels: bit 0 compose, 1 Hessian, 2 gradient, 3 constraints, 4 input staging
+ * after the first instance, 5 P/q stores; default 0xFF);
+ * results are WRONG with any bit cleared -- never use it outside a profile. */
 int mpcasm_set_option(int option, int value);
 
 /* K1  horizon extension ---------------------------------------------------

@@ -12,7 +12,8 @@
 using namespace mpcasm;
 
 namespace mpcasm {
-extern bool g_force_staged;
+extern int g_path;
+extern int g_phase_mask;
 }
 
 struct mpcasm_plan {
@@ -20,6 +21,7 @@ struct mpcasm_plan {
   int32_t* d_itab;
   double* d_dtab;
   int device;
+  int num_cus;
 };
 
 namespace {
@@ -87,6 +89,56 @@ int validate_plan(const int32_t* it, size_t n_itab, size_t n_dtab) {
     for (int o = 0; o < it[H_NOPS]; ++o) {
       if (op[2 * o] >= (uint32_t)it[H_ARENA_TOTAL]) return MPCASM_ERR_PLAN;
       if ((op[2 * o + 1] >> 16) > (uint32_t)ng || (op[2 * o + 1] & 0xFFFFu) >= (uint32_t)it[H_NCOEF])
+        return MPCASM_ERR_PLAN;
+    }
+  }
+
+  if (it[H_RS_OK] != 0 && it[H_RS_OK] != 1) return MPCASM_ERR_PLAN;
+  if (it[H_RS_OK]) {
+    if (!it[H_FUSED_OK]) return MPCASM_ERR_PLAN;
+    const int64_t jc = it[H_RS_JC], slots = jc * RS_NT;
+    if (jc < 1 || jc > RS_JC_MAX || it[H_RS_NITEM] < 0) return MPCASM_ERR_PLAN;
+    bool r = true;
+    r = r && in_range(it[H_OFF_RS_SRC], slots, n, H_WORDS);
+    r = r && in_range(it[H_OFF_RS_GIDX], slots, n, H_WORDS);
+    r = r && in_range(it[H_OFF_RS_DST], slots, n, H_WORDS);
+    r = r && in_range(it[H_DOFF_RS_COEF], slots, nd, 0);
+    r = r && in_range(it[H_OFF_RS_ITEM], (int64_t)it[H_RS_NITEM] * RS_ITEM_WORDS, n, H_WORDS);
+    r = r && in_range(it[H_OFF_RS_ISLOT], RS_NW * RS_TPW * 2, n, H_WORDS);
+    r = r && in_range(it[H_OFF_RS_TILE], RS_NW * RS_TPW, n, H_WORDS);
+    r = r && it[H_RS_NQ] >= 0 && in_range(it[H_OFF_RS_GQ], (int64_t)it[H_RS_NQ] * 4, n, H_WORDS);
+    r = r && (it[H_OFF_RS_GQ] % 4 == 0) && (it[H_OFF_RS_ITEM] % 4 == 0);
+    if (!r) return MPCASM_ERR_PLAN;
+    const int64_t vsize = (int64_t)it[H_RTOT] * it[H_LDV];
+    const int32_t* ts = it + it[H_OFF_RS_SRC];
+    const int32_t* tg = it + it[H_OFF_RS_GIDX];
+    const int32_t* td = it + it[H_OFF_RS_DST];
+    for (int64_t i = 0; i < slots; ++i)
+      if (ts[i] < 0 || ts[i] >= it[H_ARENA_TOTAL] || tg[i] < -1 || tg[i] >= ng || td[i] < -1 ||
+          td[i] >= vsize)
+        return MPCASM_ERR_PLAN;
+    const int32_t* ti = it + it[H_OFF_RS_ITEM];
+    for (int i = 0; i < it[H_RS_NITEM]; ++i) {
+      const int32_t* x = ti + i * RS_ITEM_WORDS;
+      if (x[2] < 0 || x[3] < 0 || x[3] >= it[H_NPARAMS]) return MPCASM_ERR_PLAN;
+      if (x[2] == 0) continue;
+      for (int k = 0; k < 2; ++k)
+        if (x[k] < 0 || (int64_t)x[k] + (int64_t)(x[2] - 1) * it[H_LDV] + 16 > vsize + 16)
+          return MPCASM_ERR_PLAN;
+    }
+    const int32_t* gq = it + it[H_OFF_RS_GQ];
+    for (int i = 0; i < it[H_RS_NQ]; ++i) {
+      const int32_t* x = gq + 4 * i;
+      if (x[0] < 0 || x[0] + no > vsize || x[1] < 0 || x[1] >= vsize || x[2] < 0 ||
+          x[2] >= it[H_NPARAMS] || (x[3] & 0x3FFFFFFF) >= it[H_NPARAMS] || x[3] < 0)
+        return MPCASM_ERR_PLAN;
+    }
+    const int nt = ((int)no + 15) / 16;
+    const int32_t* sl = it + it[H_OFF_RS_ISLOT];
+    const int32_t* tl = it + it[H_OFF_RS_TILE];
+    for (int i = 0; i < RS_NW * RS_TPW; ++i) {
+      if (tl[i] < -1 || tl[i] >= nt * nt) return MPCASM_ERR_PLAN;
+      if (sl[2 * i] < 0 || sl[2 * i + 1] < 0 || sl[2 * i] + sl[2 * i + 1] > it[H_RS_NITEM])
         return MPCASM_ERR_PLAN;
     }
   }
@@ -179,8 +231,13 @@ int mpcasm_device_count(void) {
 int mpcasm_last_hip(void) { return g_last_hip; }
 
 int mpcasm_set_option(int option, int value) {
-  if (option == MPCASM_OPT_FORCE_STAGED) {
-    g_force_staged = value != 0;
+  if (option == MPCASM_OPT_PATH) {
+    if (value < 0 || value > 2) return MPCASM_ERR_ARG;
+    g_path = value;
+    return MPCASM_OK;
+  }
+  if (option == MPCASM_OPT_PHASE_MASK) {
+    g_phase_mask = value;
     return MPCASM_OK;
   }
   return MPCASM_ERR_ARG;
@@ -258,6 +315,18 @@ int mpcasm_plan_create(const int32_t* h_itab, size_t n_itab, const double* h_dta
   d.nfd = it[H_NFD]; d.off_fd_idx = it[H_OFF_FD_IDX]; d.off_fd_ptr = it[H_OFF_FD_PTR];
   d.nops = it[H_NOPS]; d.off_op = it[H_OFF_OP]; d.ncoef = it[H_NCOEF];
   d.doff_coefpool = it[H_DOFF_COEFPOOL];
+  d.rs_ok = it[H_RS_OK]; d.rs_jc = it[H_RS_JC]; d.rs_sym = it[H_RS_SYM];
+  d.rs_nitem = it[H_RS_NITEM]; d.off_rs_src = it[H_OFF_RS_SRC]; d.off_rs_gidx = it[H_OFF_RS_GIDX];
+  d.off_rs_dst = it[H_OFF_RS_DST]; d.doff_rs_coef = it[H_DOFF_RS_COEF];
+  d.off_rs_item = it[H_OFF_RS_ITEM]; d.off_rs_islot = it[H_OFF_RS_ISLOT];
+  d.off_rs_tile = it[H_OFF_RS_TILE];
+  d.rs_nq = it[H_RS_NQ]; d.off_rs_gq = it[H_OFF_RS_GQ];
+  {
+    hipDeviceProp_t prop;
+    plan->num_cus = 256;
+    if (hipGetDeviceProperties(&prop, plan->device) == hipSuccess && prop.multiProcessorCount > 0)
+      plan->num_cus = prop.multiProcessorCount;
+  }
   d.max_axes = 0;
   for (int l = 0; l < it[H_NLIMIT]; ++l) {
     const int na = it[it[H_OFF_LIMIT] + l * LM_WORDS + LM_NAXES];
@@ -310,7 +379,7 @@ int mpcasm_assemble(const mpcasm_plan* plan, const double* const* h_src,
   if (rc != MPCASM_OK) return rc;
   hipError_t err;
   rc = launch_assemble(d, src, d_params, d_given, d_P, d_q, d_G, d_h, d_work, batch,
-                       static_cast<hipStream_t>(stream), &err);
+                       plan->num_cus, static_cast<hipStream_t>(stream), &err);
   if (rc == MPCASM_ERR_HIP) g_last_hip = (int)err;
   return rc;
 }
@@ -345,16 +414,20 @@ int mpcasm_preview(const double* d_PM, const double* d_given, const double* d_op
 
 namespace mpcasm {
 
-bool g_force_staged = false;  // test hook: mpcasm_set_option(MPCASM_OPT_FORCE_STAGED, 1)
+int g_path = 0;  // test hook (MPCASM_OPT_PATH): 0 best, 1 no resident kernel, 2 staged only
 
 // dispatch: fused single launch when the problem fits on chip, else staged
 int launch_assemble(const PlanDev& p, const SrcTable& src, const double* params,
                     const double* given, double* P, double* q, double* G, double* h, void* work,
-                    int batch, hipStream_t stream, hipError_t* err) {
+                    int batch, int num_cus, hipStream_t stream, hipError_t* err) {
   // LDS budget that still leaves two workgroups per CU (160 KiB each)
   constexpr size_t FUSED_LDS_LIMIT = 80 * 1024;
+  const size_t rs = resident_lds_bytes(p);
+  if (rs != 0 && rs <= FUSED_LDS_LIMIT && g_path == 0)
+    return launch_assemble_resident(p, src, params, given, P, q, G, h, batch, rs, num_cus, stream,
+                                    err);
   const size_t lds = fused_lds_bytes(p, 4);
-  if (lds != 0 && lds <= FUSED_LDS_LIMIT && !g_force_staged)
+  if (lds != 0 && lds <= FUSED_LDS_LIMIT && g_path <= 1)
     return launch_assemble_fused(p, src, params, given, P, q, G, h, batch, lds, stream, err);
   return launch_assemble_staged(p, src, params, given, P, q, G, h, work, batch, stream, err);
 }

@@ -16,6 +16,19 @@ __device__ __forceinline__ f64x4 mfma_f64_16x16x4(double a, double b, f64x4 c) {
   return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains
+// the vector-memory counter (s_waitcnt vmcnt(0)), i.e. it waits for every global
+// store in flight to be acknowledged by HBM -- a full memory round trip per
+// barrier in kernels that stream results out between LDS phases.  LDS operations
+// of a wavefront complete in order, so lgkmcnt(0) + s_barrier is sufficient for
+// data handed over through LDS; loads whose results feed LDS writes are waited
+// for by the compiler through the data dependency.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 // sum over the 64 lanes of a wavefront, result in every lane
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll

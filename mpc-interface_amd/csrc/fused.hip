@@ -26,6 +26,8 @@
 
 namespace mpcasm {
 
+int g_phase_mask = 0xFF;  // diagnostic (timing-only ablation): see mpcasm_set_option
+
 namespace {
 
 constexpr int TPW = 9;       // MFMA output tiles a wavefront may own
@@ -59,7 +61,7 @@ template <int NW>
 __global__ __launch_bounds__(NW * 64) void fused_assemble_kernel(
     PlanDev p, SrcTable src, const double* __restrict__ params, const double* __restrict__ given,
     double* __restrict__ P, double* __restrict__ q, double* __restrict__ G,
-    double* __restrict__ h, int batch) {
+    double* __restrict__ h, int batch, int phases) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   constexpr int NT = NW * 64;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -92,10 +94,10 @@ __global__ __launch_bounds__(NW * 64) void fused_assemble_kernel(
     const double* pb = params + inst * p.nparams;
     for (int i = tid; i < p.nparams; i += NT) prm[i] = pb[i];
   }
-  __syncthreads();
+  lds_barrier();
 
   // ---- phase 2: compose the workspace (K2) -------------------------------------
-  {
+  if (phases & 1) {
     const int32_t* fd_idx = p.itab + p.off_fd_idx;
     const int32_t* fd_ptr = p.itab + p.off_fd_ptr;
     const int2* ops = reinterpret_cast<const int2*>(p.itab + p.off_op);
@@ -113,6 +115,8 @@ __global__ __launch_bounds__(NW * 64) void fused_assemble_kernel(
       }
       V[fd_idx[i]] = acc;
     }
+  }
+  {
     // per output row of G: arrows and workspace row offsets of its axes
     const int32_t* rowlimit = p.itab + p.off_rowlimit;
     const int32_t* limits = p.itab + p.off_limit;
@@ -131,11 +135,11 @@ __global__ __launch_bounds__(NW * 64) void fused_assemble_kernel(
       rr_voff[R * (AXMAX + 1) + AXMAX] = naxes;
     }
   }
-  __syncthreads();
+  lds_barrier();
 
   const int32_t* gt = p.itab + p.off_gterm;
 
-  if (P != nullptr) {
+  if (P != nullptr && (phases & 2)) {
     // ---- phase 3a: Hessian on the matrix core ---------------------------------
     const int nt = (no + 15) >> 4;  // 16-column tiles per dimension
     const int li = lane & 15, lk = lane >> 4;
@@ -190,6 +194,8 @@ __global__ __launch_bounds__(NW * 64) void fused_assemble_kernel(
       }
     }
 
+  }
+  if (P != nullptr && (phases & 4)) {
     // ---- phase 3b: gradient, rows split over the wavefronts ---------------------
     double qa[QSLOT];
 #pragma unroll
@@ -218,7 +224,7 @@ __global__ __launch_bounds__(NW * 64) void fused_assemble_kernel(
     }
   }
 
-  if (G != nullptr) {
+  if (G != nullptr && (phases & 8)) {
     // ---- phase 3c: constraint rows (K4) -----------------------------------------
     double* Gb = G + (size_t)inst * nc * no;
     if ((no & 1) == 0) {
@@ -286,7 +292,7 @@ __global__ __launch_bounds__(NW * 64) void fused_assemble_kernel(
 
   // ---- phase 4: reduce q ------------------------------------------------------------
   if (P != nullptr) {
-    __syncthreads();
+    lds_barrier();
     double* qb = q + (size_t)inst * no;
     for (int c = tid; c < no; c += NT) {
       double s = 0.0;
@@ -319,7 +325,7 @@ int launch_assemble_fused(const PlanDev& p, const SrcTable& src, const double* p
     if (*err != hipSuccess) return MPCASM_ERR_HIP;
   }
   hipLaunchKernelGGL(kernel, dim3(batch), dim3(NW * 64), lds_bytes, stream, p, src, params, given,
-                     P, q, G, h, batch);
+                     P, q, G, h, batch, g_phase_mask);
   *err = hipGetLastError();
   return *err == hipSuccess ? MPCASM_OK : MPCASM_ERR_HIP;
 }

@@ -20,6 +20,9 @@ struct PlanDev {
   // fused program
   int fused_ok, arena_total, off_arena, nfd, off_fd_idx, off_fd_ptr, nops, off_op, ncoef,
       doff_coefpool, max_axes;
+  // resident program
+  int rs_ok, rs_jc, rs_sym, rs_nitem, off_rs_src, off_rs_gidx, off_rs_dst, doff_rs_coef,
+      off_rs_item, off_rs_islot, off_rs_tile, rs_nq, off_rs_gq;
 };
 
 // sources of one launch (device pointers + per-instance strides, by value)
@@ -42,9 +45,15 @@ size_t fused_lds_bytes(const PlanDev& p, int nw);
 int launch_assemble_fused(const PlanDev& p, const SrcTable& src, const double* params,
                           const double* given, double* P, double* q, double* G, double* h,
                           int batch, size_t lds_bytes, hipStream_t stream, hipError_t* err);
+// resident.hip
+size_t resident_lds_bytes(const PlanDev& p);
+int launch_assemble_resident(const PlanDev& p, const SrcTable& src, const double* params,
+                             const double* given, double* P, double* q, double* G, double* h,
+                             int batch, size_t lds_bytes, int num_cus, hipStream_t stream,
+                             hipError_t* err);
 int launch_assemble(const PlanDev& p, const SrcTable& src, const double* params,
                     const double* given, double* P, double* q, double* G, double* h, void* work,
-                    int batch, hipStream_t stream, hipError_t* err);
+                    int batch, int num_cus, hipStream_t stream, hipError_t* err);
 int launch_preview_matrices(const PlanDev& p, const SrcTable& src, double* PM, int batch,
                             hipStream_t stream, hipError_t* err);
 int launch_preview(const double* PM, const double* given, const double* optim, double* out,

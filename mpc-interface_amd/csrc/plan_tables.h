@@ -27,7 +27,7 @@
 namespace mpcasm {
 
 constexpr int32_t PLAN_MAGIC = 0x4D504341;  // 'MPCA'
-constexpr int32_t PLAN_VERSION = 4;
+constexpr int32_t PLAN_VERSION = 7;
 
 enum HeaderWord : int {
   H_MAGIC = 0,
@@ -74,7 +74,23 @@ enum HeaderWord : int {
   H_OFF_OP,        // [NOPS][2]: arena offset of the source value; (given index + 1) << 16 | coef id
   H_NCOEF,
   H_DOFF_COEFPOOL, // [NCOEF] distinct coefficients
-  H_WORDS = 48
+  // ---- resident program (persistent fused kernel: tables live in registers / LDS) ----
+  H_RS_OK,
+  H_RS_JC,          // compose ops per thread (RS_NT threads per instance)
+  H_RS_SYM,         // 1: every Hessian term has A == B, only tiles ti <= tj are computed
+  H_RS_NITEM,
+  H_OFF_RS_SRC,     // [JC][RS_NT] arena offset of the op's source value
+  H_OFF_RS_GIDX,    // [JC][RS_NT] given index or -1
+  H_OFF_RS_DST,     // [JC][RS_NT] workspace index to store the running sum to, or -1
+  H_DOFF_RS_COEF,   // [JC][RS_NT]
+  H_OFF_RS_ITEM,    // [NITEM][4]: one (tile, gterm) pair: workspace offset of the A rows (tile
+                    //             column included), of the B rows, number of rows, weight param
+  H_OFF_RS_ISLOT,   // [RS_NW][RS_TPW][2] first item, item count of a wavefront's tile slot
+  H_OFF_RS_TILE,    // [RS_NW][RS_TPW] tile index ti * nt + tj, or -1
+  H_RS_NQ,          // gradient records: one per (gterm, row)
+  H_OFF_RS_GQ,      // [NQ][4]: workspace offset of the A row, index of d, aim param,
+                    //          weight param | (1 << 30 when the term is halved)
+  H_WORDS = 64
 };
 
 // segment record
@@ -97,5 +113,6 @@ enum {
 enum { LX_ROWOFF = 0, LX_ROWS, LX_WORDS = 2 };
 
 constexpr int MAX_SOURCES = 32;
+constexpr int RS_NW = 4, RS_NT = 256, RS_TPW = 9, RS_JC_MAX = 24, RS_ITEM_WORDS = 4;
 
 }  // namespace mpcasm

@@ -11,7 +11,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmpcasm.so")
 
 OK = 0
-OPT_FORCE_STAGED = 1
+OPT_PATH = 1
+OPT_PHASE_MASK = 2
 STATUS = {
     0: "MPCASM_OK",
     -1: "MPCASM_ERR_ARG",

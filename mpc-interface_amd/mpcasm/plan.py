@@ -15,7 +15,7 @@ import numpy as np
 import scipy.sparse as sp
 
 PLAN_MAGIC = 0x4D504341
-PLAN_VERSION = 4
+PLAN_VERSION = 7
 
 # header words (csrc/plan_tables.h, enum HeaderWord)
 _H = {name: i for i, name in enumerate([
@@ -26,8 +26,13 @@ _H = {name: i for i, name in enumerate([
     "DOFF_ENTCOEF", "DOFF_PM_ENTCOEF", "NITAB", "NDTAB",
     "FUSED_OK", "ARENA_TOTAL", "OFF_ARENA", "NFD", "OFF_FD_IDX", "OFF_FD_PTR", "NOPS", "OFF_OP",
     "NCOEF", "DOFF_COEFPOOL",
+    "RS_OK", "RS_JC", "RS_SYM", "RS_NITEM", "OFF_RS_SRC", "OFF_RS_GIDX", "OFF_RS_DST",
+    "DOFF_RS_COEF", "OFF_RS_ITEM", "OFF_RS_ISLOT", "OFF_RS_TILE", "RS_NQ", "OFF_RS_GQ",
 ])}
-H_WORDS = 48
+H_WORDS = 64
+RS_NW, RS_NT, RS_TPW = 4, 256, 9          # wavefronts / threads per instance, tiles per wave
+RS_JC_MAX = 24                            # compose ops a thread can keep in registers
+RS_ITEM_WORDS = 4
 SEG_WORDS, GT_WORDS, LM_WORDS, LX_WORDS = 8, 10, 12, 2
 FUSED_MAX_OPS = 1 << 18           # beyond this the staged pipeline is used
 FUSED_MAX_ARENA = 1 << 14         # doubles
@@ -343,6 +348,99 @@ def _fused_program(b, rowptr, entbase, entk, entcoef, rtot, ldv):
                 row_tiles=row_tiles)
 
 
+def _resident_program(fused, gterms, no, ldv):
+    """Tables of the persistent fused kernel: the compose ops of ``_fused_program``
+    dealt out to the RS_NT threads of a workgroup (kept in registers for the whole
+    launch) and the Hessian work split into per-wavefront lists of MFMA items."""
+    import heapq
+
+    NT, NW, TPW = RS_NT, RS_NW, RS_TPW
+    z = np.zeros(0, dtype=np.int32)
+    out = dict(ok=0, jc=0, sym=0, src=z, gidx=z, dst=z, coef=np.zeros(0), items=z, gq=z,
+               islot=np.zeros(NW * TPW * 2, dtype=np.int32),
+               tile=-np.ones(NW * TPW, dtype=np.int32))
+    if not fused["ok"]:
+        return out
+    # ---- compose: whole elements to threads, longest first onto the lightest thread
+    fd_idx, fd_ptr = fused["fd_idx"], fused["fd_ptr"]
+    ops = fused["ops"].view(np.uint32).reshape(-1, 2)
+    pool = fused["coefpool"]
+    counts = np.diff(fd_ptr)
+    heap = [(0, t) for t in range(NT)]
+    heapq.heapify(heap)
+    owner = [[] for _ in range(NT)]
+    for i in np.argsort(-counts, kind="stable"):
+        load, t = heapq.heappop(heap)
+        owner[t].append(int(i))
+        heapq.heappush(heap, (load + int(counts[i]), t))
+    jc = max((sum(int(counts[i]) for i in own) for own in owner), default=0)
+    jc = max(jc, 1)
+    if jc > RS_JC_MAX:
+        return out
+    src = np.zeros((jc, NT), dtype=np.int32)            # arena slot 0 = constant 1.0
+    gidx = -np.ones((jc, NT), dtype=np.int32)
+    dst = -np.ones((jc, NT), dtype=np.int32)
+    coef = np.zeros((jc, NT))
+    for t, own in enumerate(owner):
+        j = 0
+        for i in sorted(own):
+            for o in range(fd_ptr[i], fd_ptr[i + 1]):
+                src[j, t] = int(ops[o, 0])
+                gidx[j, t] = (int(ops[o, 1]) >> 16) - 1
+                coef[j, t] = pool[int(ops[o, 1]) & 0xFFFF]
+                j += 1
+            dst[j - 1, t] = int(fd_idx[i])               # store after the element's last op
+    # ---- Hessian: one item = 4 workspace rows of one gterm into one 16x16 tile
+    nt = (no + 15) // 16
+    pterms = [g for g in gterms if g[6] & GT_FLAG_P]
+    sym = int(all(g[0] == g[1] for g in pterms))
+    tile_items = {}
+    for ti in range(nt):
+        for tj in range(ti if sym else 0, nt):
+            tile_items[(ti, tj)] = []
+    for g in pterms:
+        aoff, boff, nrows, wparam = g[0], g[1], g[2], g[3]
+        for (ti, tj), lst in tile_items.items():
+            if not ((g[7] >> min(ti, 30)) & 1 and (g[8] >> min(tj, 30)) & 1):
+                continue
+            lst.append([aoff * ldv + ti * 16, boff * ldv + tj * 16, nrows, wparam])
+    cost = {key: sum((it[2] + 3) // 4 for it in lst) for key, lst in tile_items.items()}
+    if len(tile_items) > NW * TPW:
+        return out
+    loads = [(0, w) for w in range(NW)]
+    heapq.heapify(loads)
+    wave_tiles = [[] for _ in range(NW)]
+    for key in sorted(tile_items, key=lambda k: -cost[k]):
+        full = []
+        while True:
+            load, w = heapq.heappop(loads)
+            if len(wave_tiles[w]) < TPW:
+                break
+            full.append((load, w))
+        for entry in full:
+            heapq.heappush(loads, entry)
+        wave_tiles[w].append(key)
+        heapq.heappush(loads, (load + cost[key], w))
+    items, islot, tile = [], out["islot"], out["tile"]
+    for w in range(NW):
+        for s_, key in enumerate(wave_tiles[w]):
+            islot[(w * TPW + s_) * 2] = len(items)
+            islot[(w * TPW + s_) * 2 + 1] = len(tile_items[key])
+            tile[w * TPW + s_] = key[0] * nt + key[1]
+            items.extend(tile_items[key])
+    # ---- gradient: one record per (gterm, row): q += w s V[a] (V[d] - aim)
+    gq = []
+    for g in gterms:
+        half = (1 << 30) if g[6] & GT_FLAG_HALF else 0
+        for k in range(g[2]):
+            gq.append([(g[0] + k) * ldv, (g[4] + k) * ldv + no, g[5], g[3] | half])
+    out["gq"] = np.asarray(gq, dtype=np.int32).reshape(-1)
+    out.update(ok=1, jc=jc, sym=sym, src=src.reshape(-1), gidx=gidx.reshape(-1),
+               dst=dst.reshape(-1), coef=coef.reshape(-1),
+               items=np.asarray(items, dtype=np.int32).reshape(-1))
+    return out
+
+
 def compile_plan(form, costs=None, limits=None):
     """Compile ``form`` (an up-to-date Formulation: sizes and IDs current).
 
@@ -447,6 +545,7 @@ def compile_plan(form, costs=None, limits=None):
             return m
         rec[7] = mask(rec[0], rec[2])
         rec[8] = mask(rec[1], rec[2]) if rec[1] >= 0 else 0
+    resident = _resident_program(fused, gterms, no, ldv)
     pm_blocks, pm_rows, r0 = [], {}, 0
     for var in form.definitions.keys():
         M = b.var_matrix[var]
@@ -473,6 +572,13 @@ def compile_plan(form, costs=None, limits=None):
         ("OFF_FD_IDX", fused["fd_idx"]),
         ("OFF_FD_PTR", fused["fd_ptr"]),
         ("OFF_OP", fused["ops"]),
+        ("OFF_RS_SRC", resident["src"]),
+        ("OFF_RS_GIDX", resident["gidx"]),
+        ("OFF_RS_DST", resident["dst"]),
+        ("OFF_RS_ITEM", resident["items"]),
+        ("OFF_RS_ISLOT", resident["islot"]),
+        ("OFF_RS_TILE", resident["tile"]),
+        ("OFF_RS_GQ", resident["gq"]),
     ]
     header = np.zeros(H_WORDS, dtype=np.int32)
     parts, off = [header], H_WORDS
@@ -480,10 +586,15 @@ def compile_plan(form, costs=None, limits=None):
         if name == "OFF_OP" and off & 1:          # the kernels read ops as 8-byte pairs
             parts.append(np.zeros(1, dtype=np.int32))
             off += 1
+        if name in ("OFF_RS_GQ", "OFF_RS_ITEM") and off & 3:   # ... and these as 16-byte quads
+            pad = 4 - (off & 3)
+            parts.append(np.zeros(pad, dtype=np.int32))
+            off += pad
         header[_H[name]] = off
         parts.append(arr)
         off += arr.size
-    dtab = np.concatenate([entcoef, pm_entcoef, fused["coefpool"]]).astype(np.float64)
+    dtab = np.concatenate([entcoef, pm_entcoef, fused["coefpool"],
+                           resident["coef"]]).astype(np.float64)
     params = np.asarray(b.params, dtype=np.float64)
     header[_H["MAGIC"]], header[_H["VERSION"]] = PLAN_MAGIC, PLAN_VERSION
     header[_H["NG"]], header[_H["NO"]], header[_H["NC"]] = b.ng, no, nc
@@ -498,6 +609,11 @@ def compile_plan(form, costs=None, limits=None):
     header[_H["NFD"]], header[_H["NOPS"]] = fused["fd_idx"].size, fused["ops"].size // 2
     header[_H["NCOEF"]] = fused["coefpool"].size
     header[_H["DOFF_COEFPOOL"]] = entcoef.size + pm_entcoef.size
+    header[_H["RS_OK"]], header[_H["RS_JC"]] = resident["ok"], resident["jc"]
+    header[_H["RS_SYM"]] = resident["sym"]
+    header[_H["RS_NITEM"]] = resident["items"].size // RS_ITEM_WORDS
+    header[_H["RS_NQ"]] = resident["gq"].size // 4
+    header[_H["DOFF_RS_COEF"]] = entcoef.size + pm_entcoef.size + fused["coefpool"].size
     header[_H["NITAB"]], header[_H["NDTAB"]] = off, dtab.size
 
     plan = Plan()
@@ -515,4 +631,5 @@ def compile_plan(form, costs=None, limits=None):
     plan.optim_ID = {v: form.optim_ID[v] for v in form.optim_variables}
     plan.given_ID = {v: form.given_ID[v] for v in form.given_variables}
     plan.n_gterms = len(gterms)
+    plan.resident = resident
     return plan

@@ -15,10 +15,14 @@ from oracle import qp_oracle as orc
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["fused", "staged"])
+PATHS = {"resident": 0, "fused": 1, "staged": 2}
+
+
+@pytest.fixture(autouse=True, params=list(PATHS))
 def kernel_path(request):
-    """Every test runs twice: on the fused single-launch kernel (taken when one
-    instance fits on chip) and on the staged K2 -> K3 -> K4 pipeline."""
+    """Every test runs on each assembly path: the persistent fused kernel, the
+    per-instance fused kernel (both taken only when one instance fits on chip) and
+    the staged K2 -> K3 -> K4 pipeline."""
     import torch
 
     if not torch.cuda.is_available():
@@ -26,9 +30,9 @@ def kernel_path(request):
     from mpcasm import capi
 
     lib = capi.load()
-    assert lib.mpcasm_set_option(capi.OPT_FORCE_STAGED, int(request.param == "staged")) == 0
+    assert lib.mpcasm_set_option(capi.OPT_PATH, PATHS[request.param]) == 0
     yield request.param
-    lib.mpcasm_set_option(capi.OPT_FORCE_STAGED, 0)
+    lib.mpcasm_set_option(capi.OPT_PATH, 0)
 
 
 def check_drop_in(form, g, prefix, parts=True):
