@@ -202,7 +202,8 @@ def main():
             "step": "mpcasm_fill_su + mpcasm_assemble",
         },
         "roofline": {
-            "kernel": "mpcasm_assemble (K2 compose + K3 hessian_mfma + K4 constraint_stack)",
+            "kernel": "mpcasm_assemble -> resident_assemble_kernel (K2 compose + K3 hessian_mfma + "
+                      "K4 constraint_stack fused in one persistent launch)",
             "bound": "hbm",
             "achieved": achieved,
             "peak": HBM_PEAK_GBPS,

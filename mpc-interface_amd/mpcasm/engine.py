@@ -268,11 +268,3 @@ class Assembler:
                 self.plan.pmrows, self.ng, self.no, _stream_handle(torch, stream))
         capi.check(rc, "mpcasm_preview")
         return out
-
-
-def shard_bounds(batch, world_size, rank):
-    """Contiguous slice ``[lo, hi)`` of a batch owned by ``rank`` (instances are
-    independent: no collective on the data path)."""
-    base, extra = divmod(int(batch), int(world_size))
-    lo = rank * base + min(rank, extra)
-    return lo, lo + base + (1 if rank < extra else 0)
