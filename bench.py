@@ -180,6 +180,17 @@ def main():
 
     # dominant kernel = the assembly (K2-K4); HBM-bound
     achieved = bytes_asm * B / (asm_ms * 1e-3) / 1e9
+    # HBM bytes per launch from the PMC passes of the same command (rocprofv3 --pmc
+    # FETCH_SIZE / WRITE_SIZE in separate runs, tools/summarize_profile.py); only
+    # quoted when it was collected at this batch size
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            pmc = json.load(f)
+        if pmc.get("batch_per_gpu") == B:
+            traffic = pmc["traffic_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
     record = {
         "metric": "QP assemblies/sec (P,q,G,h), biped N=16 batched",
         "value": value,
@@ -209,7 +220,8 @@ def main():
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS,
-            "traffic": None,
+            "traffic": traffic,
+            "algorithmic_bytes_per_launch": bytes_asm * B,
             "algorithmic_bytes_per_assembly": bytes_asm,
             "avg_launch_ms": asm_ms,
         },
