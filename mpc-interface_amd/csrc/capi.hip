@@ -424,8 +424,8 @@ int launch_assemble(const PlanDev& p, const SrcTable& src, const double* params,
   constexpr size_t FUSED_LDS_LIMIT = 80 * 1024;
   const size_t rs = resident_lds_bytes(p);
   if (rs != 0 && rs <= FUSED_LDS_LIMIT && g_path == 0)
-    return launch_assemble_resident(p, src, params, given, P, q, G, h, batch, rs, num_cus, stream,
-                                    err);
+    return launch_assemble_resident(p, src, params, given, P, q, G, h, work, batch, rs, num_cus,
+                                    stream, err);
   const size_t lds = fused_lds_bytes(p, 4);
   if (lds != 0 && lds <= FUSED_LDS_LIMIT && g_path <= 1)
     return launch_assemble_fused(p, src, params, given, P, q, G, h, batch, lds, stream, err);

@@ -49,8 +49,8 @@ int launch_assemble_fused(const PlanDev& p, const SrcTable& src, const double* p
 size_t resident_lds_bytes(const PlanDev& p);
 int launch_assemble_resident(const PlanDev& p, const SrcTable& src, const double* params,
                              const double* given, double* P, double* q, double* G, double* h,
-                             int batch, size_t lds_bytes, int num_cus, hipStream_t stream,
-                             hipError_t* err);
+                             void* work, int batch, size_t lds_bytes, int num_cus,
+                             hipStream_t stream, hipError_t* err);
 int launch_assemble(const PlanDev& p, const SrcTable& src, const double* params,
                     const double* given, double* P, double* q, double* G, double* h, void* work,
                     int batch, int num_cus, hipStream_t stream, hipError_t* err);

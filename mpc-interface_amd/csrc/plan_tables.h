@@ -27,7 +27,7 @@
 namespace mpcasm {
 
 constexpr int32_t PLAN_MAGIC = 0x4D504341;  // 'MPCA'
-constexpr int32_t PLAN_VERSION = 7;
+constexpr int32_t PLAN_VERSION = 8;
 
 enum HeaderWord : int {
   H_MAGIC = 0,
@@ -113,6 +113,8 @@ enum {
 enum { LX_ROWOFF = 0, LX_ROWS, LX_WORDS = 2 };
 
 constexpr int MAX_SOURCES = 32;
-constexpr int RS_NW = 4, RS_NT = 256, RS_TPW = 9, RS_JC_MAX = 24, RS_ITEM_WORDS = 4;
+// RS_NT threads per instance; RS_NW of its wavefronts run the matrix core, the rest the
+// vector work; RS_TPW tiles per MFMA wavefront; RS_JC_MAX compose ops per thread
+constexpr int RS_NW = 4, RS_NT = 512, RS_TPW = 9, RS_JC_MAX = 12, RS_ITEM_WORDS = 4;
 
 }  // namespace mpcasm

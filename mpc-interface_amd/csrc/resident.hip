@@ -1,23 +1,30 @@
 // resident.hip -- the persistent fused assembly kernel (K2 + K3 + K4, one launch).
 //
-// Same job as fused.hip, restructured so that a QP instance costs no table traffic
-// and no serial chains of dependent on-chip loads: the workgroups are persistent
-// (a few per CU, each loops over instances b = blockIdx.x, += gridDim.x) and
-// everything that is *structure* is loaded once per workgroup and stays on chip:
-//   * the compose program (K2): each of the 256 threads owns a fixed handful of
-//     ops `coef * arena[src] (* given[g])` and keeps them in REGISTERS (JC slots);
-//   * the constraint program (K4): each thread owns a fixed handful of 16-byte
-//     pieces of G and keeps their operand offsets in registers too;
-//   * the gradient records and the wavefront -> Hessian tile map in LDS; the
-//     Hessian term descriptors come through scalar loads (wave-uniform).
-// Per instance the kernel reads only the instance's horizon matrices, given vector
-// and parameters (coalesced, staged in LDS) and writes P, q, G, h.  All operand
-// addresses of a phase are known before the phase starts, so every phase issues
-// its LDS reads back to back instead of chasing descriptors.  P is assembled in
-// LDS from the MFMA accumulators (mirroring symmetric tiles) and streamed out with
-// 16-byte stores like G.  The workspace V is zeroed once: its structural zeros are
-// never written again.  Barriers order LDS only (lds_barrier), so result stores
-// stay in flight across phases.
+// Same job as fused.hip, restructured so that a QP instance costs no table traffic,
+// no serial chains of dependent on-chip loads and no exposed HBM latency.  The
+// workgroups (512 threads = 8 wavefronts) are persistent: a few per CU, each loops
+// over instances b = blockIdx.x, += gridDim.x.  Everything that is *structure* is
+// loaded once per workgroup and then stays on chip for the whole launch:
+//   * the compose program (K2): each thread owns a fixed handful of ops
+//     `coef * arena[src] * given[g]` and keeps them in REGISTERS (JC slots);
+//   * the input list: each thread owns a fixed handful of input doubles (pieces of
+//     the instance's horizon matrices, given vector, parameters) and PREFETCHES
+//     those of the next instance into registers while the current one is computed;
+//   * the constraint program (K4): threads of the worker wavefronts own fixed
+//     16-byte pieces of G and keep their operand offsets in registers;
+//   * Hessian (tile, term) pair lists, gradient records, row records in LDS.
+// Per instance: inputs registers -> LDS | barrier A | K2 compose the workspace
+// V[rtot][no+1] = [Mo | d = Mg.given] (Mg is never stored; the preview matrices
+// never touch HBM) | barrier B | then the wavefronts SPECIALISE: waves 0-3 run the
+// Hessian tiles on the fp64 matrix core (v_mfma_f64_16x16x4_f64) straight from LDS
+// into P in LDS (structurally-zero tiles skipped, only ti <= tj when every term is
+// symmetric, mirrored on the way); waves 4-7 run the vector work at the same time:
+// gradient as a sliced mat-vec, G rows streamed to HBM with 16-byte stores, h
+// | barrier C | P (dense in LDS, aliasing the dead source arena) and q streamed out
+// | barrier D.  Barriers order LDS only (lds_barrier), so result stores and the
+// prefetch loads stay in flight across phases.  Within a phase all operand loads
+// are issued before the first use (explicit load batches), because the compiler
+// will not hoist LDS reads over LDS writes of the same array.
 //
 // Reference semantics: body.py:149-193 (preview rows), :236-264 + restrictions.py:
 // 175-199 (constraints), :266-302, :322-329 (costs); identical plan tables and
@@ -34,61 +41,83 @@ extern int g_phase_mask;  // diagnostic (timing-only ablation), fused.hip
 
 namespace {
 
-constexpr int NW = RS_NW, NT = RS_NT, TPW = RS_TPW;
+constexpr int NT = RS_NT;         // threads of a workgroup
+constexpr int MW = RS_NW;         // wavefronts that run the matrix core
+constexpr int WT = NT - MW * 64;  // threads of the worker wavefronts
+constexpr int TPW = RS_TPW;
 constexpr int AXMAX = 4;
 constexpr int RR_WORDS = 2 + 3 * AXMAX;  // naxes, extreme param, voff[], arrow param[], center param[]
-constexpr int GU = 6;                    // 16-byte pieces of G a thread may own (fast path)
+constexpr int GU = 6;                    // 16-byte pieces of G a worker thread may own
+constexpr int PF = 3;                    // input doubles a thread may prefetch
 
 __host__ __device__ inline int even_up_i(int x) { return (x + 1) & ~1; }
 
 struct ResidentLayout {
-  int v, xa, g, prm, qpart, ints, total_doubles;  // offsets in doubles
-  int ldp;                                       // leading dimension of P in LDS
-  int ns;                                        // row slices of the gradient pass
-  int i_tile, i_rr, i_gq, i_item, i_islot;       // offsets in ints inside the int region
+  int v, arena, pl, g, prm, qpart, ptrs, ints, total_doubles;  // offsets in doubles
+  int ldp;                                                    // leading dimension of P in LDS
+  int ns;                                                     // row slices of the gradient pass
+  int i_tile, i_rr, i_gq, i_item, i_islot;  // offsets in ints inside the int region
 };
 
 __host__ __device__ inline ResidentLayout resident_layout(const PlanDev& p) {
   ResidentLayout L;
   L.ldp = even_up_i(p.no);
-  L.ns = p.no > 0 ? NT / p.no : 1;
+  L.ns = p.no > 0 ? WT / p.no : 1;
   if (L.ns < 1) L.ns = 1;
   if (L.ns > 16) L.ns = 16;
   int o = 0;
   L.v = o;     o += even_up_i(p.rtot * p.ldv) + 16;
-  const int xa = even_up_i(p.arena_total), pl = p.no * L.ldp;
-  L.xa = o;    o += xa > pl ? xa : pl;          // source arena, later P
-  L.g = o;     o += even_up_i(p.ng + 1);       // + one slot that always holds 1.0
-  L.prm = o;   o += even_up_i(p.nparams + 1);   // + one slot that always holds 0.0
+  // the input image [arena | given (+ a 1.0) | params (+ a 0.0)] is contiguous; P
+  // overlays the arena part once it is dead, but never given / params (read while P
+  // is being assembled)
+  L.arena = o;
+  const int pl = p.no * L.ldp, ar = even_up_i(p.arena_total);
+  o += ar > pl ? ar : pl;
+  L.pl = L.arena;
+  L.g = o;     o += even_up_i(p.ng + 1);
+  L.prm = o;   o += even_up_i(p.nparams + 1);
   L.qpart = o; o += L.ns * L.ldp;
+  L.ptrs = o;  o += 3 * (MAX_SOURCES + 2);
   L.ints = o;
   int i = 0;
-  L.i_gq = i;    i += p.rs_nq * 4;              // first two: 16-byte aligned
+  L.i_gq = i;    i += p.rs_nq * 4;  // first two: 16-byte aligned
   L.i_item = i;  i += (p.rs_nitem + 1) * RS_ITEM_WORDS;
-  L.i_islot = i; i += NW * TPW * 2;
-  L.i_tile = i;  i += NW * TPW;
+  L.i_islot = i; i += MW * TPW * 2;
+  L.i_tile = i;  i += MW * TPW;
   L.i_rr = i;    i += p.nc * RR_WORDS;
   o += even_up_i(i) / 2;
   L.total_doubles = o;
   return L;
 }
 
-template <int JC>
-__global__ __launch_bounds__(NT, 3) void resident_assemble_kernel(
+template <int JC, bool STAMPS>
+__global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
     PlanDev p, SrcTable src, const double* __restrict__ params, const double* __restrict__ given,
     double* __restrict__ P, double* __restrict__ q, double* __restrict__ G,
-    double* __restrict__ h, int batch, int phases) {
+    double* __restrict__ h, int batch, int phases, unsigned long long* __restrict__ stamps) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: lives in an SGPR
+  // diagnostic build only (MPCASM_OPT_PHASE_MASK bit 6): per-wave cycle sums of the phases,
+  // written to the otherwise unused workspace; no result depends on them
+  unsigned long long t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0;
+  const bool stamping = STAMPS && stamps != nullptr;
+#define MPCASM_STAMP(slot)                                         \
+  if (STAMPS && stamping) {                                        \
+    const unsigned long long t_now = __builtin_amdgcn_s_memtime(); \
+    t_acc[slot] += t_now - t_prev;                                 \
+    t_prev = t_now;                                                \
+  }
   const ResidentLayout L = resident_layout(p);
   const int no = p.no, ng = p.ng, nc = p.nc, ldv = p.ldv, ldp = L.ldp;
 
   double* V = lds + L.v;
-  double* arena = lds + L.xa;
-  double* Pl = lds + L.xa;  // aliases the arena: live only between barriers B and D
+  double* arena = lds + L.arena;
+  double* Pl = lds + L.pl;  // overlays the arena: live only between barriers B and D
   double* gl = lds + L.g;
   double* prm = lds + L.prm;
   double* qpart = lds + L.qpart;
+  double* sptr = lds + L.ptrs;  // [nsrc + 2] triples: base pointer, stride, LDS slot (raw words)
   int* itb = reinterpret_cast<int*>(lds + L.ints);
   int4* gq = reinterpret_cast<int4*>(itb + L.i_gq);
   int4* items = reinterpret_cast<int4*>(itb + L.i_item);
@@ -121,9 +150,9 @@ __global__ __launch_bounds__(NT, 3) void resident_assemble_kernel(
     for (int i = tid; i <= p.rs_nitem; i += NT)
       items[i] = i < p.rs_nitem ? t4[i] : int4{0, 0, 0, 0};
     const int32_t* t = p.itab + p.off_rs_islot;
-    for (int i = tid; i < NW * TPW * 2; i += NT) islot[i] = t[i];
+    for (int i = tid; i < MW * TPW * 2; i += NT) islot[i] = t[i];
     t = p.itab + p.off_rs_tile;
-    for (int i = tid; i < NW * TPW; i += NT) tile[i] = t[i];
+    for (int i = tid; i < MW * TPW; i += NT) tile[i] = t[i];
     const int32_t* rowlimit = p.itab + p.off_rowlimit;
     const int32_t* limits = p.itab + p.off_limit;
     const int32_t* lax = p.itab + p.off_lax;
@@ -152,54 +181,91 @@ __global__ __launch_bounds__(NT, 3) void resident_assemble_kernel(
     double2* V2 = reinterpret_cast<double2*>(V);
     const int n2 = (even_up_i(p.rtot * ldv) + 16) / 2;
     for (int i = tid; i < n2; i += NT) V2[i] = double2{0.0, 0.0};
+    // (pointer, stride) of every input stream: the sources, then given, then params
+    if (tid < p.nsrc + 2) {
+      const double* base = tid < p.nsrc ? src.ptr[tid] : (tid == p.nsrc ? given : params);
+      const long long stride =
+          tid < p.nsrc ? src.stride[tid] : (tid == p.nsrc ? (long long)ng : (long long)p.nparams);
+      const int slot = tid < p.nsrc ? (p.itab + p.off_arena)[2 * tid]
+                                    : (tid == p.nsrc ? (int)(gl - arena) : (int)(prm - arena));
+      reinterpret_cast<const double**>(sptr)[3 * tid] = base;
+      reinterpret_cast<long long*>(sptr)[3 * tid + 1] = stride;
+      reinterpret_cast<long long*>(sptr)[3 * tid + 2] = slot;
+    }
     if (tid == 0) {
-      prm[p.nparams] = 0.0;
       gl[ng] = 1.0;
+      prm[p.nparams] = 0.0;
     }
   }
   lds_barrier();
 
-  // ---- once per workgroup: the constraint program into registers -------------------
-  // piece e = tid + u NT of G (16 bytes = columns 2cp, 2cp+1 of row R)
-  const bool g_fast = (no & 1) == 0 && p.max_axes <= 2 && p.nparams < 65535 &&
-                      (long)nc * (no >> 1) <= (long)GU * NT;
-  int g_v0[GU], g_v1[GU], g_a[GU];  // g_a: arrow param of axis 0 | axis 1 << 16
-  const int npair = no >> 1;
-  const int gtotal = nc * npair;
-  if (g_fast) {
+  // ---- once per workgroup: the input list (which doubles this thread stages) -------
+  // flat input index f -> (stream, offset in stream, LDS slot); streams: the sources,
+  // given (ng), params (nparams).  in_meta: stream << 24 | offset; in_lds: slot
+  // relative to the arena, or -1.
+  const int32_t* arec = p.itab + p.off_arena;
+  const int in_total = (p.arena_total - 1) + ng + p.nparams;
+  const bool prefetching = in_total <= PF * NT && (phases & 128);
+  int in_meta[PF];  // stream << 24 | offset in the stream, or -1
 #pragma unroll
-    for (int u = 0; u < GU; ++u) {
-      const int e = tid + u * NT;
-      g_v0[u] = g_v1[u] = 0;
-      g_a[u] = p.nparams | (p.nparams << 16);
-      if (e < gtotal) {
-        const int R = e / npair, cp = e - R * npair;
-        const int* rec = rr + R * RR_WORDS;
-        g_v0[u] = rec[2] + 2 * cp;
-        g_v1[u] = rec[3] + 2 * cp;
-        g_a[u] = rec[2 + AXMAX] | (rec[3 + AXMAX] << 16);
+  for (int u = 0; u < PF; ++u) {
+    const int f = tid + u * NT;
+    in_meta[u] = -1;
+    if (prefetching && f < in_total) {
+      if (f < p.arena_total - 1) {
+        const int a = f + 1;  // arena slot (slot 0 is the constant 1.0)
+        int s = 0;
+        while (s + 1 < p.nsrc && arec[2 * (s + 1)] <= a) ++s;
+        in_meta[u] = (s << 24) | (a - arec[2 * s]);
+      } else if (f < p.arena_total - 1 + ng) {
+        in_meta[u] = (p.nsrc << 24) | (f - (p.arena_total - 1));
+      } else {
+        in_meta[u] = ((p.nsrc + 1) << 24) | (f - (p.arena_total - 1) - ng);
       }
     }
   }
-  // gradient pass: thread = (column qc, row slice qs)
-  const int qs = no > 0 ? tid / no : 0, qc = tid - qs * (no > 0 ? no : 1);
+  auto input_address = [&](int meta, long inst) -> const double* {
+    const int s = meta >> 24;
+    const double* base = reinterpret_cast<const double* const*>(sptr)[3 * s];
+    const long long stride = reinterpret_cast<const long long*>(sptr)[3 * s + 1];
+    return base + inst * stride + (meta & 0xFFFFFF);
+  };
+  auto input_slot = [&](int meta) -> int {
+    return (int)reinterpret_cast<const long long*>(sptr)[3 * (meta >> 24) + 2] + (meta & 0xFFFFFF);
+  };
+  double in_val[PF];
+#pragma unroll
+  for (int u = 0; u < PF; ++u)
+    in_val[u] = in_meta[u] >= 0 ? *input_address(in_meta[u], blockIdx.x) : 0.0;
+
+  // ---- K4 bookkeeping of the worker threads: piece e = wt + u WT of G is the 16 bytes
+  // (columns 2cp, 2cp+1) of row R; (R, cp) of the first piece and the step between pieces
+  const int wt = tid - MW * 64;  // index among the worker threads (negative on MFMA waves)
+  const int npair = no >> 1;
+  const int gtotal = nc * npair;
+  const bool g_fast = (no & 1) == 0 && p.max_axes <= 2 && (long)gtotal <= (long)GU * WT;
+  const int g_dR = npair > 0 ? WT / npair : 0, g_dcp = npair > 0 ? WT - g_dR * npair : 0;
+  const int g_R0 = npair > 0 && wt >= 0 ? wt / npair : 0;
+  const int g_cp0 = npair > 0 && wt >= 0 ? wt - g_R0 * npair : 0;
+  // gradient pass: worker thread = (column qc, row slice qs)
+  const int wtc = wt >= 0 ? wt : 0;
+  const int qs = wtc / no, qc = wtc - qs * no;
   const int NS = L.ns;
 
-  const int32_t* arec = p.itab + p.off_arena;
   const int nt = (no + 15) >> 4;
   const int li = lane & 15, lk = lane >> 4;
-  bool first = true;
 
+  if (STAMPS && stamping) t_prev = __builtin_amdgcn_s_memtime();
   for (long inst = blockIdx.x; inst < batch; inst += gridDim.x) {
-    // ---- stage this instance's inputs (the arena region is free: barrier D) -----
-    if (tid == 0) arena[0] = 1.0;
-    if ((phases & 16) || first) {
+    // ---- this instance's inputs into LDS (the regions are free: barrier D) ---------
+    if (prefetching) {
+#pragma unroll
+      for (int u = 0; u < PF; ++u)
+        if (in_meta[u] >= 0) arena[input_slot(in_meta[u])] = in_val[u];
+    } else {
       for (int s = 0; s < p.nsrc; ++s) {
-        const long stride = src.stride[s];
-        // a shared source survives in the arena only when P does not reuse the region
-        if (stride == 0 && !first && P == nullptr) continue;
         const int off = arec[2 * s], size = arec[2 * s + 1];
-        const double* sp = src.ptr[s] + inst * stride;
+        const double* sp = src.ptr[s] + inst * src.stride[s];
         for (int i = tid; i < size; i += NT) arena[off + i] = sp[i];
       }
       const double* gb = given + inst * ng;
@@ -207,172 +273,225 @@ __global__ __launch_bounds__(NT, 3) void resident_assemble_kernel(
       const double* pb = params + inst * p.nparams;
       for (int i = tid; i < p.nparams; i += NT) prm[i] = pb[i];
     }
-    first = false;
+    if (tid == 0) arena[0] = 1.0;  // P of the previous instance covered it
     lds_barrier();  // A: inputs staged
+    MPCASM_STAMP(0)
 
     // ---- K2: compose the workspace from the register-resident program -------------
     if (phases & 1) {
+      double va[JC], vg[JC];
+#pragma unroll
+      for (int j = 0; j < JC; ++j) {  // all operand loads first
+        va[j] = arena[c_sg[j] & 0xFFFF];
+        vg[j] = gl[(unsigned)c_sg[j] >> 16];
+      }
       double acc = 0.0;
 #pragma unroll
       for (int j = 0; j < JC; ++j) {
-        acc += c_coef[j] * arena[c_sg[j] & 0xFFFF] * gl[(unsigned)c_sg[j] >> 16];
-        if (c_dst[j] >= 0) {
-          V[c_dst[j]] = acc;
-          acc = 0.0;
-        }
+        acc += c_coef[j] * va[j] * vg[j];
+        if (c_dst[j] >= 0) V[c_dst[j]] = acc;
+        acc = c_dst[j] >= 0 ? 0.0 : acc;
       }
     }
     lds_barrier();  // B: workspace complete, arena dead
+    MPCASM_STAMP(1)
 
-    if (P != nullptr && (phases & 2)) {
-      // ---- K3: Hessian tiles on the matrix core -> P in LDS --------------------------
+    // the next instance's inputs start their trip from HBM now
+    if (prefetching) {
+      const long nxt = inst + gridDim.x;
+      if (nxt < batch) {
 #pragma unroll
-      for (int s = 0; s < TPW; ++s) {
-        const int t = __builtin_amdgcn_readfirstlane(tile[wave * TPW + s]);
-        if (t < 0) continue;
-        const int ti = t / nt, tj = t - ti * nt;
-        f64x4 acc = f64x4{0.0, 0.0, 0.0, 0.0};
-        const int i0 = __builtin_amdgcn_readfirstlane(islot[(wave * TPW + s) * 2]);
-        const int cnt = __builtin_amdgcn_readfirstlane(islot[(wave * TPW + s) * 2 + 1]);
-        int4 nxt = items[i0];
-        for (int it = 0; it < cnt; ++it) {
-          const int4 cur = nxt;
-          nxt = items[i0 + it + 1];  // prefetch the next pair (the table has a spare record)
-          const int nrows = __builtin_amdgcn_readfirstlane(cur.z);
-          // a weight of 0 contributes exact zeros through the products (body.py:292)
-          const double w = prm[__builtin_amdgcn_readfirstlane(cur.w)];
-          const double* ap = V + __builtin_amdgcn_readfirstlane(cur.x) + li;
-          const double* bp = V + __builtin_amdgcn_readfirstlane(cur.y) + li;
-          for (int k0 = 0; k0 < nrows; k0 += 16) {  // four MFMA k-steps per trip
-            double a[4], b[4];
+        for (int u = 0; u < PF; ++u)
+          if (in_meta[u] >= 0) in_val[u] = *input_address(in_meta[u], nxt);
+      }
+    }
+
+    if (wave < MW) {
+      if (P != nullptr && (phases & 2)) {
+        // ---- K3: Hessian tiles on the matrix core -> P in LDS ------------------------
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {  // all eight loads in flight together
-              const int k = k0 + 4 * u + lk;
-              const int kc = k < nrows ? k : nrows - 1;
-              a[u] = ap[kc * ldv];
-              b[u] = bp[kc * ldv];
-              a[u] = k < nrows ? w * a[u] : 0.0;
+        for (int s = 0; s < TPW; ++s) {
+          const int t = __builtin_amdgcn_readfirstlane(tile[wave * TPW + s]);
+          if (t < 0) continue;
+          const int ti = t / nt, tj = t - ti * nt;
+          f64x4 acc = f64x4{0.0, 0.0, 0.0, 0.0};
+          const int i0 = __builtin_amdgcn_readfirstlane(islot[(wave * TPW + s) * 2]);
+          const int cnt = __builtin_amdgcn_readfirstlane(islot[(wave * TPW + s) * 2 + 1]);
+          int4 nxt = items[i0];
+          for (int it = 0; it < cnt; ++it) {
+            const int4 cur = nxt;
+            nxt = items[i0 + it + 1];  // prefetch the next pair (the table has a spare record)
+            const int nrows = __builtin_amdgcn_readfirstlane(cur.z);
+            // a weight of 0 contributes exact zeros through the products (body.py:292)
+            const double w = prm[__builtin_amdgcn_readfirstlane(cur.w)];
+            const double* ap = V + __builtin_amdgcn_readfirstlane(cur.x) + li;
+            const double* bp = V + __builtin_amdgcn_readfirstlane(cur.y) + li;
+            for (int k0 = 0; k0 < nrows; k0 += 16) {  // four MFMA k-steps per trip
+              double a[4], b[4];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {  // all eight loads in flight together
+                const int k = k0 + 4 * u + lk;
+                const int kc = k < nrows ? k : nrows - 1;
+                a[u] = ap[kc * ldv];
+                b[u] = bp[kc * ldv];
+              }
+#pragma unroll
+              for (int u = 0; u < 4; ++u) a[u] = k0 + 4 * u + lk < nrows ? w * a[u] : 0.0;
+#pragma unroll
+              for (int u = 0; u < 4; ++u)
+                if (k0 + 4 * u < nrows) acc = mfma_f64_16x16x4(a[u], b[u], acc);
+            }
+          }
+          const bool mirror = p.rs_sym && ti != tj;
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) {
+            const int row = ti * 16 + lk + 4 * reg, col = tj * 16 + li;
+            if (row < no && col < no) {
+              Pl[row * ldp + col] = acc[reg];
+              if (mirror) Pl[col * ldp + row] = acc[reg];
+            }
+          }
+        }
+      }
+      MPCASM_STAMP(2)
+    } else {
+      if (P != nullptr && (phases & 4)) {
+        // ---- gradient: q[c] = sum_records w s V[a][c] (V[d] - aim), rows sliced NS ways --
+        double qa = 0.0;
+        if (qs < NS) {
+          const int nq = p.rs_nq;
+          for (int i0 = qs; i0 < nq; i0 += 2 * NS) {  // two records per trip, loads in flight
+            int4 e[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              const int i = i0 + u * NS;
+              e[u] = gq[i < nq ? i : nq - 1];
+            }
+            double w[2], d[2], aim[2], a[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              w[u] = prm[e[u].w & 0x3FFFFFFF];
+              d[u] = V[e[u].y];
+              aim[u] = prm[e[u].z];
+              a[u] = V[e[u].x + qc];
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-              if (k0 + 4 * u < nrows) acc = mfma_f64_16x16x4(a[u], b[u], acc);
+            for (int u = 0; u < 2; ++u) {
+              const double r = ((e[u].w >> 30) & 1 ? 0.5 : 1.0) * (d[u] - aim[u]);
+              const double t = fma(w[u] * a[u], r, qa);
+              qa = i0 + u * NS < nq ? t : qa;
+            }
           }
-        }
-        const bool mirror = p.rs_sym && ti != tj;
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-          const int row = ti * 16 + lk + 4 * reg, col = tj * 16 + li;
-          if (row < no && col < no) {
-            Pl[row * ldp + col] = acc[reg];
-            if (mirror) Pl[col * ldp + row] = acc[reg];
-          }
+          qpart[qs * ldp + qc] = qa;
         }
       }
-    }
-    if (P != nullptr && (phases & 4)) {
-      // ---- gradient: q[c] = sum_records w s V[a][c] (V[d] - aim), rows sliced NS ways --
-      double qa = 0.0;
-      if (qs < NS) {
-        const int nq = p.rs_nq;
-        for (int i0 = qs; i0 < nq; i0 += 4 * NS) {  // four records per trip, loads in flight
-          int4 e[4];
+      MPCASM_STAMP(3)
+      if (G != nullptr && (phases & 8)) {
+        // ---- K4: constraint rows straight to HBM ---------------------------------------
+        double* Gb = G + (size_t)inst * nc * no;
+        if (g_fast) {
+          // three batches of dependent LDS reads for all pieces of the thread at once:
+          // row records -> arrows and workspace rows -> arithmetic -> 16-byte stores
+          double2* G2 = reinterpret_cast<double2*>(Gb);
+          int R = g_R0, cp = g_cp0;
+          // keep the compiler from hoisting the record addresses out of the instance loop
+          // (they would live in registers for the whole launch and spill)
+          asm volatile("" : "+v"(R), "+v"(cp));
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int i = i0 + u * NS;
-            e[u] = gq[i < nq ? i : nq - 1];
+          for (int u0 = 0; u0 < GU; u0 += 3) {  // three pieces per trip
+            int v0o[3], v1o[3], a0i[3], a1i[3];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+              const int* rec = rr + (R < nc ? R : 0) * RR_WORDS;
+              v0o[u] = rec[2] + 2 * cp;
+              v1o[u] = rec[3] + 2 * cp;
+              a0i[u] = rec[2 + AXMAX];
+              a1i[u] = rec[3 + AXMAX];
+              cp += g_dcp;
+              R += g_dR;
+              if (cp >= npair) {
+                cp -= npair;
+                ++R;
+              }
+            }
+            double a0[3], a1[3];
+            double2 v0[3], v1[3];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+              a0[u] = prm[a0i[u]];
+              a1[u] = prm[a1i[u]];
+              v0[u] = *reinterpret_cast<const double2*>(V + v0o[u]);
+              v1[u] = *reinterpret_cast<const double2*>(V + v1o[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+              const int e = wt + (u0 + u) * WT;
+              double2 r;
+              r.x = fma(a1[u], v1[u].x, a0[u] * v0[u].x);
+              r.y = fma(a1[u], v1[u].y, a0[u] * v0[u].y);
+              if (e < gtotal) G2[e] = r;
+            }
           }
-          double w[4], d[4], aim[4], a[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            w[u] = prm[e[u].w & 0x3FFFFFFF];
-            d[u] = V[e[u].y];
-            aim[u] = prm[e[u].z];
-            a[u] = V[e[u].x + qc];
+        } else if ((no & 1) == 0) {
+          const int dR = WT / npair, dcp = WT - dR * npair;
+          int e = wt, R = wt / npair, cp = wt - (wt / npair) * npair;
+          double2* G2 = reinterpret_cast<double2*>(Gb);
+          while (e < gtotal) {
+            const int* rec = rr + R * RR_WORDS;
+            const int naxes = rec[0];
+            double2 accv{0.0, 0.0};
+            for (int ax = 0; ax < naxes; ++ax) {
+              const double a = prm[rec[2 + AXMAX + ax]];
+              const double2 v = *reinterpret_cast<const double2*>(V + rec[2 + ax] + 2 * cp);
+              accv.x = fma(a, v.x, accv.x);
+              accv.y = fma(a, v.y, accv.y);
+            }
+            G2[e] = accv;
+            e += WT;
+            cp += dcp;
+            R += dR;
+            if (cp >= npair) {
+              cp -= npair;
+              ++R;
+            }
           }
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const double r = ((e[u].w >> 30) & 1 ? 0.5 : 1.0) * (d[u] - aim[u]);
-            const double t = fma(w[u] * a[u], r, qa);
-            qa = i0 + u * NS < nq ? t : qa;
+        } else {
+          const int total = nc * no;
+          const int dR = WT / no, dc = WT - dR * no;
+          int e = wt, R = wt / no, c = wt - (wt / no) * no;
+          while (e < total) {
+            const int* rec = rr + R * RR_WORDS;
+            const int naxes = rec[0];
+            double accv = 0.0;
+            for (int ax = 0; ax < naxes; ++ax)
+              accv = fma(prm[rec[2 + AXMAX + ax]], V[rec[2 + ax] + c], accv);
+            Gb[e] = accv;
+            e += WT;
+            c += dc;
+            R += dR;
+            if (c >= no) {
+              c -= no;
+              ++R;
+            }
           }
         }
-        qpart[qs * ldp + qc] = qa;
-      }
-    }
-
-    if (G != nullptr && (phases & 8)) {
-      // ---- K4: constraint rows straight to HBM -------------------------------------------
-      double* Gb = G + (size_t)inst * nc * no;
-      if (g_fast) {
-        double2* G2 = reinterpret_cast<double2*>(Gb);
-#pragma unroll
-        for (int u = 0; u < GU; ++u) {
-          const int e = tid + u * NT;
-          const double a0 = prm[g_a[u] & 0xFFFF], a1 = prm[(unsigned)g_a[u] >> 16];
-          const double2 v0 = *reinterpret_cast<const double2*>(V + g_v0[u]);
-          const double2 v1 = *reinterpret_cast<const double2*>(V + g_v1[u]);
-          double2 r;
-          r.x = fma(a1, v1.x, a0 * v0.x);
-          r.y = fma(a1, v1.y, a0 * v0.y);
-          if (e < gtotal) G2[e] = r;
-        }
-      } else if ((no & 1) == 0) {
-        const int dR = NT / npair, dcp = NT - dR * npair;
-        int e = tid, R = tid / npair, cp = tid - (tid / npair) * npair;
-        double2* G2 = reinterpret_cast<double2*>(Gb);
-        while (e < gtotal) {
+        double* hb = h + (size_t)inst * nc;
+        for (int R = wt; R < nc; R += WT) {
           const int* rec = rr + R * RR_WORDS;
           const int naxes = rec[0];
-          double2 accv{0.0, 0.0};
+          double ac = 0.0, ad = 0.0;
           for (int ax = 0; ax < naxes; ++ax) {
             const double a = prm[rec[2 + AXMAX + ax]];
-            const double2 v = *reinterpret_cast<const double2*>(V + rec[2 + ax] + 2 * cp);
-            accv.x = fma(a, v.x, accv.x);
-            accv.y = fma(a, v.y, accv.y);
+            ac += a * prm[rec[2 + 2 * AXMAX + ax]];
+            ad = fma(a, V[rec[2 + ax] + no], ad);
           }
-          G2[e] = accv;
-          e += NT;
-          cp += dcp;
-          R += dR;
-          if (cp >= npair) {
-            cp -= npair;
-            ++R;
-          }
-        }
-      } else {
-        const int total = nc * no;
-        const int dR = NT / no, dc = NT - dR * no;
-        int e = tid, R = tid / no, c = tid - (tid / no) * no;
-        while (e < total) {
-          const int* rec = rr + R * RR_WORDS;
-          const int naxes = rec[0];
-          double accv = 0.0;
-          for (int ax = 0; ax < naxes; ++ax)
-            accv = fma(prm[rec[2 + AXMAX + ax]], V[rec[2 + ax] + c], accv);
-          Gb[e] = accv;
-          e += NT;
-          c += dc;
-          R += dR;
-          if (c >= no) {
-            c -= no;
-            ++R;
-          }
+          hb[R] = (prm[rec[1]] + ac) - ad;
         }
       }
-      double* hb = h + (size_t)inst * nc;
-      for (int R = tid; R < nc; R += NT) {
-        const int* rec = rr + R * RR_WORDS;
-        const int naxes = rec[0];
-        double ac = 0.0, ad = 0.0;
-        for (int ax = 0; ax < naxes; ++ax) {
-          const double a = prm[rec[2 + AXMAX + ax]];
-          ac += a * prm[rec[2 + 2 * AXMAX + ax]];
-          ad = fma(a, V[rec[2 + ax] + no], ad);
-        }
-        hb[R] = (prm[rec[1]] + ac) - ad;
-      }
+      MPCASM_STAMP(4)
     }
     lds_barrier();  // C: P and the q partials are in LDS
+    MPCASM_STAMP(5)
 
     if (P != nullptr && (phases & 32)) {
       double* Pb = P + (size_t)inst * no * no;
@@ -395,15 +514,24 @@ __global__ __launch_bounds__(NT, 3) void resident_assemble_kernel(
         qb[c] = s;
       }
     }
+    MPCASM_STAMP(6)
     lds_barrier();  // D: P read out, the region may take the next instance's sources
+    MPCASM_STAMP(7)
   }
+  if (STAMPS && stamping && lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) stamps[((size_t)blockIdx.x * (NT / 64) + wave) * 8 + i] = t_acc[i];
+  }
+#undef MPCASM_STAMP
 }
 
 template <int JC>
 int launch_jc(const PlanDev& p, const SrcTable& src, const double* params, const double* given,
-              double* P, double* q, double* G, double* h, int batch, size_t lds_bytes, int num_cus,
-              hipStream_t stream, hipError_t* err) {
-  auto kernel = resident_assemble_kernel<JC>;
+              double* P, double* q, double* G, double* h, void* work, int batch, size_t lds_bytes,
+              int num_cus, hipStream_t stream, hipError_t* err) {
+  // the stamped instantiation exists for the diagnostic option only
+  auto kernel = (g_phase_mask & 64) ? resident_assemble_kernel<JC, true>
+                                    : resident_assemble_kernel<JC, false>;
   if (lds_bytes > 64 * 1024) {
     *err = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -418,7 +546,8 @@ int launch_jc(const PlanDev& p, const SrcTable& src, const double* params, const
   long grid = (long)num_cus * per_cu;
   if (grid > batch) grid = batch;
   hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(NT), lds_bytes, stream, p, src, params,
-                     given, P, q, G, h, batch, g_phase_mask);
+                     given, P, q, G, h, batch, g_phase_mask,
+                     (g_phase_mask & 64) ? static_cast<unsigned long long*>(work) : nullptr);
   *err = hipGetLastError();
   return *err == hipSuccess ? MPCASM_OK : MPCASM_ERR_HIP;
 }
@@ -427,19 +556,19 @@ int launch_jc(const PlanDev& p, const SrcTable& src, const double* params, const
 
 // 0 when the resident kernel cannot take this plan, else its dynamic LDS bytes
 size_t resident_lds_bytes(const PlanDev& p) {
-  if (!p.rs_ok || p.rs_jc > RS_JC_MAX || p.no > NT || p.no < 1 || p.max_axes > AXMAX) return 0;
+  if (!p.rs_ok || p.rs_jc > RS_JC_MAX || p.no > WT || p.no < 1 || p.max_axes > AXMAX) return 0;
   if ((long)p.rtot * p.ldv > (1 << 20)) return 0;
   return (size_t)resident_layout(p).total_doubles * sizeof(double);
 }
 
 int launch_assemble_resident(const PlanDev& p, const SrcTable& src, const double* params,
                              const double* given, double* P, double* q, double* G, double* h,
-                             int batch, size_t lds_bytes, int num_cus, hipStream_t stream,
-                             hipError_t* err) {
-#define MPCASM_RS_ARGS p, src, params, given, P, q, G, h, batch, lds_bytes, num_cus, stream, err
+                             void* work, int batch, size_t lds_bytes, int num_cus,
+                             hipStream_t stream, hipError_t* err) {
+#define MPCASM_RS_ARGS p, src, params, given, P, q, G, h, work, batch, lds_bytes, num_cus, stream, err
+  if (p.rs_jc <= 3) return launch_jc<3>(MPCASM_RS_ARGS);
+  if (p.rs_jc <= 5) return launch_jc<5>(MPCASM_RS_ARGS);
   if (p.rs_jc <= 8) return launch_jc<8>(MPCASM_RS_ARGS);
-  if (p.rs_jc <= 12) return launch_jc<12>(MPCASM_RS_ARGS);
-  if (p.rs_jc <= 16) return launch_jc<16>(MPCASM_RS_ARGS);
   return launch_jc<RS_JC_MAX>(MPCASM_RS_ARGS);
 #undef MPCASM_RS_ARGS
 }

@@ -15,7 +15,7 @@ import numpy as np
 import scipy.sparse as sp
 
 PLAN_MAGIC = 0x4D504341
-PLAN_VERSION = 7
+PLAN_VERSION = 8
 
 # header words (csrc/plan_tables.h, enum HeaderWord)
 _H = {name: i for i, name in enumerate([
@@ -30,8 +30,8 @@ _H = {name: i for i, name in enumerate([
     "DOFF_RS_COEF", "OFF_RS_ITEM", "OFF_RS_ISLOT", "OFF_RS_TILE", "RS_NQ", "OFF_RS_GQ",
 ])}
 H_WORDS = 64
-RS_NW, RS_NT, RS_TPW = 4, 256, 9          # wavefronts / threads per instance, tiles per wave
-RS_JC_MAX = 24                            # compose ops a thread can keep in registers
+RS_NW, RS_NT, RS_TPW = 4, 512, 9          # MFMA wavefronts, threads per instance, tiles per wave
+RS_JC_MAX = 12                            # compose ops a thread can keep in registers
 RS_ITEM_WORDS = 4
 SEG_WORDS, GT_WORDS, LM_WORDS, LX_WORDS = 8, 10, 12, 2
 FUSED_MAX_OPS = 1 << 18           # beyond this the staged pipeline is used

@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""In-kernel cycle stamps of the persistent assembly kernel (diagnostic build path,
+MPCASM_OPT_PHASE_MASK bit 6): where a workgroup's time per instance goes."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "mpc-interface_amd"))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from mpcasm import capi  # noqa: E402
+
+NAMES = ["stage+A", "compose+B", "hessian", "gradient", "constr", "barC", "Pq out", "barD"]
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+    work = bench.build_workload(B, 1)
+    engine, form = work["engine"], work["form"]
+    asm = engine.Assembler(form, batch=B)
+    given = torch.as_tensor(work["given"], device="cuda")
+    lib = capi.load()
+    for _ in range(3):
+        asm.assemble(given)
+    lib.mpcasm_set_option(capi.OPT_PHASE_MASK, 0xFF | 64)
+    asm._work.zero_()
+    asm.assemble(given)
+    torch.cuda.synchronize()
+    lib.mpcasm_set_option(capi.OPT_PHASE_MASK, 0xFF)
+    raw = asm._work.view(torch.int64).cpu().numpy()
+    per_cu = int(os.environ.get("WG_PER_CU", "2"))
+    grid = min(B, 256 * per_cu)
+    t = raw[:grid * 8 * 8].reshape(grid, 8, 8).astype(np.float64)
+    per_wg = B / grid
+    print("B=%d grid=%d  instances per workgroup %.2f; cycles per instance (100 MHz ticks x?)"
+          % (B, grid, per_wg))
+    for w in range(8):
+        row = t[:, w, :].mean(axis=0) / per_wg
+        print("wave %d: " % w + "  ".join("%s %7.0f" % (n, v) for n, v in zip(NAMES, row))
+              + "   total %8.0f" % row.sum())
+
+
+if __name__ == "__main__":
+    main()
