@@ -183,6 +183,125 @@ __global__ __launch_bounds__(BLOCK) void fill_lti_kernel(const double* __restric
   }
 }
 
+// Tiny systems (n (m+n) <= 32, e.g. the LIPM: n=3, m=1): the recurrence occupies only
+// n (m+n) lanes, so one wavefront runs SPW = 64 / (n (m+n)) systems side by side and needs
+// no workgroup barrier at all (a wavefront's LDS operations complete in order); S is staged
+// in LDS as well, and the wavefront then streams S and U of its systems with 16-byte stores.
+__host__ __device__ inline size_t tiny_lds_doubles(int N, int n, int m) {
+  return even_up((size_t)m * N * n) + 2 * even_up((size_t)n * (m + n)) + even_up((size_t)n * n) +
+         even_up((size_t)N * n * n);
+}
+
+__device__ __forceinline__ void wave_lds_sync() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+__global__ __launch_bounds__(BLOCK) void fill_lti_tiny_kernel(const double* __restrict__ A,
+                                                              const double* __restrict__ B,
+                                                              double* __restrict__ S,
+                                                              double* __restrict__ U, int batch,
+                                                              int N, int n, int m, int spw) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int xw = m + n, xsz = n * xw, rl = N * n, nn = n * n;
+  const size_t per = tiny_lds_doubles(N, n, m);
+  const long sys0 = ((long)blockIdx.x * (BLOCK / 64) + wave) * spw;  // first system of this wave
+
+  // recurrence role: lane -> (system sub, element e = c n + i)
+  const int sub = lane / xsz, e = lane - sub * xsz;
+  const int c = e / n, i = e - c * n;
+  const bool worker = sub < spw && sys0 + sub < batch;
+  double* base = lds + ((size_t)wave * spw + (sub < spw ? sub : 0)) * per;
+  double* R = base;                                  // [m][rl] block-reversed A^d B
+  double* X = R + even_up((size_t)m * rl);           // [2][xw][n]
+  double* Am = X + 2 * even_up((size_t)xsz);         // [n][n]
+  double* Sl = Am + even_up((size_t)nn);             // [N][n][n] as stored in S
+  const size_t xstep = even_up((size_t)xsz);
+  if (worker) {
+    const double* Ab = A + (size_t)(sys0 + sub) * nn;
+    const double* Bb = B + (size_t)(sys0 + sub) * n * m;
+    if (e < nn) Am[e] = Ab[e];
+    double v;
+    if (c < m) {
+      v = Bb[i * m + c];
+      R[(size_t)c * rl + (size_t)(N - 1) * n + i] = v;
+    } else {
+      v = Ab[i * n + (c - m)];
+      Sl[e - n * m] = v;
+    }
+    X[e] = v;
+  }
+  wave_lds_sync();
+  for (int d = 1; d < N; ++d) {
+    const double* Xp = X + ((d - 1) & 1) * xstep;
+    double* Xc = X + (d & 1) * xstep;
+    if (worker) {
+      double v = 0.0;
+      for (int t = 0; t < n; ++t) v = fma(Am[i * n + t], Xp[c * n + t], v);
+      Xc[e] = v;
+      if (c < m)
+        R[(size_t)c * rl + (size_t)(N - 1 - d) * n + i] = v;
+      else
+        Sl[(size_t)d * nn + (e - n * m)] = v;
+    }
+    wave_lds_sync();
+  }
+
+  // write phase: all 64 lanes stream the wave's systems one after the other
+  const bool vec = (rl & 1) == 0 && ((N * nn) & 1) == 0;
+  for (int s = 0; s < spw; ++s) {
+    const long sys = sys0 + s;
+    if (sys >= batch) break;
+    const double* Rs = lds + ((size_t)wave * spw + s) * per;
+    const double* Ss = Rs + even_up((size_t)m * rl) + 2 * even_up((size_t)xsz) + even_up((size_t)nn);
+    double* Sb = S + (size_t)sys * N * nn;
+    double* Ub = U + (size_t)sys * m * N * rl;
+    if (vec) {
+      const int s2 = (N * nn) >> 1;
+      double2* S2 = reinterpret_cast<double2*>(Sb);
+      const double2* Sl2 = reinterpret_cast<const double2*>(Ss);
+      for (int q = lane; q < s2; q += 64) S2[q] = Sl2[q];
+      const int rl2 = rl >> 1;
+      const long total2 = (long)m * N * rl2;
+      const int dr = 64 / rl2, dp = 64 - dr * rl2;
+      long q = lane;
+      int row = lane / rl2;
+      int pos = lane - row * rl2;
+      int j = row / N, k = row - j * N;
+      double2* out = reinterpret_cast<double2*>(Ub);
+      while (q < total2) {
+        const int lim = (k + 1) * n, sh = (N - 1 - k) * n;
+        const double* Rj = Rs + (size_t)j * rl;
+        const int p0 = 2 * pos;
+        const int i0 = min(p0 + sh, rl - 1), i1 = min(p0 + 1 + sh, rl - 1);
+        double2 v;
+        v.x = p0 < lim ? Rj[i0] : 0.0;
+        v.y = p0 + 1 < lim ? Rj[i1] : 0.0;
+        out[q] = v;
+        q += 64;
+        pos += dp;
+        k += dr;
+        if (pos >= rl2) {
+          pos -= rl2;
+          ++k;
+        }
+        if (k >= N) {
+          j += k / N;
+          k = k % N;
+        }
+      }
+    } else {
+      for (int q = lane; q < N * nn; q += 64) Sb[q] = Ss[q];
+      const long total = (long)m * N * rl;
+      for (long q = lane; q < total; q += 64) {
+        const int row = (int)(q / rl), pos = (int)(q - (long)row * rl);
+        const int j = row / N, k = row - j * N;
+        Ub[q] = pos < (k + 1) * n ? Rs[(size_t)j * rl + pos + (N - 1 - k) * n] : 0.0;
+      }
+    }
+  }
+}
+
 // doubles of LDS one system needs in the LTV kernel
 __host__ __device__ inline size_t ltv_lds_doubles(int N, int n, int m) {
   return 2 * even_up((size_t)m * N * n) + 2 * even_up((size_t)n * n) + even_up((size_t)n * n) +
@@ -267,6 +386,126 @@ __global__ __launch_bounds__(BLOCK) void fill_ltv_kernel(const double* __restric
   }
 }
 
+// LTV, one wavefront per system (n <= 64, N n <= 1024): no workgroup barrier -- the
+// wavefront double-buffers the block row AND the step matrices in its own LDS slice,
+// loads (A_{k+1}, B_{k+1}) into registers while row k is being produced, and needs one
+// wave-level LDS sync per step.
+__host__ __device__ inline size_t ltv_wave_lds_doubles(int N, int n, int m) {
+  return 2 * even_up((size_t)m * N * n) + 2 * even_up((size_t)n * n) +
+         2 * (even_up((size_t)n * n) + even_up((size_t)n * m));
+}
+
+__global__ __launch_bounds__(BLOCK) void fill_ltv_wave_kernel(const double* __restrict__ A,
+                                                              const double* __restrict__ B,
+                                                              double* __restrict__ S,
+                                                              double* __restrict__ U, int batch,
+                                                              int N, int n, int m) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long inst = (long)blockIdx.x * (BLOCK / 64) + wave;
+  if (inst >= batch) return;  // whole wavefront; no barrier below
+
+  const int rl = N * n, nn = n * n, nm = n * m;
+  const size_t rstep = even_up((size_t)m * rl), pstep = even_up((size_t)nn);
+  const size_t abstep = even_up((size_t)nn) + even_up((size_t)nm);
+  double* Rw = lds + (size_t)wave * ltv_wave_lds_doubles(N, n, m);  // [2][m][rl]
+  double* Pk = Rw + 2 * rstep;                                      // [2][n][n] as [j][i]
+  double* AB = Pk + 2 * pstep;                                      // [2]{A_k [n][n], B_k [n][m]}
+
+  const double* Ab = A + (size_t)inst * N * nn;
+  const double* Bb = B + (size_t)inst * N * nm;
+  double* Sb = S + (size_t)inst * N * nn;
+  double* Ub = U + (size_t)inst * m * N * rl;
+
+  const int LQ = 64 / n;
+  const int lq = lane / n, li = lane - lq * n;
+  const bool worker = lq < LQ;
+  const int ej = lane / n, ei = lane - ej * n;  // S element (j, i) for lane < n n (first pass)
+
+  // both row buffers start as zeros: the blocks right of the diagonal are never written
+  for (size_t e = lane; e < 2 * rstep; e += 64) Rw[e] = 0.0;
+  // step 0 matrices
+  for (int e = lane; e < nn; e += 64) AB[e] = Ab[e];
+  for (int e = lane; e < nm; e += 64) AB[even_up((size_t)nn) + e] = Bb[e];
+  wave_lds_sync();
+
+  auto stream_row = [&](const double* Rrow, int k) {
+    for (int j = 0; j < m; ++j) {
+      const double* Rj = Rrow + (size_t)j * rl;
+      double* out = Ub + ((size_t)j * N + k) * rl;
+      if ((rl & 1) == 0) {
+        const double2* r2 = reinterpret_cast<const double2*>(Rj);
+        double2* o2 = reinterpret_cast<double2*>(out);
+        for (int q = lane; q < (rl >> 1); q += 64) o2[q] = r2[q];
+      } else {
+        for (int q = lane; q < rl; q += 64) out[q] = Rj[q];
+      }
+    }
+  };
+
+  for (int k = 0; k < N; ++k) {
+    const double* Ak = AB + (k & 1) * abstep;
+    const double* Bk = Ak + even_up((size_t)nn);
+    double* ABn = AB + ((k + 1) & 1) * abstep;
+    const double* Rp = Rw + ((k + 1) & 1) * rstep;  // row k-1
+    double* Rc = Rw + (k & 1) * rstep;              // row k
+    const double* Pp = Pk + ((k + 1) & 1) * pstep;
+    double* Pc = Pk + (k & 1) * pstep;
+
+    // next step's matrices leave HBM now (register staged; at most 2 + 1 values per lane
+    // on the small shapes this kernel is dispatched for)
+    double an[2] = {0.0, 0.0}, bn = 0.0;
+    const bool more = k + 1 < N;
+    if (more) {
+      if (lane < nn) an[0] = Ab[(size_t)(k + 1) * nn + lane];
+      if (lane + 64 < nn) an[1] = Ab[(size_t)(k + 1) * nn + lane + 64];
+      if (lane < nm) bn = Bb[(size_t)(k + 1) * nm + lane];
+    }
+
+    // S[k] = (A_k P_{k-1})^T, P_{-1} = I ; Pc[j][i] = P[i][j]
+    for (int e = lane; e < nn; e += 64) {
+      const int j = e == lane ? ej : e / n, i = e == lane ? ei : e - (e / n) * n;
+      double v;
+      if (k == 0) {
+        v = Ak[i * n + j];
+      } else {
+        v = 0.0;
+        for (int t = 0; t < n; ++t) v = fma(Ak[i * n + t], Pp[j * n + t], v);
+      }
+      Pc[e] = v;
+      Sb[(size_t)k * nn + e] = v;
+    }
+    // row k of every input: blocks l < k are A_k times row k-1, block k is B_k; blocks
+    // l > k stay zero in the buffer (zeroed once, never written)
+    if (worker) {
+      for (int j = 0; j < m; ++j) {
+        const double* Rpj = Rp + (size_t)j * rl;
+        double* Rcj = Rc + (size_t)j * rl;
+        for (int l = lq; l <= k; l += LQ) {
+          double v;
+          if (l < k) {
+            v = 0.0;
+            for (int t = 0; t < n; ++t) v = fma(Ak[li * n + t], Rpj[l * n + t], v);
+          } else {
+            v = Bk[li * m + j];
+          }
+          Rcj[l * n + li] = v;
+        }
+      }
+    }
+    // stream the PREVIOUS row (complete since the last sync; zeros included) to HBM with
+    // 16-byte stores while this one is being produced: both only read row k-1
+    if (k > 0) stream_row(Rp, k - 1);
+    if (more) {
+      if (lane < nn) ABn[lane] = an[0];
+      if (lane + 64 < nn) ABn[lane + 64] = an[1];
+      if (lane < nm) ABn[even_up((size_t)nn) + lane] = bn;
+    }
+    wave_lds_sync();
+  }
+  stream_row(Rw + ((N - 1) & 1) * rstep, N - 1);
+}
+
 template <typename K>
 hipError_t allow_lds(K kernel, size_t bytes) {
   if (bytes <= 64 * 1024) return hipSuccess;
@@ -285,7 +524,14 @@ int launch_fill_su(const double* A, const double* B, double* S, double* U, int b
     const int xsz = n * (m + n);
     // one wavefront per system when it fits comfortably, else one workgroup
     const bool small = xsz <= 64 * EPT && per * 4 <= 48 * 1024;
-    if (small) {
+    const int spw = xsz <= 32 ? 64 / xsz : 0;
+    const size_t tiny = tiny_lds_doubles(N, n, m) * sizeof(double) * 4 * (spw > 0 ? spw : 1);
+    if (spw >= 2 && tiny <= 64 * 1024) {
+      const int per_block = 4 * spw;
+      const int blocks = (batch + per_block - 1) / per_block;
+      hipLaunchKernelGGL(fill_lti_tiny_kernel, dim3(blocks), dim3(BLOCK), tiny, stream, A, B, S, U,
+                         batch, N, n, m, spw);
+    } else if (small) {
       const size_t bytes = per * 4;
       const int blocks = (batch + 3) / 4;
       hipLaunchKernelGGL((fill_lti_kernel<64, false>), dim3(blocks), dim3(BLOCK), bytes, stream, A,
@@ -306,7 +552,12 @@ int launch_fill_su(const double* A, const double* B, double* S, double* U, int b
   } else {
     const size_t per = ltv_lds_doubles(N, n, m) * sizeof(double);
     const bool small = n <= 64 && per * 4 <= 64 * 1024 && N * n <= 1024;
-    if (small) {
+    const size_t wper = ltv_wave_lds_doubles(N, n, m) * sizeof(double) * 4;
+    if (n * n <= 128 && n * m <= 64 && wper <= 64 * 1024) {
+      const int blocks = (batch + 3) / 4;
+      hipLaunchKernelGGL(fill_ltv_wave_kernel, dim3(blocks), dim3(BLOCK), wper, stream, A, B, S, U,
+                         batch, N, n, m);
+    } else if (small) {
       const size_t bytes = per * 4;
       const int blocks = (batch + 3) / 4;
       hipLaunchKernelGGL(fill_ltv_kernel<64>, dim3(blocks), dim3(BLOCK), bytes, stream, A, B, S, U,

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""K1 (mpcasm_fill_su) throughput against the HBM roofline for the BASELINE shapes.
+
+Algorithmic bytes per system: 8 (N n^2 + m N^2 n) written +
+8 (n^2 + n m) read (LTI) or 8 N (n^2 + n m) (LTV)."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "mpc-interface_amd"))
+
+import torch  # noqa: E402
+
+from mpcasm import engine  # noqa: E402
+
+CASES = [  # name, n, m, N, ltv, batch
+    ("C2 biped LIPM", 3, 1, 16, False, 4096),
+    ("C2 biped LIPM", 3, 1, 16, False, 65536),
+    ("C2 biped LIPM", 3, 1, 16, False, 524288),
+    ("C3 N=32", 3, 1, 32, False, 131072),
+    ("N=100 LTI", 3, 1, 100, False, 16384),
+    ("C4 nx=12 nu=6 N=64", 12, 6, 64, False, 1024),
+    ("C4 nx=12 nu=6 N=64", 12, 6, 64, False, 4096),
+    ("C5 LTV N=100", 3, 1, 100, True, 2048),
+    ("C5 LTV N=100", 3, 1, 100, True, 16384),
+]
+
+
+def main():
+    rng = np.random.default_rng(0)
+    print("%-22s %8s %10s %10s %9s %7s" % ("case", "batch", "MB/launch", "us/launch", "GB/s", "frac"))
+    for name, n, m, N, ltv, batch in CASES:
+        shapeA = (batch, N, n, n) if ltv else (batch, n, n)
+        shapeB = (batch, N, n, m) if ltv else (batch, n, m)
+        A = torch.as_tensor(rng.standard_normal(shapeA) / np.sqrt(n) * 0.9, device="cuda")
+        B = torch.as_tensor(rng.standard_normal(shapeB), device="cuda")
+        S = torch.empty((batch, N, n, n), dtype=torch.float64, device="cuda")
+        U = torch.empty((batch, m, N, N, n), dtype=torch.float64, device="cuda")
+        for _ in range(3):
+            engine.fill_su(A, B, N, ltv=ltv, out=(S, U))
+        torch.cuda.synchronize()
+        reps = 20
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            engine.fill_su(A, B, N, ltv=ltv, out=(S, U))
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / reps * 1e3
+        nbytes = 8 * (N * n * n + m * N * N * n) + 8 * (n * n + n * m) * (N if ltv else 1)
+        gbs = nbytes * batch / (us * 1e-6) / 1e9
+        print("%-22s %8d %10.1f %10.1f %9.0f %7.3f" % (name, batch, nbytes * batch / 1e6, us, gbs,
+                                                      gbs / 8000.0))
+        del A, B, S, U
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()
