@@ -121,8 +121,13 @@ __global__ __launch_bounds__(BLOCK) void hessian_kernel(PlanDev p,
   for (int g = 0; g < p.ngterm; ++g) {
     const int32_t* rec = gt + g * GT_WORDS;
     const int flags = rec[GT_FLAGS];
-    const bool hasP = flags & GT_FLAG_P;
-    if (!hasP && !has_qcol) continue;
+    // structurally-zero 16-column tiles of the operands (plan tile masks): a term only
+    // reaches P inside this 32x32 block when A has a tile in its rows and B in its columns
+    const unsigned ma = (unsigned)rec[GT_MASKA], mb = (unsigned)rec[GT_MASKB];
+    const bool a_here = (ma >> min(2 * bi, 30)) & 3u || 2 * bi >= 30;
+    const bool b_here = (mb >> min(2 * bj, 30)) & 3u || 2 * bj >= 30;
+    const bool hasP = (flags & GT_FLAG_P) && a_here && b_here;
+    if (!a_here || (!hasP && !has_qcol)) continue;
     const int aoff = rec[GT_AOFF], boff = rec[GT_BOFF], doff = rec[GT_DOFF];
     const int nrows = rec[GT_NROWS];
     const double w = pb[rec[GT_WPARAM]];
@@ -174,52 +179,79 @@ __global__ __launch_bounds__(BLOCK) void hessian_kernel(PlanDev p,
 }
 
 // ---------------------------------------------------------------------------
-// K4: rows of the stacked G and h; one wavefront per output row
+// K4: rows of the stacked G and h.  A workgroup takes K4_ROWS consecutive rows of
+// one instance: the first threads resolve the row records (limit, axes, arrows,
+// workspace rows) into LDS and write h, then 16 threads per row stream the row as
+// 16-byte pieces (sum over axes of arrow * workspace row), coalesced.
 // ---------------------------------------------------------------------------
-constexpr int K4_ROWS_PER_WAVE = 4;
+constexpr int K4_ROWS = 16;
+constexpr int K4_AXMAX = 8;
 
 __global__ __launch_bounds__(BLOCK) void constraints_kernel(PlanDev p,
                                                             const double* __restrict__ params,
                                                             const double* __restrict__ V,
                                                             double* __restrict__ G,
                                                             double* __restrict__ h, int nrb) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __shared__ double s_arrow[K4_ROWS][K4_AXMAX];
+  __shared__ int s_voff[K4_ROWS][K4_AXMAX];
+  __shared__ int s_nax[K4_ROWS];
+  const int tid = threadIdx.x;
   const long inst = blockIdx.x / nrb;
   const int rb = blockIdx.x - inst * nrb;
   const int no = p.no, ldv = p.ldv;
   const double* Vb = V + (size_t)inst * p.rtot * ldv;
   const double* pb = params + (size_t)inst * p.nparams;
-  double* Gb = G + (size_t)inst * p.nc * no;
-  double* hb = h + (size_t)inst * p.nc;
-  const int32_t* rowlimit = p.itab + p.off_rowlimit;
-  const int32_t* limits = p.itab + p.off_limit;
-  const int32_t* lax = p.itab + p.off_lax;
+  const int R0 = rb * K4_ROWS;
+  const int nrows = min(K4_ROWS, p.nc - R0);
 
-  const int R0 = (rb * WAVES + wave) * K4_ROWS_PER_WAVE;
-  for (int R = R0; R < min(R0 + K4_ROWS_PER_WAVE, p.nc); ++R) {
-    const int32_t* lm = limits + rowlimit[R] * LM_WORDS;
+  if (tid < nrows) {
+    const int R = R0 + tid;
+    const int32_t* lm = p.itab + p.off_limit + (p.itab + p.off_rowlimit)[R] * LM_WORDS;
     const int r = R - lm[LM_OUT0];
     const int naxes = lm[LM_NAXES];
-    const int32_t* lx = lax + lm[LM_LAX0] * LX_WORDS;
+    const int32_t* lx = p.itab + p.off_lax + lm[LM_LAX0] * LX_WORDS;
     const double* arrow = pb + lm[LM_ARROW_P] + (lm[LM_ARROW_ROWS] == 1 ? 0 : r) * naxes;
-    for (int c = lane; c < no; c += 64) {
-      double acc = 0.0;
-      for (int ax = 0; ax < naxes; ++ax) {
-        const int rr = lx[ax * LX_WORDS + LX_ROWS] == 1 ? 0 : r;
-        acc = fma(arrow[ax], Vb[(size_t)(lx[ax * LX_WORDS + LX_ROWOFF] + rr) * ldv + c], acc);
+    const double* center = pb + lm[LM_CENTER_P] + (lm[LM_CENTER_ROWS] == 1 ? 0 : r) * naxes;
+    const double extreme = pb[lm[LM_EXTREME_P] + (lm[LM_EXTREME_ROWS] == 1 ? 0 : r)];
+    double ac = 0.0, ad = 0.0;
+    s_nax[tid] = naxes;
+    for (int ax = 0; ax < naxes; ++ax) {
+      const int rr = lx[ax * LX_WORDS + LX_ROWS] == 1 ? 0 : r;
+      const int voff = (lx[ax * LX_WORDS + LX_ROWOFF] + rr) * ldv;
+      if (ax < K4_AXMAX) {
+        s_arrow[tid][ax] = arrow[ax];
+        s_voff[tid][ax] = voff;
       }
-      Gb[(size_t)R * no + c] = acc;
+      ac += arrow[ax] * center[ax];
+      ad = fma(arrow[ax], Vb[voff + no], ad);
     }
-    if (lane == 0) {
-      const double* center = pb + lm[LM_CENTER_P] + (lm[LM_CENTER_ROWS] == 1 ? 0 : r) * naxes;
-      const double extreme = pb[lm[LM_EXTREME_P] + (lm[LM_EXTREME_ROWS] == 1 ? 0 : r)];
-      double ac = 0.0, ad = 0.0;
+    h[(size_t)inst * p.nc + R] = (extreme + ac) - ad;
+  }
+  __syncthreads();
+
+  constexpr int TPR = BLOCK / K4_ROWS;  // threads per row
+  const int row = tid / TPR, lr = tid - row * TPR;
+  if (row >= nrows) return;
+  const int naxes = s_nax[row];
+  double* Grow = G + ((size_t)inst * p.nc + R0 + row) * no;
+  // rows of G start 16-byte aligned only when no is even
+  if ((no & 1) == 0) {
+    double2* G2 = reinterpret_cast<double2*>(Grow);
+    for (int cp = lr; cp < (no >> 1); cp += TPR) {
+      double2 acc{0.0, 0.0};
       for (int ax = 0; ax < naxes; ++ax) {
-        const int rr = lx[ax * LX_WORDS + LX_ROWS] == 1 ? 0 : r;
-        ac += arrow[ax] * center[ax];
-        ad = fma(arrow[ax], Vb[(size_t)(lx[ax * LX_WORDS + LX_ROWOFF] + rr) * ldv + no], ad);
+        const double a = s_arrow[row][ax];
+        const double2 v = *reinterpret_cast<const double2*>(Vb + s_voff[row][ax] + 2 * cp);
+        acc.x = fma(a, v.x, acc.x);
+        acc.y = fma(a, v.y, acc.y);
       }
-      hb[R] = (extreme + ac) - ad;
+      G2[cp] = acc;
+    }
+  } else {
+    for (int c = lr; c < no; c += TPR) {
+      double acc = 0.0;
+      for (int ax = 0; ax < naxes; ++ax) acc = fma(s_arrow[row][ax], Vb[s_voff[row][ax] + c], acc);
+      Grow[c] = acc;
     }
   }
 }
@@ -271,7 +303,8 @@ int launch_assemble_staged(const PlanDev& p, const SrcTable& src, const double* 
                        q, (int)nrb);
   }
   if (G && p.nc > 0) {
-    const unsigned nrb = ceil_div(p.nc, WAVES * K4_ROWS_PER_WAVE);
+    if (p.max_axes > K4_AXMAX) return MPCASM_ERR_LIMIT;
+    const unsigned nrb = ceil_div(p.nc, K4_ROWS);
     hipLaunchKernelGGL(constraints_kernel, dim3(nrb * batch), dim3(BLOCK), 0, stream, p, params, V,
                        G, h, (int)nrb);
   }

@@ -420,10 +420,12 @@ int g_path = 0;  // test hook (MPCASM_OPT_PATH): 0 best, 1 no resident kernel, 2
 int launch_assemble(const PlanDev& p, const SrcTable& src, const double* params,
                     const double* given, double* P, double* q, double* G, double* h, void* work,
                     int batch, int num_cus, hipStream_t stream, hipError_t* err) {
-  // LDS budget that still leaves two workgroups per CU (160 KiB each)
-  constexpr size_t FUSED_LDS_LIMIT = 80 * 1024;
+  // the persistent kernel may take a whole CU's LDS (one workgroup of 8 wavefronts per
+  // CU still beats the staged pipeline by far); the per-instance fused kernel is only
+  // worth it while two workgroups fit
+  constexpr size_t RESIDENT_LDS_LIMIT = 156 * 1024, FUSED_LDS_LIMIT = 80 * 1024;
   const size_t rs = resident_lds_bytes(p);
-  if (rs != 0 && rs <= FUSED_LDS_LIMIT && g_path == 0)
+  if (rs != 0 && rs <= RESIDENT_LDS_LIMIT && g_path == 0)
     return launch_assemble_resident(p, src, params, given, P, q, G, h, work, batch, rs, num_cus,
                                     stream, err);
   const size_t lds = fused_lds_bytes(p, 4);

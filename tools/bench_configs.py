@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Assembly throughput of the BASELINE configurations C2, C3, C4 on
+whatever path the library selects for them."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "mpc-interface_amd"))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+from mpcasm import engine, problems  # noqa: E402
+
+
+def run(name, form, batch, reps=10):
+    rng = np.random.default_rng(0)
+    asm = engine.Assembler(form, batch=batch)
+    given = torch.as_tensor(rng.normal(0, 0.1, [batch, form.given_len]), device="cuda")
+    for _ in range(2):
+        asm.assemble(given)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        asm.assemble(given)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    no, nc, ng = asm.no, asm.nc, asm.ng
+    out_bytes = 8 * (no * no + no + nc * no + nc)
+    print("%-28s B=%6d no=%4d nc=%5d rtot=%5d  %9.3f ms  %10.0f asm/s  %7.1f GB/s out"
+          % (name, batch, no, nc, asm.plan.rtot, ms, batch / ms * 1e3, out_bytes * batch / ms / 1e6))
+
+
+def main():
+    api = problems.load_api("mpc_interface")
+    form = problems.biped(api, problems.BipedConfig(step_samples=8))
+    form.update(step_times=np.array([6, 14]), step_count=0)
+    run("C2 biped N=16", form, 4096)
+    run("C2 biped N=16", form, 65536)
+    form = problems.biped(api, problems.BipedConfig(step_samples=12))
+    form.update(step_times=np.array([10, 22]), step_count=0)
+    run("biped N=24 (as shipped)", form, 16384)
+    run("C3 lipm3d N=32", problems.lipm3d(api, N=32), 16384)
+    run("C4 random LTI N=64", problems.random_lti(api, np.random.default_rng(20262), N=64), 256, 3)
+
+
+if __name__ == "__main__":
+    main()
