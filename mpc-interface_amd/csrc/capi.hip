@@ -108,6 +108,9 @@ int validate_plan(const int32_t* it, size_t n_itab, size_t n_dtab) {
     r = r && in_range(it[H_OFF_RS_TILE], RS_NW * RS_TPW, n, H_WORDS);
     r = r && it[H_RS_NQ] >= 0 && in_range(it[H_OFF_RS_GQ], (int64_t)it[H_RS_NQ] * 4, n, H_WORDS);
     r = r && (it[H_OFF_RS_GQ] % 4 == 0) && (it[H_OFF_RS_ITEM] % 4 == 0);
+    r = r && in_range(it[H_OFF_RS_RR], nc * RS_RR_WORDS, n, H_WORDS);
+    r = r && (it[H_RS_PF] == 0 || it[H_RS_PF] == RS_PF_MAX);
+    r = r && in_range(it[H_OFF_RS_INMETA], (int64_t)RS_PF_MAX * RS_NT, n, H_WORDS);
     if (!r) return MPCASM_ERR_PLAN;
     const int64_t vsize = (int64_t)it[H_RTOT] * it[H_LDV];
     const int32_t* ts = it + it[H_OFF_RS_SRC];
@@ -125,6 +128,25 @@ int validate_plan(const int32_t* it, size_t n_itab, size_t n_dtab) {
       for (int k = 0; k < 2; ++k)
         if (x[k] < 0 || (int64_t)x[k] + (int64_t)(x[2] - 1) * it[H_LDV] + 16 > vsize + 16)
           return MPCASM_ERR_PLAN;
+    }
+    const int32_t* rrw = it + it[H_OFF_RS_RR];
+    for (int64_t R = 0; R < nc; ++R) {
+      const int32_t* x = rrw + R * RS_RR_WORDS;
+      if (x[0] < 0 || x[0] > RS_AXMAX || x[1] < 0 || x[1] >= it[H_NPARAMS]) return MPCASM_ERR_PLAN;
+      for (int a = 0; a < RS_AXMAX; ++a)
+        if (x[2 + a] < 0 || x[2 + a] + no >= vsize + 1 || x[2 + RS_AXMAX + a] < 0 ||
+            x[2 + RS_AXMAX + a] > it[H_NPARAMS] || x[2 + 2 * RS_AXMAX + a] < 0 ||
+            x[2 + 2 * RS_AXMAX + a] > it[H_NPARAMS])
+          return MPCASM_ERR_PLAN;
+    }
+    const int32_t* im = it + it[H_OFF_RS_INMETA];
+    for (int i = 0; i < RS_PF_MAX * RS_NT; ++i) {
+      if (im[i] == -1) continue;
+      const int st = im[i] >> 24, off = im[i] & 0xFFFFFF;
+      if (im[i] < 0 || st > it[H_NSRC] + 1) return MPCASM_ERR_PLAN;
+      const int64_t lim = st < it[H_NSRC] ? (it + it[H_OFF_ARENA])[2 * st + 1]
+                                          : (st == it[H_NSRC] ? ng : (int64_t)it[H_NPARAMS]);
+      if (off >= lim) return MPCASM_ERR_PLAN;
     }
     const int32_t* gq = it + it[H_OFF_RS_GQ];
     for (int i = 0; i < it[H_RS_NQ]; ++i) {
@@ -321,6 +343,7 @@ int mpcasm_plan_create(const int32_t* h_itab, size_t n_itab, const double* h_dta
   d.off_rs_item = it[H_OFF_RS_ITEM]; d.off_rs_islot = it[H_OFF_RS_ISLOT];
   d.off_rs_tile = it[H_OFF_RS_TILE];
   d.rs_nq = it[H_RS_NQ]; d.off_rs_gq = it[H_OFF_RS_GQ];
+  d.off_rs_rr = it[H_OFF_RS_RR]; d.rs_pf = it[H_RS_PF]; d.off_rs_inmeta = it[H_OFF_RS_INMETA];
   {
     hipDeviceProp_t prop;
     plan->num_cus = 256;

@@ -524,7 +524,10 @@ int launch_fill_su(const double* A, const double* B, double* S, double* U, int b
     const int xsz = n * (m + n);
     // one wavefront per system when it fits comfortably, else one workgroup
     const bool small = xsz <= 64 * EPT && per * 4 <= 48 * 1024;
-    const int spw = xsz <= 32 ? 64 / xsz : 0;
+    // systems per wavefront of the tiny kernel: as many as fit its lanes, but fewer when
+    // the batch is too small to give every CU a couple of workgroups
+    int spw = xsz <= 32 ? 64 / xsz : 0;
+    while (spw > 2 && (batch + 4 * spw - 1) / (4 * spw) < 512) --spw;
     const size_t tiny = tiny_lds_doubles(N, n, m) * sizeof(double) * 4 * (spw > 0 ? spw : 1);
     if (spw >= 2 && tiny <= 64 * 1024) {
       const int per_block = 4 * spw;

@@ -27,7 +27,7 @@
 namespace mpcasm {
 
 constexpr int32_t PLAN_MAGIC = 0x4D504341;  // 'MPCA'
-constexpr int32_t PLAN_VERSION = 8;
+constexpr int32_t PLAN_VERSION = 9;
 
 enum HeaderWord : int {
   H_MAGIC = 0,
@@ -90,6 +90,9 @@ enum HeaderWord : int {
   H_RS_NQ,          // gradient records: one per (gterm, row)
   H_OFF_RS_GQ,      // [NQ][4]: workspace offset of the A row, index of d, aim param,
                     //          weight param | (1 << 30 when the term is halved)
+  H_OFF_RS_RR,      // [NC][RS_RR_WORDS] row records of the stacked G (see resident.hip)
+  H_RS_PF,          // input slots per thread (0: the inputs are too large to prefetch)
+  H_OFF_RS_INMETA,  // [RS_PF_MAX][RS_NT] stream << 24 | offset of the input double, or -1
   H_WORDS = 64
 };
 
@@ -116,5 +119,6 @@ constexpr int MAX_SOURCES = 32;
 // RS_NT threads per instance; RS_NW of its wavefronts run the matrix core, the rest the
 // vector work; RS_TPW tiles per MFMA wavefront; RS_JC_MAX compose ops per thread
 constexpr int RS_NW = 4, RS_NT = 512, RS_TPW = 9, RS_JC_MAX = 12, RS_ITEM_WORDS = 4;
+constexpr int RS_AXMAX = 4, RS_PF_MAX = 3, RS_RR_WORDS = 2 + 3 * RS_AXMAX;
 
 }  // namespace mpcasm

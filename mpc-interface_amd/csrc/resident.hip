@@ -45,10 +45,10 @@ constexpr int NT = RS_NT;         // threads of a workgroup
 constexpr int MW = RS_NW;         // wavefronts that run the matrix core
 constexpr int WT = NT - MW * 64;  // threads of the worker wavefronts
 constexpr int TPW = RS_TPW;
-constexpr int AXMAX = 4;
-constexpr int RR_WORDS = 2 + 3 * AXMAX;  // naxes, extreme param, voff[], arrow param[], center param[]
+constexpr int AXMAX = RS_AXMAX;
+constexpr int RR_WORDS = RS_RR_WORDS;  // naxes, extreme param, voff[], arrow param[], center param[]
 constexpr int GU = 6;                    // 16-byte pieces of G a worker thread may own
-constexpr int PF = 3;                    // input doubles a thread may prefetch
+constexpr int PF = RS_PF_MAX;            // input doubles a thread may prefetch
 
 __host__ __device__ inline int even_up_i(int x) { return (x + 1) & ~1; }
 
@@ -153,31 +153,8 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
     for (int i = tid; i < MW * TPW * 2; i += NT) islot[i] = t[i];
     t = p.itab + p.off_rs_tile;
     for (int i = tid; i < MW * TPW; i += NT) tile[i] = t[i];
-    const int32_t* rowlimit = p.itab + p.off_rowlimit;
-    const int32_t* limits = p.itab + p.off_limit;
-    const int32_t* lax = p.itab + p.off_lax;
-    for (int R = tid; R < nc; R += NT) {
-      const int32_t* lm = limits + rowlimit[R] * LM_WORDS;
-      const int r = R - lm[LM_OUT0];
-      const int naxes = lm[LM_NAXES];
-      const int32_t* lx = lax + lm[LM_LAX0] * LX_WORDS;
-      int* rec = rr + R * RR_WORDS;
-      rec[0] = naxes;
-      rec[1] = lm[LM_EXTREME_P] + (lm[LM_EXTREME_ROWS] == 1 ? 0 : r);
-      for (int ax = 0; ax < AXMAX; ++ax) {
-        if (ax < naxes) {
-          const int vr = lx[ax * LX_WORDS + LX_ROWS] == 1 ? 0 : r;
-          rec[2 + ax] = (lx[ax * LX_WORDS + LX_ROWOFF] + vr) * ldv;
-          rec[2 + AXMAX + ax] = lm[LM_ARROW_P] + (lm[LM_ARROW_ROWS] == 1 ? 0 : r) * naxes + ax;
-          rec[2 + 2 * AXMAX + ax] =
-              lm[LM_CENTER_P] + (lm[LM_CENTER_ROWS] == 1 ? 0 : r) * naxes + ax;
-        } else {  // missing axis: weight 0 (the extra parameter slot) on row 0
-          rec[2 + ax] = 0;
-          rec[2 + AXMAX + ax] = p.nparams;
-          rec[2 + 2 * AXMAX + ax] = p.nparams;
-        }
-      }
-    }
+    t = p.itab + p.off_rs_rr;  // row records of G, precomputed by the plan compiler
+    for (int i = tid; i < nc * RR_WORDS; i += NT) rr[i] = t[i];
     double2* V2 = reinterpret_cast<double2*>(V);
     const int n2 = (even_up_i(p.rtot * ldv) + 16) / 2;
     for (int i = tid; i < n2; i += NT) V2[i] = double2{0.0, 0.0};
@@ -204,26 +181,11 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
   // given (ng), params (nparams).  in_meta: stream << 24 | offset; in_lds: slot
   // relative to the arena, or -1.
   const int32_t* arec = p.itab + p.off_arena;
-  const int in_total = (p.arena_total - 1) + ng + p.nparams;
-  const bool prefetching = in_total <= PF * NT && (phases & 128);
-  int in_meta[PF];  // stream << 24 | offset in the stream, or -1
+  const bool prefetching = p.rs_pf == PF && (phases & 128);
+  int in_meta[PF];  // stream << 24 | offset in the stream, or -1 (precomputed by the plan)
 #pragma unroll
-  for (int u = 0; u < PF; ++u) {
-    const int f = tid + u * NT;
-    in_meta[u] = -1;
-    if (prefetching && f < in_total) {
-      if (f < p.arena_total - 1) {
-        const int a = f + 1;  // arena slot (slot 0 is the constant 1.0)
-        int s = 0;
-        while (s + 1 < p.nsrc && arec[2 * (s + 1)] <= a) ++s;
-        in_meta[u] = (s << 24) | (a - arec[2 * s]);
-      } else if (f < p.arena_total - 1 + ng) {
-        in_meta[u] = (p.nsrc << 24) | (f - (p.arena_total - 1));
-      } else {
-        in_meta[u] = ((p.nsrc + 1) << 24) | (f - (p.arena_total - 1) - ng);
-      }
-    }
-  }
+  for (int u = 0; u < PF; ++u)
+    in_meta[u] = prefetching ? (p.itab + p.off_rs_inmeta)[u * NT + tid] : -1;
   auto input_address = [&](int meta, long inst) -> const double* {
     const int s = meta >> 24;
     const double* base = reinterpret_cast<const double* const*>(sptr)[3 * s];
@@ -532,16 +494,26 @@ int launch_jc(const PlanDev& p, const SrcTable& src, const double* params, const
   // the stamped instantiation exists for the diagnostic option only
   auto kernel = (g_phase_mask & 64) ? resident_assemble_kernel<JC, true>
                                     : resident_assemble_kernel<JC, false>;
-  if (lds_bytes > 64 * 1024) {
-    *err = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  // residency of this instantiation at this LDS size: queried once, then cached (the
+  // launch path itself makes no other runtime call, so it can be graph-captured)
+  static thread_local size_t cached_lds[2] = {0, 0};
+  static thread_local int cached_per_cu[2] = {0, 0};
+  const int slot = (g_phase_mask & 64) ? 1 : 0;
+  if (cached_lds[slot] != lds_bytes) {
+    if (lds_bytes > 64 * 1024) {
+      *err = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+      if (*err != hipSuccess) return MPCASM_ERR_HIP;
+    }
+    int n = 0;
+    *err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, NT, lds_bytes);
     if (*err != hipSuccess) return MPCASM_ERR_HIP;
+    cached_per_cu[slot] = n;
+    cached_lds[slot] = lds_bytes;
   }
   // persistent grid: exactly the workgroups that are resident at once, never more
   // than there are instances
-  int per_cu = 0;
-  *err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, NT, lds_bytes);
-  if (*err != hipSuccess) return MPCASM_ERR_HIP;
+  const int per_cu = cached_per_cu[slot];
   if (per_cu < 1) return MPCASM_ERR_LIMIT;
   long grid = (long)num_cus * per_cu;
   if (grid > batch) grid = batch;

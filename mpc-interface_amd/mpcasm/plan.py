@@ -15,7 +15,7 @@ import numpy as np
 import scipy.sparse as sp
 
 PLAN_MAGIC = 0x4D504341
-PLAN_VERSION = 8
+PLAN_VERSION = 9
 
 # header words (csrc/plan_tables.h, enum HeaderWord)
 _H = {name: i for i, name in enumerate([
@@ -28,11 +28,14 @@ _H = {name: i for i, name in enumerate([
     "NCOEF", "DOFF_COEFPOOL",
     "RS_OK", "RS_JC", "RS_SYM", "RS_NITEM", "OFF_RS_SRC", "OFF_RS_GIDX", "OFF_RS_DST",
     "DOFF_RS_COEF", "OFF_RS_ITEM", "OFF_RS_ISLOT", "OFF_RS_TILE", "RS_NQ", "OFF_RS_GQ",
+    "OFF_RS_RR", "RS_PF", "OFF_RS_INMETA",
 ])}
 H_WORDS = 64
 RS_NW, RS_NT, RS_TPW = 4, 512, 9          # MFMA wavefronts, threads per instance, tiles per wave
 RS_JC_MAX = 12                            # compose ops a thread can keep in registers
 RS_ITEM_WORDS = 4
+RS_AXMAX, RS_PF = 4, 3                   # axes per constraint row record, input slots per thread
+RS_RR_WORDS = 2 + 3 * RS_AXMAX
 SEG_WORDS, GT_WORDS, LM_WORDS, LX_WORDS = 8, 10, 12, 2
 FUSED_MAX_OPS = 1 << 18           # beyond this the staged pipeline is used
 FUSED_MAX_ARENA = 1 << 14         # doubles
@@ -348,6 +351,47 @@ def _fused_program(b, rowptr, entbase, entk, entcoef, rtot, ldv):
                 row_tiles=row_tiles)
 
 
+def _resident_rows(limit_recs, lax_recs, nparams, ldv):
+    """Per row of the stacked G: [naxes, extreme param, workspace offset of every axis'
+    row, arrow param of every axis, center param of every axis]; a missing axis points
+    at workspace row 0 with the always-zero parameter slot ``nparams``."""
+    rows = []
+    for out0, nrows, naxes, lax0, p_a, a_rows, p_c, c_rows, p_e, e_rows, _, _ in limit_recs:
+        for r in range(nrows):
+            rec = [naxes, p_e + (0 if e_rows == 1 else r)]
+            voff, ap, cp = [], [], []
+            for ax in range(RS_AXMAX):
+                if ax < naxes:
+                    off, rs = lax_recs[lax0 + ax]
+                    voff.append((off + (0 if rs == 1 else r)) * ldv)
+                    ap.append(p_a + (0 if a_rows == 1 else r) * naxes + ax)
+                    cp.append(p_c + (0 if c_rows == 1 else r) * naxes + ax)
+                else:
+                    voff.append(0)
+                    ap.append(nparams)
+                    cp.append(nparams)
+            rows.append(rec + voff + ap + cp)
+    return np.asarray(rows, dtype=np.int32).reshape(-1)
+
+
+def _resident_inputs(sources, arena_off, ng, nparams):
+    """Which input doubles every thread of the persistent kernel stages: flat index
+    f = thread + slot * RS_NT over [sources..., given, params] ->
+    stream << 24 | offset in the stream, or -1."""
+    total = sum(s.array.size for s in sources) + ng + nparams
+    if total > RS_PF * RS_NT or any(s.array.size >= 1 << 24 for s in sources):
+        return 0, -np.ones(RS_PF * RS_NT, dtype=np.int32)
+    meta = []
+    for sid, s in enumerate(sources):
+        meta.append((sid << 24) | np.arange(s.array.size, dtype=np.int64))
+    meta.append((len(sources) << 24) | np.arange(ng, dtype=np.int64))
+    meta.append(((len(sources) + 1) << 24) | np.arange(nparams, dtype=np.int64))
+    flat = np.concatenate(meta) if meta else np.zeros(0, dtype=np.int64)
+    out = -np.ones(RS_PF * RS_NT, dtype=np.int64)
+    out[:flat.size] = flat
+    return RS_PF, out.astype(np.int32)
+
+
 def _resident_program(fused, gterms, no, ldv):
     """Tables of the persistent fused kernel: the compose ops of ``_fused_program``
     dealt out to the RS_NT threads of a workgroup (kept in registers for the whole
@@ -546,6 +590,11 @@ def compile_plan(form, costs=None, limits=None):
         rec[7] = mask(rec[0], rec[2])
         rec[8] = mask(rec[1], rec[2]) if rec[1] >= 0 else 0
     resident = _resident_program(fused, gterms, no, ldv)
+    rs_rr = _resident_rows(limit_recs, lax_recs, len(b.params), ldv)
+    arena_offsets = fused["arena"].reshape(-1, 2)[:, 0] if len(b.sources) else []
+    rs_pf, rs_inmeta = _resident_inputs(b.sources, arena_offsets, b.ng, len(b.params))
+    if any(rec[2] > RS_AXMAX for rec in limit_recs):
+        rs_rr = np.zeros(0, dtype=np.int32)      # too many axes: no resident kernel
     pm_blocks, pm_rows, r0 = [], {}, 0
     for var in form.definitions.keys():
         M = b.var_matrix[var]
@@ -579,6 +628,8 @@ def compile_plan(form, costs=None, limits=None):
         ("OFF_RS_ISLOT", resident["islot"]),
         ("OFF_RS_TILE", resident["tile"]),
         ("OFF_RS_GQ", resident["gq"]),
+        ("OFF_RS_RR", rs_rr),
+        ("OFF_RS_INMETA", rs_inmeta),
     ]
     header = np.zeros(H_WORDS, dtype=np.int32)
     parts, off = [header], H_WORDS
@@ -613,6 +664,9 @@ def compile_plan(form, costs=None, limits=None):
     header[_H["RS_SYM"]] = resident["sym"]
     header[_H["RS_NITEM"]] = resident["items"].size // RS_ITEM_WORDS
     header[_H["RS_NQ"]] = resident["gq"].size // 4
+    header[_H["RS_PF"]] = rs_pf
+    if rs_rr.size != nc * RS_RR_WORDS:
+        header[_H["RS_OK"]] = 0                  # a constraint with more than RS_AXMAX axes
     header[_H["DOFF_RS_COEF"]] = entcoef.size + pm_entcoef.size + fused["coefpool"].size
     header[_H["NITAB"]], header[_H["NDTAB"]] = off, dtab.size
 

@@ -24,8 +24,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def short(name):
-    for key in ("resident_assemble_kernel", "fused_assemble_kernel", "fill_lti_kernel",
-                "fill_ltv_kernel", "compose_rowsets_kernel", "hessian_kernel",
+    for key in ("resident_assemble_kernel", "fused_assemble_kernel", "fill_lti_tiny_kernel",
+                "fill_lti_kernel", "fill_ltv_wave_kernel", "fill_ltv_kernel", "compose_rowsets_kernel", "hessian_kernel",
                 "constraints_kernel", "compose_preview_kernel", "preview_kernel"):
         if key in name:
             return key
