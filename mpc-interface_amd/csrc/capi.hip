@@ -108,7 +108,7 @@ int validate_plan(const int32_t* it, size_t n_itab, size_t n_dtab) {
     r = r && in_range(it[H_OFF_RS_TILE], RS_NW * RS_TPW, n, H_WORDS);
     r = r && it[H_RS_NQ] >= 0 && in_range(it[H_OFF_RS_GQ], (int64_t)it[H_RS_NQ] * 4, n, H_WORDS);
     r = r && (it[H_OFF_RS_GQ] % 4 == 0) && (it[H_OFF_RS_ITEM] % 4 == 0);
-    r = r && in_range(it[H_OFF_RS_RR], nc * RS_RR_WORDS, n, H_WORDS);
+    r = r && in_range(it[H_OFF_RS_RR], nc * RS_RR_WORDS, n, H_WORDS) && it[H_OFF_RS_RR] % 4 == 0;
     r = r && (it[H_RS_PF] == 0 || it[H_RS_PF] == RS_PF_MAX);
     r = r && in_range(it[H_OFF_RS_INMETA], (int64_t)RS_PF_MAX * RS_NT, n, H_WORDS);
     if (!r) return MPCASM_ERR_PLAN;
@@ -132,11 +132,13 @@ int validate_plan(const int32_t* it, size_t n_itab, size_t n_dtab) {
     const int32_t* rrw = it + it[H_OFF_RS_RR];
     for (int64_t R = 0; R < nc; ++R) {
       const int32_t* x = rrw + R * RS_RR_WORDS;
-      if (x[0] < 0 || x[0] > RS_AXMAX || x[1] < 0 || x[1] >= it[H_NPARAMS]) return MPCASM_ERR_PLAN;
+      if (x[RR_NAXES] < 0 || x[RR_NAXES] > RS_AXMAX || x[RR_EXTREME] < 0 ||
+          x[RR_EXTREME] >= it[H_NPARAMS])
+        return MPCASM_ERR_PLAN;
       for (int a = 0; a < RS_AXMAX; ++a)
-        if (x[2 + a] < 0 || x[2 + a] + no >= vsize + 1 || x[2 + RS_AXMAX + a] < 0 ||
-            x[2 + RS_AXMAX + a] > it[H_NPARAMS] || x[2 + 2 * RS_AXMAX + a] < 0 ||
-            x[2 + 2 * RS_AXMAX + a] > it[H_NPARAMS])
+        if (x[RR_VOFF + a] < 0 || x[RR_VOFF + a] + no >= vsize + 1 || x[RR_ARROW + a] < 0 ||
+            x[RR_ARROW + a] > it[H_NPARAMS] || x[RR_CENTER + a] < 0 ||
+            x[RR_CENTER + a] > it[H_NPARAMS])
           return MPCASM_ERR_PLAN;
     }
     const int32_t* im = it + it[H_OFF_RS_INMETA];

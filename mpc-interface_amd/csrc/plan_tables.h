@@ -27,7 +27,7 @@
 namespace mpcasm {
 
 constexpr int32_t PLAN_MAGIC = 0x4D504341;  // 'MPCA'
-constexpr int32_t PLAN_VERSION = 9;
+constexpr int32_t PLAN_VERSION = 10;
 
 enum HeaderWord : int {
   H_MAGIC = 0,
@@ -119,6 +119,8 @@ constexpr int MAX_SOURCES = 32;
 // RS_NT threads per instance; RS_NW of its wavefronts run the matrix core, the rest the
 // vector work; RS_TPW tiles per MFMA wavefront; RS_JC_MAX compose ops per thread
 constexpr int RS_NW = 4, RS_NT = 512, RS_TPW = 9, RS_JC_MAX = 12, RS_ITEM_WORDS = 4;
-constexpr int RS_AXMAX = 4, RS_PF_MAX = 3, RS_RR_WORDS = 2 + 3 * RS_AXMAX;
+// row record of G: voff[4], arrow param[4], center param[4], naxes, extreme param, 2 pad
+constexpr int RS_AXMAX = 4, RS_PF_MAX = 3, RS_RR_WORDS = 16;
+enum { RR_VOFF = 0, RR_ARROW = 4, RR_CENTER = 8, RR_NAXES = 12, RR_EXTREME = 13 };
 
 }  // namespace mpcasm

@@ -46,14 +46,14 @@ constexpr int MW = RS_NW;         // wavefronts that run the matrix core
 constexpr int WT = NT - MW * 64;  // threads of the worker wavefronts
 constexpr int TPW = RS_TPW;
 constexpr int AXMAX = RS_AXMAX;
-constexpr int RR_WORDS = RS_RR_WORDS;  // naxes, extreme param, voff[], arrow param[], center param[]
+constexpr int RR_WORDS = RS_RR_WORDS;
 constexpr int GU = 6;                    // 16-byte pieces of G a worker thread may own
 constexpr int PF = RS_PF_MAX;            // input doubles a thread may prefetch
 
 __host__ __device__ inline int even_up_i(int x) { return (x + 1) & ~1; }
 
 struct ResidentLayout {
-  int v, arena, pl, g, prm, qpart, ptrs, ints, total_doubles;  // offsets in doubles
+  int v, arena, pl, g, prm, qpart, rvec, ptrs, ints, total_doubles;  // offsets in doubles
   int ldp;                                                    // leading dimension of P in LDS
   int ns;                                                     // row slices of the gradient pass
   int i_tile, i_rr, i_gq, i_item, i_islot;  // offsets in ints inside the int region
@@ -66,7 +66,7 @@ __host__ __device__ inline ResidentLayout resident_layout(const PlanDev& p) {
   if (L.ns < 1) L.ns = 1;
   if (L.ns > 16) L.ns = 16;
   int o = 0;
-  L.v = o;     o += even_up_i(p.rtot * p.ldv) + 16;
+  L.v = o;     o += even_up_i(p.rtot * p.ldv) + 3 * p.ldv + 16;  // MFMA k-steps may overrun
   // the input image [arena | given (+ a 1.0) | params (+ a 0.0)] is contiguous; P
   // overlays the arena part once it is dead, but never given / params (read while P
   // is being assembled)
@@ -77,14 +77,15 @@ __host__ __device__ inline ResidentLayout resident_layout(const PlanDev& p) {
   L.g = o;     o += even_up_i(p.ng + 1);
   L.prm = o;   o += even_up_i(p.nparams + 1);
   L.qpart = o; o += L.ns * L.ldp;
+  L.rvec = o;  o += (WT / 64) * even_up_i(p.rs_nq);  // one copy per worker wavefront
   L.ptrs = o;  o += 3 * (MAX_SOURCES + 2);
   L.ints = o;
   int i = 0;
-  L.i_gq = i;    i += p.rs_nq * 4;  // first two: 16-byte aligned
+  L.i_gq = i;    i += p.rs_nq * 4;  // first three: 16-byte aligned
   L.i_item = i;  i += (p.rs_nitem + 1) * RS_ITEM_WORDS;
+  L.i_rr = i;    i += p.nc * RR_WORDS;
   L.i_islot = i; i += MW * TPW * 2;
   L.i_tile = i;  i += MW * TPW;
-  L.i_rr = i;    i += p.nc * RR_WORDS;
   o += even_up_i(i) / 2;
   L.total_doubles = o;
   return L;
@@ -117,6 +118,7 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
   double* gl = lds + L.g;
   double* prm = lds + L.prm;
   double* qpart = lds + L.qpart;
+  double* rvec = lds + L.rvec;
   double* sptr = lds + L.ptrs;  // [nsrc + 2] triples: base pointer, stride, LDS slot (raw words)
   int* itb = reinterpret_cast<int*>(lds + L.ints);
   int4* gq = reinterpret_cast<int4*>(itb + L.i_gq);
@@ -156,7 +158,7 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
     t = p.itab + p.off_rs_rr;  // row records of G, precomputed by the plan compiler
     for (int i = tid; i < nc * RR_WORDS; i += NT) rr[i] = t[i];
     double2* V2 = reinterpret_cast<double2*>(V);
-    const int n2 = (even_up_i(p.rtot * ldv) + 16) / 2;
+    const int n2 = (even_up_i(p.rtot * ldv) + 3 * ldv + 16) / 2;
     for (int i = tid; i < n2; i += NT) V2[i] = double2{0.0, 0.0};
     // (pointer, stride) of every input stream: the sources, then given, then params
     if (tid < p.nsrc + 2) {
@@ -292,10 +294,9 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
               double a[4], b[4];
 #pragma unroll
               for (int u = 0; u < 4; ++u) {  // all eight loads in flight together
-                const int k = k0 + 4 * u + lk;
-                const int kc = k < nrows ? k : nrows - 1;
-                a[u] = ap[kc * ldv];
-                b[u] = bp[kc * ldv];
+                const int k = k0 + 4 * u + lk;  // rows past the term are read and masked
+                a[u] = ap[k * ldv];
+                b[u] = bp[k * ldv];
               }
 #pragma unroll
               for (int u = 0; u < 4; ++u) a[u] = k0 + 4 * u + lk < nrows ? w * a[u] : 0.0;
@@ -319,10 +320,15 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
     } else {
       if (P != nullptr && (phases & 4)) {
         // ---- gradient: q[c] = sum_records w s V[a][c] (V[d] - aim), rows sliced NS ways --
-        double qa = 0.0;
-        if (qs < NS) {
+        // q[c] = sum_records w s V[a][c] (V[d] - aim): thread = (column qc, row slice qs)
+        // (the opaque copies keep derived addresses from being hoisted out of the instance
+        // loop into long-lived registers)
+        int qs_ = qs, qc_ = qc;
+        asm volatile("" : "+v"(qs_), "+v"(qc_));
+        if (qs_ < NS) {
           const int nq = p.rs_nq;
-          for (int i0 = qs; i0 < nq; i0 += 2 * NS) {  // two records per trip, loads in flight
+          double qa = 0.0;
+          for (int i0 = qs_; i0 < nq; i0 += 2 * NS) {  // two records per trip, loads in flight
             int4 e[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -335,7 +341,7 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
               w[u] = prm[e[u].w & 0x3FFFFFFF];
               d[u] = V[e[u].y];
               aim[u] = prm[e[u].z];
-              a[u] = V[e[u].x + qc];
+              a[u] = V[e[u].x + qc_];
             }
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -344,7 +350,7 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
               qa = i0 + u * NS < nq ? t : qa;
             }
           }
-          qpart[qs * ldp + qc] = qa;
+          qpart[qs_ * ldp + qc_] = qa;
         }
       }
       MPCASM_STAMP(3)
@@ -361,14 +367,14 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
           asm volatile("" : "+v"(R), "+v"(cp));
 #pragma unroll
           for (int u0 = 0; u0 < GU; u0 += 3) {  // three pieces per trip
-            int v0o[3], v1o[3], a0i[3], a1i[3];
+            int2 vo[3], ai[3];
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
               const int* rec = rr + (R < nc ? R : 0) * RR_WORDS;
-              v0o[u] = rec[2] + 2 * cp;
-              v1o[u] = rec[3] + 2 * cp;
-              a0i[u] = rec[2 + AXMAX];
-              a1i[u] = rec[3 + AXMAX];
+              vo[u] = *reinterpret_cast<const int2*>(rec + RR_VOFF);
+              ai[u] = *reinterpret_cast<const int2*>(rec + RR_ARROW);
+              vo[u].x += 2 * cp;
+              vo[u].y += 2 * cp;
               cp += g_dcp;
               R += g_dR;
               if (cp >= npair) {
@@ -380,10 +386,10 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
             double2 v0[3], v1[3];
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
-              a0[u] = prm[a0i[u]];
-              a1[u] = prm[a1i[u]];
-              v0[u] = *reinterpret_cast<const double2*>(V + v0o[u]);
-              v1[u] = *reinterpret_cast<const double2*>(V + v1o[u]);
+              a0[u] = prm[ai[u].x];
+              a1[u] = prm[ai[u].y];
+              v0[u] = *reinterpret_cast<const double2*>(V + vo[u].x);
+              v1[u] = *reinterpret_cast<const double2*>(V + vo[u].y);
             }
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
@@ -400,11 +406,11 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
           double2* G2 = reinterpret_cast<double2*>(Gb);
           while (e < gtotal) {
             const int* rec = rr + R * RR_WORDS;
-            const int naxes = rec[0];
+            const int naxes = rec[RR_NAXES];
             double2 accv{0.0, 0.0};
             for (int ax = 0; ax < naxes; ++ax) {
-              const double a = prm[rec[2 + AXMAX + ax]];
-              const double2 v = *reinterpret_cast<const double2*>(V + rec[2 + ax] + 2 * cp);
+              const double a = prm[rec[RR_ARROW + ax]];
+              const double2 v = *reinterpret_cast<const double2*>(V + rec[RR_VOFF + ax] + 2 * cp);
               accv.x = fma(a, v.x, accv.x);
               accv.y = fma(a, v.y, accv.y);
             }
@@ -423,10 +429,10 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
           int e = wt, R = wt / no, c = wt - (wt / no) * no;
           while (e < total) {
             const int* rec = rr + R * RR_WORDS;
-            const int naxes = rec[0];
+            const int naxes = rec[RR_NAXES];
             double accv = 0.0;
             for (int ax = 0; ax < naxes; ++ax)
-              accv = fma(prm[rec[2 + AXMAX + ax]], V[rec[2 + ax] + c], accv);
+              accv = fma(prm[rec[RR_ARROW + ax]], V[rec[RR_VOFF + ax] + c], accv);
             Gb[e] = accv;
             e += WT;
             c += dc;
@@ -440,14 +446,14 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
         double* hb = h + (size_t)inst * nc;
         for (int R = wt; R < nc; R += WT) {
           const int* rec = rr + R * RR_WORDS;
-          const int naxes = rec[0];
+          const int naxes = rec[RR_NAXES];
           double ac = 0.0, ad = 0.0;
           for (int ax = 0; ax < naxes; ++ax) {
-            const double a = prm[rec[2 + AXMAX + ax]];
-            ac += a * prm[rec[2 + 2 * AXMAX + ax]];
-            ad = fma(a, V[rec[2 + ax] + no], ad);
+            const double a = prm[rec[RR_ARROW + ax]];
+            ac += a * prm[rec[RR_CENTER + ax]];
+            ad = fma(a, V[rec[RR_VOFF + ax] + no], ad);
           }
-          hb[R] = (prm[rec[1]] + ac) - ad;
+          hb[R] = (prm[rec[RR_EXTREME]] + ac) - ad;
         }
       }
       MPCASM_STAMP(4)

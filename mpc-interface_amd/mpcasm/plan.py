@@ -15,7 +15,7 @@ import numpy as np
 import scipy.sparse as sp
 
 PLAN_MAGIC = 0x4D504341
-PLAN_VERSION = 9
+PLAN_VERSION = 10
 
 # header words (csrc/plan_tables.h, enum HeaderWord)
 _H = {name: i for i, name in enumerate([
@@ -35,7 +35,7 @@ RS_NW, RS_NT, RS_TPW = 4, 512, 9          # MFMA wavefronts, threads per instanc
 RS_JC_MAX = 12                            # compose ops a thread can keep in registers
 RS_ITEM_WORDS = 4
 RS_AXMAX, RS_PF = 4, 3                   # axes per constraint row record, input slots per thread
-RS_RR_WORDS = 2 + 3 * RS_AXMAX
+RS_RR_WORDS = 16                          # row record: voff[4], arrow param[4], center param[4], naxes, extreme param, pad
 SEG_WORDS, GT_WORDS, LM_WORDS, LX_WORDS = 8, 10, 12, 2
 FUSED_MAX_OPS = 1 << 18           # beyond this the staged pipeline is used
 FUSED_MAX_ARENA = 1 << 14         # doubles
@@ -352,13 +352,14 @@ def _fused_program(b, rowptr, entbase, entk, entcoef, rtot, ldv):
 
 
 def _resident_rows(limit_recs, lax_recs, nparams, ldv):
-    """Per row of the stacked G: [naxes, extreme param, workspace offset of every axis'
-    row, arrow param of every axis, center param of every axis]; a missing axis points
-    at workspace row 0 with the always-zero parameter slot ``nparams``."""
+    """Per row of the stacked G, 16 words: workspace offset of every axis' row [4], arrow
+    param of every axis [4], center param of every axis [4], naxes, extreme param, 2 pad;
+    a missing axis points at workspace row 0 with the always-zero parameter slot
+    ``nparams``."""
     rows = []
     for out0, nrows, naxes, lax0, p_a, a_rows, p_c, c_rows, p_e, e_rows, _, _ in limit_recs:
         for r in range(nrows):
-            rec = [naxes, p_e + (0 if e_rows == 1 else r)]
+            tail = [naxes, p_e + (0 if e_rows == 1 else r), 0, 0]
             voff, ap, cp = [], [], []
             for ax in range(RS_AXMAX):
                 if ax < naxes:
@@ -370,7 +371,7 @@ def _resident_rows(limit_recs, lax_recs, nparams, ldv):
                     voff.append(0)
                     ap.append(nparams)
                     cp.append(nparams)
-            rows.append(rec + voff + ap + cp)
+            rows.append(voff + ap + cp + tail)
     return np.asarray(rows, dtype=np.int32).reshape(-1)
 
 
@@ -637,7 +638,7 @@ def compile_plan(form, costs=None, limits=None):
         if name == "OFF_OP" and off & 1:          # the kernels read ops as 8-byte pairs
             parts.append(np.zeros(1, dtype=np.int32))
             off += 1
-        if name in ("OFF_RS_GQ", "OFF_RS_ITEM") and off & 3:   # ... and these as 16-byte quads
+        if name in ("OFF_RS_GQ", "OFF_RS_ITEM", "OFF_RS_RR") and off & 3:   # ... 16-byte quads
             pad = 4 - (off & 3)
             parts.append(np.zeros(pad, dtype=np.int32))
             off += pad
