@@ -206,17 +206,22 @@ class Assembler:
         strides = (ctypes.c_int64 * max(n, 1))(*self._src_stride)
         return ptrs, strides
 
-    def assemble(self, given=None, out=None, stream=None, want_cost=True, want_constraints=True):
-        """Assemble the whole batch; returns ``(P, q, G, h)`` device tensors
-        (``None`` for a skipped half).  ``given``: ``(B, ng)`` or ``(ng,)``."""
+    def assemble(self, given=None, out=None, stream=None, want_cost=True, want_constraints=True,
+                 count=None):
+        """Assemble the batch; returns ``(P, q, G, h)`` device tensors (``None`` for a
+        skipped half).  ``given``: ``(B, ng)`` or ``(ng,)``.  ``count`` < batch assembles
+        only the first ``count`` instances (buffers keep their full capacity)."""
         torch = self._torch
         B, ng, no, nc = self.batch, self.ng, self.no, self.nc
+        n_run = B if count is None else int(count)
+        if not 0 <= n_run <= B:
+            raise ValueError("count must lie in [0, %d]" % B)
         if ng:
             g = _as_device(torch, given, self.device).reshape(-1, ng)
             if g.shape[0] == 1 and B > 1:
                 g = g.repeat(B, 1)
-            if g.shape[0] != B:
-                raise ValueError("given must have %d rows, got %d" % (B, g.shape[0]))
+            if g.shape[0] < n_run or (count is None and g.shape[0] != B):
+                raise ValueError("given must have %d rows, got %d" % (n_run, g.shape[0]))
         else:
             g = None
         if out is None:
@@ -235,7 +240,7 @@ class Assembler:
         with torch.cuda.device(self.device):
             rc = capi.load().mpcasm_assemble(
                 self._handle, ptrs, strides, self.params.data_ptr(), ptr(g), ptr(P), ptr(q),
-                ptr(G), ptr(h), self._work.data_ptr(), B, _stream_handle(torch, stream))
+                ptr(G), ptr(h), self._work.data_ptr(), n_run, _stream_handle(torch, stream))
         capi.check(rc, "mpcasm_assemble")
         return P, q, G, h
 

@@ -1,0 +1,140 @@
+"""Batched tick driver for a fleet of biped walkers.
+
+The reference's walking loop (use_examples/simple_functional_example/
+biped_mpc_loop.py:17-95) advances ONE walker: every tick it counts the step times
+down, re-plans the step indicator matrix (tools.update_step_matrices -> plan_steps),
+moves the stepping-area centres (tools.update_stepping_area) and re-assembles the QP,
+whose width changes with the walking phase (34 / 36 unknowns at N=16).
+
+Here a whole fleet advances in lock-step ticks, every walker with its own phase.
+The QP *structure* depends only on the number ``p`` of steps inside the preview, so
+the fleet is split into structure buckets (one compiled plan and one persistent
+assembly launch per bucket and tick); what differs between walkers of a bucket is
+numbers: the step indicator matrix ``E`` (a per-instance source), the stepping-area
+centres (per-instance parameters) and the given vector.
+"""
+import numpy as np
+
+from . import problems
+
+
+def steps_in_preview(step_times, N):
+    """Boolean mask of the step instants inside ``[0, N - 1)`` (tools.py:84 with count=0)."""
+    return (step_times >= 0) & (step_times < N - 1)
+
+
+def step_indicator(step_times, N):
+    """``E[b, k, s] = 1`` when preview sample ``k`` lies after the ``s``-th step instant of
+    walker ``b`` (tools.plan_steps, tools.py:79-101, for walkers that all have the same
+    number of steps in the preview).  ``step_times``: ``(B, p)`` kept instants."""
+    k = np.arange(N).reshape(1, N, 1)
+    return (k > step_times[:, None, :]).astype(np.float64)
+
+
+def stepping_centers(step_count, p, xy):
+    """Alternating left/right centres of the next ``p`` stepping areas for every walker
+    (tools.find_step_centers, tools.py:158-165): ``(B, p, 2)``."""
+    side = (-1.0) ** (np.asarray(step_count) + 1)
+    alt = np.tile([1.0, -1.0], p // 2 + 1)[:p]
+    out = np.empty((len(side), p, 2))
+    out[:, :, 0] = xy[0]
+    out[:, :, 1] = side[:, None] * alt[None, :] * xy[1]
+    return out
+
+
+class FleetClock:
+    """Vectorised step-time bookkeeping (biped_mpc_loop.py:41-45): every tick the step
+    times count down; when the first reaches -1 they wrap by ``step_samples`` and the
+    walker's step count goes up."""
+
+    def __init__(self, step_samples, n_steps, phases):
+        phases = np.asarray(phases, dtype=np.int64)
+        base = np.array([(i + 1) * step_samples - 1 for i in range(n_steps)], dtype=np.int64)
+        self.n = int(step_samples)
+        self.step_times = base[None, :] - phases[:, None]
+        self.step_count = np.zeros(len(phases), dtype=np.int64)
+
+    def tick(self):
+        self.step_times -= 1
+        wrap = self.step_times[:, 0] == -1
+        self.step_times[wrap] += self.n
+        self.step_count[wrap] += 1
+
+
+class WalkerFleet:
+    """``batch`` walkers on the biped formulation of ``problems.biped``.
+
+    ``phases[b]`` in ``[0, step_samples)`` is how many ticks walker ``b`` is ahead in its
+    step cycle.  :meth:`tick` assembles the QPs of all walkers for the current tick and
+    advances the clocks; it returns one entry per structure bucket:
+    ``{"p": steps in preview, "index": walker ids, "P", "q", "G", "h": device tensors}``.
+    """
+
+    def __init__(self, batch, phases=None, conf=None, api=None, device=None):
+        from .engine import Assembler, require_device
+
+        self._torch = require_device()
+        self.conf = conf or problems.BipedConfig()
+        self.api = api or problems.load_api("mpc_interface")
+        self.batch = int(batch)
+        n = self.conf.step_samples
+        self.N = self.conf.horizon_lenght
+        phases = np.arange(self.batch) % n if phases is None else np.asarray(phases)
+        self.clock = FleetClock(n, self.conf.num_steps, phases)
+        self.device = device
+
+        # one template formulation + assembler per structure bucket (steps in preview)
+        self.buckets = {}
+        for phi in range(n):
+            times = np.array([(i + 1) * n - 1 - phi for i in range(self.conf.num_steps)])
+            p = int(steps_in_preview(times, self.N).sum())
+            if p in self.buckets:
+                continue
+            form = problems.biped(self.api, self.conf)
+            form.update(step_times=times, step_count=0)
+            asm = Assembler(form, batch=self.batch, device=device)
+            torch = self._torch
+            E = torch.zeros((self.batch, self.N, p, 1), dtype=torch.float64, device=asm.device)
+            asm.bind_source(("steps", 0), E)
+            # the stepping area is the first box: its facets are the first limits
+            n_facets = len(form.constraint_boxes["stepping area"].constraints)
+            first = sum(len(group) for group in form.constraints.values())
+            self.buckets[p] = dict(form=form, asm=asm, E=E, facets=range(first, first + n_facets))
+
+    @property
+    def given_len(self):
+        return next(iter(self.buckets.values()))["asm"].ng
+
+    def structure_of(self):
+        """Steps in the preview of every walker right now (its structure bucket)."""
+        return steps_in_preview(self.clock.step_times, self.N).sum(axis=1)
+
+    def tick(self, given):
+        """Assemble this tick's QPs (``given``: ``(batch, ng)`` tensor or array), then
+        advance every walker's clock."""
+        torch = self._torch
+        p_of = self.structure_of()
+        out = []
+        for p, bucket in self.buckets.items():
+            idx = np.nonzero(p_of == p)[0]
+            if idx.size == 0:
+                continue
+            asm = bucket["asm"]
+            times = self.clock.step_times[idx]
+            kept = times[steps_in_preview(times, self.N)].reshape(idx.size, p)
+            bucket["E"][:idx.size, :, :, 0] = torch.as_tensor(step_indicator(kept, self.N),
+                                                              device=asm.device)
+            centers = stepping_centers(self.clock.step_count[idx], p, self.conf.stepping_center)
+            for k in bucket["facets"]:
+                sl, (rows, cols) = asm.param_slice("limit", k, "center")
+                asm.params[:idx.size, sl] = torch.as_tensor(
+                    centers.reshape(idx.size, rows * cols), device=asm.device)
+            index = torch.as_tensor(idx, device=asm.device)
+            g = given if isinstance(given, torch.Tensor) else torch.as_tensor(
+                np.asarray(given, dtype=np.float64), device=asm.device)
+            g = g.to(asm.device).index_select(0, index)
+            P, q, G, h = asm.assemble(g, count=idx.size)
+            out.append({"p": p, "index": idx, "P": P[:idx.size], "q": q[:idx.size],
+                        "G": G[:idx.size], "h": h[:idx.size]})
+        self.clock.tick()
+        return out

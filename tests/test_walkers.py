@@ -1,0 +1,90 @@
+"""The batched tick driver: vectorised clock, step indicator and
+stepping centres against the single-walker host logic (CPU), and a fleet of walkers in
+different phases against the oracle stepped walker by walker (GPU)."""
+import numpy as np
+import pytest
+
+from helpers import RTOL_TIGHT, assert_close, golden
+from mpcasm import problems
+from mpcasm.walkers import FleetClock, WalkerFleet, step_indicator, stepping_centers, \
+    steps_in_preview
+from oracle import qp_oracle as orc
+import mpc_interface.tools as tools
+
+
+def test_fleet_clock_matches_the_single_walker_clock():
+    n, phases = 8, np.arange(11) % 8
+    fleet = FleetClock(n, 2, phases)
+    singles = []
+    for phi in phases:
+        c = problems.StepClock(n, 2)
+        for _ in range(phi):
+            c.tick()
+        singles.append(c)
+    for _ in range(20):
+        for b, c in enumerate(singles):
+            assert np.array_equal(fleet.step_times[b], c.step_times)
+            assert fleet.step_count[b] == c.step_count
+        fleet.tick()
+        for c in singles:
+            c.tick()
+
+
+def test_step_indicator_and_centres_match_tools():
+    N = 16
+    for times in (np.array([6, 14]), np.array([7, 15]), np.array([0, 8]), np.array([3, 11])):
+        keep = steps_in_preview(times, N)
+        E = step_indicator(times[keep][None, :], N)[0]
+        assert np.array_equal(E, tools.plan_steps(N, 0, step_times=times))
+    for count in range(4):
+        for p in (1, 2, 3):
+            c = stepping_centers(np.array([count]), p, [0.0, 0.28])[0]
+            assert_close(c, tools.find_step_centers(count, p, [0.0, 0.28]), 0)
+
+
+def test_bucket_widths_follow_the_golden_tick_sequence():
+    """One walker in phase 0 reproduces the reference's shape sequence (34/36 wide)."""
+    g = golden("g3_biped_N16")
+    clock = FleetClock(8, 2, [0])
+    for tick in range(18):
+        p = int(steps_in_preview(clock.step_times, 16).sum())
+        assert 32 + 2 * p == g["shapes"][tick][2]
+        clock.tick()
+
+
+@pytest.mark.gpu
+def test_fleet_against_the_oracle(gpu_api):
+    conf = problems.BipedConfig(step_samples=8)
+    batch = 19
+    phases = np.arange(batch) % 8
+    fleet = WalkerFleet(batch, phases=phases, conf=conf, api=gpu_api)
+    ref = problems.biped(gpu_api, conf)          # one formulation, re-pointed at each walker
+    clocks = []
+    for phi in phases:
+        c = problems.StepClock(conf.step_samples, 2)
+        for _ in range(phi):
+            c.tick()
+        clocks.append(c)
+    rng = np.random.default_rng(3)
+    widths = set()
+    for tick in range(10):
+        given = rng.normal(0, 0.1, [batch, fleet.given_len])
+        results = fleet.tick(given)
+        seen = np.zeros(batch, dtype=bool)
+        for res in results:
+            P, q, G, h = (res[k].cpu().numpy() for k in ("P", "q", "G", "h"))
+            widths.add(P.shape[1])
+            for row, b in enumerate(res["index"]):
+                seen[b] = True
+                if tick in (0, 3, 9) or b < 3:
+                    ref.update(step_times=clocks[b].step_times, step_count=clocks[b].step_count)
+                    A, hh, Q, qq = orc.assemble(ref, given[b].reshape(-1, 1))
+                    assert Q.shape[0] == P.shape[1] == 32 + 2 * res["p"]
+                    assert_close(P[row], Q, RTOL_TIGHT, "P")
+                    assert_close(q[row], qq.ravel(), RTOL_TIGHT, "q")
+                    assert_close(G[row], A, RTOL_TIGHT, "G")
+                    assert_close(h[row], hh.ravel(), RTOL_TIGHT, "h")
+        assert seen.all()
+        for c in clocks:
+            c.tick()
+    assert widths == {34, 36}
