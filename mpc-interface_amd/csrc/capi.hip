@@ -392,6 +392,7 @@ int mpcasm_assemble(const mpcasm_plan* plan, const double* const* h_src,
                     double* d_P, double* d_q, double* d_G, double* d_h, void* d_work, int batch,
                     void* stream) {
   if (!plan || batch < 0) return MPCASM_ERR_ARG;
+  if (batch == 0) return MPCASM_OK;  // nothing to do (empty buffers may be null)
   const PlanDev& d = plan->dev;
   if ((d.nsrc && (!h_src || !h_src_stride)) || (d.nparams && !d_params) || (d.ng && !d_given))
     return MPCASM_ERR_ARG;

@@ -330,3 +330,64 @@ def test_errors_and_edges(gpu_api):
     # a definition that depends on an undefined variable is refused at incorporation
     with pytest.raises(AssertionError):
         form.incorporate_definition("bad", gpu_api.LineCombo({"nope_x": 1}))
+
+
+def test_edge_shapes(gpu_api):
+    """Degenerate shapes: costs only (no inequality rows), constraints only, every
+    domain variable unknown (empty given vector), batches of one and zero."""
+    import torch
+    from mpcasm.engine import Assembler
+
+    api = gpu_api
+    rng = np.random.default_rng(12)
+    A, B = problems.random_lti_matrices(rng, 3, 1)
+    ext = api.ExtendedSystem.from_cotrol_system(
+        api.ControlSystem(["u"], ["p", "v", "a"], A, B), "x", 5)
+
+    def base():
+        form = api.Formulation()
+        form.incorporate_dynamics("plant", ext)
+        return form
+
+    # costs only
+    form = base()
+    form.incorporate_goal("track", api.Cost("p", 2.0, aim=[0.5]))
+    form.identify_qp_domain(["u"])
+    form.make_preview_matrices()
+    given = rng.standard_normal([form.given_len, 1])
+    Q, q = form.generate_all_qp_costs(given)
+    PM = orc.preview_matrices(form)
+    Qo, qo = orc.qp_all_costs(form, PM, given)
+    assert_close(Q, Qo, RTOL_TIGHT)
+    assert_close(q, qo, RTOL_TIGHT)
+    asm = Assembler(form, batch=2)
+    P, qq, G, h = asm.assemble(np.tile(given.T, (2, 1)))
+    assert G is None and h is None and P.shape == (2, 5, 5)
+
+    # constraints only, one instance, odd number of unknowns (scalar store paths)
+    form = base()
+    form.incorporate_constraint("cap", [api.Constraint("v", 1.0), api.Constraint("p", 2.0, arrow=[-1])])
+    form.identify_qp_domain(["u"])
+    form.make_preview_matrices()
+    Ag, hg = form.generate_all_qp_constraints(given)
+    Ao, ho = orc.qp_all_constraints(form, orc.preview_matrices(form), given)
+    assert_close(Ag, Ao, RTOL_TIGHT)
+    assert_close(hg, ho, RTOL_TIGHT)
+
+    # every domain variable unknown: the given vector is empty
+    form = base()
+    form.incorporate_goal("track", api.Cost("p", 1.0, aim=[0.1]))
+    form.incorporate_constraint("cap", api.Constraint("v", 1.0))
+    form.identify_qp_domain(["u", "x0"])
+    form.make_preview_matrices()
+    assert form.given_len == 0 and form.optim_len == 8
+    empty = form.arrange_given({})
+    A_, h_, Q_, q_ = form.generate_all_qp_matrices(empty)
+    Ao, ho, Qo, qo = orc.assemble(form, np.zeros([0, 1]))
+    for mine, ref in ((A_, Ao), (h_, ho), (Q_, Qo), (q_, qo)):
+        assert_close(mine, ref, RTOL_TIGHT)
+
+    # a batch of zero instances is a no-op
+    asm = Assembler(problems.body_case(api), batch=0)
+    P, qq, G, h = asm.assemble(torch.zeros((0, asm.ng), dtype=torch.float64, device="cuda"))
+    assert P.shape[0] == 0 and G.shape[0] == 0
