@@ -92,7 +92,8 @@ __global__ __launch_bounds__(BLOCK) void hessian_kernel(PlanDev p,
                                                         const double* __restrict__ params,
                                                         const double* __restrict__ V,
                                                         double* __restrict__ P,
-                                                        double* __restrict__ q, int nrb) {
+                                                        double* __restrict__ q, int nrb,
+                                                        int q_only) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const long inst = blockIdx.x / nrb;
   const int rb = blockIdx.x - inst * nrb;
@@ -100,8 +101,9 @@ __global__ __launch_bounds__(BLOCK) void hessian_kernel(PlanDev p,
   const int nbr = (no + 31) / 32;      // block rows
   const int nbc = (no + 1 + 31) / 32;  // block columns (q is column `no`)
   const int blk = rb * WAVES + wave;
-  if (blk >= nbr * nbc) return;
-  const int bi = blk / nbc, bj = blk - bi * nbc;
+  if (blk >= (q_only ? nbr : nbr * nbc)) return;
+  // q_only: P comes from hessian_gemm_kernel; only the block column holding q is computed
+  const int bi = q_only ? blk : blk / nbc, bj = q_only ? no / 32 : blk - (blk / nbc) * nbc;
   const bool has_qcol = (bj == no / 32);
   const double* Vb = V + (size_t)inst * p.rtot * p.ldv;
   const double* pb = params + (size_t)inst * p.nparams;
@@ -126,7 +128,7 @@ __global__ __launch_bounds__(BLOCK) void hessian_kernel(PlanDev p,
     const unsigned ma = (unsigned)rec[GT_MASKA], mb = (unsigned)rec[GT_MASKB];
     const bool a_here = (ma >> min(2 * bi, 30)) & 3u || 2 * bi >= 30;
     const bool b_here = (mb >> min(2 * bj, 30)) & 3u || 2 * bj >= 30;
-    const bool hasP = (flags & GT_FLAG_P) && a_here && b_here;
+    const bool hasP = (flags & GT_FLAG_P) && a_here && b_here && !q_only;
     if (!a_here || (!hasP && !has_qcol)) continue;
     const int aoff = rec[GT_AOFF], boff = rec[GT_BOFF], doff = rec[GT_DOFF];
     const int nrows = rec[GT_NROWS];
@@ -170,12 +172,207 @@ __global__ __launch_bounds__(BLOCK) void hessian_kernel(PlanDev p,
         const int row = bi * 32 + ti * 16 + lk + 4 * reg;
         const int col = bj * 32 + tj * 16 + li;
         if (row < no) {
-          if (col < no)
-            Pb[(size_t)row * no + col] = acc[ti][tj][reg];
-          else if (col == no)
+          if (col < no) {
+            if (!q_only) Pb[(size_t)row * no + col] = acc[ti][tj][reg];
+          } else if (col == no)
             qb[row] = acc[ti][tj][reg];
         }
       }
+}
+
+// ---------------------------------------------------------------------------
+// K3 for wide problems (no >= 128, BASELINE config C4): P = sum_terms (w A)^T B as an
+// LDS-tiled batched GEMM on the fp64 matrix core.  A workgroup owns a 128 x 128 block
+// of one instance's P (four wavefronts, 64 x 64 = 4 x 4 MFMA tiles each, accumulators
+// in registers for the whole K loop); the rows of the workspace are staged 16 at a
+// time through LDS with coalesced 16-byte loads (row stride padded to 144 doubles so
+// that the fragment reads of the four k-rows fall on disjoint bank halves).  When
+// every term is symmetric only blocks bi <= bj are computed and mirrored on store.
+// The gradient is computed by gradient_kernel.
+// ---------------------------------------------------------------------------
+constexpr int GB = 128, GK = 16, GLD = GB + 16;
+
+__global__ __launch_bounds__(BLOCK) void hessian_gemm_kernel(PlanDev p,
+                                                             const double* __restrict__ params,
+                                                             const double* __restrict__ V,
+                                                             double* __restrict__ P, int nb,
+                                                             int npairs, int sym) {
+  __shared__ __attribute__((aligned(16))) double As[2][GK * GLD];
+  __shared__ __attribute__((aligned(16))) double Bs[2][GK * GLD];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const long inst = blockIdx.x / npairs;
+  int pr = blockIdx.x - inst * npairs;
+  int bi = 0, bj = 0;
+  if (sym) {  // pair index -> (bi <= bj)
+    int rowlen = nb;
+    while (pr >= rowlen) {
+      pr -= rowlen;
+      --rowlen;
+      ++bi;
+    }
+    bj = bi + pr;
+  } else {
+    bi = pr / nb;
+    bj = pr - bi * nb;
+  }
+  const int no = p.no, ldv = p.ldv;
+  const double* Vb = V + (size_t)inst * p.rtot * ldv;
+  const double* pb = params + (size_t)inst * p.nparams;
+  const int32_t* gt = p.itab + p.off_gterm;
+  const int li = lane & 15, lk = lane >> 4;
+  const int wr = wave >> 1, wc = wave & 1;
+
+  f64x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
+
+  // staging role: thread -> (row within a group of 4, 16-byte column piece)
+  const int srow = tid >> 6, scol = (tid & 63) * 2;
+  const int acol = bi * GB + scol, bcol = bj * GB + scol;
+  const unsigned amask = 0xFFu << min(8 * bi, 24), bmask = 0xFFu << min(8 * bj, 24);
+
+  // the K loop runs over stages (term g, rows k0 .. k0 + GK); terms whose tile masks
+  // show no structural non-zero in this block's rows / columns are skipped (blocks beyond
+  // tile 30 are never skipped)
+  int g = -1, k0 = 0, nrows = 0, aoff = 0, boff = 0;
+  double w = 0.0;
+  auto next_stage = [&]() -> bool {
+    k0 += GK;
+    while (k0 >= nrows) {
+      ++g;
+      if (g >= p.ngterm) return false;
+      const int32_t* rec = gt + g * GT_WORDS;
+      if (!(rec[GT_FLAGS] & GT_FLAG_P)) continue;
+      if (8 * bi < 30 && !((unsigned)rec[GT_MASKA] & amask)) continue;
+      if (8 * bj < 30 && !((unsigned)rec[GT_MASKB] & bmask)) continue;
+      aoff = rec[GT_AOFF];
+      boff = rec[GT_BOFF];
+      nrows = rec[GT_NROWS];
+      w = pb[rec[GT_WPARAM]];
+      k0 = 0;
+    }
+    return true;
+  };
+  double2 ra[GK / 4], rb[GK / 4];
+  auto load_stage = [&]() {  // HBM/L2 -> registers
+#pragma unroll
+    for (int rr = 0; rr < GK / 4; ++rr) {
+      const int k = k0 + 4 * rr + srow;
+      double2 a{0.0, 0.0}, b{0.0, 0.0};
+      if (k < nrows) {
+        const double* ar = Vb + (size_t)(aoff + k) * ldv;
+        const double* br = Vb + (size_t)(boff + k) * ldv;
+        if (acol + 1 < no) {
+          a = *reinterpret_cast<const double2*>(ar + acol);
+        } else if (acol < no) {
+          a.x = ar[acol];
+        }
+        if (bcol + 1 < no) {
+          b = *reinterpret_cast<const double2*>(br + bcol);
+        } else if (bcol < no) {
+          b.x = br[bcol];
+        }
+      }
+      a.x *= w;
+      a.y *= w;
+      ra[rr] = a;
+      rb[rr] = b;
+    }
+  };
+  auto store_stage = [&](int buf) {  // registers -> LDS
+#pragma unroll
+    for (int rr = 0; rr < GK / 4; ++rr) {
+      *reinterpret_cast<double2*>(As[buf] + (4 * rr + srow) * GLD + scol) = ra[rr];
+      *reinterpret_cast<double2*>(Bs[buf] + (4 * rr + srow) * GLD + scol) = rb[rr];
+    }
+  };
+
+  bool more = next_stage();
+  if (more) {
+    load_stage();
+    store_stage(0);
+  }
+  int buf = 0;
+  __syncthreads();
+  while (more) {
+    const bool have_next = next_stage();
+    if (have_next) load_stage();  // in flight while this stage is multiplied
+#pragma unroll
+    for (int kk = 0; kk < GK; kk += 4) {
+      double a[4], b[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        a[t] = As[buf][(kk + lk) * GLD + wr * 64 + t * 16 + li];
+        b[t] = Bs[buf][(kk + lk) * GLD + wc * 64 + t * 16 + li];
+      }
+#pragma unroll
+      for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb) acc[ta][tb] = mfma_f64_16x16x4(a[ta], b[tb], acc[ta][tb]);
+    }
+    if (have_next) store_stage(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+    more = have_next;
+  }
+
+  double* Pb = P + (size_t)inst * no * no;
+  const bool mirror = sym && bi != bj;
+#pragma unroll
+  for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+    for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int row = bi * GB + wr * 64 + ta * 16 + lk + 4 * reg;
+        const int col = bj * GB + wc * 64 + tb * 16 + li;
+        if (row < no && col < no) {
+          Pb[(size_t)row * no + col] = acc[ta][tb][reg];
+          if (mirror) Pb[(size_t)col * no + row] = acc[ta][tb][reg];
+        }
+      }
+}
+
+// Gradient for wide problems: q[c] = sum_terms w s sum_k V[a + k][c] (V[d + k][no] - aim).
+// A workgroup takes 64 columns of one instance; its four wavefronts split the rows of
+// every term (coalesced 512-byte row pieces) and reduce through LDS.
+__global__ __launch_bounds__(BLOCK) void gradient_kernel(PlanDev p,
+                                                         const double* __restrict__ params,
+                                                         const double* __restrict__ V,
+                                                         double* __restrict__ q, int ncb) {
+  __shared__ double part[WAVES][64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long inst = blockIdx.x / ncb;
+  const int cb = blockIdx.x - inst * ncb;
+  const int no = p.no, ldv = p.ldv;
+  const int c = cb * 64 + lane;
+  const double* Vb = V + (size_t)inst * p.rtot * ldv;
+  const double* pb = params + (size_t)inst * p.nparams;
+  const int32_t* gt = p.itab + p.off_gterm;
+  double acc = 0.0;
+  for (int g = 0; g < p.ngterm; ++g) {
+    const int32_t* rec = gt + g * GT_WORDS;
+    const double w = pb[rec[GT_WPARAM]];
+    const double aim = pb[rec[GT_AIMPARAM]];
+    const double scale = (rec[GT_FLAGS] & GT_FLAG_HALF) ? 0.5 : 1.0;
+    const int aoff = rec[GT_AOFF], doff = rec[GT_DOFF], nrows = rec[GT_NROWS];
+    for (int k = wave; k < nrows; k += WAVES) {
+      const double r = scale * (Vb[(size_t)(doff + k) * ldv + no] - aim);
+      if (c < no) acc = fma(w * Vb[(size_t)(aoff + k) * ldv + c], r, acc);
+    }
+  }
+  part[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && c < no) {
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) s += part[w][lane];
+    q[(size_t)inst * no + c] = s;
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -296,11 +493,21 @@ int launch_assemble_staged(const PlanDev& p, const SrcTable& src, const double* 
     hipLaunchKernelGGL(compose_rowsets_kernel, dim3(nrb * batch), dim3(BLOCK), 0, stream, p, src,
                        given, V, (int)nrb);
   }
-  if (P && p.no > 0) {
+  if (P && p.no >= GB) {
+    // wide problems: P by the LDS-tiled GEMM, q by the block kernel on its own column
+    const int nb = (int)ceil_div(p.no, GB);
+    const int sym = p.rs_sym_any;
+    const int npairs = sym ? nb * (nb + 1) / 2 : nb * nb;
+    hipLaunchKernelGGL(hessian_gemm_kernel, dim3((unsigned)npairs * batch), dim3(BLOCK), 0, stream,
+                       p, params, V, P, nb, npairs, sym);
+    const unsigned ncb = ceil_div(p.no, 64);
+    hipLaunchKernelGGL(gradient_kernel, dim3(ncb * batch), dim3(BLOCK), 0, stream, p, params, V, q,
+                       (int)ncb);
+  } else if (P && p.no > 0) {
     const unsigned nblk = ceil_div(p.no, 32) * ceil_div(p.no + 1, 32);
     const unsigned nrb = ceil_div(nblk, WAVES);
     hipLaunchKernelGGL(hessian_kernel, dim3(nrb * batch), dim3(BLOCK), 0, stream, p, params, V, P,
-                       q, (int)nrb);
+                       q, (int)nrb, 0);
   }
   if (G && p.nc > 0) {
     if (p.max_axes > K4_AXMAX) return MPCASM_ERR_LIMIT;

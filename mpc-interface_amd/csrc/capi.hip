@@ -352,6 +352,11 @@ int mpcasm_plan_create(const int32_t* h_itab, size_t n_itab, const double* h_dta
     if (hipGetDeviceProperties(&prop, plan->device) == hipSuccess && prop.multiProcessorCount > 0)
       plan->num_cus = prop.multiProcessorCount;
   }
+  d.rs_sym_any = 1;
+  for (int g = 0; g < it[H_NGTERM]; ++g) {
+    const int32_t* r = it + it[H_OFF_GTERM] + g * GT_WORDS;
+    if ((r[GT_FLAGS] & GT_FLAG_P) && r[GT_AOFF] != r[GT_BOFF]) d.rs_sym_any = 0;
+  }
   d.max_axes = 0;
   for (int l = 0; l < it[H_NLIMIT]; ++l) {
     const int na = it[it[H_OFF_LIMIT] + l * LM_WORDS + LM_NAXES];

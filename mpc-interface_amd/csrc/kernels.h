@@ -19,7 +19,7 @@ struct PlanDev {
   int doff_entcoef, doff_pm_entcoef;
   // fused program
   int fused_ok, arena_total, off_arena, nfd, off_fd_idx, off_fd_ptr, nops, off_op, ncoef,
-      doff_coefpool, max_axes;
+      doff_coefpool, max_axes, rs_sym_any;  // rs_sym_any: every Hessian term has A == B
   // resident program
   int rs_ok, rs_jc, rs_sym, rs_nitem, off_rs_src, off_rs_gidx, off_rs_dst, doff_rs_coef,
       off_rs_item, off_rs_islot, off_rs_tile, rs_nq, off_rs_gq, off_rs_rr, rs_pf, off_rs_inmeta;

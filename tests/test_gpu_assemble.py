@@ -391,3 +391,19 @@ def test_edge_shapes(gpu_api):
     asm = Assembler(problems.body_case(api), batch=0)
     P, qq, G, h = asm.assemble(torch.zeros((0, asm.ng), dtype=torch.float64, device="cuda"))
     assert P.shape[0] == 0 and G.shape[0] == 0
+
+
+def test_wide_hessian_with_a_crossed_term(gpu_api):
+    """no >= 128 takes the LDS-tiled GEMM for P; a crossed cost makes P non-symmetric, so
+    every block (not only bi <= bj) has to be computed."""
+    form = problems.random_lti(gpu_api, np.random.default_rng(7), nx=4, nu=3, N=48)
+    form.incorporate_goal("crossed", gpu_api.Cost("s0", 0.3, aim=[0.1], cross="s2",
+                                                  cross_aim=[-0.2]))
+    form.make_preview_matrices()
+    assert form.optim_len == 144
+    given = np.random.default_rng(8).standard_normal([form.given_len, 1])
+    A, h, Q, q = form.generate_all_qp_matrices(given)
+    Ao, ho, Qo, qo = orc.assemble(form, given)
+    assert np.abs(Qo - Qo.T).max() > 1e-6
+    for mine, ref in ((A, Ao), (h, ho), (Q, Qo), (q, qo)):
+        assert_close(mine, ref, RTOL_TIGHT)
