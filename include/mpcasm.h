@@ -58,9 +58,11 @@ const char* mpcasm_status_string(int status);
 enum { MPCASM_OPT_PATH = 1, MPCASM_OPT_PHASE_MASK = 2 };
 /* MPCASM_OPT_PHASE_MASK is a profiling aid (timing-only ablation of the fused
  * kernels: bit 0 compose, 1 Hessian, 2 gradient, 3 constraints, 4 input staging
- * after the first instance, 5 P/q stores; default 0xFF; bit 6 additionally makes
- * the persistent kernel write per-wavefront cycle sums of its phases into d_work);
- * results are WRONG with any bit cleared -- never use it outside a profile. */
+ * after the first instance, 5 P/q stores, 7 register prefetch of the next instance's
+ * inputs; bit 6, off by default, makes the persistent kernel also write per-wavefront
+ * cycle sums of its phases into d_work, which mpcasm_workspace_bytes sizes for it;
+ * default 0xBF).  Results are WRONG with any of bits 0-5 cleared -- never use it
+ * outside a profile. */
 int mpcasm_set_option(int option, int value);
 
 /* K1  horizon extension ---------------------------------------------------

@@ -123,6 +123,7 @@ __global__ __launch_bounds__(BLOCK) void hessian_kernel(PlanDev p,
   for (int g = 0; g < p.ngterm; ++g) {
     const int32_t* rec = gt + g * GT_WORDS;
     const int flags = rec[GT_FLAGS];
+    if (flags & GT_FLAG_DIAG) continue;  // added analytically at the store
     // structurally-zero 16-column tiles of the operands (plan tile masks): a term only
     // reaches P inside this 32x32 block when A has a tile in its rows and B in its columns
     const unsigned ma = (unsigned)rec[GT_MASKA], mb = (unsigned)rec[GT_MASKB];
@@ -172,10 +173,12 @@ __global__ __launch_bounds__(BLOCK) void hessian_kernel(PlanDev p,
         const int row = bi * 32 + ti * 16 + lk + 4 * reg;
         const int col = bj * 32 + tj * 16 + li;
         if (row < no) {
+          double dP = 0.0, dq = 0.0;
+          if (row == col || col == no) diagonal_terms(p, pb, row, dP, dq);
           if (col < no) {
-            if (!q_only) Pb[(size_t)row * no + col] = acc[ti][tj][reg];
+            if (!q_only) Pb[(size_t)row * no + col] = acc[ti][tj][reg] + (row == col ? dP : 0.0);
           } else if (col == no)
-            qb[row] = acc[ti][tj][reg];
+            qb[row] = acc[ti][tj][reg] + dq;
         }
       }
 }
@@ -245,7 +248,7 @@ __global__ __launch_bounds__(BLOCK) void hessian_gemm_kernel(PlanDev p,
       ++g;
       if (g >= p.ngterm) return false;
       const int32_t* rec = gt + g * GT_WORDS;
-      if (!(rec[GT_FLAGS] & GT_FLAG_P)) continue;
+      if (!(rec[GT_FLAGS] & GT_FLAG_P)) continue;  // (diagonal terms carry no P flag)
       if (8 * bi < 30 && !((unsigned)rec[GT_MASKA] & amask)) continue;
       if (8 * bj < 30 && !((unsigned)rec[GT_MASKB] & bmask)) continue;
       aoff = rec[GT_AOFF];
@@ -330,8 +333,14 @@ __global__ __launch_bounds__(BLOCK) void hessian_gemm_kernel(PlanDev p,
         const int row = bi * GB + wr * 64 + ta * 16 + lk + 4 * reg;
         const int col = bj * GB + wc * 64 + tb * 16 + li;
         if (row < no && col < no) {
-          Pb[(size_t)row * no + col] = acc[ta][tb][reg];
-          if (mirror) Pb[(size_t)col * no + row] = acc[ta][tb][reg];
+          double v = acc[ta][tb][reg];
+          if (row == col) {
+            double dP, dq;
+            diagonal_terms(p, pb, row, dP, dq);
+            v += dP;
+          }
+          Pb[(size_t)row * no + col] = v;
+          if (mirror) Pb[(size_t)col * no + row] = v;
         }
       }
 }
@@ -356,6 +365,7 @@ __global__ __launch_bounds__(BLOCK) void gradient_kernel(PlanDev p,
   double acc = 0.0;
   for (int g = 0; g < p.ngterm; ++g) {
     const int32_t* rec = gt + g * GT_WORDS;
+    if (rec[GT_FLAGS] & GT_FLAG_DIAG) continue;
     const double w = pb[rec[GT_WPARAM]];
     const double aim = pb[rec[GT_AIMPARAM]];
     const double scale = (rec[GT_FLAGS] & GT_FLAG_HALF) ? 0.5 : 1.0;
@@ -371,7 +381,9 @@ __global__ __launch_bounds__(BLOCK) void gradient_kernel(PlanDev p,
     double s = 0.0;
 #pragma unroll
     for (int w = 0; w < WAVES; ++w) s += part[w][lane];
-    q[(size_t)inst * no + c] = s;
+    double dP, dq;
+    diagonal_terms(p, pb, c, dP, dq);
+    q[(size_t)inst * no + c] = s + dq;
   }
 }
 

@@ -5,6 +5,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <new>
 
 #include "kernels.h"
@@ -63,6 +64,7 @@ int validate_plan(const int32_t* it, size_t n_itab, size_t n_dtab) {
   ok = ok && in_range(it[H_OFF_PM_ENTK], it[H_PM_NENT], n, H_WORDS);
   ok = ok && in_range(it[H_DOFF_ENTCOEF], it[H_NENT], nd, 0);
   ok = ok && in_range(it[H_DOFF_PM_ENTCOEF], it[H_PM_NENT], nd, 0);
+  ok = ok && in_range(it[H_DOFF_DIAGCOEF], it[H_NDIAGCOEF], nd, 0);
   if (it[H_FUSED_OK] != 0 && it[H_FUSED_OK] != 1) return MPCASM_ERR_PLAN;
   if (it[H_FUSED_OK]) {
     ok = ok && it[H_ARENA_TOTAL] >= 1 && it[H_NFD] >= 0 && it[H_NOPS] >= 0 && it[H_NCOEF] >= 0;
@@ -150,6 +152,14 @@ int validate_plan(const int32_t* it, size_t n_itab, size_t n_dtab) {
                                           : (st == it[H_NSRC] ? ng : (int64_t)it[H_NPARAMS]);
       if (off >= lim) return MPCASM_ERR_PLAN;
     }
+    for (int c = 0; c < no; ++c) {  // diagonal gterms on one column: RS_DIAG_MAX slots
+      int on = 0;
+      for (int g = 0; g < it[H_NGTERM]; ++g) {
+        const int32_t* r = it + it[H_OFF_GTERM] + g * GT_WORDS;
+        if ((r[GT_FLAGS] & GT_FLAG_DIAG) && c >= r[GT_AOFF] && c < r[GT_AOFF] + r[GT_NROWS]) ++on;
+      }
+      if (on > RS_DIAG_MAX) return MPCASM_ERR_PLAN;
+    }
     const int32_t* gq = it + it[H_OFF_RS_GQ];
     for (int i = 0; i < it[H_RS_NQ]; ++i) {
       const int32_t* x = gq + 4 * i;
@@ -196,6 +206,14 @@ int validate_plan(const int32_t* it, size_t n_itab, size_t n_dtab) {
   for (int g = 0; g < it[H_NGTERM]; ++g) {
     const int32_t* r = gt + g * GT_WORDS;
     const int nr = r[GT_NROWS];
+    if (r[GT_WPARAM] < 0 || r[GT_WPARAM] >= it[H_NPARAMS]) return MPCASM_ERR_PLAN;
+    if (r[GT_AIMPARAM] < 0 || r[GT_AIMPARAM] >= it[H_NPARAMS]) return MPCASM_ERR_PLAN;
+    if (r[GT_FLAGS] & GT_FLAG_DIAG) {  // columns c0 .. c0+nr-1 of the unknowns, coefficient list
+      if ((r[GT_FLAGS] & GT_FLAG_P) || nr < 0 || r[GT_AOFF] < 0 || r[GT_AOFF] + nr > no ||
+          r[GT_BOFF] < 0 || r[GT_BOFF] + nr > it[H_NDIAGCOEF])
+        return MPCASM_ERR_PLAN;
+      continue;
+    }
     if (nr < 0 || r[GT_AOFF] < 0 || r[GT_AOFF] + nr > it[H_RTOT]) return MPCASM_ERR_PLAN;
     if (r[GT_DOFF] < 0 || r[GT_DOFF] + nr > it[H_RTOT]) return MPCASM_ERR_PLAN;
     if ((r[GT_FLAGS] & GT_FLAG_P) && (r[GT_BOFF] < 0 || r[GT_BOFF] + nr > it[H_RTOT]))
@@ -352,9 +370,12 @@ int mpcasm_plan_create(const int32_t* h_itab, size_t n_itab, const double* h_dta
     if (hipGetDeviceProperties(&prop, plan->device) == hipSuccess && prop.multiProcessorCount > 0)
       plan->num_cus = prop.multiProcessorCount;
   }
+  d.doff_diagcoef = it[H_DOFF_DIAGCOEF];
+  d.ndiag = 0;
   d.rs_sym_any = 1;
   for (int g = 0; g < it[H_NGTERM]; ++g) {
     const int32_t* r = it + it[H_OFF_GTERM] + g * GT_WORDS;
+    if (r[GT_FLAGS] & GT_FLAG_DIAG) ++d.ndiag;
     if ((r[GT_FLAGS] & GT_FLAG_P) && r[GT_AOFF] != r[GT_BOFF]) d.rs_sym_any = 0;
   }
   d.max_axes = 0;
@@ -388,7 +409,10 @@ int mpcasm_plan_sizes(const mpcasm_plan* plan, int64_t out[8]) {
 
 int mpcasm_workspace_bytes(const mpcasm_plan* plan, int batch, size_t* out_bytes) {
   if (!plan || !out_bytes || batch < 0) return MPCASM_ERR_ARG;
-  *out_bytes = assemble_workspace_bytes(plan->dev, batch);
+  // the staged pipeline's workspace; never less than the cycle stamps of the diagnostic
+  // persistent kernel take (8 wavefronts x 8 counters per resident workgroup)
+  const size_t groups = (size_t)std::min<long>(batch, (long)plan->num_cus * 8);
+  *out_bytes = std::max(assemble_workspace_bytes(plan->dev, batch), groups * 8 * 8 * sizeof(uint64_t));
   return MPCASM_OK;
 }
 

@@ -36,6 +36,28 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+// Contribution of the diagonal gterms (GT_FLAG_DIAG, plan_tables.h) to P[c][c] and q[c]:
+// rows coef_k e_{c0+k} never enter the workspace; body.py:292-300 reduces to
+// P[c][c] += (w coef) coef and q[c] += w (coef (0 - aim)).  `prm`: the instance's params.
+__device__ __forceinline__ void diagonal_terms(const PlanDev& p, const double* prm, int c,
+                                               double& dP, double& dq) {
+  dP = 0.0;
+  dq = 0.0;
+  if (p.ndiag == 0) return;
+  const int32_t* gt = p.itab + p.off_gterm;
+  const double* cf = p.dtab + p.doff_diagcoef;
+  for (int g = 0; g < p.ngterm; ++g) {
+    const int32_t* rec = gt + g * GT_WORDS;
+    if (!(rec[GT_FLAGS] & GT_FLAG_DIAG)) continue;
+    const int k = c - rec[GT_AOFF];
+    if (k < 0 || k >= rec[GT_NROWS]) continue;
+    const double w = prm[rec[GT_WPARAM]], aim = prm[rec[GT_AIMPARAM]];
+    const double co = cf[rec[GT_BOFF] + k];
+    dP += (w * co) * co;
+    dq += w * (co * (0.0 - aim));
+  }
+}
+
 // One element of a composed row: sum_e coef[e] * base_row(entbase[e], entk[e])[c]
 // (flattened definition graph, body.py:158-193).  Column c belongs to at most
 // one segment of each base variable (colseg); a segment is either an identity

@@ -26,7 +26,7 @@
 
 namespace mpcasm {
 
-int g_phase_mask = 0xFF;  // diagnostic (timing-only ablation): see mpcasm_set_option
+int g_phase_mask = 0xBF;  // diagnostic (timing-only ablation): see mpcasm_set_option
 
 namespace {
 
@@ -189,7 +189,11 @@ __global__ __launch_bounds__(NW * 64) void fused_assemble_kernel(
         for (int reg = 0; reg < 4; ++reg) {
           const int row = trow[s] * 16 + lk + 4 * reg;
           const int col = tcol[s] * 16 + li;
-          if (row < no && col < no) Pb[(size_t)row * no + col] = acc[s][reg];
+          if (row < no && col < no) {
+            double dP = 0.0, dq = 0.0;
+            if (row == col) diagonal_terms(p, prm, row, dP, dq);
+            Pb[(size_t)row * no + col] = acc[s][reg] + dP;
+          }
         }
       }
     }
@@ -202,6 +206,7 @@ __global__ __launch_bounds__(NW * 64) void fused_assemble_kernel(
     for (int c = 0; c < QSLOT; ++c) qa[c] = 0.0;
     for (int g = 0; g < p.ngterm; ++g) {
       const int32_t* rec = gt + g * GT_WORDS;
+      if (rec[GT_FLAGS] & GT_FLAG_DIAG) continue;  // added analytically below
       const double w = prm[rec[GT_WPARAM]];
       if (w == 0.0) continue;
       const double aim = prm[rec[GT_AIMPARAM]];
@@ -298,7 +303,9 @@ __global__ __launch_bounds__(NW * 64) void fused_assemble_kernel(
       double s = 0.0;
 #pragma unroll
       for (int w = 0; w < NW; ++w) s += qpart[w * L.nop + c];
-      qb[c] = s;
+      double dP, dq;
+      diagonal_terms(p, prm, c, dP, dq);
+      qb[c] = s + dq;
     }
   }
 }

@@ -23,6 +23,7 @@ struct PlanDev {
   // resident program
   int rs_ok, rs_jc, rs_sym, rs_nitem, off_rs_src, off_rs_gidx, off_rs_dst, doff_rs_coef,
       off_rs_item, off_rs_islot, off_rs_tile, rs_nq, off_rs_gq, off_rs_rr, rs_pf, off_rs_inmeta;
+  int doff_diagcoef, ndiag;  // diagonal gterms: coefficient list, number of such terms
 };
 
 // sources of one launch (device pointers + per-instance strides, by value)

@@ -27,7 +27,7 @@
 namespace mpcasm {
 
 constexpr int32_t PLAN_MAGIC = 0x4D504341;  // 'MPCA'
-constexpr int32_t PLAN_VERSION = 10;
+constexpr int32_t PLAN_VERSION = 11;
 
 enum HeaderWord : int {
   H_MAGIC = 0,
@@ -93,6 +93,8 @@ enum HeaderWord : int {
   H_OFF_RS_RR,      // [NC][RS_RR_WORDS] row records of the stacked G (see resident.hip)
   H_RS_PF,          // input slots per thread (0: the inputs are too large to prefetch)
   H_OFF_RS_INMETA,  // [RS_PF_MAX][RS_NT] stream << 24 | offset of the input double, or -1
+  H_DOFF_DIAGCOEF,  // [NDIAGCOEF] coefficients of the diagonal gterms
+  H_NDIAGCOEF,
   H_WORDS = 64
 };
 
@@ -104,7 +106,10 @@ enum { SEG_KIND_GATHER = 0, SEG_KIND_IDENTITY = 1 };
 // GT_MASKA / GT_MASKB: bit t set when 16-column tile t of the optim columns holds a
 // structural non-zero in the A / B rows (tiles >= 30 fold onto bit 30)
 enum { GT_AOFF = 0, GT_BOFF, GT_NROWS, GT_WPARAM, GT_DOFF, GT_AIMPARAM, GT_FLAGS, GT_MASKA, GT_MASKB, GT_PAD, GT_WORDS = 10 };
-enum { GT_FLAG_P = 1, GT_FLAG_HALF = 2 };
+// GT_FLAG_DIAG: the term's rows are coef_k e_{c0+k} on the unknowns (a cost on a free
+// variable itself): no workspace rows; P[c][c] += (w coef) coef, q[c] += w (coef (0 - aim))
+// for c = c0 + k, with c0 = GT_AOFF, coef at dtab[H_DOFF_DIAGCOEF + GT_BOFF + k], k < GT_NROWS
+enum { GT_FLAG_P = 1, GT_FLAG_HALF = 2, GT_FLAG_DIAG = 4 };
 
 // limit record
 enum {
@@ -121,6 +126,8 @@ constexpr int MAX_SOURCES = 32;
 constexpr int RS_NW = 4, RS_NT = 512, RS_TPW = 9, RS_JC_MAX = 12, RS_ITEM_WORDS = 4;
 // row record of G: voff[4], arrow param[4], center param[4], naxes, extreme param, 2 pad
 constexpr int RS_AXMAX = 4, RS_PF_MAX = 3, RS_RR_WORDS = 16;
+// diagonal gterms the persistent kernel takes on one column of the unknowns
+constexpr int RS_DIAG_MAX = 2;
 enum { RR_VOFF = 0, RR_ARROW = 4, RR_CENTER = 8, RR_NAXES = 12, RR_EXTREME = 13 };
 
 }  // namespace mpcasm

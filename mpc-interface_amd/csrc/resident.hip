@@ -49,11 +49,12 @@ constexpr int AXMAX = RS_AXMAX;
 constexpr int RR_WORDS = RS_RR_WORDS;
 constexpr int GU = 6;                    // 16-byte pieces of G a worker thread may own
 constexpr int PF = RS_PF_MAX;            // input doubles a thread may prefetch
+static_assert(RS_DIAG_MAX == 2, "the per-column diagonal table holds two terms");
 
 __host__ __device__ inline int even_up_i(int x) { return (x + 1) & ~1; }
 
 struct ResidentLayout {
-  int v, arena, pl, g, prm, qpart, rvec, ptrs, ints, total_doubles;  // offsets in doubles
+  int v, arena, pl, g, prm, qpart, dvec, dcoef, dpar, ptrs, ints, total_doubles;  // offsets in doubles
   int ldp;                                                    // leading dimension of P in LDS
   int ns;                                                     // row slices of the gradient pass
   int i_tile, i_rr, i_gq, i_item, i_islot;  // offsets in ints inside the int region
@@ -77,7 +78,11 @@ __host__ __device__ inline ResidentLayout resident_layout(const PlanDev& p) {
   L.g = o;     o += even_up_i(p.ng + 1);
   L.prm = o;   o += even_up_i(p.nparams + 1);
   L.qpart = o; o += L.ns * L.ldp;
-  L.rvec = o;  o += (WT / 64) * even_up_i(p.rs_nq);  // one copy per worker wavefront
+  // diagonal gterms: addends of P[c][c] and q[c] of this instance, then per column the
+  // (weight, aim) parameter slots and coefficients of the (at most RS_DIAG_MAX) terms on it
+  L.dvec = o;  o += 2 * L.ldp;
+  L.dcoef = o; o += RS_DIAG_MAX * L.ldp;
+  L.dpar = o;  o += RS_DIAG_MAX * L.ldp;
   L.ptrs = o;  o += 3 * (MAX_SOURCES + 2);
   L.ints = o;
   int i = 0;
@@ -118,7 +123,9 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
   double* gl = lds + L.g;
   double* prm = lds + L.prm;
   double* qpart = lds + L.qpart;
-  double* rvec = lds + L.rvec;
+  double* dvec = lds + L.dvec;
+  double2* dcoef = reinterpret_cast<double2*>(lds + L.dcoef);
+  int4* dpar = reinterpret_cast<int4*>(lds + L.dpar);
   double* sptr = lds + L.ptrs;  // [nsrc + 2] triples: base pointer, stride, LDS slot (raw words)
   int* itb = reinterpret_cast<int*>(lds + L.ints);
   int4* gq = reinterpret_cast<int4*>(itb + L.i_gq);
@@ -127,6 +134,12 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
   int* tile = itb + L.i_tile;
   int* rr = itb + L.i_rr;
 
+#ifdef MPCASM_POISON_LDS
+  // debugging aid: every byte of LDS starts as a NaN pattern, so that a read of a location
+  // the kernel never wrote shows up in the results whatever the previous launch left behind
+  for (int i = tid; i < L.total_doubles; i += NT) lds[i] = __builtin_nan("");
+  lds_barrier();
+#endif
   // ---- once per workgroup: the compose program into registers ------------------
   int c_sg[JC], c_dst[JC];  // c_sg: arena offset | given index << 16 (index ng: the constant 1)
   double c_coef[JC];
@@ -174,6 +187,32 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
     if (tid == 0) {
       gl[ng] = 1.0;
       prm[p.nparams] = 0.0;
+    }
+    if (p.ndiag != 0 && tid < no) {
+      // the diagonal gterms on column tid; free slots read the 0.0 behind the parameters
+      int4 par = int4{p.nparams, p.nparams, p.nparams, p.nparams};
+      double2 co = double2{0.0, 0.0};
+      const int32_t* gt = p.itab + p.off_gterm;
+      int n = 0;
+      for (int g = 0; g < p.ngterm; ++g) {
+        const int32_t* rec = gt + g * GT_WORDS;
+        const int k = tid - rec[GT_AOFF];
+        if (!(rec[GT_FLAGS] & GT_FLAG_DIAG) || k < 0 || k >= rec[GT_NROWS] || n >= RS_DIAG_MAX)
+          continue;
+        const double cf = (p.dtab + p.doff_diagcoef)[rec[GT_BOFF] + k];
+        if (n == 0) {
+          par.x = rec[GT_WPARAM];
+          par.y = rec[GT_AIMPARAM];
+          co.x = cf;
+        } else {
+          par.z = rec[GT_WPARAM];
+          par.w = rec[GT_AIMPARAM];
+          co.y = cf;
+        }
+        ++n;
+      }
+      dpar[tid] = par;
+      dcoef[tid] = co;
     }
   }
   lds_barrier();
@@ -241,6 +280,18 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
     lds_barrier();  // A: inputs staged
     MPCASM_STAMP(0)
 
+    // diagonal gterms (costs on free variables themselves): their addends of P[c][c], q[c]
+    if (p.ndiag != 0) {
+      int c = tid;
+      asm volatile("" : "+v"(c));  // opaque: nothing derived from it is hoisted out of the loop
+      if (c < no) {  // body.py:292-300 for rows coef e_c: P[c][c] += (w coef) coef, q[c] += ...
+        const int4 par = dpar[c];
+        const double2 co = dcoef[c];
+        const double w0 = prm[par.x], a0 = prm[par.y], w1 = prm[par.z], a1 = prm[par.w];
+        dvec[c] = (w0 * co.x) * co.x + (w1 * co.y) * co.y;
+        dvec[ldp + c] = w0 * (co.x * (0.0 - a0)) + w1 * (co.y * (0.0 - a1));
+      }
+    }
     // ---- K2: compose the workspace from the register-resident program -------------
     if (phases & 1) {
       double va[JC], vg[JC];
@@ -310,8 +361,9 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
           for (int reg = 0; reg < 4; ++reg) {
             const int row = ti * 16 + lk + 4 * reg, col = tj * 16 + li;
             if (row < no && col < no) {
-              Pl[row * ldp + col] = acc[reg];
-              if (mirror) Pl[col * ldp + row] = acc[reg];
+              const double v = acc[reg] + (p.ndiag != 0 && row == col ? dvec[row] : 0.0);
+              Pl[row * ldp + col] = v;
+              if (mirror) Pl[col * ldp + row] = v;
             }
           }
         }
@@ -479,7 +531,7 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
       for (int c = tid; c < no; c += NT) {
         double s = 0.0;
         for (int w = 0; w < NS; ++w) s += qpart[w * ldp + c];
-        qb[c] = s;
+        qb[c] = s + (p.ndiag != 0 ? dvec[ldp + c] : 0.0);
       }
     }
     MPCASM_STAMP(6)

@@ -13,6 +13,8 @@ LIB_PATH = os.path.join(_HERE, "libmpcasm.so")
 OK = 0
 OPT_PATH = 1
 OPT_PHASE_MASK = 2
+PHASE_DEFAULT = 0xBF   # every phase on, cycle stamps (bit 6) off
+PHASE_STAMPS = 0x40
 STATUS = {
     0: "MPCASM_OK",
     -1: "MPCASM_ERR_ARG",
@@ -75,6 +77,12 @@ def load():
                 "libmpcasm.so is missing (%s): build it with `make -C mpc-interface_amd` "
                 "or __graft_entry__.build(); the assembly kernels have no fallback" % LIB_PATH
             )
+        try:
+            # torch ships its own HIP runtime: load it first so that this library binds to the
+            # same copy (two runtimes in one process do not share devices or streams)
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = ctypes.CDLL(LIB_PATH)
         for name, (restype, argtypes) in SIGNATURES.items():
             fn = getattr(lib, name)       # AttributeError = symbol not exported

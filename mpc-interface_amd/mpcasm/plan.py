@@ -15,7 +15,7 @@ import numpy as np
 import scipy.sparse as sp
 
 PLAN_MAGIC = 0x4D504341
-PLAN_VERSION = 10
+PLAN_VERSION = 11
 
 # header words (csrc/plan_tables.h, enum HeaderWord)
 _H = {name: i for i, name in enumerate([
@@ -28,19 +28,20 @@ _H = {name: i for i, name in enumerate([
     "NCOEF", "DOFF_COEFPOOL",
     "RS_OK", "RS_JC", "RS_SYM", "RS_NITEM", "OFF_RS_SRC", "OFF_RS_GIDX", "OFF_RS_DST",
     "DOFF_RS_COEF", "OFF_RS_ITEM", "OFF_RS_ISLOT", "OFF_RS_TILE", "RS_NQ", "OFF_RS_GQ",
-    "OFF_RS_RR", "RS_PF", "OFF_RS_INMETA",
+    "OFF_RS_RR", "RS_PF", "OFF_RS_INMETA", "DOFF_DIAGCOEF", "NDIAGCOEF",
 ])}
 H_WORDS = 64
 RS_NW, RS_NT, RS_TPW = 4, 512, 9          # MFMA wavefronts, threads per instance, tiles per wave
 RS_JC_MAX = 12                            # compose ops a thread can keep in registers
 RS_ITEM_WORDS = 4
+RS_DIAG_MAX = 2                           # diagonal gterms per column (persistent kernel)
 RS_AXMAX, RS_PF = 4, 3                   # axes per constraint row record, input slots per thread
 RS_RR_WORDS = 16                          # row record: voff[4], arrow param[4], center param[4], naxes, extreme param, pad
 SEG_WORDS, GT_WORDS, LM_WORDS, LX_WORDS = 8, 10, 12, 2
 FUSED_MAX_OPS = 1 << 18           # beyond this the staged pipeline is used
 FUSED_MAX_ARENA = 1 << 14         # doubles
 SEG_GATHER, SEG_IDENTITY = 0, 1
-GT_FLAG_P, GT_FLAG_HALF = 1, 2
+GT_FLAG_P, GT_FLAG_HALF, GT_FLAG_DIAG = 1, 2, 4
 MAX_SOURCES = 32
 
 
@@ -210,7 +211,9 @@ class _Builder:
     # ---- row-sets -----------------------------------------------------------
     def rowset(self, var, schedule, L):
         """Rows of ``L @ M_var[schedule]`` (or ``M_var[schedule]``); returns
-        ``(offset, nrows)`` in the workspace.  ``schedule`` falsy = all rows."""
+        ``(row-set id, nrows)``.  ``schedule`` falsy = all rows.  Workspace offsets are
+        handed out later, only to the row-sets some kernel really has to read
+        (:meth:`place_rowsets`)."""
         M = self.var_matrix[var]
         if schedule:
             pick = list(schedule)
@@ -235,11 +238,49 @@ class _Builder:
         block = sp.csr_matrix(block)
         block.sum_duplicates()
         block.sort_indices()
-        out = (self.rtot, block.shape[0])
+        out = (len(self.rowset_rows), block.shape[0])
         self.rowset_rows.append(block)
-        self.rtot += block.shape[0]
         self.rowset_keys[key] = out
         return out
+
+    def diagonal_rowset(self, rid):
+        """``(first optim column, coefficients)`` when row ``r`` of the row-set is
+        ``coef[r] * e_{col0 + r}`` on the unknowns and has no given part (a cost on a
+        free variable itself, e.g. the jerk of the LIPM); else ``None``."""
+        block = self.rowset_rows[rid]
+        n = block.shape[0]
+        if n == 0 or block.nnz != n or np.any(np.diff(block.indptr) != 1):
+            return None
+        starts = np.asarray(self.base_row0)
+        cols, coefs = [], []
+        for r in range(n):
+            gidx = int(block.indices[r])
+            u = int(np.searchsorted(starts, gidx, side="right") - 1)
+            k = gidx - int(starts[u])
+            segs = sorted(set(int(x) for x in self.colseg[u] if x >= 0))
+            if len(segs) != 1:
+                return None
+            seg = self.segments[segs[0]]
+            if seg[6] != SEG_IDENTITY or seg[4] < self.ng or k >= seg[5]:
+                return None
+            cols.append(seg[4] - self.ng + k)
+            coefs.append(float(block.data[r]))
+        if any(c != cols[0] + i for i, c in enumerate(cols)):
+            return None
+        return cols[0], np.asarray(coefs)
+
+    def place_rowsets(self, needed):
+        """Workspace row offset of every needed row-set (id order); the others are never
+        materialised."""
+        offsets, blocks = {}, []
+        self.rtot = 0
+        for rid, block in enumerate(self.rowset_rows):
+            if rid in needed:
+                offsets[rid] = self.rtot
+                self.rtot += block.shape[0]
+                blocks.append(block)
+        self.placed_blocks = blocks
+        return offsets
 
     # ---- parameters -----------------------------------------------------------
     def param(self, key, getter):
@@ -406,6 +447,12 @@ def _resident_program(fused, gterms, no, ldv):
                tile=-np.ones(NW * TPW, dtype=np.int32))
     if not fused["ok"]:
         return out
+    on_column = np.zeros(no + 1, dtype=np.int64)
+    for g in gterms:
+        if g[6] & GT_FLAG_DIAG:
+            on_column[g[0]:g[0] + g[2]] += 1
+    if on_column.max() > RS_DIAG_MAX:
+        return out
     # ---- compose: whole elements to threads, longest first onto the lightest thread
     fd_idx, fd_ptr = fused["fd_idx"], fused["fd_ptr"]
     ops = fused["ops"].view(np.uint32).reshape(-1, 2)
@@ -476,6 +523,8 @@ def _resident_program(fused, gterms, no, ldv):
     # ---- gradient: one record per (gterm, row): q += w s V[a] (V[d] - aim)
     gq = []
     for g in gterms:
+        if g[6] & GT_FLAG_DIAG:
+            continue                       # handled as a diagonal update, no workspace rows
         half = (1 << 30) if g[6] & GT_FLAG_HALF else 0
         for k in range(g[2]):
             gq.append([(g[0] + k) * ldv, (g[4] + k) * ldv + no, g[5], g[3] | half])
@@ -503,8 +552,8 @@ def compile_plan(form, costs=None, limits=None):
         limits = [l for group in form.constraints.values() for l in group]
         limits += [l for box in form.constraint_boxes.values() for l in box.constraints]
 
-    # ---- costs -> gterms (body.py:266-302) -------------------------------------
-    gterms = []
+    # ---- costs -> terms (body.py:266-302) ----------------------------------------
+    terms = []
     for name, cost in costs.items():
         p_w = b.param(("cost", name, "weight"), lambda c=cost: [[float(c.weight)]])
         aim = np.asarray(cost.aim, dtype=np.float64)
@@ -527,13 +576,9 @@ def compile_plan(form, costs=None, limits=None):
                 raise ValueError(
                     "cost '{}': {} rows of '{}' against {} rows of '{}'".format(
                         name, nv, cost.variable + axis, ncr, cost.cross + axis))
-            if not crossed and va == ca:
-                #  q += w V^T (Vg g - aim)
-                gterms.append([va, va, nv, p_w, va, p_aim + i, GT_FLAG_P, 0, 0, 0])
-            else:
-                #  P += w V^T C ;  q += w/2 V^T (Cg g - cross_aim) + w/2 C^T (Vg g - aim)
-                gterms.append([va, ca, nv, p_w, ca, p_caim + i, GT_FLAG_P | GT_FLAG_HALF, 0, 0, 0])
-                gterms.append([ca, -1, nv, p_w, va, p_aim + i, GT_FLAG_HALF, 0, 0, 0])
+            diag = b.diagonal_rowset(va) if (not crossed and va == ca) else None
+            terms.append(dict(va=va, ca=ca, n=nv, w=p_w, aim=p_aim + i, caim=p_caim + i,
+                              plain=(not crossed and va == ca), diag=diag))
 
     # ---- limits (body.py:236-264, restrictions.py:147-199) -----------------------
     limit_recs, lax_recs, rowlimit, limit_rows = [], [], [], []
@@ -552,7 +597,7 @@ def compile_plan(form, costs=None, limits=None):
                 raise ValueError(
                     "constraint on '{}': {} rows cannot fill {} lines".format(
                         limit.variable + axis, rs, nrows))
-            lax_recs.append([off, rs])
+            lax_recs.append([off, rs])          # off is a row-set id until place_rowsets
         arrow = np.asarray(limit.arrow, dtype=np.float64).reshape(-1, naxes)
         center = np.asarray(limit.center, dtype=np.float64).reshape(-1, naxes)
         extreme = np.asarray(limit.extreme, dtype=np.float64).reshape(-1, 1)
@@ -574,15 +619,46 @@ def compile_plan(form, costs=None, limits=None):
         out0 += nrows
     nc = out0
 
+    # ---- place the row-sets some kernel reads; build the gterms -----------------------
+    needed = set(rec[0] for rec in lax_recs)
+    for t in terms:
+        if t["diag"] is None:
+            needed.update((t["va"], t["ca"]))
+    where = b.place_rowsets(needed)
+    for rec in lax_recs:
+        rec[0] = where[rec[0]]
+    gterms, diag_coefs = [], []
+    for t in terms:
+        if t["diag"] is not None:
+            # P[c][c] += (w coef) coef,  q[c] += w (coef (0 - aim))  on c = col0 .. col0 + n - 1
+            col0, coefs = t["diag"]
+            gterms.append([col0, sum(len(c) for c in diag_coefs), t["n"], t["w"], 0, t["aim"],
+                           GT_FLAG_DIAG, 0, 0, 0])
+            diag_coefs.append(coefs)
+        elif t["plain"]:
+            #  q += w V^T (Vg g - aim)
+            va = where[t["va"]]
+            gterms.append([va, va, t["n"], t["w"], va, t["aim"], GT_FLAG_P, 0, 0, 0])
+        else:
+            #  P += w V^T C ;  q += w/2 V^T (Cg g - cross_aim) + w/2 C^T (Vg g - aim)
+            va, ca = where[t["va"]], where[t["ca"]]
+            gterms.append([va, ca, t["n"], t["w"], ca, t["caim"], GT_FLAG_P | GT_FLAG_HALF,
+                           0, 0, 0])
+            gterms.append([ca, -1, t["n"], t["w"], va, t["aim"], GT_FLAG_HALF, 0, 0, 0])
+    diag_coefs = np.concatenate(diag_coefs) if diag_coefs else np.zeros(0)
+
     # ---- tables ---------------------------------------------------------------------
     rowptr, entbase, entk, entcoef, rtot = _csr_tables(
-        b.rowset_rows, b.base_row0, b.base_rows, b.total_base_rows)
+        b.placed_blocks, b.base_row0, b.base_rows, b.total_base_rows)
     assert rtot == b.rtot
     ldv = no + 1 + ((no + 1) & 1)
     fused = _fused_program(b, rowptr, entbase, entk, entcoef, rtot, ldv)
     # structural tile masks of the gterm operands (exact zeros of the workspace)
     tiles = fused["row_tiles"]
     for rec in gterms:
+        if rec[6] & GT_FLAG_DIAG:
+            continue
+
         def mask(off, n):
             m = 0
             for r in range(off, off + n):
@@ -645,8 +721,8 @@ def compile_plan(form, costs=None, limits=None):
         header[_H[name]] = off
         parts.append(arr)
         off += arr.size
-    dtab = np.concatenate([entcoef, pm_entcoef, fused["coefpool"],
-                           resident["coef"]]).astype(np.float64)
+    dtab = np.concatenate([entcoef, pm_entcoef, fused["coefpool"], resident["coef"],
+                           diag_coefs]).astype(np.float64)
     params = np.asarray(b.params, dtype=np.float64)
     header[_H["MAGIC"]], header[_H["VERSION"]] = PLAN_MAGIC, PLAN_VERSION
     header[_H["NG"]], header[_H["NO"]], header[_H["NC"]] = b.ng, no, nc
@@ -669,6 +745,9 @@ def compile_plan(form, costs=None, limits=None):
     if rs_rr.size != nc * RS_RR_WORDS:
         header[_H["RS_OK"]] = 0                  # a constraint with more than RS_AXMAX axes
     header[_H["DOFF_RS_COEF"]] = entcoef.size + pm_entcoef.size + fused["coefpool"].size
+    header[_H["DOFF_DIAGCOEF"]] = (entcoef.size + pm_entcoef.size + fused["coefpool"].size
+                                   + resident["coef"].size)
+    header[_H["NDIAGCOEF"]] = diag_coefs.size
     header[_H["NITAB"]], header[_H["NDTAB"]] = off, dtab.size
 
     plan = Plan()

@@ -62,6 +62,12 @@ def run(plan, given, params=None, sources=None):
     gt = _section(it, "OFF_GTERM", it[H["NGTERM"]] * P.GT_WORDS).reshape(-1, P.GT_WORDS)
     for a, b, n, pw, d, pa, flags, _ma, _mb, _pad in gt:
         w, aim = params[pw], params[pa]
+        if flags & P.GT_FLAG_DIAG:       # rows coef_k e_{a+k}: diagonal update
+            cf = dt[it[H["DOFF_DIAGCOEF"]] + b:it[H["DOFF_DIAGCOEF"]] + b + n]
+            idx = np.arange(a, a + n)
+            Pm[idx, idx] += (w * cf) * cf
+            q[idx] += w * (cf * (0.0 - aim))
+            continue
         scale = 0.5 if flags & P.GT_FLAG_HALF else 1.0
         A = w * V[a:a + n, :no]
         if flags & P.GT_FLAG_P:
@@ -127,6 +133,8 @@ def run_fused_workspace(plan, given, sources=None):
     # tile masks promise exact zeros outside the marked 16-column tiles
     gt = _section(it, "OFF_GTERM", it[H["NGTERM"]] * P.GT_WORDS).reshape(-1, P.GT_WORDS)
     for a, b, n, pw, d, pa, flags, ma, mb, _pad in gt:
+        if flags & P.GT_FLAG_DIAG:
+            continue
         for off, mask in ((a, ma), (b, mb)):
             if off < 0:
                 continue

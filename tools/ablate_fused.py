@@ -46,7 +46,7 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             times[name].append(e0.elapsed_time(e1) / 20 * 1e3)
-    lib.mpcasm_set_option(capi.OPT_PHASE_MASK, 0xFF)
+    lib.mpcasm_set_option(capi.OPT_PHASE_MASK, capi.PHASE_DEFAULT)
     print("B=%d  no=%d nc=%d  (us per launch: median / min)" % (B, asm.no, asm.nc))
     for name, _ in masks:
         t = np.array(times[name])

@@ -27,11 +27,11 @@ def main():
     lib = capi.load()
     for _ in range(3):
         asm.assemble(given)
-    lib.mpcasm_set_option(capi.OPT_PHASE_MASK, 0xFF | 64)
+    lib.mpcasm_set_option(capi.OPT_PHASE_MASK, capi.PHASE_DEFAULT | capi.PHASE_STAMPS)
     asm._work.zero_()
     asm.assemble(given)
     torch.cuda.synchronize()
-    lib.mpcasm_set_option(capi.OPT_PHASE_MASK, 0xFF)
+    lib.mpcasm_set_option(capi.OPT_PHASE_MASK, capi.PHASE_DEFAULT)
     raw = asm._work.view(torch.int64).cpu().numpy()
     per_cu = int(os.environ.get("WG_PER_CU", "2"))
     grid = min(B, 256 * per_cu)
