@@ -39,7 +39,7 @@ bool in_range(int64_t off, int64_t len, int64_t n, int64_t lo) {
   return off >= lo && len >= 0 && off + len <= n;
 }
 
-int validate_plan(const int32_t* it, size_t n_itab, size_t n_dtab) {
+int validate_plan(const int32_t* it, const double* h_dtab, size_t n_itab, size_t n_dtab) {
   if (n_itab < (size_t)H_WORDS) return MPCASM_ERR_PLAN;
   if (it[H_MAGIC] != PLAN_MAGIC || it[H_VERSION] != PLAN_VERSION) return MPCASM_ERR_PLAN;
   if ((size_t)it[H_NITAB] != n_itab || (size_t)it[H_NDTAB] != n_dtab) return MPCASM_ERR_PLAN;
@@ -99,7 +99,12 @@ int validate_plan(const int32_t* it, size_t n_itab, size_t n_dtab) {
   if (it[H_RS_OK]) {
     if (!it[H_FUSED_OK]) return MPCASM_ERR_PLAN;
     const int64_t jc = it[H_RS_JC], slots = jc * RS_NT;
-    if (jc < 1 || jc > RS_JC_MAX || it[H_RS_NITEM] < 0) return MPCASM_ERR_PLAN;
+    const int64_t img = it[H_RS_IMG], unit = it[H_RS_UNIT], nchunk = it[H_RS_NCHUNK];
+    if (jc < 1 || jc > RS_JC_MAX || it[H_RS_NITEM] < 0 || it[H_RS_NSPLIT] < 0)
+      return MPCASM_ERR_PLAN;
+    if ((unit != 4 && unit != 16) || img < 128 || img % 128 || img > 65535 ||
+        nchunk * 64 * unit != img * 8 || it[H_NPARAMS] > 65535)
+      return MPCASM_ERR_PLAN;
     bool r = true;
     r = r && in_range(it[H_OFF_RS_SRC], slots, n, H_WORDS);
     r = r && in_range(it[H_OFF_RS_GIDX], slots, n, H_WORDS);
@@ -108,28 +113,40 @@ int validate_plan(const int32_t* it, size_t n_itab, size_t n_dtab) {
     r = r && in_range(it[H_OFF_RS_ITEM], (int64_t)it[H_RS_NITEM] * RS_ITEM_WORDS, n, H_WORDS);
     r = r && in_range(it[H_OFF_RS_ISLOT], RS_NW * RS_TPW * 2, n, H_WORDS);
     r = r && in_range(it[H_OFF_RS_TILE], RS_NW * RS_TPW, n, H_WORDS);
-    r = r && it[H_RS_NQ] >= 0 && in_range(it[H_OFF_RS_GQ], (int64_t)it[H_RS_NQ] * 4, n, H_WORDS);
-    r = r && (it[H_OFF_RS_GQ] % 4 == 0) && (it[H_OFF_RS_ITEM] % 4 == 0);
+    r = r && in_range(it[H_OFF_RS_SPLIT], it[H_RS_NSPLIT], n, H_WORDS);
+    r = r && (it[H_OFF_RS_ITEM] % 4 == 0);
     r = r && in_range(it[H_OFF_RS_RR], nc * RS_RR_WORDS, n, H_WORDS) && it[H_OFF_RS_RR] % 4 == 0;
-    r = r && (it[H_RS_PF] == 0 || it[H_RS_PF] == RS_PF_MAX);
-    r = r && in_range(it[H_OFF_RS_INMETA], (int64_t)RS_PF_MAX * RS_NT, n, H_WORDS);
+    r = r && in_range(it[H_OFF_RS_INMETA], nchunk * 64 * 2, n, H_WORDS) &&
+        it[H_OFF_RS_INMETA] % 2 == 0;
+    r = r && in_range(it[H_DOFF_RS_CONST], 4, nd, 0) && it[H_DOFF_RS_CONST] % 2 == 0;
+    r = r && in_range(it[H_RS_IMG_GIVEN], ng + 1, img, 0);
+    r = r && in_range(it[H_RS_IMG_PARAMS], (int64_t)it[H_NPARAMS] + 1, img, 0);
     if (!r) return MPCASM_ERR_PLAN;
+    {
+      const double* c = h_dtab + it[H_DOFF_RS_CONST];
+      if (c[0] != 1.0 || c[1] != 1.0 || c[2] != 0.0 || c[3] != 0.0) return MPCASM_ERR_PLAN;
+    }
     const int64_t vsize = (int64_t)it[H_RTOT] * it[H_LDV];
     const int32_t* ts = it + it[H_OFF_RS_SRC];
     const int32_t* tg = it + it[H_OFF_RS_GIDX];
     const int32_t* td = it + it[H_OFF_RS_DST];
     for (int64_t i = 0; i < slots; ++i)
-      if (ts[i] < 0 || ts[i] >= it[H_ARENA_TOTAL] || tg[i] < -1 || tg[i] >= ng || td[i] < -1 ||
-          td[i] >= vsize)
+      if (ts[i] < 0 || ts[i] >= img || tg[i] < 0 || tg[i] >= img || td[i] < -1 ||
+          (td[i] >= 0 && (td[i] & ~RS_DST_ACC) >= vsize))
         return MPCASM_ERR_PLAN;
+    const int32_t* sp = it + it[H_OFF_RS_SPLIT];
+    for (int i = 0; i < it[H_RS_NSPLIT]; ++i)
+      if (sp[i] < 0 || sp[i] >= vsize) return MPCASM_ERR_PLAN;
     const int32_t* ti = it + it[H_OFF_RS_ITEM];
     for (int i = 0; i < it[H_RS_NITEM]; ++i) {
       const int32_t* x = ti + i * RS_ITEM_WORDS;
-      if (x[2] < 0 || x[3] < 0 || x[3] >= it[H_NPARAMS]) return MPCASM_ERR_PLAN;
-      if (x[2] == 0) continue;
-      for (int k = 0; k < 2; ++k)
-        if (x[k] < 0 || (int64_t)x[k] + (int64_t)(x[2] - 1) * it[H_LDV] + 16 > vsize + 16)
-          return MPCASM_ERR_PLAN;
+      const int rows = x[RI_ROWS] & 0xFFFFFF;
+      if (x[RI_ROWS] < 0 || (x[RI_ROWS] >> 27) != 0 || x[RI_PARAMS] < 0 ||
+          (x[RI_PARAMS] & 0xFFFF) >= it[H_NPARAMS] || (x[RI_PARAMS] >> 16) >= it[H_NPARAMS])
+        return MPCASM_ERR_PLAN;
+      if (rows == 0) continue;
+      for (int k = 0; k < 2; ++k)  // 16 columns from the offset: the slack behind V covers them
+        if (x[k] < 0 || x[k] / it[H_LDV] + rows > it[H_RTOT]) return MPCASM_ERR_PLAN;
     }
     const int32_t* rrw = it + it[H_OFF_RS_RR];
     for (int64_t R = 0; R < nc; ++R) {
@@ -143,14 +160,17 @@ int validate_plan(const int32_t* it, size_t n_itab, size_t n_dtab) {
             x[RR_CENTER + a] > it[H_NPARAMS])
           return MPCASM_ERR_PLAN;
     }
+    // every input load stays inside its stream: sources, given, params, the constants
     const int32_t* im = it + it[H_OFF_RS_INMETA];
-    for (int i = 0; i < RS_PF_MAX * RS_NT; ++i) {
-      if (im[i] == -1) continue;
-      const int st = im[i] >> 24, off = im[i] & 0xFFFFFF;
-      if (im[i] < 0 || st > it[H_NSRC] + 1) return MPCASM_ERR_PLAN;
-      const int64_t lim = st < it[H_NSRC] ? (it + it[H_OFF_ARENA])[2 * st + 1]
-                                          : (st == it[H_NSRC] ? ng : (int64_t)it[H_NPARAMS]);
-      if (off >= lim) return MPCASM_ERR_PLAN;
+    for (int64_t i = 0; i < nchunk * 64; ++i) {
+      const int st = im[2 * i];
+      const int64_t off = im[2 * i + 1];
+      if (st < 0 || st > it[H_NSRC] + 2 || off < 0 || off % unit) return MPCASM_ERR_PLAN;
+      const int64_t lim = st < it[H_NSRC]        ? (it + it[H_OFF_ARENA])[2 * st + 1]
+                          : st == it[H_NSRC]     ? ng
+                          : st == it[H_NSRC] + 1 ? (int64_t)it[H_NPARAMS]
+                                                 : 4;
+      if (off + unit > lim * 8) return MPCASM_ERR_PLAN;
     }
     for (int c = 0; c < no; ++c) {  // diagonal gterms on one column: RS_DIAG_MAX slots
       int on = 0;
@@ -160,18 +180,11 @@ int validate_plan(const int32_t* it, size_t n_itab, size_t n_dtab) {
       }
       if (on > RS_DIAG_MAX) return MPCASM_ERR_PLAN;
     }
-    const int32_t* gq = it + it[H_OFF_RS_GQ];
-    for (int i = 0; i < it[H_RS_NQ]; ++i) {
-      const int32_t* x = gq + 4 * i;
-      if (x[0] < 0 || x[0] + no > vsize || x[1] < 0 || x[1] >= vsize || x[2] < 0 ||
-          x[2] >= it[H_NPARAMS] || (x[3] & 0x3FFFFFFF) >= it[H_NPARAMS] || x[3] < 0)
-        return MPCASM_ERR_PLAN;
-    }
-    const int nt = ((int)no + 15) / 16;
+    const int nt = ((int)no + 15) / 16, ntb = (int)no / 16 + 1;
     const int32_t* sl = it + it[H_OFF_RS_ISLOT];
     const int32_t* tl = it + it[H_OFF_RS_TILE];
     for (int i = 0; i < RS_NW * RS_TPW; ++i) {
-      if (tl[i] < -1 || tl[i] >= nt * nt) return MPCASM_ERR_PLAN;
+      if (tl[i] < -1 || tl[i] >= nt * ntb) return MPCASM_ERR_PLAN;
       if (sl[2 * i] < 0 || sl[2 * i + 1] < 0 || sl[2 * i] + sl[2 * i + 1] > it[H_RS_NITEM])
         return MPCASM_ERR_PLAN;
     }
@@ -314,7 +327,7 @@ int mpcasm_plan_create(const int32_t* h_itab, size_t n_itab, const double* h_dta
                        mpcasm_plan** out_plan) {
   if (!h_itab || !out_plan || (n_dtab && !h_dtab)) return MPCASM_ERR_ARG;
   *out_plan = nullptr;
-  const int rc = validate_plan(h_itab, n_itab, n_dtab);
+  const int rc = validate_plan(h_itab, h_dtab, n_itab, n_dtab);
   if (rc != MPCASM_OK) return rc;
   if (mpcasm_device_count() == 0) return MPCASM_ERR_NODEVICE;
 
@@ -362,8 +375,11 @@ int mpcasm_plan_create(const int32_t* h_itab, size_t n_itab, const double* h_dta
   d.off_rs_dst = it[H_OFF_RS_DST]; d.doff_rs_coef = it[H_DOFF_RS_COEF];
   d.off_rs_item = it[H_OFF_RS_ITEM]; d.off_rs_islot = it[H_OFF_RS_ISLOT];
   d.off_rs_tile = it[H_OFF_RS_TILE];
-  d.rs_nq = it[H_RS_NQ]; d.off_rs_gq = it[H_OFF_RS_GQ];
-  d.off_rs_rr = it[H_OFF_RS_RR]; d.rs_pf = it[H_RS_PF]; d.off_rs_inmeta = it[H_OFF_RS_INMETA];
+  d.rs_nsplit = it[H_RS_NSPLIT]; d.off_rs_split = it[H_OFF_RS_SPLIT];
+  d.off_rs_rr = it[H_OFF_RS_RR]; d.rs_unit = it[H_RS_UNIT]; d.rs_nchunk = it[H_RS_NCHUNK];
+  d.off_rs_inmeta = it[H_OFF_RS_INMETA]; d.rs_img = it[H_RS_IMG];
+  d.rs_img_given = it[H_RS_IMG_GIVEN]; d.rs_img_params = it[H_RS_IMG_PARAMS];
+  d.doff_rs_const = it[H_DOFF_RS_CONST];
   {
     hipDeviceProp_t prop;
     plan->num_cus = 256;
@@ -480,7 +496,8 @@ int launch_assemble(const PlanDev& p, const SrcTable& src, const double* params,
   // worth it while two workgroups fit
   constexpr size_t RESIDENT_LDS_LIMIT = 156 * 1024, FUSED_LDS_LIMIT = 80 * 1024;
   const size_t rs = resident_lds_bytes(p);
-  if (rs != 0 && rs <= RESIDENT_LDS_LIMIT && g_path == 0)
+  if (rs != 0 && rs <= RESIDENT_LDS_LIMIT && g_path == 0 &&
+      resident_inputs_aligned(p, src, params, given))
     return launch_assemble_resident(p, src, params, given, P, q, G, h, work, batch, rs, num_cus,
                                     stream, err);
   const size_t lds = fused_lds_bytes(p, 4);

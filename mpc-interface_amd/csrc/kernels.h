@@ -22,7 +22,8 @@ struct PlanDev {
       doff_coefpool, max_axes, rs_sym_any;  // rs_sym_any: every Hessian term has A == B
   // resident program
   int rs_ok, rs_jc, rs_sym, rs_nitem, off_rs_src, off_rs_gidx, off_rs_dst, doff_rs_coef,
-      off_rs_item, off_rs_islot, off_rs_tile, rs_nq, off_rs_gq, off_rs_rr, rs_pf, off_rs_inmeta;
+      off_rs_item, off_rs_islot, off_rs_tile, rs_nsplit, off_rs_split, off_rs_rr, rs_unit,
+      rs_nchunk, off_rs_inmeta, rs_img, rs_img_given, rs_img_params, doff_rs_const;
   int doff_diagcoef, ndiag;  // diagonal gterms: coefficient list, number of such terms
 };
 
@@ -48,6 +49,9 @@ int launch_assemble_fused(const PlanDev& p, const SrcTable& src, const double* p
                           int batch, size_t lds_bytes, hipStream_t stream, hipError_t* err);
 // resident.hip
 size_t resident_lds_bytes(const PlanDev& p);
+// whether this launch's buffers meet the alignment the plan's input loads assume
+bool resident_inputs_aligned(const PlanDev& p, const SrcTable& src, const double* params,
+                             const double* given);
 int launch_assemble_resident(const PlanDev& p, const SrcTable& src, const double* params,
                              const double* given, double* P, double* q, double* G, double* h,
                              void* work, int batch, size_t lds_bytes, int num_cus,

@@ -27,7 +27,7 @@
 namespace mpcasm {
 
 constexpr int32_t PLAN_MAGIC = 0x4D504341;  // 'MPCA'
-constexpr int32_t PLAN_VERSION = 11;
+constexpr int32_t PLAN_VERSION = 12;
 
 enum HeaderWord : int {
   H_MAGIC = 0,
@@ -79,23 +79,29 @@ enum HeaderWord : int {
   H_RS_JC,          // compose ops per thread (RS_NT threads per instance)
   H_RS_SYM,         // 1: every Hessian term has A == B, only tiles ti <= tj are computed
   H_RS_NITEM,
-  H_OFF_RS_SRC,     // [JC][RS_NT] arena offset of the op's source value
-  H_OFF_RS_GIDX,    // [JC][RS_NT] given index or -1
-  H_OFF_RS_DST,     // [JC][RS_NT] workspace index to store the running sum to, or -1
+  H_OFF_RS_SRC,     // [JC][RS_NT] image offset of the op's source value
+  H_OFF_RS_GIDX,    // [JC][RS_NT] image offset of the op's given value (or of a constant 1.0)
+  H_OFF_RS_DST,     // [JC][RS_NT] workspace index the running sum goes to (| RS_DST_ACC: added
+                    //             to it, the element is shared by two threads), or -1
   H_DOFF_RS_COEF,   // [JC][RS_NT]
-  H_OFF_RS_ITEM,    // [NITEM][4]: one (tile, gterm) pair: workspace offset of the A rows (tile
-                    //             column included), of the B rows, number of rows, weight param
+  H_OFF_RS_ITEM,    // [NITEM][4]: one (tile, gterm) pair, see the RI_* words below
   H_OFF_RS_ISLOT,   // [RS_NW][RS_TPW][2] first item, item count of a wavefront's tile slot
-  H_OFF_RS_TILE,    // [RS_NW][RS_TPW] tile index ti * nt + tj, or -1
-  H_RS_NQ,          // gradient records: one per (gterm, row)
-  H_OFF_RS_GQ,      // [NQ][4]: workspace offset of the A row, index of d, aim param,
-                    //          weight param | (1 << 30 when the term is halved)
+  H_OFF_RS_TILE,    // [RS_NW][RS_TPW] tile index ti * (no / 16 + 1) + tj, or -1
+  H_RS_NSPLIT,      // workspace elements composed by two threads
+  H_OFF_RS_SPLIT,   // [NSPLIT] their workspace indices (zeroed before every compose)
   H_OFF_RS_RR,      // [NC][RS_RR_WORDS] row records of the stacked G (see resident.hip)
-  H_RS_PF,          // input slots per thread (0: the inputs are too large to prefetch)
-  H_OFF_RS_INMETA,  // [RS_PF_MAX][RS_NT] stream << 24 | offset of the input double, or -1
+  // the input image of one instance in LDS: [1 | sources | given, 1 | params, 0 | 0...],
+  // filled by LDS-DMA loads of RS_UNIT bytes per lane, 64 lanes per chunk
+  H_RS_UNIT,        // 16 or 4 (bytes per lane)
+  H_RS_NCHUNK,
+  H_OFF_RS_INMETA,  // [NCHUNK * 64][2] input stream, byte offset inside the instance's slice
+  H_RS_IMG,         // doubles of the image (a multiple of 128)
+  H_RS_IMG_GIVEN,   // image offset of given[0]  (given[ng] reads 1.0)
+  H_RS_IMG_PARAMS,  // image offset of params[0] (params[nparams] reads 0.0)
+  H_DOFF_RS_CONST,  // [4] 1, 1, 0, 0: the constant input stream (even offset)
   H_DOFF_DIAGCOEF,  // [NDIAGCOEF] coefficients of the diagonal gterms
   H_NDIAGCOEF,
-  H_WORDS = 64
+  H_WORDS = 80
 };
 
 // segment record
@@ -125,7 +131,16 @@ constexpr int MAX_SOURCES = 32;
 // vector work; RS_TPW tiles per MFMA wavefront; RS_JC_MAX compose ops per thread
 constexpr int RS_NW = 4, RS_NT = 512, RS_TPW = 9, RS_JC_MAX = 12, RS_ITEM_WORDS = 4;
 // row record of G: voff[4], arrow param[4], center param[4], naxes, extreme param, 2 pad
-constexpr int RS_AXMAX = 4, RS_PF_MAX = 3, RS_RR_WORDS = 16;
+constexpr int RS_AXMAX = 4, RS_RR_WORDS = 16;
+constexpr int32_t RS_DST_ACC = 1 << 30;
+// item record.  RI_A / RI_B: workspace offset of the first A / B row, tile column included;
+// RI_ROWS: rows | mode << 24 | (1 << 26 when the term is halved); RI_PARAMS: weight param |
+// aim param << 16.  Column `no` of a workspace row holds d, so the tile column no / 16 of
+// the B operand carries the gradient: mode 0 tile outside that column; 1 B rows == d rows,
+// P and q from one product (b[no] <- s (d - aim)); 2 P only (b[no] <- 0); 3 q only (the B
+// rows are the d rows, every other column <- 0)
+enum { RI_A = 0, RI_B, RI_ROWS, RI_PARAMS };
+enum { RI_MODE_PLAIN = 0, RI_MODE_PQ = 1, RI_MODE_P = 2, RI_MODE_Q = 3 };
 // diagonal gterms the persistent kernel takes on one column of the unknowns
 constexpr int RS_DIAG_MAX = 2;
 enum { RR_VOFF = 0, RR_ARROW = 4, RR_CENTER = 8, RR_NAXES = 12, RR_EXTREME = 13 };

@@ -6,25 +6,33 @@
 // over instances b = blockIdx.x, += gridDim.x.  Everything that is *structure* is
 // loaded once per workgroup and then stays on chip for the whole launch:
 //   * the compose program (K2): each thread owns a fixed handful of ops
-//     `coef * arena[src] * given[g]` and keeps them in REGISTERS (JC slots);
-//   * the input list: each thread owns a fixed handful of input doubles (pieces of
-//     the instance's horizon matrices, given vector, parameters) and PREFETCHES
-//     those of the next instance into registers while the current one is computed;
-//   * the constraint program (K4): threads of the worker wavefronts own fixed
-//     16-byte pieces of G and keep their operand offsets in registers;
-//   * Hessian (tile, term) pair lists, gradient records, row records in LDS.
-// Per instance: inputs registers -> LDS | barrier A | K2 compose the workspace
-// V[rtot][no+1] = [Mo | d = Mg.given] (Mg is never stored; the preview matrices
-// never touch HBM) | barrier B | then the wavefronts SPECIALISE: waves 0-3 run the
-// Hessian tiles on the fp64 matrix core (v_mfma_f64_16x16x4_f64) straight from LDS
-// into P in LDS (structurally-zero tiles skipped, only ti <= tj when every term is
-// symmetric, mirrored on the way); waves 4-7 run the vector work at the same time:
-// gradient as a sliced mat-vec, G rows streamed to HBM with 16-byte stores, h
-// | barrier C | P (dense in LDS, aliasing the dead source arena) and q streamed out
-// | barrier D.  Barriers order LDS only (lds_barrier), so result stores and the
-// prefetch loads stay in flight across phases.  Within a phase all operand loads
-// are issued before the first use (explicit load batches), because the compiler
-// will not hoist LDS reads over LDS writes of the same array.
+//     `coef * image[src] * image[given]` and keeps them in REGISTERS (JC slots);
+//   * the input list: which bytes of the instance's horizon matrices, given vector and
+//     parameters land where in the LDS input image (per-lane load addresses);
+//   * Hessian (tile, term) item lists, row records of G in LDS.
+//
+// The wavefronts SPECIALISE.  Waves 0-3 ("matrix waves") are the only ones that read
+// HBM: they fetch the next instance's input image with LDS-DMA loads
+// (global_load_lds_dwordx4: no registers, no staging pass) into the other half of a
+// double buffer, and run the Hessian tiles on the fp64 matrix core
+// (v_mfma_f64_16x16x4_f64).  The gradient rides along: column `no` of a workspace row
+// holds d, so the tile column that contains it yields q = sum_k w a[k][.] s (d[k] - aim)
+// from the same products.  Waves 4-7 ("stream waves") only write HBM: the rows of G
+// and h while the matrix waves work on P.  A wave's memory counter (vmcnt) therefore
+// never mixes a load it must wait for with a store it need not wait for.
+//
+// Per instance, three barriers:
+//   A | all: diagonal terms, K2 compose the workspace V[rtot][no+1] = [Mo | d = Mg.given]
+//       from the image (Mg is never stored; the preview matrices never touch HBM)
+//   B | matrix waves: start the next image's loads, Hessian + gradient tiles -> P, q in LDS
+//       (structurally-zero tiles skipped, only ti <= tj when every term is symmetric,
+//       mirrored on the way); stream waves: G, h -> HBM
+//   C | matrix waves: wait for the image, clear the workspace elements that two threads
+//       add into; all: P, q -> HBM with 16-byte stores
+// Barriers order LDS only (lds_barrier), so result stores stay in flight across phases.
+// Within a phase all operand loads are issued before the first use (explicit load
+// batches), because the compiler will not hoist LDS reads over LDS writes of the same
+// array.
 //
 // Reference semantics: body.py:149-193 (preview rows), :236-264 + restrictions.py:
 // 175-199 (constraints), :266-302, :322-329 (costs); identical plan tables and
@@ -47,54 +55,68 @@ constexpr int WT = NT - MW * 64;  // threads of the worker wavefronts
 constexpr int TPW = RS_TPW;
 constexpr int AXMAX = RS_AXMAX;
 constexpr int RR_WORDS = RS_RR_WORDS;
-constexpr int GU = 6;                    // 16-byte pieces of G a worker thread may own
-constexpr int PF = RS_PF_MAX;            // input doubles a thread may prefetch
+constexpr int GU = 6;  // 16-byte pieces of G a worker thread may own
 static_assert(RS_DIAG_MAX == 2, "the per-column diagonal table holds two terms");
 
 __host__ __device__ inline int even_up_i(int x) { return (x + 1) & ~1; }
 
 struct ResidentLayout {
-  int v, arena, pl, g, prm, qpart, dvec, dcoef, dpar, ptrs, ints, total_doubles;  // offsets in doubles
-  int ldp;                                                    // leading dimension of P in LDS
-  int ns;                                                     // row slices of the gradient pass
-  int i_tile, i_rr, i_gq, i_item, i_islot;  // offsets in ints inside the int region
+  // offsets in doubles
+  int v, pl, ql, dvec, dcoef, dpar, img, streams, ints, total_doubles;
+  int ldp;                                            // leading dimension of P in LDS
+  int i_item, i_rr, i_meta, i_islot, i_tile, i_split;  // offsets in ints inside the int region
 };
 
 __host__ __device__ inline ResidentLayout resident_layout(const PlanDev& p) {
   ResidentLayout L;
   L.ldp = even_up_i(p.no);
-  L.ns = p.no > 0 ? WT / p.no : 1;
-  if (L.ns < 1) L.ns = 1;
-  if (L.ns > 16) L.ns = 16;
   int o = 0;
-  L.v = o;     o += even_up_i(p.rtot * p.ldv) + 3 * p.ldv + 16;  // MFMA k-steps may overrun
-  // the input image [arena | given (+ a 1.0) | params (+ a 0.0)] is contiguous; P
-  // overlays the arena part once it is dead, but never given / params (read while P
-  // is being assembled)
-  L.arena = o;
-  const int pl = p.no * L.ldp, ar = even_up_i(p.arena_total);
-  o += ar > pl ? ar : pl;
-  L.pl = L.arena;
-  L.g = o;     o += even_up_i(p.ng + 1);
-  L.prm = o;   o += even_up_i(p.nparams + 1);
-  L.qpart = o; o += L.ns * L.ldp;
+  L.v = o;      o += even_up_i(p.rtot * p.ldv) + 3 * p.ldv + 16;  // MFMA k-steps may overrun
+  L.pl = o;     o += p.no * L.ldp;
+  L.ql = o;     o += L.ldp;
   // diagonal gterms: addends of P[c][c] and q[c] of this instance, then per column the
   // (weight, aim) parameter slots and coefficients of the (at most RS_DIAG_MAX) terms on it
-  L.dvec = o;  o += 2 * L.ldp;
-  L.dcoef = o; o += RS_DIAG_MAX * L.ldp;
-  L.dpar = o;  o += RS_DIAG_MAX * L.ldp;
-  L.ptrs = o;  o += 3 * (MAX_SOURCES + 2);
+  L.dvec = o;   o += 2 * L.ldp;
+  L.dcoef = o;  o += RS_DIAG_MAX * L.ldp;
+  L.dpar = o;   o += RS_DIAG_MAX * L.ldp;
+  L.img = o;    o += 2 * p.rs_img;  // two input images: this instance's, the next one's
+  L.streams = o; o += 2 * (MAX_SOURCES + 3);  // (base pointer, bytes per instance) per stream
   L.ints = o;
-  int i = 0;
-  L.i_gq = i;    i += p.rs_nq * 4;  // first three: 16-byte aligned
+  int i = 0;  // the first three start 16-byte aligned
   L.i_item = i;  i += (p.rs_nitem + 1) * RS_ITEM_WORDS;
   L.i_rr = i;    i += p.nc * RR_WORDS;
+  L.i_meta = i;  i += p.rs_nchunk * 64 * 2;
   L.i_islot = i; i += MW * TPW * 2;
   L.i_tile = i;  i += MW * TPW;
+  L.i_split = i; i += p.rs_nsplit;
   o += even_up_i(i) / 2;
   L.total_doubles = o;
   return L;
 }
+
+// One LDS-DMA load: every lane's `bytes` (16 or 4) from its own global address to
+// lds_base + lane * bytes.  M0 carries the LDS base; it is compiler-reserved, so it is
+// saved, set and restored inside the one statement.  The compiler does not count this
+// load: the issuing wave waits for it itself (dma_wait).
+__device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_base) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_base)
+      : "memory");
+}
+__device__ __forceinline__ void dma4(const void* gsrc, unsigned lds_base) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_base)
+      : "memory");
+}
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 template <int JC, bool STAMPS>
 __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
@@ -115,33 +137,28 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
     t_prev = t_now;                                                \
   }
   const ResidentLayout L = resident_layout(p);
-  const int no = p.no, ng = p.ng, nc = p.nc, ldv = p.ldv, ldp = L.ldp;
+  const int no = p.no, nc = p.nc, ldv = p.ldv, ldp = L.ldp;
 
   double* V = lds + L.v;
-  double* arena = lds + L.arena;
-  double* Pl = lds + L.pl;  // overlays the arena: live only between barriers B and D
-  double* gl = lds + L.g;
-  double* prm = lds + L.prm;
-  double* qpart = lds + L.qpart;
+  double* Pl = lds + L.pl;
+  double* ql = lds + L.ql;
   double* dvec = lds + L.dvec;
   double2* dcoef = reinterpret_cast<double2*>(lds + L.dcoef);
   int4* dpar = reinterpret_cast<int4*>(lds + L.dpar);
-  double* sptr = lds + L.ptrs;  // [nsrc + 2] triples: base pointer, stride, LDS slot (raw words)
+  double* strm = lds + L.streams;  // [nsrc + 3] pairs: base pointer, bytes per instance (raw)
   int* itb = reinterpret_cast<int*>(lds + L.ints);
-  int4* gq = reinterpret_cast<int4*>(itb + L.i_gq);
   int4* items = reinterpret_cast<int4*>(itb + L.i_item);
+  int* rr = itb + L.i_rr;
+  int2* meta = reinterpret_cast<int2*>(itb + L.i_meta);
   int* islot = itb + L.i_islot;
   int* tile = itb + L.i_tile;
-  int* rr = itb + L.i_rr;
+  int* split = itb + L.i_split;
+  // LDS byte address of the image double buffer (the low half of a flat LDS address)
+  const unsigned img_lds = (unsigned)(uintptr_t)(lds + L.img);
+  const int unit = p.rs_unit, nchunk = p.rs_nchunk;
 
-#ifdef MPCASM_POISON_LDS
-  // debugging aid: every byte of LDS starts as a NaN pattern, so that a read of a location
-  // the kernel never wrote shows up in the results whatever the previous launch left behind
-  for (int i = tid; i < L.total_doubles; i += NT) lds[i] = __builtin_nan("");
-  lds_barrier();
-#endif
   // ---- once per workgroup: the compose program into registers ------------------
-  int c_sg[JC], c_dst[JC];  // c_sg: arena offset | given index << 16 (index ng: the constant 1)
+  int c_sg[JC], c_dst[JC];  // c_sg: image offset of the source | of the given value << 16
   double c_coef[JC];
   {
     const int32_t* tsrc = p.itab + p.off_rs_src;
@@ -151,17 +168,14 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
 #pragma unroll
     for (int j = 0; j < JC; ++j) {
       const bool have = j < p.rs_jc;
-      const int gi = have ? tg[j * NT + tid] : -1;
-      c_sg[j] = (have ? tsrc[j * NT + tid] : 0) | ((gi < 0 ? ng : gi) << 16);
+      c_sg[j] = have ? (tsrc[j * NT + tid] | (tg[j * NT + tid] << 16)) : 0;
       c_dst[j] = have ? tdst[j * NT + tid] : -1;
       c_coef[j] = have ? tcoef[j * NT + tid] : 0.0;
     }
   }
   // ---- once per workgroup: structure tables into LDS, workspace zeroed -----------
   {
-    const int4* t4 = reinterpret_cast<const int4*>(p.itab + p.off_rs_gq);
-    for (int i = tid; i < p.rs_nq; i += NT) gq[i] = t4[i];
-    t4 = reinterpret_cast<const int4*>(p.itab + p.off_rs_item);
+    const int4* t4 = reinterpret_cast<const int4*>(p.itab + p.off_rs_item);
     for (int i = tid; i <= p.rs_nitem; i += NT)
       items[i] = i < p.rs_nitem ? t4[i] : int4{0, 0, 0, 0};
     const int32_t* t = p.itab + p.off_rs_islot;
@@ -170,23 +184,22 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
     for (int i = tid; i < MW * TPW; i += NT) tile[i] = t[i];
     t = p.itab + p.off_rs_rr;  // row records of G, precomputed by the plan compiler
     for (int i = tid; i < nc * RR_WORDS; i += NT) rr[i] = t[i];
+    t = p.itab + p.off_rs_split;
+    for (int i = tid; i < p.rs_nsplit; i += NT) split[i] = t[i];
+    const int2* t2 = reinterpret_cast<const int2*>(p.itab + p.off_rs_inmeta);
+    for (int i = tid; i < nchunk * 64; i += NT) meta[i] = t2[i];
     double2* V2 = reinterpret_cast<double2*>(V);
     const int n2 = (even_up_i(p.rtot * ldv) + 3 * ldv + 16) / 2;
     for (int i = tid; i < n2; i += NT) V2[i] = double2{0.0, 0.0};
-    // (pointer, stride) of every input stream: the sources, then given, then params
-    if (tid < p.nsrc + 2) {
-      const double* base = tid < p.nsrc ? src.ptr[tid] : (tid == p.nsrc ? given : params);
+    // input streams: the sources, then given, params, the plan's constants
+    if (tid < p.nsrc + 3) {
+      const int s = tid - p.nsrc;
+      const double* base = s < 0 ? src.ptr[tid]
+                                 : (s == 0 ? given : (s == 1 ? params : p.dtab + p.doff_rs_const));
       const long long stride =
-          tid < p.nsrc ? src.stride[tid] : (tid == p.nsrc ? (long long)ng : (long long)p.nparams);
-      const int slot = tid < p.nsrc ? (p.itab + p.off_arena)[2 * tid]
-                                    : (tid == p.nsrc ? (int)(gl - arena) : (int)(prm - arena));
-      reinterpret_cast<const double**>(sptr)[3 * tid] = base;
-      reinterpret_cast<long long*>(sptr)[3 * tid + 1] = stride;
-      reinterpret_cast<long long*>(sptr)[3 * tid + 2] = slot;
-    }
-    if (tid == 0) {
-      gl[ng] = 1.0;
-      prm[p.nparams] = 0.0;
+          s < 0 ? src.stride[tid] : (s == 0 ? (long long)p.ng : (s == 1 ? (long long)p.nparams : 0));
+      reinterpret_cast<const double**>(strm)[2 * tid] = base;
+      reinterpret_cast<long long*>(strm)[2 * tid + 1] = stride * (long long)sizeof(double);
     }
     if (p.ndiag != 0 && tid < no) {
       // the diagonal gterms on column tid; free slots read the 0.0 behind the parameters
@@ -217,29 +230,26 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
   }
   lds_barrier();
 
-  // ---- once per workgroup: the input list (which doubles this thread stages) -------
-  // flat input index f -> (stream, offset in stream, LDS slot); streams: the sources,
-  // given (ng), params (nparams).  in_meta: stream << 24 | offset; in_lds: slot
-  // relative to the arena, or -1.
-  const int32_t* arec = p.itab + p.off_arena;
-  const bool prefetching = p.rs_pf == PF && (phases & 128);
-  int in_meta[PF];  // stream << 24 | offset in the stream, or -1 (precomputed by the plan)
-#pragma unroll
-  for (int u = 0; u < PF; ++u)
-    in_meta[u] = prefetching ? (p.itab + p.off_rs_inmeta)[u * NT + tid] : -1;
-  auto input_address = [&](int meta, long inst) -> const double* {
-    const int s = meta >> 24;
-    const double* base = reinterpret_cast<const double* const*>(sptr)[3 * s];
-    const long long stride = reinterpret_cast<const long long*>(sptr)[3 * s + 1];
-    return base + inst * stride + (meta & 0xFFFFFF);
+  // the matrix waves fetch instance `inst`'s image into buffer `buf` (chunks dealt round robin)
+  auto fetch_image = [&](long inst, int buf) {
+    const unsigned dst0 = img_lds + (unsigned)buf * (unsigned)p.rs_img * 8u;
+    for (int k = wave; k < nchunk; k += MW) {
+      const int2 m = meta[k * 64 + lane];
+      const char* base = reinterpret_cast<const char* const*>(strm)[2 * m.x];
+      const long long stride = reinterpret_cast<const long long*>(strm)[2 * m.x + 1];
+      const char* a = base + inst * stride + m.y;
+      const unsigned dst = __builtin_amdgcn_readfirstlane(dst0 + (unsigned)(k * 64 * unit));
+      if (unit == 16)
+        dma16(a, dst);
+      else
+        dma4(a, dst);
+    }
   };
-  auto input_slot = [&](int meta) -> int {
-    return (int)reinterpret_cast<const long long*>(sptr)[3 * (meta >> 24) + 2] + (meta & 0xFFFFFF);
-  };
-  double in_val[PF];
-#pragma unroll
-  for (int u = 0; u < PF; ++u)
-    in_val[u] = in_meta[u] >= 0 ? *input_address(in_meta[u], blockIdx.x) : 0.0;
+  const bool lookahead = (phases & 128) != 0;  // diagnostic: off = fetch only when needed
+  if (wave < MW) {
+    fetch_image(blockIdx.x, 0);
+    dma_wait();
+  }
 
   // ---- K4 bookkeeping of the worker threads: piece e = wt + u WT of G is the 16 bytes
   // (columns 2cp, 2cp+1) of row R; (R, cp) of the first piece and the step between pieces
@@ -250,34 +260,16 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
   const int g_dR = npair > 0 ? WT / npair : 0, g_dcp = npair > 0 ? WT - g_dR * npair : 0;
   const int g_R0 = npair > 0 && wt >= 0 ? wt / npair : 0;
   const int g_cp0 = npair > 0 && wt >= 0 ? wt - g_R0 * npair : 0;
-  // gradient pass: worker thread = (column qc, row slice qs)
-  const int wtc = wt >= 0 ? wt : 0;
-  const int qs = wtc / no, qc = wtc - qs * no;
-  const int NS = L.ns;
 
-  const int nt = (no + 15) >> 4;
+  const int tq = no >> 4, ntb = tq + 1, qli = no & 15;  // the tile column that holds d
   const int li = lane & 15, lk = lane >> 4;
 
   if (STAMPS && stamping) t_prev = __builtin_amdgcn_s_memtime();
-  for (long inst = blockIdx.x; inst < batch; inst += gridDim.x) {
-    // ---- this instance's inputs into LDS (the regions are free: barrier D) ---------
-    if (prefetching) {
-#pragma unroll
-      for (int u = 0; u < PF; ++u)
-        if (in_meta[u] >= 0) arena[input_slot(in_meta[u])] = in_val[u];
-    } else {
-      for (int s = 0; s < p.nsrc; ++s) {
-        const int off = arec[2 * s], size = arec[2 * s + 1];
-        const double* sp = src.ptr[s] + inst * src.stride[s];
-        for (int i = tid; i < size; i += NT) arena[off + i] = sp[i];
-      }
-      const double* gb = given + inst * ng;
-      for (int i = tid; i < ng; i += NT) gl[i] = gb[i];
-      const double* pb = params + inst * p.nparams;
-      for (int i = tid; i < p.nparams; i += NT) prm[i] = pb[i];
-    }
-    if (tid == 0) arena[0] = 1.0;  // P of the previous instance covered it
-    lds_barrier();  // A: inputs staged
+  int buf = 0;
+  for (long inst = blockIdx.x; inst < batch; inst += gridDim.x, buf ^= 1) {
+    const double* img = lds + L.img + buf * p.rs_img;
+    const double* prm = img + p.rs_img_params;
+    lds_barrier();  // A: this instance's image landed, P and q of the previous one read out
     MPCASM_STAMP(0)
 
     // diagonal gterms (costs on free variables themselves): their addends of P[c][c], q[c]
@@ -297,50 +289,62 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
       double va[JC], vg[JC];
 #pragma unroll
       for (int j = 0; j < JC; ++j) {  // all operand loads first
-        va[j] = arena[c_sg[j] & 0xFFFF];
-        vg[j] = gl[(unsigned)c_sg[j] >> 16];
+        va[j] = img[c_sg[j] & 0xFFFF];
+        vg[j] = img[(unsigned)c_sg[j] >> 16];
       }
       double acc = 0.0;
 #pragma unroll
       for (int j = 0; j < JC; ++j) {
         acc += c_coef[j] * va[j] * vg[j];
-        if (c_dst[j] >= 0) V[c_dst[j]] = acc;
+        if (c_dst[j] >= 0) {
+          if (c_dst[j] & RS_DST_ACC)  // two threads share the element (cleared after C)
+            __hip_atomic_fetch_add(&V[c_dst[j] & ~RS_DST_ACC], acc, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+          else
+            V[c_dst[j]] = acc;
+        }
         acc = c_dst[j] >= 0 ? 0.0 : acc;
       }
     }
-    lds_barrier();  // B: workspace complete, arena dead
+    lds_barrier();  // B: workspace complete
     MPCASM_STAMP(1)
 
-    // the next instance's inputs start their trip from HBM now
-    if (prefetching) {
-      const long nxt = inst + gridDim.x;
-      if (nxt < batch) {
-#pragma unroll
-        for (int u = 0; u < PF; ++u)
-          if (in_meta[u] >= 0) in_val[u] = *input_address(in_meta[u], nxt);
-      }
-    }
-
+    const long nxt = inst + gridDim.x;
     if (wave < MW) {
+      // the next instance's image starts its trip from HBM now
+      if (lookahead && nxt < batch && (phases & 16)) fetch_image(nxt, buf ^ 1);
+      MPCASM_STAMP(7)
       if (P != nullptr && (phases & 2)) {
-        // ---- K3: Hessian tiles on the matrix core -> P in LDS ------------------------
-#pragma unroll
+        // ---- K3: Hessian and gradient tiles on the matrix core -> P, q in LDS ----------
+#pragma unroll 1
         for (int s = 0; s < TPW; ++s) {
           const int t = __builtin_amdgcn_readfirstlane(tile[wave * TPW + s]);
           if (t < 0) continue;
-          const int ti = t / nt, tj = t - ti * nt;
+          const int ti = t / ntb, tj = t - ti * ntb;
           f64x4 acc = f64x4{0.0, 0.0, 0.0, 0.0};
           const int i0 = __builtin_amdgcn_readfirstlane(islot[(wave * TPW + s) * 2]);
           const int cnt = __builtin_amdgcn_readfirstlane(islot[(wave * TPW + s) * 2 + 1]);
-          int4 nxt = items[i0];
+          int4 nx = items[i0];
           for (int it = 0; it < cnt; ++it) {
-            const int4 cur = nxt;
-            nxt = items[i0 + it + 1];  // prefetch the next pair (the table has a spare record)
-            const int nrows = __builtin_amdgcn_readfirstlane(cur.z);
+            const int4 cur = nx;
+            nx = items[i0 + it + 1];  // prefetch the next item (the table has a spare record)
+            const int word = __builtin_amdgcn_readfirstlane(cur.z);
+            const int par = __builtin_amdgcn_readfirstlane(cur.w);
+            const int nrows = word & 0xFFFFFF, mode = (word >> 24) & 3;
             // a weight of 0 contributes exact zeros through the products (body.py:292)
-            const double w = prm[__builtin_amdgcn_readfirstlane(cur.w)];
+            const double w = prm[par & 0xFFFF];
             const double* ap = V + __builtin_amdgcn_readfirstlane(cur.x) + li;
             const double* bp = V + __builtin_amdgcn_readfirstlane(cur.y) + li;
+            // the B operand becomes m1 b - m2: in the lane that holds column `no`,
+            // s (d - aim) (modes PQ, Q) or 0 (mode P); elsewhere b, or 0 (mode Q)
+            double m1 = 1.0, m2 = 0.0;
+            if (mode != RI_MODE_PLAIN) {
+              const double sc = (word >> 26) & 1 ? 0.5 : 1.0;
+              const double aim = prm[par >> 16];
+              const bool ql_ = li == qli;
+              m1 = ql_ ? (mode == RI_MODE_P ? 0.0 : sc) : (mode == RI_MODE_Q ? 0.0 : 1.0);
+              m2 = ql_ && mode != RI_MODE_P ? sc * aim : 0.0;
+            }
             for (int k0 = 0; k0 < nrows; k0 += 16) {  // four MFMA k-steps per trip
               double a[4], b[4];
 #pragma unroll
@@ -351,6 +355,10 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
               }
 #pragma unroll
               for (int u = 0; u < 4; ++u) a[u] = k0 + 4 * u + lk < nrows ? w * a[u] : 0.0;
+              if (mode != RI_MODE_PLAIN) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) b[u] = fma(m1, b[u], -m2);
+              }
 #pragma unroll
               for (int u = 0; u < 4; ++u)
                 if (k0 + 4 * u < nrows) acc = mfma_f64_16x16x4(a[u], b[u], acc);
@@ -364,48 +372,14 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
               const double v = acc[reg] + (p.ndiag != 0 && row == col ? dvec[row] : 0.0);
               Pl[row * ldp + col] = v;
               if (mirror) Pl[col * ldp + row] = v;
+            } else if (row < no && col == no) {
+              ql[row] = acc[reg] + (p.ndiag != 0 ? dvec[ldp + row] : 0.0);
             }
           }
         }
       }
       MPCASM_STAMP(2)
     } else {
-      if (P != nullptr && (phases & 4)) {
-        // ---- gradient: q[c] = sum_records w s V[a][c] (V[d] - aim), rows sliced NS ways --
-        // q[c] = sum_records w s V[a][c] (V[d] - aim): thread = (column qc, row slice qs)
-        // (the opaque copies keep derived addresses from being hoisted out of the instance
-        // loop into long-lived registers)
-        int qs_ = qs, qc_ = qc;
-        asm volatile("" : "+v"(qs_), "+v"(qc_));
-        if (qs_ < NS) {
-          const int nq = p.rs_nq;
-          double qa = 0.0;
-          for (int i0 = qs_; i0 < nq; i0 += 2 * NS) {  // two records per trip, loads in flight
-            int4 e[2];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-              const int i = i0 + u * NS;
-              e[u] = gq[i < nq ? i : nq - 1];
-            }
-            double w[2], d[2], aim[2], a[2];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-              w[u] = prm[e[u].w & 0x3FFFFFFF];
-              d[u] = V[e[u].y];
-              aim[u] = prm[e[u].z];
-              a[u] = V[e[u].x + qc_];
-            }
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-              const double r = ((e[u].w >> 30) & 1 ? 0.5 : 1.0) * (d[u] - aim[u]);
-              const double t = fma(w[u] * a[u], r, qa);
-              qa = i0 + u * NS < nq ? t : qa;
-            }
-          }
-          qpart[qs_ * ldp + qc_] = qa;
-        }
-      }
-      MPCASM_STAMP(3)
       if (G != nullptr && (phases & 8)) {
         // ---- K4: constraint rows straight to HBM ---------------------------------------
         double* Gb = G + (size_t)inst * nc * no;
@@ -508,11 +482,20 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
           hb[R] = (prm[rec[RR_EXTREME]] + ac) - ad;
         }
       }
-      MPCASM_STAMP(4)
+      MPCASM_STAMP(3)
     }
-    lds_barrier();  // C: P and the q partials are in LDS
-    MPCASM_STAMP(5)
+    lds_barrier();  // C: P and q are in LDS, the workspace is dead
+    MPCASM_STAMP(4)
 
+    if (wave < MW) {
+      if (!lookahead && nxt < batch && (phases & 16)) fetch_image(nxt, buf ^ 1);
+      // The next image is complete before barrier A.  The wait comes before this wave's
+      // P stores so that it never waits for a store, only for loads issued a phase ago.
+      dma_wait();
+      // elements that two threads add into start the next compose from zero
+      for (int i = tid; i < p.rs_nsplit; i += MW * 64) V[split[i]] = 0.0;
+    }
+    MPCASM_STAMP(5)
     if (P != nullptr && (phases & 32)) {
       double* Pb = P + (size_t)inst * no * no;
       if ((no & 1) == 0) {
@@ -528,15 +511,9 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
         }
       }
       double* qb = q + (size_t)inst * no;
-      for (int c = tid; c < no; c += NT) {
-        double s = 0.0;
-        for (int w = 0; w < NS; ++w) s += qpart[w * ldp + c];
-        qb[c] = s + (p.ndiag != 0 ? dvec[ldp + c] : 0.0);
-      }
+      for (int c = tid; c < no; c += NT) qb[c] = ql[c];
     }
     MPCASM_STAMP(6)
-    lds_barrier();  // D: P read out, the region may take the next instance's sources
-    MPCASM_STAMP(7)
   }
   if (STAMPS && stamping && lane == 0) {
 #pragma unroll
@@ -589,6 +566,18 @@ size_t resident_lds_bytes(const PlanDev& p) {
   if (!p.rs_ok || p.rs_jc > RS_JC_MAX || p.no > WT || p.no < 1 || p.max_axes > AXMAX) return 0;
   if ((long)p.rtot * p.ldv > (1 << 20)) return 0;
   return (size_t)resident_layout(p).total_doubles * sizeof(double);
+}
+
+// the 16-byte input loads need every stream 16-byte aligned in every instance
+bool resident_inputs_aligned(const PlanDev& p, const SrcTable& src, const double* params,
+                             const double* given) {
+  if (p.rs_unit != 16) return true;
+  auto ok = [](const void* base, long long stride) {
+    return (reinterpret_cast<uintptr_t>(base) & 15) == 0 && (stride & 1) == 0;
+  };
+  for (int s = 0; s < p.nsrc; ++s)
+    if (!ok(src.ptr[s], src.stride[s])) return false;
+  return ok(given, p.ng) && ok(params, p.nparams);
 }
 
 int launch_assemble_resident(const PlanDev& p, const SrcTable& src, const double* params,

@@ -15,7 +15,7 @@ import numpy as np
 import scipy.sparse as sp
 
 PLAN_MAGIC = 0x4D504341
-PLAN_VERSION = 11
+PLAN_VERSION = 12
 
 # header words (csrc/plan_tables.h, enum HeaderWord)
 _H = {name: i for i, name in enumerate([
@@ -27,15 +27,19 @@ _H = {name: i for i, name in enumerate([
     "FUSED_OK", "ARENA_TOTAL", "OFF_ARENA", "NFD", "OFF_FD_IDX", "OFF_FD_PTR", "NOPS", "OFF_OP",
     "NCOEF", "DOFF_COEFPOOL",
     "RS_OK", "RS_JC", "RS_SYM", "RS_NITEM", "OFF_RS_SRC", "OFF_RS_GIDX", "OFF_RS_DST",
-    "DOFF_RS_COEF", "OFF_RS_ITEM", "OFF_RS_ISLOT", "OFF_RS_TILE", "RS_NQ", "OFF_RS_GQ",
-    "OFF_RS_RR", "RS_PF", "OFF_RS_INMETA", "DOFF_DIAGCOEF", "NDIAGCOEF",
+    "DOFF_RS_COEF", "OFF_RS_ITEM", "OFF_RS_ISLOT", "OFF_RS_TILE", "RS_NSPLIT", "OFF_RS_SPLIT",
+    "OFF_RS_RR", "RS_UNIT", "RS_NCHUNK", "OFF_RS_INMETA", "RS_IMG", "RS_IMG_GIVEN",
+    "RS_IMG_PARAMS", "DOFF_RS_CONST", "DOFF_DIAGCOEF", "NDIAGCOEF",
 ])}
-H_WORDS = 64
+H_WORDS = 80
+assert len(_H) <= H_WORDS
 RS_NW, RS_NT, RS_TPW = 4, 512, 9          # MFMA wavefronts, threads per instance, tiles per wave
 RS_JC_MAX = 12                            # compose ops a thread can keep in registers
 RS_ITEM_WORDS = 4
 RS_DIAG_MAX = 2                           # diagonal gterms per column (persistent kernel)
-RS_AXMAX, RS_PF = 4, 3                   # axes per constraint row record, input slots per thread
+RS_AXMAX = 4                              # axes per constraint row record
+RS_DST_ACC = 1 << 30                      # compose destination shared by two threads
+RI_MODE_PLAIN, RI_MODE_PQ, RI_MODE_P, RI_MODE_Q = 0, 1, 2, 3
 RS_RR_WORDS = 16                          # row record: voff[4], arrow param[4], center param[4], naxes, extreme param, pad
 SEG_WORDS, GT_WORDS, LM_WORDS, LX_WORDS = 8, 10, 12, 2
 FUSED_MAX_OPS = 1 << 18           # beyond this the staged pipeline is used
@@ -416,36 +420,73 @@ def _resident_rows(limit_recs, lax_recs, nparams, ldv):
     return np.asarray(rows, dtype=np.int32).reshape(-1)
 
 
-def _resident_inputs(sources, arena_off, ng, nparams):
-    """Which input doubles every thread of the persistent kernel stages: flat index
-    f = thread + slot * RS_NT over [sources..., given, params] ->
-    stream << 24 | offset in the stream, or -1."""
-    total = sum(s.array.size for s in sources) + ng + nparams
-    if total > RS_PF * RS_NT or any(s.array.size >= 1 << 24 for s in sources):
-        return 0, -np.ones(RS_PF * RS_NT, dtype=np.int32)
-    meta = []
-    for sid, s in enumerate(sources):
-        meta.append((sid << 24) | np.arange(s.array.size, dtype=np.int64))
-    meta.append((len(sources) << 24) | np.arange(ng, dtype=np.int64))
-    meta.append(((len(sources) + 1) << 24) | np.arange(nparams, dtype=np.int64))
-    flat = np.concatenate(meta) if meta else np.zeros(0, dtype=np.int64)
-    out = -np.ones(RS_PF * RS_NT, dtype=np.int64)
-    out[:flat.size] = flat
-    return RS_PF, out.astype(np.int32)
+def _resident_image(sources, ng, nparams):
+    """The input image of one instance in LDS and the LDS-DMA loads that fill it.
+
+    Doubles, in order: ``1, 1 | source 0 | source 1 ... | given, 1 | params, 0 | 0 ...``
+    (a 1.0 behind ``given`` for ops without a given factor, a 0.0 behind ``params`` for the
+    missing axes of a constraint row; every block starts on an even offset; the total is a
+    multiple of 128).  Input streams: the sources, then given, params, and a constant
+    stream ``[1, 1, 0, 0]`` owned by the plan.  One load moves ``unit`` bytes per lane, 64
+    lanes to consecutive LDS addresses: 16 when every pair of doubles of the image comes
+    from consecutive, even-aligned elements of one stream, else 4.
+    Returns the per-lane table ``meta[nchunk * 64][2]`` = (stream, byte offset)."""
+    nsrc = len(sources)
+    s_given, s_params, s_const = nsrc, nsrc + 1, nsrc + 2
+    slots = []                                   # per double of the image: (stream, element)
+
+    def push_const(first):                       # 1.0 is element 0 / 1, 0.0 is 2 / 3
+        slots.append((s_const, first))
+        if len(slots) & 1:
+            slots.append((s_const, first + 1))
+
+    def pad_even():
+        if len(slots) & 1:
+            slots.append((s_const, 3))
+
+    push_const(0)
+    src_off = []
+    for sid, src in enumerate(sources):
+        src_off.append(len(slots))
+        slots.extend((sid, k) for k in range(src.array.size))
+        pad_even()
+    given_off = len(slots)
+    slots.extend((s_given, k) for k in range(ng))
+    push_const(0)
+    pad_even()
+    params_off = len(slots)
+    slots.extend((s_params, k) for k in range(nparams))
+    push_const(2)
+    pad_even()
+    while len(slots) % 128:
+        slots.extend([(s_const, 2), (s_const, 3)])
+    arr = np.asarray(slots, dtype=np.int64)
+    even, odd = arr[0::2], arr[1::2]
+    paired = bool(np.all((even[:, 0] == odd[:, 0]) & (odd[:, 1] == even[:, 1] + 1)
+                         & (even[:, 1] % 2 == 0)))
+    if paired:
+        unit = 16
+        meta = np.stack([even[:, 0], even[:, 1] * 8], axis=1)
+    else:
+        unit = 4
+        meta = np.stack([np.repeat(arr[:, 0], 2),
+                         (np.repeat(arr[:, 1] * 8, 2) + np.tile([0, 4], len(arr)))], axis=1)
+    return dict(unit=unit, nchunk=meta.shape[0] // 64, meta=meta.astype(np.int32).reshape(-1),
+                img=len(slots), given=given_off, params=params_off, src_off=src_off)
 
 
-def _resident_program(fused, gterms, no, ldv):
+def _resident_program(fused, gterms, no, ldv, image, ng, nparams):
     """Tables of the persistent fused kernel: the compose ops of ``_fused_program``
     dealt out to the RS_NT threads of a workgroup (kept in registers for the whole
-    launch) and the Hessian work split into per-wavefront lists of MFMA items."""
+    launch) and the Hessian + gradient work split into per-wavefront lists of MFMA items."""
     import heapq
 
     NT, NW, TPW = RS_NT, RS_NW, RS_TPW
     z = np.zeros(0, dtype=np.int32)
-    out = dict(ok=0, jc=0, sym=0, src=z, gidx=z, dst=z, coef=np.zeros(0), items=z, gq=z,
+    out = dict(ok=0, jc=0, sym=0, src=z, gidx=z, dst=z, coef=np.zeros(0), items=z, split=z,
                islot=np.zeros(NW * TPW * 2, dtype=np.int32),
                tile=-np.ones(NW * TPW, dtype=np.int32))
-    if not fused["ok"]:
+    if not fused["ok"] or image["img"] > 65535 or nparams > 65535:
         return out
     on_column = np.zeros(no + 1, dtype=np.int64)
     for g in gterms:
@@ -453,52 +494,100 @@ def _resident_program(fused, gterms, no, ldv):
             on_column[g[0]:g[0] + g[2]] += 1
     if on_column.max() > RS_DIAG_MAX:
         return out
-    # ---- compose: whole elements to threads, longest first onto the lightest thread
+    # ---- compose: elements to threads, longest first onto the lightest thread; an element
+    # with more ops than a thread may hold is shared by two threads (both add their part)
     fd_idx, fd_ptr = fused["fd_idx"], fused["fd_ptr"]
     ops = fused["ops"].view(np.uint32).reshape(-1, 2)
     pool = fused["coefpool"]
     counts = np.diff(fd_ptr)
-    heap = [(0, t) for t in range(NT)]
-    heapq.heapify(heap)
-    owner = [[] for _ in range(NT)]
-    for i in np.argsort(-counts, kind="stable"):
-        load, t = heapq.heappop(heap)
-        owner[t].append(int(i))
-        heapq.heappush(heap, (load + int(counts[i]), t))
-    jc = max((sum(int(counts[i]) for i in own) for own in owner), default=0)
-    jc = max(jc, 1)
-    if jc > RS_JC_MAX:
+    owner, split = None, []
+    for cap in (3, 5, 8, RS_JC_MAX):
+        if counts.size and counts.max() > 2 * cap:
+            continue
+        pieces = []                               # (first op, last op, element, shared)
+        for i, c in enumerate(counts):
+            lo, hi = int(fd_ptr[i]), int(fd_ptr[i + 1])
+            if c > cap:
+                mid = lo + (int(c) + 1) // 2
+                pieces += [(lo, mid, i, True), (mid, hi, i, True)]
+            else:
+                pieces.append((lo, hi, i, False))
+        heap = [(0, t) for t in range(NT)]
+        heapq.heapify(heap)
+        trial = [[] for _ in range(NT)]
+        for pc in sorted(pieces, key=lambda pc: pc[0] - pc[1]):
+            load, t = heapq.heappop(heap)
+            trial[t].append(pc)
+            heapq.heappush(heap, (load + pc[1] - pc[0], t))
+        if max((sum(pc[1] - pc[0] for pc in own) for own in trial), default=0) <= cap:
+            owner = trial
+            split = sorted({int(fd_idx[pc[2]]) for pc in pieces if pc[3]})
+            break
+    if owner is None:
         return out
-    src = np.zeros((jc, NT), dtype=np.int32)            # arena slot 0 = constant 1.0
-    gidx = -np.ones((jc, NT), dtype=np.int32)
+    jc = max(1, max((sum(pc[1] - pc[0] for pc in own) for own in owner), default=0))
+    arena = fused["arena"].reshape(-1, 2)
+
+    def image_offset(a):                          # fused arena offset -> image offset
+        if a == 0:
+            return 0                              # the constant 1.0
+        for sid, (off, size) in enumerate(arena):
+            if off <= a < off + size:
+                return image["src_off"][sid] + a - off
+        raise AssertionError("arena offset outside every source")
+
+    src = np.zeros((jc, NT), dtype=np.int32)            # image[0] = 1.0
+    gidx = np.full((jc, NT), image["given"] + ng, dtype=np.int32)   # ... and given[ng] = 1.0
     dst = -np.ones((jc, NT), dtype=np.int32)
     coef = np.zeros((jc, NT))
     for t, own in enumerate(owner):
         j = 0
-        for i in sorted(own):
-            for o in range(fd_ptr[i], fd_ptr[i + 1]):
-                src[j, t] = int(ops[o, 0])
-                gidx[j, t] = (int(ops[o, 1]) >> 16) - 1
+        for lo, hi, i, shared in sorted(own):
+            for o in range(lo, hi):
+                src[j, t] = image_offset(int(ops[o, 0]))
+                gi = (int(ops[o, 1]) >> 16) - 1
+                if gi >= 0:
+                    gidx[j, t] = image["given"] + gi
                 coef[j, t] = pool[int(ops[o, 1]) & 0xFFFF]
                 j += 1
-            dst[j - 1, t] = int(fd_idx[i])               # store after the element's last op
-    # ---- Hessian: one item = 4 workspace rows of one gterm into one 16x16 tile
-    nt = (no + 15) // 16
-    pterms = [g for g in gterms if g[6] & GT_FLAG_P]
+            dst[j - 1, t] = int(fd_idx[i]) | (RS_DST_ACC if shared else 0)
+    # ---- Hessian and gradient: one item = the rows of one gterm into one 16x16 tile.
+    # Column `no` of a workspace row is d, so tile column tq = no // 16 of the B operand
+    # yields q[c] = sum_k w a[k][c] s (d[k] - aim) next to (or instead of) the P columns.
+    nt, tq = (no + 15) // 16, no // 16
+    ntb = tq + 1
+    terms = [g for g in gterms if not g[6] & GT_FLAG_DIAG]
+    pterms = [g for g in terms if g[6] & GT_FLAG_P]
     sym = int(all(g[0] == g[1] for g in pterms))
     tile_items = {}
     for ti in range(nt):
-        for tj in range(ti if sym else 0, nt):
+        for tj in range(ti if sym else 0, ntb):
             tile_items[(ti, tj)] = []
-    for g in pterms:
-        aoff, boff, nrows, wparam = g[0], g[1], g[2], g[3]
-        for (ti, tj), lst in tile_items.items():
-            if not ((g[7] >> min(ti, 30)) & 1 and (g[8] >> min(tj, 30)) & 1):
-                continue
-            lst.append([aoff * ldv + ti * 16, boff * ldv + tj * 16, nrows, wparam])
-    cost = {key: sum((it[2] + 3) // 4 for it in lst) for key, lst in tile_items.items()}
-    if len(tile_items) > NW * TPW:
+    if len(tile_items) > NW * TPW or any(g[2] >= 1 << 24 for g in terms):
         return out
+
+    def bit(mask, t):
+        return (mask >> min(t, 30)) & 1
+
+    for g in terms:
+        aoff, boff, nrows, wparam, doff, aimparam, flags = g[:7]
+        words = nrows | ((1 << 26) if flags & GT_FLAG_HALF else 0)
+        par = wparam | (aimparam << 16)
+        for (ti, tj), lst in tile_items.items():
+            if not bit(g[7], ti):
+                continue
+            p_part = bool(flags & GT_FLAG_P) and tj < nt and bool(bit(g[8], tj))
+            q_part = tj == tq
+            a = aoff * ldv + ti * 16
+            if p_part and q_part and boff == doff:
+                lst.append([a, boff * ldv + tj * 16, words | (RI_MODE_PQ << 24), par])
+                continue
+            if p_part:
+                mode = RI_MODE_P if q_part else RI_MODE_PLAIN
+                lst.append([a, boff * ldv + tj * 16, words | (mode << 24), par])
+            if q_part:
+                lst.append([a, doff * ldv + tj * 16, words | (RI_MODE_Q << 24), par])
+    cost = {key: sum(((it[2] & 0xFFFFFF) + 3) // 4 for it in lst) for key, lst in tile_items.items()}
     loads = [(0, w) for w in range(NW)]
     heapq.heapify(loads)
     wave_tiles = [[] for _ in range(NW)]
@@ -518,20 +607,12 @@ def _resident_program(fused, gterms, no, ldv):
         for s_, key in enumerate(wave_tiles[w]):
             islot[(w * TPW + s_) * 2] = len(items)
             islot[(w * TPW + s_) * 2 + 1] = len(tile_items[key])
-            tile[w * TPW + s_] = key[0] * nt + key[1]
+            tile[w * TPW + s_] = key[0] * ntb + key[1]
             items.extend(tile_items[key])
-    # ---- gradient: one record per (gterm, row): q += w s V[a] (V[d] - aim)
-    gq = []
-    for g in gterms:
-        if g[6] & GT_FLAG_DIAG:
-            continue                       # handled as a diagonal update, no workspace rows
-        half = (1 << 30) if g[6] & GT_FLAG_HALF else 0
-        for k in range(g[2]):
-            gq.append([(g[0] + k) * ldv, (g[4] + k) * ldv + no, g[5], g[3] | half])
-    out["gq"] = np.asarray(gq, dtype=np.int32).reshape(-1)
     out.update(ok=1, jc=jc, sym=sym, src=src.reshape(-1), gidx=gidx.reshape(-1),
                dst=dst.reshape(-1), coef=coef.reshape(-1),
-               items=np.asarray(items, dtype=np.int32).reshape(-1))
+               items=np.asarray(items, dtype=np.int32).reshape(-1),
+               split=np.asarray(split, dtype=np.int32))
     return out
 
 
@@ -666,10 +747,9 @@ def compile_plan(form, costs=None, limits=None):
             return m
         rec[7] = mask(rec[0], rec[2])
         rec[8] = mask(rec[1], rec[2]) if rec[1] >= 0 else 0
-    resident = _resident_program(fused, gterms, no, ldv)
+    image = _resident_image(b.sources, b.ng, len(b.params))
+    resident = _resident_program(fused, gterms, no, ldv, image, b.ng, len(b.params))
     rs_rr = _resident_rows(limit_recs, lax_recs, len(b.params), ldv)
-    arena_offsets = fused["arena"].reshape(-1, 2)[:, 0] if len(b.sources) else []
-    rs_pf, rs_inmeta = _resident_inputs(b.sources, arena_offsets, b.ng, len(b.params))
     if any(rec[2] > RS_AXMAX for rec in limit_recs):
         rs_rr = np.zeros(0, dtype=np.int32)      # too many axes: no resident kernel
     pm_blocks, pm_rows, r0 = [], {}, 0
@@ -704,9 +784,9 @@ def compile_plan(form, costs=None, limits=None):
         ("OFF_RS_ITEM", resident["items"]),
         ("OFF_RS_ISLOT", resident["islot"]),
         ("OFF_RS_TILE", resident["tile"]),
-        ("OFF_RS_GQ", resident["gq"]),
+        ("OFF_RS_SPLIT", resident["split"]),
         ("OFF_RS_RR", rs_rr),
-        ("OFF_RS_INMETA", rs_inmeta),
+        ("OFF_RS_INMETA", image["meta"]),
     ]
     header = np.zeros(H_WORDS, dtype=np.int32)
     parts, off = [header], H_WORDS
@@ -714,15 +794,19 @@ def compile_plan(form, costs=None, limits=None):
         if name == "OFF_OP" and off & 1:          # the kernels read ops as 8-byte pairs
             parts.append(np.zeros(1, dtype=np.int32))
             off += 1
-        if name in ("OFF_RS_GQ", "OFF_RS_ITEM", "OFF_RS_RR") and off & 3:   # ... 16-byte quads
+        if name in ("OFF_RS_ITEM", "OFF_RS_RR", "OFF_RS_INMETA") and off & 3:   # ... 16-byte quads
             pad = 4 - (off & 3)
             parts.append(np.zeros(pad, dtype=np.int32))
             off += pad
         header[_H[name]] = off
         parts.append(arr)
         off += arr.size
-    dtab = np.concatenate([entcoef, pm_entcoef, fused["coefpool"], resident["coef"],
-                           diag_coefs]).astype(np.float64)
+    dparts = [entcoef, pm_entcoef, fused["coefpool"], resident["coef"], diag_coefs]
+    ndt = sum(part.size for part in dparts)
+    dparts.append(np.zeros(ndt & 1))             # the constant stream starts 16-byte aligned
+    header[_H["DOFF_RS_CONST"]] = ndt + (ndt & 1)
+    dparts.append(np.array([1.0, 1.0, 0.0, 0.0]))
+    dtab = np.concatenate(dparts).astype(np.float64)
     params = np.asarray(b.params, dtype=np.float64)
     header[_H["MAGIC"]], header[_H["VERSION"]] = PLAN_MAGIC, PLAN_VERSION
     header[_H["NG"]], header[_H["NO"]], header[_H["NC"]] = b.ng, no, nc
@@ -740,8 +824,10 @@ def compile_plan(form, costs=None, limits=None):
     header[_H["RS_OK"]], header[_H["RS_JC"]] = resident["ok"], resident["jc"]
     header[_H["RS_SYM"]] = resident["sym"]
     header[_H["RS_NITEM"]] = resident["items"].size // RS_ITEM_WORDS
-    header[_H["RS_NQ"]] = resident["gq"].size // 4
-    header[_H["RS_PF"]] = rs_pf
+    header[_H["RS_NSPLIT"]] = resident["split"].size
+    header[_H["RS_UNIT"]], header[_H["RS_NCHUNK"]] = image["unit"], image["nchunk"]
+    header[_H["RS_IMG"]] = image["img"]
+    header[_H["RS_IMG_GIVEN"]], header[_H["RS_IMG_PARAMS"]] = image["given"], image["params"]
     if rs_rr.size != nc * RS_RR_WORDS:
         header[_H["RS_OK"]] = 0                  # a constraint with more than RS_AXMAX axes
     header[_H["DOFF_RS_COEF"]] = entcoef.size + pm_entcoef.size + fused["coefpool"].size

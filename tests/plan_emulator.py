@@ -142,3 +142,122 @@ def run_fused_workspace(plan, given, sources=None):
                 if not (mask >> min(t, 30)) & 1:
                     assert not V[off:off + n, 16 * t:min(16 * t + 16, no)].any()
     return V
+
+
+def run_resident(plan, given, params=None, sources=None):
+    """P, q, G, h of one instance from the *resident program* (the tables of the persistent
+    kernel, csrc/resident.hip): the input image assembled load by load, the per-thread
+    compose ops (shared elements added up), the per-wavefront (tile, term) items with the
+    gradient riding in column ``no`` of the B operand, the row records of G."""
+    it, dt = plan.itab, plan.dtab
+    ng, no, nc, ldv = plan.ng, plan.no, plan.nc, plan.ldv
+    assert it[H["RS_OK"]] == 1
+    srcs = [s.array for s in plan.sources] if sources is None else sources
+    params = plan.params if params is None else np.asarray(params, dtype=float)
+    g = np.asarray(given, dtype=float).ravel()
+    nsrc, nparams = it[H["NSRC"]], it[H["NPARAMS"]]
+    # ---- the image: one LDS-DMA load moves `unit` bytes per lane to consecutive addresses
+    unit, nchunk, img = it[H["RS_UNIT"]], it[H["RS_NCHUNK"]], it[H["RS_IMG"]]
+    const = dt[it[H["DOFF_RS_CONST"]]:it[H["DOFF_RS_CONST"]] + 4]
+    streams = [np.ascontiguousarray(a, dtype=np.float64).ravel().view(np.uint8) for a in srcs]
+    streams += [g.view(np.uint8), np.ascontiguousarray(params).view(np.uint8),
+                np.ascontiguousarray(const).view(np.uint8)]
+    meta = _section(it, "OFF_RS_INMETA", nchunk * 64 * 2).reshape(-1, 2)
+    image = np.full(img * 8, 0xFF, dtype=np.uint8)          # NaN pattern where nothing lands
+    assert meta.shape[0] * unit == img * 8
+    for lane, (st, off) in enumerate(meta):
+        assert 0 <= st < nsrc + 3 and off % unit == 0 and off + unit <= streams[st].size
+        image[lane * unit:(lane + 1) * unit] = streams[st][off:off + unit]
+    image = image.view(np.float64)
+    prm = image[it[H["RS_IMG_PARAMS"]]:]
+    assert image[0] == 1.0 and image[it[H["RS_IMG_GIVEN"]] + ng] == 1.0 and prm[nparams] == 0.0
+    assert np.array_equal(prm[:nparams], params)
+    # ---- compose
+    jc = it[H["RS_JC"]]
+    src = _section(it, "OFF_RS_SRC", jc * P.RS_NT).reshape(jc, P.RS_NT)
+    gix = _section(it, "OFF_RS_GIDX", jc * P.RS_NT).reshape(jc, P.RS_NT)
+    dst = _section(it, "OFF_RS_DST", jc * P.RS_NT).reshape(jc, P.RS_NT)
+    cf = dt[it[H["DOFF_RS_COEF"]]:it[H["DOFF_RS_COEF"]] + jc * P.RS_NT].reshape(jc, P.RS_NT)
+    V = np.zeros(plan.rtot * ldv + 3 * ldv + 32)
+    split = _section(it, "OFF_RS_SPLIT", it[H["RS_NSPLIT"]])
+    written = np.zeros(V.size, dtype=np.int64)
+    for t in range(P.RS_NT):
+        acc = 0.0
+        for j in range(jc):
+            acc += cf[j, t] * image[src[j, t]] * image[gix[j, t]]
+            d = int(dst[j, t])
+            if d >= 0:
+                if d & P.RS_DST_ACC:
+                    d &= ~P.RS_DST_ACC
+                    assert d in split
+                    V[d] += acc
+                    written[d] += 1
+                else:
+                    assert written[d] == 0
+                    V[d] = acc
+                    written[d] = 99
+                acc = 0.0
+    assert all(written[d] in (1, 2) for d in split)
+    # ---- Hessian and gradient tiles
+    tq = no // 16
+    ntb, nt, qli = tq + 1, (no + 15) // 16, no % 16
+    tile = _section(it, "OFF_RS_TILE", P.RS_NW * P.RS_TPW)
+    islot = _section(it, "OFF_RS_ISLOT", P.RS_NW * P.RS_TPW * 2).reshape(-1, 2)
+    items = _section(it, "OFF_RS_ITEM", it[H["RS_NITEM"]] * 4).reshape(-1, 4)
+    dP, dq = np.zeros(no), np.zeros(no)
+    gt = _section(it, "OFF_GTERM", it[H["NGTERM"]] * P.GT_WORDS).reshape(-1, P.GT_WORDS)
+    for a, b, n, pw, d, pa, flags, _ma, _mb, _pad in gt:
+        if flags & P.GT_FLAG_DIAG:
+            c = dt[it[H["DOFF_DIAGCOEF"]] + b:it[H["DOFF_DIAGCOEF"]] + b + n]
+            idx = np.arange(a, a + n)
+            dP[idx] += (prm[pw] * c) * c
+            dq[idx] += prm[pw] * (c * (0.0 - prm[pa]))
+    Pm, q = np.full((no, no), np.nan), np.full(no, np.nan)
+    lanes = np.arange(16)
+    for slot in range(P.RS_NW * P.RS_TPW):
+        t = tile[slot]
+        if t < 0:
+            continue
+        ti, tj = divmod(int(t), ntb)
+        acc = np.zeros((16, 16))
+        for x in items[islot[slot, 0]:islot[slot, 0] + islot[slot, 1]]:
+            rows, mode, half = x[2] & 0xFFFFFF, (x[2] >> 24) & 3, (x[2] >> 26) & 1
+            w, aim = prm[x[3] & 0xFFFF], prm[x[3] >> 16]
+            assert mode == P.RI_MODE_PLAIN or tj == tq
+            s = 0.5 if half else 1.0
+            for k in range(rows):
+                av = w * V[x[0] + k * ldv + lanes]
+                bv = V[x[1] + k * ldv + lanes].copy()
+                if mode != P.RI_MODE_PLAIN:
+                    dval = s * (bv[qli] - aim)
+                    if mode == P.RI_MODE_Q:
+                        bv[:] = 0.0
+                    bv[qli] = 0.0 if mode == P.RI_MODE_P else dval
+                acc += np.outer(av, bv)
+        for i in range(16):
+            row = ti * 16 + i
+            if row >= no:
+                continue
+            for jx in range(16):
+                col = tj * 16 + jx
+                if col < no:
+                    Pm[row, col] = acc[i, jx] + (dP[row] if row == col else 0.0)
+                    if it[H["RS_SYM"]] and ti != tj:
+                        Pm[col, row] = Pm[row, col]
+                elif col == no:
+                    q[row] = acc[i, jx] + dq[row]
+    # ---- constraint rows
+    rr = _section(it, "OFF_RS_RR", nc * P.RS_RR_WORDS).reshape(nc, P.RS_RR_WORDS)
+    G, h = np.zeros((nc, no)), np.zeros(nc)
+    for R in range(nc):
+        rec = rr[R]
+        ac = ad = 0.0
+        for ax in range(rec[12]):
+            arrow = prm[rec[4 + ax]]
+            G[R] += arrow * V[rec[ax]:rec[ax] + no]
+            ac += arrow * prm[rec[8 + ax]]
+            ad += arrow * V[rec[ax] + no]
+        for ax in range(rec[12], P.RS_AXMAX):       # the kernel's fast path reads two axes
+            assert prm[rec[4 + ax]] == 0.0
+        h[R] = (prm[rec[13]] + ac) - ad
+    return {"P": Pm, "q": q, "G": G, "h": h, "V": V[:plan.rtot * ldv].reshape(plan.rtot, ldv)}

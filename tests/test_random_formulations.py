@@ -112,6 +112,12 @@ def test_plan_tables_random(cpu_api, seed):
     assert_close(out["h"], h.ravel(), 1e-12)
     if plan.itab[plan_emulator.H["FUSED_OK"]]:
         assert_close(plan_emulator.run_fused_workspace(plan, given), out["V"], 1e-12)
+    if plan.itab[plan_emulator.H["RS_OK"]]:
+        res = plan_emulator.run_resident(plan, given)
+        assert_close(res["P"], Q, 1e-12)
+        assert_close(res["q"], q.ravel(), 1e-12)
+        assert_close(res["G"], A, 1e-12)
+        assert_close(res["h"], h.ravel(), 1e-12)
 
 
 @pytest.mark.gpu

@@ -28,10 +28,12 @@ def main():
     given = torch.as_tensor(work["given"], device="cuda")
     lib = capi.load()
     lib.mpcasm_set_option(capi.OPT_PATH, int(os.environ.get("MPCASM_PATH", "0")))
+    pf = 0x80 if os.environ.get("MPCASM_PREFETCH", "1") == "1" else 0   # register prefetch
     masks = [("all", 0x3F), ("none", 0), ("staging", 0x10), ("compose", 1), ("hessian", 2),
              ("gradient", 4), ("constraints", 8), ("Pq-store", 0x20), ("no-staging", 0x2F),
              ("no-compose", 0x3E), ("no-hessian", 0x3D), ("no-grad", 0x3B), ("no-constr", 0x37),
-             ("no-Pstore", 0x1F)]
+             ("no-Pstore", 0x1F), ("no-grad-constr", 0x33), ("no-hess-grad", 0x39)]
+    masks = [(name, mask | pf) for name, mask in masks]
     times = {name: [] for name, _ in masks}
     for rnd in range(6):
         for name, mask in masks:

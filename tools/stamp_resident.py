@@ -15,7 +15,7 @@ import torch  # noqa: E402
 import bench  # noqa: E402
 from mpcasm import capi  # noqa: E402
 
-NAMES = ["stage+A", "compose+B", "hessian", "gradient", "constr", "barC", "Pq out", "barD"]
+NAMES = ["barA", "compose+B", "hess+q", "G,h", "barC", "dma wait", "Pq out", "fetch"]
 
 
 def main():
