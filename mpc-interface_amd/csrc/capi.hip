@@ -100,7 +100,7 @@ int validate_plan(const int32_t* it, const double* h_dtab, size_t n_itab, size_t
     if (!it[H_FUSED_OK]) return MPCASM_ERR_PLAN;
     const int64_t jc = it[H_RS_JC], slots = jc * RS_NT;
     const int64_t img = it[H_RS_IMG], unit = it[H_RS_UNIT], nchunk = it[H_RS_NCHUNK];
-    if (jc < 1 || jc > RS_JC_MAX || it[H_RS_NITEM] < 0 || it[H_RS_NSPLIT] < 0)
+    if (jc < 1 || jc > RS_JC_MAX || it[H_RS_NTRIP] < 0 || it[H_RS_NSPLIT] < 0)
       return MPCASM_ERR_PLAN;
     if ((unit != 4 && unit != 16) || img < 128 || img % 128 || img > 65535 ||
         nchunk * 64 * unit != img * 8 || it[H_NPARAMS] > 65535)
@@ -110,11 +110,10 @@ int validate_plan(const int32_t* it, const double* h_dtab, size_t n_itab, size_t
     r = r && in_range(it[H_OFF_RS_GIDX], slots, n, H_WORDS);
     r = r && in_range(it[H_OFF_RS_DST], slots, n, H_WORDS);
     r = r && in_range(it[H_DOFF_RS_COEF], slots, nd, 0);
-    r = r && in_range(it[H_OFF_RS_ITEM], (int64_t)it[H_RS_NITEM] * RS_ITEM_WORDS, n, H_WORDS);
-    r = r && in_range(it[H_OFF_RS_ISLOT], RS_NW * RS_TPW * 2, n, H_WORDS);
-    r = r && in_range(it[H_OFF_RS_TILE], RS_NW * RS_TPW, n, H_WORDS);
+    r = r && in_range(it[H_OFF_RS_TRIP], (int64_t)it[H_RS_NTRIP] * RS_TRIP_WORDS, n, H_WORDS);
+    r = r && in_range(it[H_OFF_RS_WTRIP], RS_WAVES * 2, n, H_WORDS);
     r = r && in_range(it[H_OFF_RS_SPLIT], it[H_RS_NSPLIT], n, H_WORDS);
-    r = r && (it[H_OFF_RS_ITEM] % 4 == 0);
+    r = r && (it[H_OFF_RS_TRIP] % 4 == 0);
     r = r && in_range(it[H_OFF_RS_RR], nc * RS_RR_WORDS, n, H_WORDS) && it[H_OFF_RS_RR] % 4 == 0;
     r = r && in_range(it[H_OFF_RS_INMETA], nchunk * 64 * 2, n, H_WORDS) &&
         it[H_OFF_RS_INMETA] % 2 == 0;
@@ -137,16 +136,42 @@ int validate_plan(const int32_t* it, const double* h_dtab, size_t n_itab, size_t
     const int32_t* sp = it + it[H_OFF_RS_SPLIT];
     for (int i = 0; i < it[H_RS_NSPLIT]; ++i)
       if (sp[i] < 0 || sp[i] >= vsize) return MPCASM_ERR_PLAN;
-    const int32_t* ti = it + it[H_OFF_RS_ITEM];
-    for (int i = 0; i < it[H_RS_NITEM]; ++i) {
-      const int32_t* x = ti + i * RS_ITEM_WORDS;
-      const int rows = x[RI_ROWS] & 0xFFFFFF;
-      if (x[RI_ROWS] < 0 || (x[RI_ROWS] >> 27) != 0 || x[RI_PARAMS] < 0 ||
-          (x[RI_PARAMS] & 0xFFFF) >= it[H_NPARAMS] || (x[RI_PARAMS] >> 16) >= it[H_NPARAMS])
+    const int nt = ((int)no + 15) / 16, ntb = (int)no / 16 + 1;
+    const int32_t* tr = it + it[H_OFF_RS_TRIP];
+    for (int i = 0; i < it[H_RS_NTRIP]; ++i) {
+      const int32_t* x = tr + i * RS_TRIP_WORDS;
+      const int rows = x[RT_WORD] & 31, mode = (x[RT_WORD] >> RT_MODE) & 3;
+      const int ti = (x[RT_WORD] >> RT_TI) & 127, tj = (x[RT_WORD] >> RT_TJ) & 127;
+      if (x[RT_WORD] < 0 || (x[RT_WORD] >> 24) != 0 || rows > 16 || ti >= nt || tj >= ntb ||
+          (mode != RI_MODE_PLAIN && tj != ntb - 1) || x[RT_PARAMS] < 0 ||
+          (x[RT_PARAMS] & 0xFFFF) >= it[H_NPARAMS] || (x[RT_PARAMS] >> 16) >= it[H_NPARAMS])
         return MPCASM_ERR_PLAN;
-      if (rows == 0) continue;
       for (int k = 0; k < 2; ++k)  // 16 columns from the offset: the slack behind V covers them
-        if (x[k] < 0 || x[k] / it[H_LDV] + rows > it[H_RTOT]) return MPCASM_ERR_PLAN;
+        if (x[k] < 0 || (rows > 0 && x[k] / it[H_LDV] + rows > it[H_RTOT]) ||
+            (rows == 0 && x[k] != 0))
+          return MPCASM_ERR_PLAN;
+    }
+    {  // every wavefront's trips: consecutive, whole tiles (first ... last)
+      const int32_t* wt = it + it[H_OFF_RS_WTRIP];
+      int next = 0;
+      for (int w = 0; w < RS_WAVES; ++w) {
+        if (wt[2 * w] != next || wt[2 * w + 1] < 0 || (wt[2 * w + 1] & 1)) return MPCASM_ERR_PLAN;
+        next += wt[2 * w + 1];
+        if (next > it[H_RS_NTRIP]) return MPCASM_ERR_PLAN;
+        int open = -1;
+        for (int i = wt[2 * w]; i < next; ++i) {
+          const int word = tr[i * RS_TRIP_WORDS + RT_WORD], tile = word >> RT_TI;
+          if (word == 0 && open == -1) continue;  // padding between tiles
+          if ((word >> RT_FIRST) & 1) {
+            if (open != -1) return MPCASM_ERR_PLAN;
+            open = tile;
+          }
+          if (open != tile) return MPCASM_ERR_PLAN;
+          if ((word >> RT_LAST) & 1) open = -1;
+        }
+        if (open != -1) return MPCASM_ERR_PLAN;
+      }
+      if (next != it[H_RS_NTRIP]) return MPCASM_ERR_PLAN;
     }
     const int32_t* rrw = it + it[H_OFF_RS_RR];
     for (int64_t R = 0; R < nc; ++R) {
@@ -179,14 +204,6 @@ int validate_plan(const int32_t* it, const double* h_dtab, size_t n_itab, size_t
         if ((r[GT_FLAGS] & GT_FLAG_DIAG) && c >= r[GT_AOFF] && c < r[GT_AOFF] + r[GT_NROWS]) ++on;
       }
       if (on > RS_DIAG_MAX) return MPCASM_ERR_PLAN;
-    }
-    const int nt = ((int)no + 15) / 16, ntb = (int)no / 16 + 1;
-    const int32_t* sl = it + it[H_OFF_RS_ISLOT];
-    const int32_t* tl = it + it[H_OFF_RS_TILE];
-    for (int i = 0; i < RS_NW * RS_TPW; ++i) {
-      if (tl[i] < -1 || tl[i] >= nt * ntb) return MPCASM_ERR_PLAN;
-      if (sl[2 * i] < 0 || sl[2 * i + 1] < 0 || sl[2 * i] + sl[2 * i + 1] > it[H_RS_NITEM])
-        return MPCASM_ERR_PLAN;
     }
   }
 
@@ -371,10 +388,9 @@ int mpcasm_plan_create(const int32_t* h_itab, size_t n_itab, const double* h_dta
   d.nops = it[H_NOPS]; d.off_op = it[H_OFF_OP]; d.ncoef = it[H_NCOEF];
   d.doff_coefpool = it[H_DOFF_COEFPOOL];
   d.rs_ok = it[H_RS_OK]; d.rs_jc = it[H_RS_JC]; d.rs_sym = it[H_RS_SYM];
-  d.rs_nitem = it[H_RS_NITEM]; d.off_rs_src = it[H_OFF_RS_SRC]; d.off_rs_gidx = it[H_OFF_RS_GIDX];
+  d.rs_ntrip = it[H_RS_NTRIP]; d.off_rs_src = it[H_OFF_RS_SRC]; d.off_rs_gidx = it[H_OFF_RS_GIDX];
   d.off_rs_dst = it[H_OFF_RS_DST]; d.doff_rs_coef = it[H_DOFF_RS_COEF];
-  d.off_rs_item = it[H_OFF_RS_ITEM]; d.off_rs_islot = it[H_OFF_RS_ISLOT];
-  d.off_rs_tile = it[H_OFF_RS_TILE];
+  d.off_rs_trip = it[H_OFF_RS_TRIP]; d.off_rs_wtrip = it[H_OFF_RS_WTRIP];
   d.rs_nsplit = it[H_RS_NSPLIT]; d.off_rs_split = it[H_OFF_RS_SPLIT];
   d.off_rs_rr = it[H_OFF_RS_RR]; d.rs_unit = it[H_RS_UNIT]; d.rs_nchunk = it[H_RS_NCHUNK];
   d.off_rs_inmeta = it[H_OFF_RS_INMETA]; d.rs_img = it[H_RS_IMG];

@@ -21,8 +21,8 @@ struct PlanDev {
   int fused_ok, arena_total, off_arena, nfd, off_fd_idx, off_fd_ptr, nops, off_op, ncoef,
       doff_coefpool, max_axes, rs_sym_any;  // rs_sym_any: every Hessian term has A == B
   // resident program
-  int rs_ok, rs_jc, rs_sym, rs_nitem, off_rs_src, off_rs_gidx, off_rs_dst, doff_rs_coef,
-      off_rs_item, off_rs_islot, off_rs_tile, rs_nsplit, off_rs_split, off_rs_rr, rs_unit,
+  int rs_ok, rs_jc, rs_sym, rs_ntrip, off_rs_src, off_rs_gidx, off_rs_dst, doff_rs_coef,
+      off_rs_trip, off_rs_wtrip, rs_nsplit, off_rs_split, off_rs_rr, rs_unit,
       rs_nchunk, off_rs_inmeta, rs_img, rs_img_given, rs_img_params, doff_rs_const;
   int doff_diagcoef, ndiag;  // diagonal gterms: coefficient list, number of such terms
 };

@@ -27,7 +27,7 @@
 namespace mpcasm {
 
 constexpr int32_t PLAN_MAGIC = 0x4D504341;  // 'MPCA'
-constexpr int32_t PLAN_VERSION = 12;
+constexpr int32_t PLAN_VERSION = 13;
 
 enum HeaderWord : int {
   H_MAGIC = 0,
@@ -78,15 +78,14 @@ enum HeaderWord : int {
   H_RS_OK,
   H_RS_JC,          // compose ops per thread (RS_NT threads per instance)
   H_RS_SYM,         // 1: every Hessian term has A == B, only tiles ti <= tj are computed
-  H_RS_NITEM,
+  H_RS_NTRIP,
   H_OFF_RS_SRC,     // [JC][RS_NT] image offset of the op's source value
   H_OFF_RS_GIDX,    // [JC][RS_NT] image offset of the op's given value (or of a constant 1.0)
   H_OFF_RS_DST,     // [JC][RS_NT] workspace index the running sum goes to (| RS_DST_ACC: added
                     //             to it, the element is shared by two threads), or -1
   H_DOFF_RS_COEF,   // [JC][RS_NT]
-  H_OFF_RS_ITEM,    // [NITEM][4]: one (tile, gterm) pair, see the RI_* words below
-  H_OFF_RS_ISLOT,   // [RS_NW][RS_TPW][2] first item, item count of a wavefront's tile slot
-  H_OFF_RS_TILE,    // [RS_NW][RS_TPW] tile index ti * (no / 16 + 1) + tj, or -1
+  H_OFF_RS_TRIP,    // [NTRIP][4]: up to 16 rows of one gterm into one tile, see RT_* below
+  H_OFF_RS_WTRIP,   // [RS_WAVES][2] first trip, trip count of every wavefront
   H_RS_NSPLIT,      // workspace elements composed by two threads
   H_OFF_RS_SPLIT,   // [NSPLIT] their workspace indices (zeroed before every compose)
   H_OFF_RS_RR,      // [NC][RS_RR_WORDS] row records of the stacked G (see resident.hip)
@@ -127,19 +126,24 @@ enum {
 enum { LX_ROWOFF = 0, LX_ROWS, LX_WORDS = 2 };
 
 constexpr int MAX_SOURCES = 32;
-// RS_NT threads per instance; RS_NW of its wavefronts run the matrix core, the rest the
-// vector work; RS_TPW tiles per MFMA wavefront; RS_JC_MAX compose ops per thread
-constexpr int RS_NW = 4, RS_NT = 512, RS_TPW = 9, RS_JC_MAX = 12, RS_ITEM_WORDS = 4;
+// RS_NT threads per instance = RS_WAVES wavefronts; the first RS_NW ("matrix waves") fetch
+// the inputs, the others stream G; all of them run Hessian tiles; RS_JC_MAX compose ops
+// per thread
+constexpr int RS_NW = 4, RS_NT = 512, RS_WAVES = RS_NT / 64, RS_JC_MAX = 12, RS_TRIP_WORDS = 4;
+constexpr int RS_TILES_MAX = 128;
 // row record of G: voff[4], arrow param[4], center param[4], naxes, extreme param, 2 pad
 constexpr int RS_AXMAX = 4, RS_RR_WORDS = 16;
 constexpr int32_t RS_DST_ACC = 1 << 30;
-// item record.  RI_A / RI_B: workspace offset of the first A / B row, tile column included;
-// RI_ROWS: rows | mode << 24 | (1 << 26 when the term is halved); RI_PARAMS: weight param |
-// aim param << 16.  Column `no` of a workspace row holds d, so the tile column no / 16 of
-// the B operand carries the gradient: mode 0 tile outside that column; 1 B rows == d rows,
-// P and q from one product (b[no] <- s (d - aim)); 2 P only (b[no] <- 0); 3 q only (the B
-// rows are the d rows, every other column <- 0)
-enum { RI_A = 0, RI_B, RI_ROWS, RI_PARAMS };
+// trip record: up to 16 workspace rows of one gterm into one 16x16 tile (four MFMA
+// k-steps).  RT_A / RT_B: workspace offset of the first A / B row, tile column included;
+// RT_WORD: rows | mode << 5 | (1 << 7 when the term is halved) | first trip of its tile << 8
+// | last << 9 | ti << 10 | tj << 17; RT_PARAMS: weight param | aim param << 16.  A
+// wavefront's trips of one tile are consecutive.  Column `no` of a workspace row holds d,
+// so the tile column no / 16 of the B operand carries the gradient: mode 0 tile outside
+// that column; 1 B rows == d rows, P and q from one product (b[no] <- s (d - aim)); 2 P
+// only (b[no] <- 0); 3 q only (the B rows are the d rows, every other column <- 0)
+enum { RT_A = 0, RT_B, RT_WORD, RT_PARAMS };
+enum { RT_MODE = 5, RT_HALF = 7, RT_FIRST = 8, RT_LAST = 9, RT_TI = 10, RT_TJ = 17 };
 enum { RI_MODE_PLAIN = 0, RI_MODE_PQ = 1, RI_MODE_P = 2, RI_MODE_Q = 3 };
 // diagonal gterms the persistent kernel takes on one column of the unknowns
 constexpr int RS_DIAG_MAX = 2;

@@ -52,7 +52,6 @@ namespace {
 constexpr int NT = RS_NT;         // threads of a workgroup
 constexpr int MW = RS_NW;         // wavefronts that run the matrix core
 constexpr int WT = NT - MW * 64;  // threads of the worker wavefronts
-constexpr int TPW = RS_TPW;
 constexpr int AXMAX = RS_AXMAX;
 constexpr int RR_WORDS = RS_RR_WORDS;
 constexpr int GU = 6;  // 16-byte pieces of G a worker thread may own
@@ -64,7 +63,7 @@ struct ResidentLayout {
   // offsets in doubles
   int v, pl, ql, dvec, dcoef, dpar, img, streams, ints, total_doubles;
   int ldp;                                            // leading dimension of P in LDS
-  int i_item, i_rr, i_meta, i_islot, i_tile, i_split;  // offsets in ints inside the int region
+  int i_trip, i_rr, i_meta, i_wtrip, i_split;  // offsets in ints inside the int region
 };
 
 __host__ __device__ inline ResidentLayout resident_layout(const PlanDev& p) {
@@ -83,11 +82,10 @@ __host__ __device__ inline ResidentLayout resident_layout(const PlanDev& p) {
   L.streams = o; o += 2 * (MAX_SOURCES + 3);  // (base pointer, bytes per instance) per stream
   L.ints = o;
   int i = 0;  // the first three start 16-byte aligned
-  L.i_item = i;  i += (p.rs_nitem + 1) * RS_ITEM_WORDS;
+  L.i_trip = i;  i += (p.rs_ntrip + 2) * RS_TRIP_WORDS;  // two spare records: read ahead
   L.i_rr = i;    i += p.nc * RR_WORDS;
   L.i_meta = i;  i += p.rs_nchunk * 64 * 2;
-  L.i_islot = i; i += MW * TPW * 2;
-  L.i_tile = i;  i += MW * TPW;
+  L.i_wtrip = i; i += RS_WAVES * 2;
   L.i_split = i; i += p.rs_nsplit;
   o += even_up_i(i) / 2;
   L.total_doubles = o;
@@ -147,11 +145,10 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
   int4* dpar = reinterpret_cast<int4*>(lds + L.dpar);
   double* strm = lds + L.streams;  // [nsrc + 3] pairs: base pointer, bytes per instance (raw)
   int* itb = reinterpret_cast<int*>(lds + L.ints);
-  int4* items = reinterpret_cast<int4*>(itb + L.i_item);
+  int4* trips = reinterpret_cast<int4*>(itb + L.i_trip);
   int* rr = itb + L.i_rr;
   int2* meta = reinterpret_cast<int2*>(itb + L.i_meta);
-  int* islot = itb + L.i_islot;
-  int* tile = itb + L.i_tile;
+  int* wtrip = itb + L.i_wtrip;
   int* split = itb + L.i_split;
   // LDS byte address of the image double buffer (the low half of a flat LDS address)
   const unsigned img_lds = (unsigned)(uintptr_t)(lds + L.img);
@@ -175,13 +172,11 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
   }
   // ---- once per workgroup: structure tables into LDS, workspace zeroed -----------
   {
-    const int4* t4 = reinterpret_cast<const int4*>(p.itab + p.off_rs_item);
-    for (int i = tid; i <= p.rs_nitem; i += NT)
-      items[i] = i < p.rs_nitem ? t4[i] : int4{0, 0, 0, 0};
-    const int32_t* t = p.itab + p.off_rs_islot;
-    for (int i = tid; i < MW * TPW * 2; i += NT) islot[i] = t[i];
-    t = p.itab + p.off_rs_tile;
-    for (int i = tid; i < MW * TPW; i += NT) tile[i] = t[i];
+    const int4* t4 = reinterpret_cast<const int4*>(p.itab + p.off_rs_trip);
+    for (int i = tid; i < p.rs_ntrip + 2; i += NT)
+      trips[i] = i < p.rs_ntrip ? t4[i] : int4{0, 0, 0, 0};
+    const int32_t* t = p.itab + p.off_rs_wtrip;
+    for (int i = tid; i < RS_WAVES * 2; i += NT) wtrip[i] = t[i];
     t = p.itab + p.off_rs_rr;  // row records of G, precomputed by the plan compiler
     for (int i = tid; i < nc * RR_WORDS; i += NT) rr[i] = t[i];
     t = p.itab + p.off_rs_split;
@@ -191,6 +186,7 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
     double2* V2 = reinterpret_cast<double2*>(V);
     const int n2 = (even_up_i(p.rtot * ldv) + 3 * ldv + 16) / 2;
     for (int i = tid; i < n2; i += NT) V2[i] = double2{0.0, 0.0};
+    for (int i = tid; i < 2 * ldp; i += NT) dvec[i] = 0.0;  // stays zero without diagonal gterms
     // input streams: the sources, then given, params, the plan's constants
     if (tid < p.nsrc + 3) {
       const int s = tid - p.nsrc;
@@ -261,7 +257,7 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
   const int g_R0 = npair > 0 && wt >= 0 ? wt / npair : 0;
   const int g_cp0 = npair > 0 && wt >= 0 ? wt - g_R0 * npair : 0;
 
-  const int tq = no >> 4, ntb = tq + 1, qli = no & 15;  // the tile column that holds d
+  const int qli = no & 15;  // the lane column that holds d in the last tile column
   const int li = lane & 15, lk = lane >> 4;
 
   if (STAMPS && stamping) t_prev = __builtin_amdgcn_s_memtime();
@@ -272,114 +268,54 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
     lds_barrier();  // A: this instance's image landed, P and q of the previous one read out
     MPCASM_STAMP(0)
 
-    // diagonal gterms (costs on free variables themselves): their addends of P[c][c], q[c]
-    if (p.ndiag != 0) {
-      int c = tid;
-      asm volatile("" : "+v"(c));  // opaque: nothing derived from it is hoisted out of the loop
-      if (c < no) {  // body.py:292-300 for rows coef e_c: P[c][c] += (w coef) coef, q[c] += ...
-        const int4 par = dpar[c];
-        const double2 co = dcoef[c];
-        const double w0 = prm[par.x], a0 = prm[par.y], w1 = prm[par.z], a1 = prm[par.w];
-        dvec[c] = (w0 * co.x) * co.x + (w1 * co.y) * co.y;
-        dvec[ldp + c] = w0 * (co.x * (0.0 - a0)) + w1 * (co.y * (0.0 - a1));
-      }
-    }
-    // ---- K2: compose the workspace from the register-resident program -------------
-    if (phases & 1) {
-      double va[JC], vg[JC];
-#pragma unroll
-      for (int j = 0; j < JC; ++j) {  // all operand loads first
-        va[j] = img[c_sg[j] & 0xFFFF];
-        vg[j] = img[(unsigned)c_sg[j] >> 16];
-      }
-      double acc = 0.0;
-#pragma unroll
-      for (int j = 0; j < JC; ++j) {
-        acc += c_coef[j] * va[j] * vg[j];
-        if (c_dst[j] >= 0) {
-          if (c_dst[j] & RS_DST_ACC)  // two threads share the element (cleared after C)
-            __hip_atomic_fetch_add(&V[c_dst[j] & ~RS_DST_ACC], acc, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_WORKGROUP);
-          else
-            V[c_dst[j]] = acc;
+    auto compose = [&]() {
+      // diagonal gterms (costs on free variables themselves): their addends of P[c][c], q[c]
+      if (p.ndiag != 0) {
+        int c = tid;
+        asm volatile("" : "+v"(c));  // opaque: nothing derived from it is hoisted out of the loop
+        if (c < no) {  // body.py:292-300 for rows coef e_c: P[c][c] += (w coef) coef, q[c] += ...
+          const int4 par = dpar[c];
+          const double2 co = dcoef[c];
+          const double w0 = prm[par.x], a0 = prm[par.y], w1 = prm[par.z], a1 = prm[par.w];
+          dvec[c] = (w0 * co.x) * co.x + (w1 * co.y) * co.y;
+          dvec[ldp + c] = w0 * (co.x * (0.0 - a0)) + w1 * (co.y * (0.0 - a1));
         }
-        acc = c_dst[j] >= 0 ? 0.0 : acc;
       }
-    }
-    lds_barrier();  // B: workspace complete
-    MPCASM_STAMP(1)
-
+      // ---- K2: compose the workspace from the register-resident program -------------
+      if (phases & 1) {
+        double va[JC], vg[JC];
+  #pragma unroll
+        for (int j = 0; j < JC; ++j) {  // all operand loads first
+          va[j] = img[c_sg[j] & 0xFFFF];
+          vg[j] = img[(unsigned)c_sg[j] >> 16];
+        }
+        double acc = 0.0;
+  #pragma unroll
+        for (int j = 0; j < JC; ++j) {
+          acc += c_coef[j] * va[j] * vg[j];
+          if (c_dst[j] >= 0) {
+            if (c_dst[j] & RS_DST_ACC)  // two threads share the element (cleared after C)
+              __hip_atomic_fetch_add(&V[c_dst[j] & ~RS_DST_ACC], acc, __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_WORKGROUP);
+            else
+              V[c_dst[j]] = acc;
+          }
+          acc = c_dst[j] >= 0 ? 0.0 : acc;
+        }
+      }
+    };
     const long nxt = inst + gridDim.x;
     if (wave < MW) {
+      compose();
+      lds_barrier();  // B: workspace complete
+      MPCASM_STAMP(1)
       // the next instance's image starts its trip from HBM now
       if (lookahead && nxt < batch && (phases & 16)) fetch_image(nxt, buf ^ 1);
       MPCASM_STAMP(7)
-      if (P != nullptr && (phases & 2)) {
-        // ---- K3: Hessian and gradient tiles on the matrix core -> P, q in LDS ----------
-#pragma unroll 1
-        for (int s = 0; s < TPW; ++s) {
-          const int t = __builtin_amdgcn_readfirstlane(tile[wave * TPW + s]);
-          if (t < 0) continue;
-          const int ti = t / ntb, tj = t - ti * ntb;
-          f64x4 acc = f64x4{0.0, 0.0, 0.0, 0.0};
-          const int i0 = __builtin_amdgcn_readfirstlane(islot[(wave * TPW + s) * 2]);
-          const int cnt = __builtin_amdgcn_readfirstlane(islot[(wave * TPW + s) * 2 + 1]);
-          int4 nx = items[i0];
-          for (int it = 0; it < cnt; ++it) {
-            const int4 cur = nx;
-            nx = items[i0 + it + 1];  // prefetch the next item (the table has a spare record)
-            const int word = __builtin_amdgcn_readfirstlane(cur.z);
-            const int par = __builtin_amdgcn_readfirstlane(cur.w);
-            const int nrows = word & 0xFFFFFF, mode = (word >> 24) & 3;
-            // a weight of 0 contributes exact zeros through the products (body.py:292)
-            const double w = prm[par & 0xFFFF];
-            const double* ap = V + __builtin_amdgcn_readfirstlane(cur.x) + li;
-            const double* bp = V + __builtin_amdgcn_readfirstlane(cur.y) + li;
-            // the B operand becomes m1 b - m2: in the lane that holds column `no`,
-            // s (d - aim) (modes PQ, Q) or 0 (mode P); elsewhere b, or 0 (mode Q)
-            double m1 = 1.0, m2 = 0.0;
-            if (mode != RI_MODE_PLAIN) {
-              const double sc = (word >> 26) & 1 ? 0.5 : 1.0;
-              const double aim = prm[par >> 16];
-              const bool ql_ = li == qli;
-              m1 = ql_ ? (mode == RI_MODE_P ? 0.0 : sc) : (mode == RI_MODE_Q ? 0.0 : 1.0);
-              m2 = ql_ && mode != RI_MODE_P ? sc * aim : 0.0;
-            }
-            for (int k0 = 0; k0 < nrows; k0 += 16) {  // four MFMA k-steps per trip
-              double a[4], b[4];
-#pragma unroll
-              for (int u = 0; u < 4; ++u) {  // all eight loads in flight together
-                const int k = k0 + 4 * u + lk;  // rows past the term are read and masked
-                a[u] = ap[k * ldv];
-                b[u] = bp[k * ldv];
-              }
-#pragma unroll
-              for (int u = 0; u < 4; ++u) a[u] = k0 + 4 * u + lk < nrows ? w * a[u] : 0.0;
-              if (mode != RI_MODE_PLAIN) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) b[u] = fma(m1, b[u], -m2);
-              }
-#pragma unroll
-              for (int u = 0; u < 4; ++u)
-                if (k0 + 4 * u < nrows) acc = mfma_f64_16x16x4(a[u], b[u], acc);
-            }
-          }
-          const bool mirror = p.rs_sym && ti != tj;
-#pragma unroll
-          for (int reg = 0; reg < 4; ++reg) {
-            const int row = ti * 16 + lk + 4 * reg, col = tj * 16 + li;
-            if (row < no && col < no) {
-              const double v = acc[reg] + (p.ndiag != 0 && row == col ? dvec[row] : 0.0);
-              Pl[row * ldp + col] = v;
-              if (mirror) Pl[col * ldp + row] = v;
-            } else if (row < no && col == no) {
-              ql[row] = acc[reg] + (p.ndiag != 0 ? dvec[ldp + row] : 0.0);
-            }
-          }
-        }
-      }
-      MPCASM_STAMP(2)
     } else {
+      compose();
+      lds_barrier();  // B: workspace complete
+      MPCASM_STAMP(1)
       if (G != nullptr && (phases & 8)) {
         // ---- K4: constraint rows straight to HBM ---------------------------------------
         double* Gb = G + (size_t)inst * nc * no;
@@ -427,8 +363,12 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
             }
           }
         } else if ((no & 1) == 0) {
+          // (opaque copies of the thread index keep the general paths' per-thread constants
+          // from being computed once and then held in registers for the whole launch)
+          int w_ = wt;
+          asm volatile("" : "+v"(w_));
           const int dR = WT / npair, dcp = WT - dR * npair;
-          int e = wt, R = wt / npair, cp = wt - (wt / npair) * npair;
+          int e = w_, R = w_ / npair, cp = w_ - (w_ / npair) * npair;
           double2* G2 = reinterpret_cast<double2*>(Gb);
           while (e < gtotal) {
             const int* rec = rr + R * RR_WORDS;
@@ -450,9 +390,11 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
             }
           }
         } else {
+          int w_ = wt;
+          asm volatile("" : "+v"(w_));
           const int total = nc * no;
           const int dR = WT / no, dc = WT - dR * no;
-          int e = wt, R = wt / no, c = wt - (wt / no) * no;
+          int e = w_, R = w_ / no, c = w_ - (w_ / no) * no;
           while (e < total) {
             const int* rec = rr + R * RR_WORDS;
             const int naxes = rec[RR_NAXES];
@@ -470,7 +412,9 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
           }
         }
         double* hb = h + (size_t)inst * nc;
-        for (int R = wt; R < nc; R += WT) {
+        int Rh = wt;
+        asm volatile("" : "+v"(Rh));
+        for (int R = Rh; R < nc; R += WT) {
           const int* rec = rr + R * RR_WORDS;
           const int naxes = rec[RR_NAXES];
           double ac = 0.0, ad = 0.0;
@@ -484,6 +428,95 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
       }
       MPCASM_STAMP(3)
     }
+    if (P != nullptr && (phases & 2)) {
+      // ---- K3: this wavefront's Hessian and gradient tiles on the matrix core -> P, q in
+      // LDS.  The operands of trip t+1 are loaded while the MFMAs of trip t run; two
+      // operand register sets take turns (the plan pads every list to an even length).
+      const int t0 = __builtin_amdgcn_readfirstlane(wtrip[2 * wave]);
+      const int tn = __builtin_amdgcn_readfirstlane(wtrip[2 * wave + 1]);
+      if (tn > 0) {
+        double opa[2][4], opb[2][4], opw[2], opaim[2];
+        int opword[2];
+        int4 rec = trips[t0 + 1];  // the record after the one being loaded
+        auto load_operands = [&](const int4& r, int set) {  // rows past the trip are read too
+          const double* ap = V + __builtin_amdgcn_readfirstlane(r.x) + li;
+          const double* bp = V + __builtin_amdgcn_readfirstlane(r.y) + li;
+          const int par = __builtin_amdgcn_readfirstlane(r.w);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            opa[set][u] = ap[(4 * u + lk) * ldv];
+            opb[set][u] = bp[(4 * u + lk) * ldv];
+          }
+          opw[set] = prm[par & 0xFFFF];
+          opaim[set] = prm[par >> 16];
+          opword[set] = __builtin_amdgcn_readfirstlane(r.z);
+        };
+        load_operands(trips[t0], 0);
+        f64x4 acc = f64x4{0.0, 0.0, 0.0, 0.0};
+        for (int t = 0; t < tn; t += 2) {
+#pragma unroll
+          for (int set = 0; set < 2; ++set) {
+            // the next trip's operands (after the last trip: a spare record's)
+            const int4 nrec = rec;
+            rec = trips[t0 + t + set + 2];
+            load_operands(nrec, set ^ 1);
+            const int word = opword[set];
+            const int rows = word & 31, mode = (word >> RT_MODE) & 3;
+            double a[4], b[4];
+            // a weight of 0 contributes exact zeros through the products (body.py:292)
+            const double w = opw[set];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              a[u] = w * opa[set][u];
+              b[u] = opb[set][u];
+            }
+            if (mode != RI_MODE_PLAIN) {
+              // the B operand becomes m1 b - m2: in the lane that holds column `no`,
+              // s (d - aim) (modes PQ, Q) or 0 (mode P); elsewhere b, or 0 (mode Q)
+              const double sc = (word >> RT_HALF) & 1 ? 0.5 : 1.0;
+              const bool ql_ = li == qli;
+              const double m1 =
+                  ql_ ? (mode == RI_MODE_P ? 0.0 : sc) : (mode == RI_MODE_Q ? 0.0 : 1.0);
+              const double m2 = ql_ && mode != RI_MODE_P ? sc * opaim[set] : 0.0;
+#pragma unroll
+              for (int u = 0; u < 4; ++u) b[u] = fma(m1, b[u], -m2);
+            }
+            if (rows == 16) {
+#pragma unroll
+              for (int u = 0; u < 4; ++u) acc = mfma_f64_16x16x4(a[u], b[u], acc);
+            } else {
+#pragma unroll
+              for (int u = 0; u < 4; ++u)
+                if (4 * u < rows) acc = mfma_f64_16x16x4(4 * u + lk < rows ? a[u] : 0.0, b[u], acc);
+            }
+            if ((word >> RT_LAST) & 1) {  // the tile is complete: into P (and q) in LDS
+              const int ti = (word >> RT_TI) & 127, tj = (word >> RT_TJ) & 127;
+              const int row0 = ti * 16 + lk, col = tj * 16 + li;
+              const bool mirror = p.rs_sym && ti != tj;
+              const bool inside = ti * 16 + 16 <= no && tj * 16 + 16 <= no;
+              // the diagonal addend of this lane's column (zero unless diagonal gterms exist)
+              const double dg = ti == tj ? dvec[col < ldp ? col : 0] : 0.0;
+#pragma unroll
+              for (int reg = 0; reg < 4; ++reg) {
+                const int row = row0 + 4 * reg;
+                const double v = acc[reg] + (row == col ? dg : 0.0);
+                if (inside || (row < no && col < no)) {
+                  Pl[row * ldp + col] = v;
+                  if (mirror) Pl[col * ldp + row] = v;
+                }
+              }
+              if (col == no) {
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg)
+                  if (row0 + 4 * reg < no) ql[row0 + 4 * reg] = acc[reg] + dvec[ldp + row0 + 4 * reg];
+              }
+              acc = f64x4{0.0, 0.0, 0.0, 0.0};
+            }
+          }
+        }
+      }
+    }
+    MPCASM_STAMP(2)
     lds_barrier();  // C: P and q are in LDS, the workspace is dead
     MPCASM_STAMP(4)
 
@@ -498,20 +531,22 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
     MPCASM_STAMP(5)
     if (P != nullptr && (phases & 32)) {
       double* Pb = P + (size_t)inst * no * no;
+      int t_ = tid;
+      asm volatile("" : "+v"(t_));
       if ((no & 1) == 0) {
         // ldp == no here, so P in LDS is dense: a flat 16-byte copy
         const int total = no * npair;
         double2* P2 = reinterpret_cast<double2*>(Pb);
         const double2* Pl2 = reinterpret_cast<const double2*>(Pl);
-        for (int e = tid; e < total; e += NT) P2[e] = Pl2[e];
+        for (int e = t_; e < total; e += NT) P2[e] = Pl2[e];
       } else {
-        for (int e = tid; e < no * no; e += NT) {
+        for (int e = t_; e < no * no; e += NT) {
           const int row = e / no;
           Pb[e] = Pl[row * ldp + (e - row * no)];
         }
       }
       double* qb = q + (size_t)inst * no;
-      for (int c = tid; c < no; c += NT) qb[c] = ql[c];
+      for (int c = t_; c < no; c += NT) qb[c] = ql[c];
     }
     MPCASM_STAMP(6)
   }

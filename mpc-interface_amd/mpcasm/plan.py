@@ -15,7 +15,7 @@ import numpy as np
 import scipy.sparse as sp
 
 PLAN_MAGIC = 0x4D504341
-PLAN_VERSION = 12
+PLAN_VERSION = 13
 
 # header words (csrc/plan_tables.h, enum HeaderWord)
 _H = {name: i for i, name in enumerate([
@@ -26,16 +26,20 @@ _H = {name: i for i, name in enumerate([
     "DOFF_ENTCOEF", "DOFF_PM_ENTCOEF", "NITAB", "NDTAB",
     "FUSED_OK", "ARENA_TOTAL", "OFF_ARENA", "NFD", "OFF_FD_IDX", "OFF_FD_PTR", "NOPS", "OFF_OP",
     "NCOEF", "DOFF_COEFPOOL",
-    "RS_OK", "RS_JC", "RS_SYM", "RS_NITEM", "OFF_RS_SRC", "OFF_RS_GIDX", "OFF_RS_DST",
-    "DOFF_RS_COEF", "OFF_RS_ITEM", "OFF_RS_ISLOT", "OFF_RS_TILE", "RS_NSPLIT", "OFF_RS_SPLIT",
+    "RS_OK", "RS_JC", "RS_SYM", "RS_NTRIP", "OFF_RS_SRC", "OFF_RS_GIDX", "OFF_RS_DST",
+    "DOFF_RS_COEF", "OFF_RS_TRIP", "OFF_RS_WTRIP", "RS_NSPLIT", "OFF_RS_SPLIT",
     "OFF_RS_RR", "RS_UNIT", "RS_NCHUNK", "OFF_RS_INMETA", "RS_IMG", "RS_IMG_GIVEN",
     "RS_IMG_PARAMS", "DOFF_RS_CONST", "DOFF_DIAGCOEF", "NDIAGCOEF",
 ])}
 H_WORDS = 80
 assert len(_H) <= H_WORDS
-RS_NW, RS_NT, RS_TPW = 4, 512, 9          # MFMA wavefronts, threads per instance, tiles per wave
+RS_NW, RS_NT = 4, 512                     # matrix wavefronts (they fetch the inputs), threads per instance
+RS_WAVES = RS_NT // 64
+RS_TILES_MAX = 128                        # 7-bit tile coordinates; no <= 256 anyway
 RS_JC_MAX = 12                            # compose ops a thread can keep in registers
-RS_ITEM_WORDS = 4
+RS_TRIP_WORDS = 4
+# trip record, word 2: rows | mode << 5 | half << 7 | first << 8 | last << 9 | ti << 10 | tj << 17
+RT_MODE, RT_HALF, RT_FIRST, RT_LAST, RT_TI, RT_TJ = 5, 7, 8, 9, 10, 17
 RS_DIAG_MAX = 2                           # diagonal gterms per column (persistent kernel)
 RS_AXMAX = 4                              # axes per constraint row record
 RS_DST_ACC = 1 << 30                      # compose destination shared by two threads
@@ -475,17 +479,16 @@ def _resident_image(sources, ng, nparams):
                 img=len(slots), given=given_off, params=params_off, src_off=src_off)
 
 
-def _resident_program(fused, gterms, no, ldv, image, ng, nparams):
+def _resident_program(fused, gterms, no, ldv, image, ng, nparams, nc_rows):
     """Tables of the persistent fused kernel: the compose ops of ``_fused_program``
     dealt out to the RS_NT threads of a workgroup (kept in registers for the whole
     launch) and the Hessian + gradient work split into per-wavefront lists of MFMA items."""
     import heapq
 
-    NT, NW, TPW = RS_NT, RS_NW, RS_TPW
+    NT, NW = RS_NT, RS_NW
     z = np.zeros(0, dtype=np.int32)
-    out = dict(ok=0, jc=0, sym=0, src=z, gidx=z, dst=z, coef=np.zeros(0), items=z, split=z,
-               islot=np.zeros(NW * TPW * 2, dtype=np.int32),
-               tile=-np.ones(NW * TPW, dtype=np.int32))
+    out = dict(ok=0, jc=0, sym=0, src=z, gidx=z, dst=z, coef=np.zeros(0), trips=z, split=z,
+               wtrip=np.zeros(RS_WAVES * 2, dtype=np.int32))
     if not fused["ok"] or image["img"] > 65535 or nparams > 65535:
         return out
     on_column = np.zeros(no + 1, dtype=np.int64)
@@ -551,67 +554,89 @@ def _resident_program(fused, gterms, no, ldv, image, ng, nparams):
                 coef[j, t] = pool[int(ops[o, 1]) & 0xFFFF]
                 j += 1
             dst[j - 1, t] = int(fd_idx[i]) | (RS_DST_ACC if shared else 0)
-    # ---- Hessian and gradient: one item = the rows of one gterm into one 16x16 tile.
-    # Column `no` of a workspace row is d, so tile column tq = no // 16 of the B operand
-    # yields q[c] = sum_k w a[k][c] s (d[k] - aim) next to (or instead of) the P columns.
+    # ---- Hessian and gradient on the matrix core.  A *trip* is up to 16 rows of one gterm
+    # into one 16x16 tile (four MFMA k-steps); every wavefront walks its own list of trips,
+    # tile by tile.  Column `no` of a workspace row is d, so tile column tq = no // 16 of
+    # the B operand yields q[c] = sum_k w a[k][c] s (d[k] - aim) next to (or instead of)
+    # the P columns.
     nt, tq = (no + 15) // 16, no // 16
     ntb = tq + 1
     terms = [g for g in gterms if not g[6] & GT_FLAG_DIAG]
     pterms = [g for g in terms if g[6] & GT_FLAG_P]
     sym = int(all(g[0] == g[1] for g in pterms))
-    tile_items = {}
+    tile_trips = {}
     for ti in range(nt):
         for tj in range(ti if sym else 0, ntb):
-            tile_items[(ti, tj)] = []
-    if len(tile_items) > NW * TPW or any(g[2] >= 1 << 24 for g in terms):
+            tile_trips[(ti, tj)] = []
+    if ntb > RS_TILES_MAX:
         return out
 
     def bit(mask, t):
         return (mask >> min(t, 30)) & 1
 
+    def trips_of(a, b, nrows, mode, half, par):
+        flags = (mode << RT_MODE) | (half << RT_HALF)
+        return [[a + k0 * ldv, b + k0 * ldv, min(16, nrows - k0) | flags, par]
+                for k0 in range(0, nrows, 16)]
+
     for g in terms:
         aoff, boff, nrows, wparam, doff, aimparam, flags = g[:7]
-        words = nrows | ((1 << 26) if flags & GT_FLAG_HALF else 0)
+        half = 1 if flags & GT_FLAG_HALF else 0
         par = wparam | (aimparam << 16)
-        for (ti, tj), lst in tile_items.items():
+        for (ti, tj), lst in tile_trips.items():
             if not bit(g[7], ti):
                 continue
             p_part = bool(flags & GT_FLAG_P) and tj < nt and bool(bit(g[8], tj))
             q_part = tj == tq
             a = aoff * ldv + ti * 16
             if p_part and q_part and boff == doff:
-                lst.append([a, boff * ldv + tj * 16, words | (RI_MODE_PQ << 24), par])
+                lst += trips_of(a, boff * ldv + tj * 16, nrows, RI_MODE_PQ, half, par)
                 continue
             if p_part:
                 mode = RI_MODE_P if q_part else RI_MODE_PLAIN
-                lst.append([a, boff * ldv + tj * 16, words | (mode << 24), par])
+                lst += trips_of(a, boff * ldv + tj * 16, nrows, mode, half, par)
             if q_part:
-                lst.append([a, doff * ldv + tj * 16, words | (RI_MODE_Q << 24), par])
-    cost = {key: sum(((it[2] & 0xFFFFFF) + 3) // 4 for it in lst) for key, lst in tile_items.items()}
-    loads = [(0, w) for w in range(NW)]
+                lst += trips_of(a, doff * ldv + tj * 16, nrows, RI_MODE_Q, half, par)
+    for (ti, tj), lst in tile_trips.items():
+        if not lst:
+            lst.append([0, 0, 0, 0])               # nothing to add up: the tile is still written
+        lst[0][2] |= 1 << RT_FIRST
+        lst[-1][2] |= 1 << RT_LAST
+        for trip in lst:
+            trip[2] |= (ti << RT_TI) | (tj << RT_TJ)
+    # tiles to wavefronts, heaviest first onto the least loaded.  Costs in (measured,
+    # rounded) cycles of one wavefront: a trip, a tile store, a 16-byte piece of G, a
+    # chunk of the input fetch.  The matrix waves start with the fetch on their account,
+    # the stream waves with their share of G.
+    cost = {key: 400 + sum(900 + 70 * (((trip[2] & 31) + 3) // 4) for trip in lst)
+            for key, lst in tile_trips.items()}
+    stream_threads = NT - NW * 64
+    pieces = nc_rows * max(no // 2, 1)
+    loads = []
+    for w in range(RS_WAVES):
+        if w < NW:
+            loads.append((350 * len(range(w, image["nchunk"], NW)), w))
+        else:                                      # threads of this wave own pieces e = wt + u WT
+            first = (w - NW) * 64
+            own = len(range(first, pieces, stream_threads))
+            loads.append((800 * own + 600, w))
     heapq.heapify(loads)
-    wave_tiles = [[] for _ in range(NW)]
-    for key in sorted(tile_items, key=lambda k: -cost[k]):
-        full = []
-        while True:
-            load, w = heapq.heappop(loads)
-            if len(wave_tiles[w]) < TPW:
-                break
-            full.append((load, w))
-        for entry in full:
-            heapq.heappush(loads, entry)
+    wave_tiles = [[] for _ in range(RS_WAVES)]
+    for key in sorted(tile_trips, key=lambda k: -cost[k]):
+        load, w = heapq.heappop(loads)
         wave_tiles[w].append(key)
         heapq.heappush(loads, (load + cost[key], w))
-    items, islot, tile = [], out["islot"], out["tile"]
-    for w in range(NW):
-        for s_, key in enumerate(wave_tiles[w]):
-            islot[(w * TPW + s_) * 2] = len(items)
-            islot[(w * TPW + s_) * 2 + 1] = len(tile_items[key])
-            tile[w * TPW + s_] = key[0] * ntb + key[1]
-            items.extend(tile_items[key])
+    trips, wtrip = [], np.zeros(RS_WAVES * 2, dtype=np.int32)
+    for w in range(RS_WAVES):
+        wtrip[2 * w] = len(trips)
+        for key in wave_tiles[w]:
+            trips.extend(tile_trips[key])
+        if (len(trips) - wtrip[2 * w]) & 1:
+            trips.append([0, 0, 0, 0])             # the kernel walks trips in pairs
+        wtrip[2 * w + 1] = len(trips) - wtrip[2 * w]
     out.update(ok=1, jc=jc, sym=sym, src=src.reshape(-1), gidx=gidx.reshape(-1),
                dst=dst.reshape(-1), coef=coef.reshape(-1),
-               items=np.asarray(items, dtype=np.int32).reshape(-1),
+               trips=np.asarray(trips, dtype=np.int32).reshape(-1), wtrip=wtrip,
                split=np.asarray(split, dtype=np.int32))
     return out
 
@@ -748,7 +773,7 @@ def compile_plan(form, costs=None, limits=None):
         rec[7] = mask(rec[0], rec[2])
         rec[8] = mask(rec[1], rec[2]) if rec[1] >= 0 else 0
     image = _resident_image(b.sources, b.ng, len(b.params))
-    resident = _resident_program(fused, gterms, no, ldv, image, b.ng, len(b.params))
+    resident = _resident_program(fused, gterms, no, ldv, image, b.ng, len(b.params), nc)
     rs_rr = _resident_rows(limit_recs, lax_recs, len(b.params), ldv)
     if any(rec[2] > RS_AXMAX for rec in limit_recs):
         rs_rr = np.zeros(0, dtype=np.int32)      # too many axes: no resident kernel
@@ -781,9 +806,8 @@ def compile_plan(form, costs=None, limits=None):
         ("OFF_RS_SRC", resident["src"]),
         ("OFF_RS_GIDX", resident["gidx"]),
         ("OFF_RS_DST", resident["dst"]),
-        ("OFF_RS_ITEM", resident["items"]),
-        ("OFF_RS_ISLOT", resident["islot"]),
-        ("OFF_RS_TILE", resident["tile"]),
+        ("OFF_RS_TRIP", resident["trips"]),
+        ("OFF_RS_WTRIP", resident["wtrip"]),
         ("OFF_RS_SPLIT", resident["split"]),
         ("OFF_RS_RR", rs_rr),
         ("OFF_RS_INMETA", image["meta"]),
@@ -794,7 +818,7 @@ def compile_plan(form, costs=None, limits=None):
         if name == "OFF_OP" and off & 1:          # the kernels read ops as 8-byte pairs
             parts.append(np.zeros(1, dtype=np.int32))
             off += 1
-        if name in ("OFF_RS_ITEM", "OFF_RS_RR", "OFF_RS_INMETA") and off & 3:   # ... 16-byte quads
+        if name in ("OFF_RS_TRIP", "OFF_RS_RR", "OFF_RS_INMETA") and off & 3:   # ... 16-byte quads
             pad = 4 - (off & 3)
             parts.append(np.zeros(pad, dtype=np.int32))
             off += pad
@@ -823,7 +847,7 @@ def compile_plan(form, costs=None, limits=None):
     header[_H["DOFF_COEFPOOL"]] = entcoef.size + pm_entcoef.size
     header[_H["RS_OK"]], header[_H["RS_JC"]] = resident["ok"], resident["jc"]
     header[_H["RS_SYM"]] = resident["sym"]
-    header[_H["RS_NITEM"]] = resident["items"].size // RS_ITEM_WORDS
+    header[_H["RS_NTRIP"]] = resident["trips"].size // RS_TRIP_WORDS
     header[_H["RS_NSPLIT"]] = resident["split"].size
     header[_H["RS_UNIT"]], header[_H["RS_NCHUNK"]] = image["unit"], image["nchunk"]
     header[_H["RS_IMG"]] = image["img"]

@@ -201,9 +201,8 @@ def run_resident(plan, given, params=None, sources=None):
     # ---- Hessian and gradient tiles
     tq = no // 16
     ntb, nt, qli = tq + 1, (no + 15) // 16, no % 16
-    tile = _section(it, "OFF_RS_TILE", P.RS_NW * P.RS_TPW)
-    islot = _section(it, "OFF_RS_ISLOT", P.RS_NW * P.RS_TPW * 2).reshape(-1, 2)
-    items = _section(it, "OFF_RS_ITEM", it[H["RS_NITEM"]] * 4).reshape(-1, 4)
+    trips = _section(it, "OFF_RS_TRIP", it[H["RS_NTRIP"]] * 4).reshape(-1, 4)
+    wtrip = _section(it, "OFF_RS_WTRIP", P.RS_WAVES * 2).reshape(-1, 2)
     dP, dq = np.zeros(no), np.zeros(no)
     gt = _section(it, "OFF_GTERM", it[H["NGTERM"]] * P.GT_WORDS).reshape(-1, P.GT_WORDS)
     for a, b, n, pw, d, pa, flags, _ma, _mb, _pad in gt:
@@ -214,14 +213,21 @@ def run_resident(plan, given, params=None, sources=None):
             dq[idx] += prm[pw] * (c * (0.0 - prm[pa]))
     Pm, q = np.full((no, no), np.nan), np.full(no, np.nan)
     lanes = np.arange(16)
-    for slot in range(P.RS_NW * P.RS_TPW):
-        t = tile[slot]
-        if t < 0:
-            continue
-        ti, tj = divmod(int(t), ntb)
-        acc = np.zeros((16, 16))
-        for x in items[islot[slot, 0]:islot[slot, 0] + islot[slot, 1]]:
-            rows, mode, half = x[2] & 0xFFFFFF, (x[2] >> 24) & 3, (x[2] >> 26) & 1
+    assert wtrip[:, 1].sum() == len(trips)
+    for first_trip, count in wtrip:
+        assert count % 2 == 0
+        acc, open_tile = None, None
+        for x in trips[first_trip:first_trip + count]:
+            word = int(x[2])
+            if word == 0 and open_tile is None:
+                continue                                  # padding to an even count
+            rows, mode, half = word & 31, (word >> P.RT_MODE) & 3, (word >> P.RT_HALF) & 1
+            ti, tj = (word >> P.RT_TI) & 127, (word >> P.RT_TJ) & 127
+            assert rows <= 16 and ti < nt and tj < ntb
+            if (word >> P.RT_FIRST) & 1:
+                assert open_tile is None
+                acc, open_tile = np.zeros((16, 16)), (ti, tj)
+            assert open_tile == (ti, tj)
             w, aim = prm[x[3] & 0xFFFF], prm[x[3] >> 16]
             assert mode == P.RI_MODE_PLAIN or tj == tq
             s = 0.5 if half else 1.0
@@ -234,18 +240,23 @@ def run_resident(plan, given, params=None, sources=None):
                         bv[:] = 0.0
                     bv[qli] = 0.0 if mode == P.RI_MODE_P else dval
                 acc += np.outer(av, bv)
-        for i in range(16):
-            row = ti * 16 + i
-            if row >= no:
-                continue
-            for jx in range(16):
-                col = tj * 16 + jx
-                if col < no:
-                    Pm[row, col] = acc[i, jx] + (dP[row] if row == col else 0.0)
-                    if it[H["RS_SYM"]] and ti != tj:
-                        Pm[col, row] = Pm[row, col]
-                elif col == no:
-                    q[row] = acc[i, jx] + dq[row]
+            if (word >> P.RT_LAST) & 1:
+                for i in range(16):
+                    row = ti * 16 + i
+                    if row >= no:
+                        continue
+                    for jx in range(16):
+                        col = tj * 16 + jx
+                        if col < no:
+                            assert np.isnan(Pm[row, col])
+                            Pm[row, col] = acc[i, jx] + (dP[row] if row == col else 0.0)
+                            if it[H["RS_SYM"]] and ti != tj:
+                                Pm[col, row] = Pm[row, col]
+                        elif col == no:
+                            assert np.isnan(q[row])
+                            q[row] = acc[i, jx] + dq[row]
+                open_tile = None
+        assert open_tile is None
     # ---- constraint rows
     rr = _section(it, "OFF_RS_RR", nc * P.RS_RR_WORDS).reshape(nc, P.RS_RR_WORDS)
     G, h = np.zeros((nc, no)), np.zeros(nc)

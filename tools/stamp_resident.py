@@ -15,7 +15,7 @@ import torch  # noqa: E402
 import bench  # noqa: E402
 from mpcasm import capi  # noqa: E402
 
-NAMES = ["barA", "compose+B", "hess+q", "G,h", "barC", "dma wait", "Pq out", "fetch"]
+NAMES = ["barA", "compose+B", "tiles", "G,h", "barC", "dma wait", "Pq out", "fetch"]
 
 
 def main():
