@@ -70,7 +70,7 @@ __host__ __device__ inline ResidentLayout resident_layout(const PlanDev& p) {
   ResidentLayout L;
   L.ldp = even_up_i(p.no);
   int o = 0;
-  L.v = o;      o += even_up_i(p.rtot * p.ldv) + 3 * p.ldv + 16;  // MFMA k-steps may overrun
+  L.v = o;      o += even_up_i(p.rtot * p.ldv) + 15 * p.ldv + 16;  // a trip reads 16 rows x 16 columns
   L.pl = o;     o += p.no * L.ldp;
   L.ql = o;     o += L.ldp;
   // diagonal gterms: addends of P[c][c] and q[c] of this instance, then per column the
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
     const int2* t2 = reinterpret_cast<const int2*>(p.itab + p.off_rs_inmeta);
     for (int i = tid; i < nchunk * 64; i += NT) meta[i] = t2[i];
     double2* V2 = reinterpret_cast<double2*>(V);
-    const int n2 = (even_up_i(p.rtot * ldv) + 3 * ldv + 16) / 2;
+    const int n2 = (even_up_i(p.rtot * ldv) + 15 * ldv + 16) / 2;
     for (int i = tid; i < n2; i += NT) V2[i] = double2{0.0, 0.0};
     for (int i = tid; i < 2 * ldp; i += NT) dvec[i] = 0.0;  // stays zero without diagonal gterms
     // input streams: the sources, then given, params, the plan's constants
@@ -259,6 +259,10 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
 
   const int qli = no & 15;  // the lane column that holds d in the last tile column
   const int li = lane & 15, lk = lane >> 4;
+  // Row of a trip this lane feeds to MFMA k-step 0 (the step u adds 2u).  Lanes 0-31 and
+  // 32-63 are the two groups an 8-byte LDS read is served in; inside a group the rows of
+  // lk and lk+1 lie 8 apart, which with ldv = 2 (mod 4) is half the banks: no conflicts.
+  const int krow = (lk >> 1) + 8 * (lk & 1);
 
   if (STAMPS && stamping) t_prev = __builtin_amdgcn_s_memtime();
   int buf = 0;
@@ -443,9 +447,9 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
           const double* bp = V + __builtin_amdgcn_readfirstlane(r.y) + li;
           const int par = __builtin_amdgcn_readfirstlane(r.w);
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            opa[set][u] = ap[(4 * u + lk) * ldv];
-            opb[set][u] = bp[(4 * u + lk) * ldv];
+          for (int u = 0; u < 4; ++u) {  // k-step u takes rows 2u, 2u+1, 2u+8, 2u+9 (see krow)
+            opa[set][u] = ap[(2 * u + krow) * ldv];
+            opb[set][u] = bp[(2 * u + krow) * ldv];
           }
           opw[set] = prm[par & 0xFFFF];
           opaim[set] = prm[par >> 16];
@@ -487,7 +491,7 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
             } else {
 #pragma unroll
               for (int u = 0; u < 4; ++u)
-                if (4 * u < rows) acc = mfma_f64_16x16x4(4 * u + lk < rows ? a[u] : 0.0, b[u], acc);
+                if (2 * u < rows) acc = mfma_f64_16x16x4(2 * u + krow < rows ? a[u] : 0.0, b[u], acc);
             }
             if ((word >> RT_LAST) & 1) {  // the tile is complete: into P (and q) in LDS
               const int ti = (word >> RT_TI) & 127, tj = (word >> RT_TJ) & 127;

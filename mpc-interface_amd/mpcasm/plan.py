@@ -757,7 +757,8 @@ def compile_plan(form, costs=None, limits=None):
     rowptr, entbase, entk, entcoef, rtot = _csr_tables(
         b.placed_blocks, b.base_row0, b.base_rows, b.total_base_rows)
     assert rtot == b.rtot
-    ldv = no + 1 + ((no + 1) & 1)
+    ldv = no + 1
+    ldv += (2 - ldv) % 4      # = 2 mod 4: rows 8 apart fall into opposite halves of the LDS banks
     fused = _fused_program(b, rowptr, entbase, entk, entcoef, rtot, ldv)
     # structural tile masks of the gterm operands (exact zeros of the workspace)
     tiles = fused["row_tiles"]

@@ -178,7 +178,7 @@ def run_resident(plan, given, params=None, sources=None):
     gix = _section(it, "OFF_RS_GIDX", jc * P.RS_NT).reshape(jc, P.RS_NT)
     dst = _section(it, "OFF_RS_DST", jc * P.RS_NT).reshape(jc, P.RS_NT)
     cf = dt[it[H["DOFF_RS_COEF"]]:it[H["DOFF_RS_COEF"]] + jc * P.RS_NT].reshape(jc, P.RS_NT)
-    V = np.zeros(plan.rtot * ldv + 3 * ldv + 32)
+    V = np.zeros(plan.rtot * ldv + 15 * ldv + 32)
     split = _section(it, "OFF_RS_SPLIT", it[H["RS_NSPLIT"]])
     written = np.zeros(V.size, dtype=np.int64)
     for t in range(P.RS_NT):

@@ -33,8 +33,9 @@ def main():
     torch.cuda.synchronize()
     lib.mpcasm_set_option(capi.OPT_PHASE_MASK, capi.PHASE_DEFAULT)
     raw = asm._work.view(torch.int64).cpu().numpy()
-    per_cu = int(os.environ.get("WG_PER_CU", "2"))
-    grid = min(B, 256 * per_cu)
+    n64 = (raw.size // 64) * 64
+    used = int((raw[:n64].reshape(-1, 64)[: 256 * 8].sum(axis=1) != 0).sum())  # workgroups that stamped
+    grid = max(1, min(B, used))
     t = raw[:grid * 8 * 8].reshape(grid, 8, 8).astype(np.float64)
     per_wg = B / grid
     print("B=%d grid=%d  instances per workgroup %.2f; cycles per instance (100 MHz ticks x?)"
