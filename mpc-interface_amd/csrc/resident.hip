@@ -226,10 +226,45 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
   }
   lds_barrier();
 
-  // the matrix waves fetch instance `inst`'s image into buffer `buf` (chunks dealt round robin)
+  // The matrix waves fetch instance `inst`'s image into buffer `buf` (chunks dealt round
+  // robin).  With registers to spare (FK > 0) a lane keeps the address of its piece of the
+  // first FK chunks of its wave -- pointer into instance 0 and bytes per instance -- so that
+  // a load costs one multiply-add; further chunks look their stream up in LDS.
+  constexpr int FK = JC <= 5 ? 3 : 0;
+  const char* f_base[FK > 0 ? FK : 1];
+  int f_stride[FK > 0 ? FK : 1];
+  bool f_fast = FK > 0;
+  if (FK > 0 && wave < MW) {
+#pragma unroll
+    for (int j = 0; j < FK; ++j) {
+      const int k = wave + j * MW;
+      const int2 m = meta[(k < nchunk ? k : 0) * 64 + lane];
+      const long long stride = reinterpret_cast<const long long*>(strm)[2 * m.x + 1];
+      f_base[j] = reinterpret_cast<const char* const*>(strm)[2 * m.x] + m.y;
+      f_stride[j] = (int)stride;
+      f_fast = f_fast && stride >= 0 && stride < (1ll << 31);
+    }
+  }
+  f_fast = __builtin_amdgcn_readfirstlane(__all(f_fast));
   auto fetch_image = [&](long inst, int buf) {
     const unsigned dst0 = img_lds + (unsigned)buf * (unsigned)p.rs_img * 8u;
-    for (int k = wave; k < nchunk; k += MW) {
+    int kfirst = wave;
+    if (FK > 0 && f_fast) {
+#pragma unroll
+      for (int j = 0; j < FK; ++j) {
+        const int k = wave + j * MW;
+        if (k < nchunk) {
+          const char* a = f_base[j] + (unsigned long long)inst * (unsigned)f_stride[j];
+          const unsigned dst = __builtin_amdgcn_readfirstlane(dst0 + (unsigned)(k * 64 * unit));
+          if (unit == 16)
+            dma16(a, dst);
+          else
+            dma4(a, dst);
+        }
+      }
+      kfirst = wave + FK * MW;
+    }
+    for (int k = kfirst; k < nchunk; k += MW) {
       const int2 m = meta[k * 64 + lane];
       const char* base = reinterpret_cast<const char* const*>(strm)[2 * m.x];
       const long long stride = reinterpret_cast<const long long*>(strm)[2 * m.x + 1];
