@@ -104,6 +104,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=4096, help="instances per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--two-kernels", action="store_true",
+                    help="step = mpcasm_fill_su (S, U through HBM) + mpcasm_assemble instead of the "
+                         "default single launch that builds the horizon matrices on chip")
+    ap.add_argument("--fused", action="store_true", help="(the default; kept for scripts)")
     args = ap.parse_args()
 
     import torch
@@ -130,15 +134,23 @@ def main():
     A = torch.as_tensor(work["A"], device=dev)
     Bm = torch.as_tensor(work["B"], device=dev)
     given = torch.as_tensor(work["given"], device=dev)
-    S = torch.empty((B, N, 3, 3), dtype=torch.float64, device=dev)
-    U = torch.empty((B, 1, N, N, 3), dtype=torch.float64, device=dev)
-    asm = engine.Assembler(form, batch=B, device=dev)
+    fused = not args.two_kernels
+    if fused:
+        # K1 inside the assembly: per-instance (A, B) in, the kernel builds what it needs of
+        # S, U in LDS (SURVEY.md section 8d counts exactly these bytes for an assembly)
+        asm = engine.Assembler(form, batch=B, device=dev, lti=["LIP"])
+        asm.bind_lti("LIP", A, Bm)
+    else:
+        S = torch.empty((B, N, 3, 3), dtype=torch.float64, device=dev)
+        U = torch.empty((B, 1, N, N, 3), dtype=torch.float64, device=dev)
+        asm = engine.Assembler(form, batch=B, device=dev)
+        asm.bind_source(("LIP", 0), U[:, 0])
+        asm.bind_source(("LIP", 1), S)
     asm.set_param("cost", "track vel_x", "aim", work["aims"])
-    asm.bind_source(("LIP", 0), U[:, 0])
-    asm.bind_source(("LIP", 1), S)
 
     def step():
-        engine.fill_su(A, Bm, N, out=(S, U))
+        if not fused:
+            engine.fill_su(A, Bm, N, out=(S, U))
         return asm.assemble(given)
 
     def sync_all():
@@ -157,7 +169,8 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         ev[k][0].record()
-        engine.fill_su(A, Bm, N, out=(S, U))
+        if not fused:
+            engine.fill_su(A, Bm, N, out=(S, U))
         ev[k][1].record()
         asm.assemble(given)
         ev[k][2].record()
@@ -174,7 +187,8 @@ def main():
     no, ng, nc = asm.no, asm.ng, asm.nc
     nparams = int(asm.params.shape[1])
     bytes_fill = 8 * (N * 9 + N * N * 3) + 8 * (9 + 3)                    # written + read
-    bytes_asm = 8 * (no * no + no + nc * no + nc) + 8 * (ng + nparams) + 8 * (N * 9 + N * N * 3)
+    bytes_out = 8 * (no * no + no + nc * no + nc)
+    bytes_asm = bytes_out + 8 * (ng + nparams) + (8 * (9 + 3) if fused else 8 * (N * 9 + N * N * 3))
     total = world * B * args.steps
     value = total / elapsed
 
@@ -210,11 +224,13 @@ def main():
             "batch_per_gpu": B,
             "global_batch": B * world,
             "horizon": N,
-            "step": "mpcasm_fill_su + mpcasm_assemble",
+            "step": "mpcasm_assemble, horizon matrices built on chip from per-instance (A,B) "
+                    "(K1 fused)" if fused else "mpcasm_fill_su + mpcasm_assemble",
         },
         "roofline": {
-            "kernel": "mpcasm_assemble -> resident_assemble_kernel (K2 compose + K3 hessian_mfma + "
-                      "K4 constraint_stack fused in one persistent launch)",
+            "kernel": "mpcasm_assemble -> resident_assemble_kernel (%sK2 compose + K3 hessian_mfma "
+                      "+ K4 constraint_stack fused in one persistent launch)"
+                      % ("K1 horizon tables + " if fused else ""),
             "bound": "hbm",
             "achieved": achieved,
             "peak": HBM_PEAK_GBPS,
@@ -225,14 +241,15 @@ def main():
             "algorithmic_bytes_per_assembly": bytes_asm,
             "avg_launch_ms": asm_ms,
         },
-        "fill": {
+        "hbm_GBps_end_to_end": (bytes_asm + (0 if fused else bytes_fill)) * value / 1e9,
+    }
+    if not fused:
+        record["fill"] = {
             "kernel": "mpcasm_fill_su (K1 toeplitz_fill)",
             "algorithmic_bytes_per_system": bytes_fill,
             "avg_launch_ms": fill_ms,
             "achieved_GBps": bytes_fill * B / (fill_ms * 1e-3) / 1e9,
-        },
-        "hbm_GBps_end_to_end": (bytes_asm + bytes_fill) * value / 1e9,
-    }
+        }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         rate, count, secs = cpu_baseline(work)
         record["cpu_baseline"] = {

@@ -102,8 +102,10 @@ int validate_plan(const int32_t* it, const double* h_dtab, size_t n_itab, size_t
     const int64_t img = it[H_RS_IMG], unit = it[H_RS_UNIT], nchunk = it[H_RS_NCHUNK];
     if (jc < 1 || jc > RS_JC_MAX || it[H_RS_NTRIP] < 0 || it[H_RS_NSPLIT] < 0)
       return MPCASM_ERR_PLAN;
-    if ((unit != 4 && unit != 16) || img < 128 || img % 128 || img > 65535 ||
-        nchunk * 64 * unit != img * 8 || it[H_NPARAMS] > 65535)
+    const int64_t dma = it[H_RS_IMG_DMA], nlti = it[H_RS_NLTI];
+    if ((unit != 4 && unit != 16) || dma < 128 || dma % 128 || img < dma || (img & 1) ||
+        img > 65535 || nchunk * 64 * unit != dma * 8 || it[H_NPARAMS] > 65535 || nlti < 0 ||
+        nlti > RS_LTI_MAX)
       return MPCASM_ERR_PLAN;
     bool r = true;
     r = r && in_range(it[H_OFF_RS_SRC], slots, n, H_WORDS);
@@ -118,8 +120,9 @@ int validate_plan(const int32_t* it, const double* h_dtab, size_t n_itab, size_t
     r = r && in_range(it[H_OFF_RS_INMETA], nchunk * 64 * 2, n, H_WORDS) &&
         it[H_OFF_RS_INMETA] % 2 == 0;
     r = r && in_range(it[H_DOFF_RS_CONST], 4, nd, 0) && it[H_DOFF_RS_CONST] % 2 == 0;
-    r = r && in_range(it[H_RS_IMG_GIVEN], ng + 1, img, 0);
-    r = r && in_range(it[H_RS_IMG_PARAMS], (int64_t)it[H_NPARAMS] + 1, img, 0);
+    r = r && in_range(it[H_RS_IMG_GIVEN], ng + 1, dma, 0);
+    r = r && in_range(it[H_RS_IMG_PARAMS], (int64_t)it[H_NPARAMS] + 1, dma, 0);
+    r = r && in_range(it[H_OFF_RS_LTI], nlti * RS_LTI_WORDS, n, H_WORDS);
     if (!r) return MPCASM_ERR_PLAN;
     {
       const double* c = h_dtab + it[H_DOFF_RS_CONST];
@@ -184,6 +187,18 @@ int validate_plan(const int32_t* it, const double* h_dtab, size_t n_itab, size_t
             x[RR_ARROW + a] > it[H_NPARAMS] || x[RR_CENTER + a] < 0 ||
             x[RR_CENTER + a] > it[H_NPARAMS])
           return MPCASM_ERR_PLAN;
+    }
+    for (int64_t g = 0; g < nlti; ++g) {  // generated groups: loaded A, B and the tables
+      const int32_t* x = it + it[H_OFF_RS_LTI] + g * RS_LTI_WORDS;
+      const int64_t gn = x[LT_N], gm = x[LT_M], gN = x[LT_HORIZON];
+      if (gn < 1 || gm < 1 || gN < 1 || gn > 64 || gm > 64 || gN > 4096) return MPCASM_ERR_PLAN;
+      int stages = 0;
+      while ((1ll << stages) < gN) ++stages;
+      // A and B inside the first chunk of the loads (the generating wave fetches it itself)
+      if (!in_range(x[LT_A], gn * gn, 8 * unit, 0) || !in_range(x[LT_B], gn * gm, 8 * unit, 0) ||
+          !in_range(x[LT_TA], gN * gn * gn, img, dma) || !in_range(x[LT_TB], gN * gn * gm, img, dma) ||
+          !in_range(x[LT_TP], (stages + 1) * gn * gn, img, dma))
+        return MPCASM_ERR_PLAN;
     }
     // every input load stays inside its stream: sources, given, params, the constants
     const int32_t* im = it + it[H_OFF_RS_INMETA];
@@ -396,6 +411,7 @@ int mpcasm_plan_create(const int32_t* h_itab, size_t n_itab, const double* h_dta
   d.off_rs_inmeta = it[H_OFF_RS_INMETA]; d.rs_img = it[H_RS_IMG];
   d.rs_img_given = it[H_RS_IMG_GIVEN]; d.rs_img_params = it[H_RS_IMG_PARAMS];
   d.doff_rs_const = it[H_DOFF_RS_CONST];
+  d.rs_nlti = it[H_RS_NLTI]; d.off_rs_lti = it[H_OFF_RS_LTI]; d.rs_img_dma = it[H_RS_IMG_DMA];
   {
     hipDeviceProp_t prop;
     plan->num_cus = 256;
@@ -475,6 +491,7 @@ int mpcasm_preview_matrices(const mpcasm_plan* plan, const double* const* h_src,
                             const int64_t* h_src_stride, double* d_PM, int batch, void* stream) {
   if (!plan || !d_PM || batch < 0) return MPCASM_ERR_ARG;
   if (plan->dev.nsrc && (!h_src || !h_src_stride)) return MPCASM_ERR_ARG;
+  if (plan->dev.rs_nlti != 0) return MPCASM_ERR_LIMIT;  // the plan has no S, U to read
   if (batch == 0) return MPCASM_OK;
   SrcTable src;
   int rc = make_src_table(plan, h_src, h_src_stride, &src);
@@ -512,10 +529,12 @@ int launch_assemble(const PlanDev& p, const SrcTable& src, const double* params,
   // worth it while two workgroups fit
   constexpr size_t RESIDENT_LDS_LIMIT = 156 * 1024, FUSED_LDS_LIMIT = 80 * 1024;
   const size_t rs = resident_lds_bytes(p);
-  if (rs != 0 && rs <= RESIDENT_LDS_LIMIT && g_path == 0 &&
+  if (rs != 0 && rs <= RESIDENT_LDS_LIMIT && (g_path == 0 || p.rs_nlti != 0) &&
       resident_inputs_aligned(p, src, params, given))
     return launch_assemble_resident(p, src, params, given, P, q, G, h, work, batch, rs, num_cus,
                                     stream, err);
+  // horizon matrices generated on chip exist in the persistent kernel only
+  if (p.rs_nlti != 0) return MPCASM_ERR_LIMIT;
   const size_t lds = fused_lds_bytes(p, 4);
   if (lds != 0 && lds <= FUSED_LDS_LIMIT && g_path <= 1)
     return launch_assemble_fused(p, src, params, given, P, q, G, h, batch, lds, stream, err);

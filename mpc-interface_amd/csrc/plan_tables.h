@@ -27,7 +27,7 @@
 namespace mpcasm {
 
 constexpr int32_t PLAN_MAGIC = 0x4D504341;  // 'MPCA'
-constexpr int32_t PLAN_VERSION = 13;
+constexpr int32_t PLAN_VERSION = 14;
 
 enum HeaderWord : int {
   H_MAGIC = 0,
@@ -100,6 +100,12 @@ enum HeaderWord : int {
   H_DOFF_RS_CONST,  // [4] 1, 1, 0, 0: the constant input stream (even offset)
   H_DOFF_DIAGCOEF,  // [NDIAGCOEF] coefficients of the diagonal gterms
   H_NDIAGCOEF,
+  // source groups generated on chip (K1 fused into the persistent kernel): the horizon
+  // matrices U_0..U_{m-1}, S of an LTI system are not read; its A and B arrive through the
+  // streams of the group's first two sources and the image gets tables built from them
+  H_RS_NLTI,
+  H_OFF_RS_LTI,     // [NLTI][RS_LTI_WORDS], see LT_* below
+  H_RS_IMG_DMA,     // doubles of the image that the loads fill (a multiple of 128, <= RS_IMG)
   H_WORDS = 80
 };
 
@@ -131,6 +137,11 @@ constexpr int MAX_SOURCES = 32;
 // per thread
 constexpr int RS_NW = 4, RS_NT = 512, RS_WAVES = RS_NT / 64, RS_JC_MAX = 12, RS_TRIP_WORDS = 4;
 constexpr int RS_TILES_MAX = 128;
+// generated source group: sizes; image offsets of A [n][n] and B [n][m] (loaded), of the
+// tables TA[k][i][j] = (A^{k+1})[i][j] and TB[d][i][j] = (A^d B)[i][j], k, d < N, and of
+// the powers A^(2^s) they are built from
+enum { LT_N = 0, LT_M, LT_HORIZON, LT_A, LT_B, LT_TA, LT_TB, LT_TP, RS_LTI_WORDS = 8 };
+constexpr int RS_LTI_MAX = 4;
 // row record of G: voff[4], arrow param[4], center param[4], naxes, extreme param, 2 pad
 constexpr int RS_AXMAX = 4, RS_RR_WORDS = 16;
 constexpr int32_t RS_DST_ACC = 1 << 30;

@@ -63,7 +63,7 @@ struct ResidentLayout {
   // offsets in doubles
   int v, pl, ql, dvec, dcoef, dpar, img, streams, ints, total_doubles;
   int ldp;                                            // leading dimension of P in LDS
-  int i_trip, i_rr, i_meta, i_wtrip, i_split;  // offsets in ints inside the int region
+  int i_trip, i_rr, i_meta, i_wtrip, i_split, i_lti;  // offsets in ints inside the int region
 };
 
 __host__ __device__ inline ResidentLayout resident_layout(const PlanDev& p) {
@@ -87,6 +87,7 @@ __host__ __device__ inline ResidentLayout resident_layout(const PlanDev& p) {
   L.i_meta = i;  i += p.rs_nchunk * 64 * 2;
   L.i_wtrip = i; i += RS_WAVES * 2;
   L.i_split = i; i += p.rs_nsplit;
+  L.i_lti = i;   i += p.rs_nlti * RS_LTI_WORDS;
   o += even_up_i(i) / 2;
   L.total_doubles = o;
   return L;
@@ -150,8 +151,9 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
   int2* meta = reinterpret_cast<int2*>(itb + L.i_meta);
   int* wtrip = itb + L.i_wtrip;
   int* split = itb + L.i_split;
+  int* lti = itb + L.i_lti;
   // LDS byte address of the image double buffer (the low half of a flat LDS address)
-  const unsigned img_lds = (unsigned)(uintptr_t)(lds + L.img);
+  const unsigned img_lds = (unsigned)(uintptr_t)(lds + L.img);  // (rs_img doubles each, rs_img_dma of them loaded)
   const int unit = p.rs_unit, nchunk = p.rs_nchunk;
 
   // ---- once per workgroup: the compose program into registers ------------------
@@ -181,6 +183,8 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
     for (int i = tid; i < nc * RR_WORDS; i += NT) rr[i] = t[i];
     t = p.itab + p.off_rs_split;
     for (int i = tid; i < p.rs_nsplit; i += NT) split[i] = t[i];
+    t = p.itab + p.off_rs_lti;
+    for (int i = tid; i < p.rs_nlti * RS_LTI_WORDS; i += NT) lti[i] = t[i];
     const int2* t2 = reinterpret_cast<const int2*>(p.itab + p.off_rs_inmeta);
     for (int i = tid; i < nchunk * 64; i += NT) meta[i] = t2[i];
     double2* V2 = reinterpret_cast<double2*>(V);
@@ -276,10 +280,102 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
         dma4(a, dst);
     }
   };
+  const int li = lane & 15, lk = lane >> 4;
+  // Row of a trip this lane feeds to MFMA k-step 0 (the step u adds 2u).  Lanes 0-31 and
+  // 32-63 are the two groups an 8-byte LDS read is served in; inside a group the rows of
+  // lk and lk+1 lie 8 apart, which with ldv = 2 (mod 4) is half the banks: no conflicts.
+  const int krow = (lk >> 1) + 8 * (lk & 1);
+  // K1 on chip: the horizon matrices of an LTI system, as the tables the compose ops read
+  // (TA[k][i][j] = (A^{k+1})[i][j], TB[d][i][j] = (A^d B)[i][j]; tools.py:14-33), from the
+  // A and B that arrived with the image.  One wavefront per system, doubling the number of
+  // finished blocks per pass: X_{h+d} = A^h X_d with A^h = (A^{h/2})^2 -- log2(N) dependent
+  // passes instead of the N - 1 of the reference's recurrence (the rounding differs by a few
+  // ulp).  LDS operations of one wavefront complete in order, so a pass sees the last one.
+  // Wave 0 does it: A and B lie in the first chunk of the image, which wave 0 fetched and
+  // waited for itself (no other wave's loads are known to have landed before barrier A).
+  auto generate_sources = [&](int buf) {
+    double* im = lds + L.img + buf * p.rs_img;
+    for (int g = 0; g < p.rs_nlti && wave == 0; ++g) {
+      const int* rec = lti + g * RS_LTI_WORDS;
+      const int n = rec[LT_N], m = rec[LT_M], N = rec[LT_HORIZON], nn = n * n, nm = n * m;
+      const double* Am = im + rec[LT_A];
+      const double* Bm = im + rec[LT_B];
+      double* TA = im + rec[LT_TA];
+      double* TB = im + rec[LT_TB];
+      double* TP = im + rec[LT_TP];
+      if (n <= 4 && n + m <= 16) {
+        // Small systems: the reference's own recurrence X_d = A X_{d-1}, X_0 = [B | A]
+        // (tools.py:21-30), on the matrix core.  One v_mfma_f64_16x16x4 computes A (padded
+        // to 16x4) times a 4x16 block; its result rows 0-3 come back in register 0 of
+        // exactly the lanes that hold the B operand of the next step (row k = lane / 16,
+        // column j = lane % 16), so the chain needs no data movement at all: N - 1
+        // dependent MFMAs, each followed by one store of the new block into the tables.
+        const bool live = lk < n && li < n + m;
+        const double a_op = li < n && lk < n ? Am[li * n + lk] : 0.0;  // A[i = li][k = lk]
+        double x = !live ? 0.0 : (li < m ? Bm[lk * m + li] : Am[lk * n + (li - m)]);
+        // element (row lk, column li) of block d: TB[d][lk][li] or TA[d][lk][li - m]
+        double* out = li < m ? TB + lk * m + li : TA + lk * n + (li - m);
+        const int step = li < m ? nm : nn;
+        // (the block is stored from a copy, so that the next MFMA, which overwrites the
+        // registers of x, need not wait for the store to have read them)
+        for (int d = 0; d < N; d += 2) {
+          double w0 = x;
+          asm volatile("" : "+v"(w0));
+          if (live) out[d * step] = w0;
+          const f64x4 y0 = mfma_f64_16x16x4(a_op, x, f64x4{0.0, 0.0, 0.0, 0.0});
+          double w1 = y0[0];
+          asm volatile("" : "+v"(w1));
+          if (live && d + 1 < N) out[(d + 1) * step] = w1;
+          const f64x4 y1 = mfma_f64_16x16x4(a_op, y0[0], f64x4{0.0, 0.0, 0.0, 0.0});
+          x = y1[0];
+        }
+        continue;
+      }
+      for (int e = lane; e < nn; e += 64) {
+        const double v = Am[e];
+        TA[e] = v;
+        TP[e] = v;
+      }
+      for (int e = lane; e < nm; e += 64) TB[e] = Bm[e];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      int have = 1;  // TA[0..have), TB[0..have) done; TP[s] = A^have
+      for (int s_ = 0; have < N; ++s_) {
+        const double* Pw = TP + s_ * nn;
+        const int cnt = have < N - have ? have : N - have;
+        const int na = cnt * nn, nb = cnt * nm, total = na + nb + nn;
+        for (int e = lane; e < total; e += 64) {
+          // element (i, j) of Pw . X with X a finished n x w block; the product lands `have`
+          // blocks further (or, for X = Pw itself, in the next power)
+          const double* X;
+          double* out;
+          int w, r;
+          if (e < na) {
+            const int d = e / nn;
+            r = e - d * nn;
+            X = TA + d * nn, out = TA + (have + d) * nn, w = n;
+          } else if (e < na + nb) {
+            const int d = (e - na) / nm;
+            r = (e - na) - d * nm;
+            X = TB + d * nm, out = TB + (have + d) * nm, w = m;
+          } else {
+            r = e - na - nb;
+            X = Pw, out = TP + (s_ + 1) * nn, w = n;
+          }
+          const int i = r / w, j = r - i * w;
+          double acc = 0.0;
+          for (int t = 0; t < n; ++t) acc = fma(Pw[i * n + t], X[t * w + j], acc);
+          out[r] = acc;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        have += cnt;
+      }
+    }
+  };
   const bool lookahead = (phases & 128) != 0;  // diagnostic: off = fetch only when needed
   if (wave < MW) {
     fetch_image(blockIdx.x, 0);
     dma_wait();
+    if (p.rs_nlti != 0) generate_sources(0);
   }
 
   // ---- K4 bookkeeping of the worker threads: piece e = wt + u WT of G is the 16 bytes
@@ -293,11 +389,6 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
   const int g_cp0 = npair > 0 && wt >= 0 ? wt - g_R0 * npair : 0;
 
   const int qli = no & 15;  // the lane column that holds d in the last tile column
-  const int li = lane & 15, lk = lane >> 4;
-  // Row of a trip this lane feeds to MFMA k-step 0 (the step u adds 2u).  Lanes 0-31 and
-  // 32-63 are the two groups an 8-byte LDS read is served in; inside a group the rows of
-  // lk and lk+1 lie 8 apart, which with ldv = 2 (mod 4) is half the banks: no conflicts.
-  const int krow = (lk >> 1) + 8 * (lk & 1);
 
   if (STAMPS && stamping) t_prev = __builtin_amdgcn_s_memtime();
   int buf = 0;
@@ -564,6 +655,7 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
       // The next image is complete before barrier A.  The wait comes before this wave's
       // P stores so that it never waits for a store, only for loads issued a phase ago.
       dma_wait();
+      if (p.rs_nlti != 0 && nxt < batch) generate_sources(buf ^ 1);
       // elements that two threads add into start the next compose from zero
       for (int i = tid; i < p.rs_nsplit; i += MW * 64) V[split[i]] = 0.0;
     }

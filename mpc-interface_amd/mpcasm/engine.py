@@ -107,16 +107,20 @@ class Assembler:
         values broadcast over the batch, override with :meth:`set_param`;
       * horizon matrices -- shared by default (the Formulation's own arrays),
         bind a ``(B, N, p, n)`` tensor with :meth:`bind_source` for per-instance
-        dynamics (e.g. the output of :func:`fill_su`).
+        dynamics (e.g. the output of :func:`fill_su`);
+      * or, for the dynamics named in ``lti``, no horizon matrices at all: the kernel
+        builds them on chip from the system's ``(A, B)`` (K1 fused into the assembly) --
+        shared by default (recovered from the Formulation's ``S, U``), per instance with
+        :meth:`bind_lti`.
     """
 
-    def __init__(self, form, batch=1, device=None, costs=None, limits=None):
+    def __init__(self, form, batch=1, device=None, costs=None, limits=None, lti=()):
         torch = require_device()
         self._torch = torch
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None \
             else torch.device(device)
         self.batch = int(batch)
-        self.plan = compile_plan(form, costs=costs, limits=limits)
+        self.plan = compile_plan(form, costs=costs, limits=limits, lti=tuple(lti))
         p = self.plan
         self.ng, self.no, self.nc = p.ng, p.no, p.nc
 
@@ -134,6 +138,12 @@ class Assembler:
         self._src = [_as_device(torch, s.array, self.device) for s in p.sources]
         self._src_stride = [0] * len(p.sources)
         self._src_index = {s.key: i for i, s in enumerate(p.sources)}
+        self._lti = {g["name"]: g for g in p.lti}
+        for g in p.lti:     # S[0][j][i] = A[i][j], U_j[0][0][i] = B[i][j]  (tools.py:14-33)
+            ids = g["ids"]
+            A = p.sources[ids[-1]].array[0].T
+            Bm = np.stack([p.sources[ids[j]].array[0, 0, :] for j in range(g["m"])], axis=1)
+            self.bind_lti(g["name"], A, Bm)
 
         base = torch.as_tensor(p.params, dtype=torch.float64, device=self.device)
         self.params = base.unsqueeze(0).repeat(self.batch, 1).contiguous()
@@ -174,6 +184,8 @@ class Assembler:
         shape ``(N, p, n)`` (shared) or ``(B, N, p, n)`` (one per instance)."""
         torch = self._torch
         i = self._src_index[key]
+        if key[0] in self._lti:
+            raise ValueError("the horizon matrices of %r are generated on chip: bind_lti" % key[0])
         shape = tuple(self.plan.sources[i].array.shape)
         t = _as_device(torch, tensor, self.device)
         if tuple(t.shape) == shape:
@@ -183,6 +195,24 @@ class Assembler:
         else:
             raise ValueError("source %r expects %s or %s, got %s"
                              % (key, shape, (self.batch,) + shape, tuple(t.shape)))
+
+    def bind_lti(self, name, A, B):
+        """System matrices of a dynamics compiled as ``lti``: ``A`` ``(n, n)`` / ``(B, n, n)``
+        and ``B`` ``(n, m)`` / ``(B, n, m)``, x+ = A x + B u.  They travel in the slots of
+        the group's first two horizon matrices (include/mpcasm.h)."""
+        torch = self._torch
+        g = self._lti[name]
+        n, m = g["n"], g["m"]
+        for slot, (t, shape) in enumerate(((A, (n, n)), (B, (n, m)))):
+            t = _as_device(torch, t, self.device)
+            i = g["ids"][slot]
+            if tuple(t.shape) == shape:
+                self._src[i], self._src_stride[i] = t.contiguous(), 0
+            elif tuple(t.shape) == (self.batch,) + shape:
+                self._src[i], self._src_stride[i] = t.contiguous(), shape[0] * shape[1]
+            else:
+                raise ValueError("%s of %r expects %s or %s, got %s" % (
+                    "AB"[slot], name, shape, (self.batch,) + shape, tuple(t.shape)))
 
     def param_slice(self, kind, name, field):
         """Columns of :attr:`params` holding one field, e.g.

@@ -15,7 +15,7 @@ import numpy as np
 import scipy.sparse as sp
 
 PLAN_MAGIC = 0x4D504341
-PLAN_VERSION = 13
+PLAN_VERSION = 14
 
 # header words (csrc/plan_tables.h, enum HeaderWord)
 _H = {name: i for i, name in enumerate([
@@ -29,13 +29,15 @@ _H = {name: i for i, name in enumerate([
     "RS_OK", "RS_JC", "RS_SYM", "RS_NTRIP", "OFF_RS_SRC", "OFF_RS_GIDX", "OFF_RS_DST",
     "DOFF_RS_COEF", "OFF_RS_TRIP", "OFF_RS_WTRIP", "RS_NSPLIT", "OFF_RS_SPLIT",
     "OFF_RS_RR", "RS_UNIT", "RS_NCHUNK", "OFF_RS_INMETA", "RS_IMG", "RS_IMG_GIVEN",
-    "RS_IMG_PARAMS", "DOFF_RS_CONST", "DOFF_DIAGCOEF", "NDIAGCOEF",
+    "RS_IMG_PARAMS", "DOFF_RS_CONST", "DOFF_DIAGCOEF", "NDIAGCOEF", "RS_NLTI", "OFF_RS_LTI",
+    "RS_IMG_DMA",
 ])}
 H_WORDS = 80
 assert len(_H) <= H_WORDS
 RS_NW, RS_NT = 4, 512                     # matrix wavefronts (they fetch the inputs), threads per instance
 RS_WAVES = RS_NT // 64
 RS_TILES_MAX = 128                        # 7-bit tile coordinates; no <= 256 anyway
+RS_LTI_WORDS, RS_LTI_MAX = 8, 4           # record of a source group generated on chip; groups per plan
 RS_JC_MAX = 12                            # compose ops a thread can keep in registers
 RS_TRIP_WORDS = 4
 # trip record, word 2: rows | mode << 5 | half << 7 | first << 8 | last << 9 | ti << 10 | tj << 17
@@ -424,20 +426,49 @@ def _resident_rows(limit_recs, lax_recs, nparams, ldv):
     return np.asarray(rows, dtype=np.int32).reshape(-1)
 
 
-def _resident_image(sources, ng, nparams):
+def _lti_groups(form, sources, names):
+    """Source groups whose horizon matrices the persistent kernel generates on chip from
+    the system's own ``(A, B)``: for every dynamics name in ``names`` the sources
+    ``(name, 0..m-1)`` = ``U_j`` ``(N, N, n)`` and ``(name, m)`` = ``S`` ``(N, n, n)``
+    (``matrices = U + [S]``, dynamics.py:199; S[k,j,i] = (A^{k+1})[i,j],
+    U_j[k,l,i] = (A^{k-l} B)[i,j], tools.py:14-33)."""
+    groups = []
+    for name in names:
+        dyn = form.dynamics[name]
+        m = len(dyn.matrices) - 1
+        ids = {s.key[1]: i for i, s in enumerate(sources) if s.key[0] == name and len(s.key) == 2}
+        if m < 1 or sorted(ids) != list(range(m + 1)):
+            raise ValueError("dynamics %r: every horizon matrix U_0..U_%d, S must be used by the "
+                             "formulation to generate them on chip" % (name, m - 1))
+        N, n = sources[ids[m]].array.shape[0], sources[ids[m]].array.shape[1]
+        if sources[ids[m]].array.shape != (N, n, n) or any(
+                sources[ids[j]].array.shape != (N, N, n) for j in range(m)):
+            raise ValueError("dynamics %r: unexpected shapes of the horizon matrices" % name)
+        groups.append(dict(name=name, n=n, m=m, N=N, ids=[ids[k] for k in range(m + 1)]))
+    if len(groups) > RS_LTI_MAX:
+        raise ValueError("at most %d source groups can be generated on chip" % RS_LTI_MAX)
+    return groups
+
+
+def _resident_image(sources, ng, nparams, groups=()):
     """The input image of one instance in LDS and the LDS-DMA loads that fill it.
 
     Doubles, in order: ``1, 1 | source 0 | source 1 ... | given, 1 | params, 0 | 0 ...``
     (a 1.0 behind ``given`` for ops without a given factor, a 0.0 behind ``params`` for the
-    missing axes of a constraint row; every block starts on an even offset; the total is a
-    multiple of 128).  Input streams: the sources, then given, params, and a constant
-    stream ``[1, 1, 0, 0]`` owned by the plan.  One load moves ``unit`` bytes per lane, 64
-    lanes to consecutive LDS addresses: 16 when every pair of doubles of the image comes
-    from consecutive, even-aligned elements of one stream, else 4.
+    missing axes of a constraint row; every block starts on an even offset; this part, which
+    the loads fill, is a multiple of 128 doubles).  The sources of a group that is
+    generated on chip are not loaded: the group's ``A`` (stream of its first source) and
+    ``B`` (stream of its second) are, and behind the loaded part the image has room for
+    the tables ``(A^{k+1})[i][j]``, ``(A^d B)[i][j]`` (k, d < N) and for the powers
+    ``A^(2^s)`` they are built from.  Input streams: the sources, then given, params, and
+    a constant stream ``[1, 1, 0, 0]`` owned by the plan.  One load moves ``unit`` bytes
+    per lane, 64 lanes to consecutive LDS addresses: 16 when every pair of doubles of the
+    image comes from consecutive, even-aligned elements of one stream, else 4.
     Returns the per-lane table ``meta[nchunk * 64][2]`` = (stream, byte offset)."""
     nsrc = len(sources)
     s_given, s_params, s_const = nsrc, nsrc + 1, nsrc + 2
     slots = []                                   # per double of the image: (stream, element)
+    generated = {i: g for g in groups for i in g["ids"]}
 
     def push_const(first):                       # 1.0 is element 0 / 1, 0.0 is 2 / 3
         slots.append((s_const, first))
@@ -449,9 +480,21 @@ def _resident_image(sources, ng, nparams):
             slots.append((s_const, 3))
 
     push_const(0)
+    # A through the group's first stream, B through its second.  They come first: the wave
+    # that builds the tables must have fetched them itself, and chunk 0 is wave 0's.
+    for g in groups:
+        g["img_a"] = len(slots)
+        slots.extend((g["ids"][0], k) for k in range(g["n"] * g["n"]))
+        pad_even()
+        g["img_b"] = len(slots)
+        slots.extend((g["ids"][1], k) for k in range(g["n"] * g["m"]))
+        pad_even()
+    first_chunk = len(slots)
     src_off = []
     for sid, src in enumerate(sources):
         src_off.append(len(slots))
+        if sid in generated:
+            continue
         slots.extend((sid, k) for k in range(src.array.size))
         pad_even()
     given_off = len(slots)
@@ -475,8 +518,35 @@ def _resident_image(sources, ng, nparams):
         unit = 4
         meta = np.stack([np.repeat(arr[:, 0], 2),
                          (np.repeat(arr[:, 1] * 8, 2) + np.tile([0, 4], len(arr)))], axis=1)
+    if first_chunk * 8 > 64 * unit:
+        raise ValueError("the (A, B) of the systems generated on chip must fit one load "
+                         "(%d bytes), they take %d" % (64 * unit, first_chunk * 8))
+    total = len(slots)
+    for g in groups:                             # tables behind the loaded part
+        n, m, N = g["n"], g["m"], g["N"]
+        g["stages"] = max(1, int(np.ceil(np.log2(N)))) if N > 1 else 1
+        g["tab_a"], total = total, total + N * n * n
+        g["tab_b"], total = total, total + N * n * m
+        g["tab_p"], total = total, total + (g["stages"] + 1) * n * n
+        total += total & 1
     return dict(unit=unit, nchunk=meta.shape[0] // 64, meta=meta.astype(np.int32).reshape(-1),
-                img=len(slots), given=given_off, params=params_off, src_off=src_off)
+                img=total, dma=len(slots), given=given_off, params=params_off, src_off=src_off,
+                groups=list(groups))
+
+
+def _lti_table_offset(g, k, flat):
+    """Image offset of element ``flat`` of the group's k-th horizon matrix inside the
+    generated tables, or None where the matrix is structurally zero (U above the diagonal)."""
+    n, m, N = g["n"], g["m"], g["N"]
+    if k == m:                                   # S[kk][j][i] = (A^{kk+1})[i][j]
+        kk, rem = divmod(flat, n * n)
+        j, i = divmod(rem, n)
+        return g["tab_a"] + (kk * n + i) * n + j
+    kk, rem = divmod(flat, N * n)                # U_k[kk][l][i] = (A^{kk-l} B)[i][k]
+    l, i = divmod(rem, n)
+    if l > kk:
+        return None
+    return g["tab_b"] + ((kk - l) * n + i) * m + k
 
 
 def _resident_program(fused, gterms, no, ldv, image, ng, nparams, nc_rows):
@@ -502,23 +572,41 @@ def _resident_program(fused, gterms, no, ldv, image, ng, nparams, nc_rows):
     fd_idx, fd_ptr = fused["fd_idx"], fused["fd_ptr"]
     ops = fused["ops"].view(np.uint32).reshape(-1, 2)
     pool = fused["coefpool"]
-    counts = np.diff(fd_ptr)
+    arena = fused["arena"].reshape(-1, 2)
+    generated = {i: (g, k) for g in image["groups"] for k, i in enumerate(g["ids"])}
+
+    def image_offset(a):                          # fused arena offset -> image offset, or None
+        if a == 0:
+            return 0                              # the constant 1.0
+        for sid, (off, size) in enumerate(arena):
+            if off <= a < off + size:
+                if sid in generated:
+                    return _lti_table_offset(*generated[sid], a - off)
+                return image["src_off"][sid] + a - off
+        raise AssertionError("arena offset outside every source")
+
+    # ops that read a structural zero of a generated source are dropped (exact zeros)
+    op_img = [image_offset(int(a)) for a in ops[:, 0]]
+    kept = [[o for o in range(int(fd_ptr[i]), int(fd_ptr[i + 1])) if op_img[o] is not None]
+            for i in range(len(fd_idx))]
+    counts = np.asarray([len(k) for k in kept], dtype=np.int64)
     owner, split = None, []
     for cap in (3, 5, 8, RS_JC_MAX):
         if counts.size and counts.max() > 2 * cap:
             continue
-        pieces = []                               # (first op, last op, element, shared)
+        pieces = []                               # (first, last position in kept[i], element, shared)
         for i, c in enumerate(counts):
-            lo, hi = int(fd_ptr[i]), int(fd_ptr[i + 1])
+            if c == 0:
+                continue                          # the element stays zero
             if c > cap:
-                mid = lo + (int(c) + 1) // 2
-                pieces += [(lo, mid, i, True), (mid, hi, i, True)]
+                mid = (int(c) + 1) // 2
+                pieces += [(0, mid, i, True), (mid, int(c), i, True)]
             else:
-                pieces.append((lo, hi, i, False))
+                pieces.append((0, int(c), i, False))
         heap = [(0, t) for t in range(NT)]
         heapq.heapify(heap)
         trial = [[] for _ in range(NT)]
-        for pc in sorted(pieces, key=lambda pc: pc[0] - pc[1]):
+        for pc in sorted(pieces, key=lambda pc: (pc[0] - pc[1], pc[2], pc[0])):
             load, t = heapq.heappop(heap)
             trial[t].append(pc)
             heapq.heappush(heap, (load + pc[1] - pc[0], t))
@@ -529,25 +617,15 @@ def _resident_program(fused, gterms, no, ldv, image, ng, nparams, nc_rows):
     if owner is None:
         return out
     jc = max(1, max((sum(pc[1] - pc[0] for pc in own) for own in owner), default=0))
-    arena = fused["arena"].reshape(-1, 2)
-
-    def image_offset(a):                          # fused arena offset -> image offset
-        if a == 0:
-            return 0                              # the constant 1.0
-        for sid, (off, size) in enumerate(arena):
-            if off <= a < off + size:
-                return image["src_off"][sid] + a - off
-        raise AssertionError("arena offset outside every source")
-
     src = np.zeros((jc, NT), dtype=np.int32)            # image[0] = 1.0
     gidx = np.full((jc, NT), image["given"] + ng, dtype=np.int32)   # ... and given[ng] = 1.0
     dst = -np.ones((jc, NT), dtype=np.int32)
     coef = np.zeros((jc, NT))
     for t, own in enumerate(owner):
         j = 0
-        for lo, hi, i, shared in sorted(own):
-            for o in range(lo, hi):
-                src[j, t] = image_offset(int(ops[o, 0]))
+        for lo, hi, i, shared in sorted(own, key=lambda pc: (pc[2], pc[0])):
+            for o in kept[i][lo:hi]:
+                src[j, t] = op_img[o]
                 gi = (int(ops[o, 1]) >> 16) - 1
                 if gi >= 0:
                     gidx[j, t] = image["given"] + gi
@@ -641,12 +719,15 @@ def _resident_program(fused, gterms, no, ldv, image, ng, nparams, nc_rows):
     return out
 
 
-def compile_plan(form, costs=None, limits=None):
+def compile_plan(form, costs=None, limits=None, lti=()):
     """Compile ``form`` (an up-to-date Formulation: sizes and IDs current).
 
     ``costs``: dict name -> Cost to include (default ``form.goals``);
     ``limits``: list of Constraint in stacking order (default: every limit of
-    ``form.constraints`` then of ``form.constraint_boxes``, body.py:306-315).
+    ``form.constraints`` then of ``form.constraint_boxes``, body.py:306-315);
+    ``lti``: names of ExtendedSystem dynamics whose horizon matrices the assembly kernel
+    generates on chip from per-instance ``(A, B)`` instead of reading ``S, U`` (K1 fused into
+    the assembly; only the persistent kernel can run such a plan).
     """
     b = _Builder(form)
     b.flatten_definitions()
@@ -773,7 +854,8 @@ def compile_plan(form, costs=None, limits=None):
             return m
         rec[7] = mask(rec[0], rec[2])
         rec[8] = mask(rec[1], rec[2]) if rec[1] >= 0 else 0
-    image = _resident_image(b.sources, b.ng, len(b.params))
+    groups = _lti_groups(form, b.sources, lti)
+    image = _resident_image(b.sources, b.ng, len(b.params), groups)
     resident = _resident_program(fused, gterms, no, ldv, image, b.ng, len(b.params), nc)
     rs_rr = _resident_rows(limit_recs, lax_recs, len(b.params), ldv)
     if any(rec[2] > RS_AXMAX for rec in limit_recs):
@@ -812,6 +894,9 @@ def compile_plan(form, costs=None, limits=None):
         ("OFF_RS_SPLIT", resident["split"]),
         ("OFF_RS_RR", rs_rr),
         ("OFF_RS_INMETA", image["meta"]),
+        ("OFF_RS_LTI", np.asarray(
+            [[g["n"], g["m"], g["N"], g["img_a"], g["img_b"], g["tab_a"], g["tab_b"], g["tab_p"]]
+             for g in groups], dtype=np.int32).reshape(-1)),
     ]
     header = np.zeros(H_WORDS, dtype=np.int32)
     parts, off = [header], H_WORDS
@@ -852,6 +937,8 @@ def compile_plan(form, costs=None, limits=None):
     header[_H["RS_NSPLIT"]] = resident["split"].size
     header[_H["RS_UNIT"]], header[_H["RS_NCHUNK"]] = image["unit"], image["nchunk"]
     header[_H["RS_IMG"]] = image["img"]
+    header[_H["RS_IMG_DMA"]] = image["dma"]
+    header[_H["RS_NLTI"]] = len(groups)
     header[_H["RS_IMG_GIVEN"]], header[_H["RS_IMG_PARAMS"]] = image["given"], image["params"]
     if rs_rr.size != nc * RS_RR_WORDS:
         header[_H["RS_OK"]] = 0                  # a constraint with more than RS_AXMAX axes
@@ -877,4 +964,5 @@ def compile_plan(form, costs=None, limits=None):
     plan.given_ID = {v: form.given_ID[v] for v in form.given_variables}
     plan.n_gterms = len(gterms)
     plan.resident = resident
+    plan.lti = [dict(name=g["name"], n=g["n"], m=g["m"], N=g["N"], ids=list(g["ids"])) for g in groups]
     return plan

@@ -157,18 +157,27 @@ def run_resident(plan, given, params=None, sources=None):
     g = np.asarray(given, dtype=float).ravel()
     nsrc, nparams = it[H["NSRC"]], it[H["NPARAMS"]]
     # ---- the image: one LDS-DMA load moves `unit` bytes per lane to consecutive addresses
-    unit, nchunk, img = it[H["RS_UNIT"]], it[H["RS_NCHUNK"]], it[H["RS_IMG"]]
+    unit, nchunk, img = int(it[H["RS_UNIT"]]), int(it[H["RS_NCHUNK"]]), int(it[H["RS_IMG"]])
     const = dt[it[H["DOFF_RS_CONST"]]:it[H["DOFF_RS_CONST"]] + 4]
     streams = [np.ascontiguousarray(a, dtype=np.float64).ravel().view(np.uint8) for a in srcs]
     streams += [g.view(np.uint8), np.ascontiguousarray(params).view(np.uint8),
                 np.ascontiguousarray(const).view(np.uint8)]
     meta = _section(it, "OFF_RS_INMETA", nchunk * 64 * 2).reshape(-1, 2)
     image = np.full(img * 8, 0xFF, dtype=np.uint8)          # NaN pattern where nothing lands
-    assert meta.shape[0] * unit == img * 8
+    assert meta.shape[0] * unit == it[H["RS_IMG_DMA"]] * 8 <= img * 8
     for lane, (st, off) in enumerate(meta):
         assert 0 <= st < nsrc + 3 and off % unit == 0 and off + unit <= streams[st].size
         image[lane * unit:(lane + 1) * unit] = streams[st][off:off + unit]
     image = image.view(np.float64)
+    # horizon matrices generated on chip: tables (A^{k+1})[i][j] and (A^d B)[i][j], k, d < N,
+    # from the group's A and B (which arrived through the streams of its first two sources)
+    lti = _section(it, "OFF_RS_LTI", it[H["RS_NLTI"]] * P.RS_LTI_WORDS).reshape(-1, P.RS_LTI_WORDS)
+    for n, m, N, ia, ib, ta, tb, tp in lti:
+        Am = image[ia:ia + n * n].reshape(n, n).copy()
+        Bm = image[ib:ib + n * m].reshape(n, m).copy()
+        for k in range(N):
+            image[ta + k * n * n:ta + (k + 1) * n * n] = np.linalg.matrix_power(Am, k + 1).ravel()
+            image[tb + k * n * m:tb + (k + 1) * n * m] = (np.linalg.matrix_power(Am, k) @ Bm).ravel()
     prm = image[it[H["RS_IMG_PARAMS"]]:]
     assert image[0] == 1.0 and image[it[H["RS_IMG_GIVEN"]] + ng] == 1.0 and prm[nparams] == 0.0
     assert np.array_equal(prm[:nparams], params)

@@ -224,6 +224,52 @@ def test_biped_batch_per_instance_dynamics(gpu_api):
         assert_close(h[b], ho.ravel(), RTOL_TIGHT)
 
 
+def test_biped_batch_horizon_matrices_generated_on_chip(gpu_api, kernel_path):
+    """K1 fused into the assembly: the plan is compiled with ``lti=["LIP"]``, the kernel gets
+    per-instance ``(A, B)`` and builds what it needs of ``S, U`` in LDS.  Same numbers as
+    fill_su + assemble; both QP widths; shared and per-instance systems."""
+    from mpcasm import engine
+
+    if kernel_path != "resident":
+        pytest.skip("generated sources exist in the persistent kernel only")
+    get_A, get_B, _ = gpu_api.tools.get_system_matrices("J->CCC")
+    for times, width in (([7, 15], 34), ([6, 14], 36)):
+        conf = problems.BipedConfig(step_samples=8)
+        form = problems.biped(gpu_api, conf)
+        form.update(step_times=np.array(times), step_count=0)
+        assert form.optim_len == width
+        batch = 300 if width == 36 else 5
+        rng = np.random.default_rng(width)
+        given = rng.normal(0, 0.1, [batch, form.given_len])
+        asm = engine.Assembler(form, batch=batch, lti=["LIP"])
+        assert asm.plan.resident["ok"] and asm.plan.lti[0]["n"] == 3
+        # shared system: (A, B) recovered from the formulation's own S, U
+        ref = engine.Assembler(form, batch=batch)
+        for mine, theirs in zip(asm.assemble(given), ref.assemble(given)):
+            assert_close(mine.cpu().numpy(), theirs.cpu().numpy(), RTOL_TIGHT)
+        with pytest.raises(ValueError):
+            asm.bind_source(("LIP", 0), np.zeros((16, 16, 3)))
+        # one system per instance
+        taus = rng.uniform(0.08, 0.12, batch)
+        A = np.stack([get_A(tau=t) for t in taus])
+        B = np.stack([get_B(tau=t) for t in taus])
+        asm.bind_lti("LIP", A, B)
+        P, q, G, h = (t.cpu().numpy() for t in asm.assemble(given))
+        lip = form.dynamics["LIP"]
+        keep = list(lip.matrices)
+        for b in (0, 3, batch - 1):
+            Sb, Ub = orc.extend_matrices(conf.horizon_lenght, A[b], B[b])
+            lip.matrices = Ub + [Sb]
+            lip.update_definitions()
+            Ao, ho, Qo, qo = orc.assemble(form, given[b].reshape(-1, 1))
+            assert_close(P[b], Qo, RTOL_TIGHT)
+            assert_close(q[b], qo.ravel(), RTOL_TIGHT)
+            assert_close(G[b], Ao, RTOL_TIGHT)
+            assert_close(h[b], ho.ravel(), RTOL_TIGHT)
+        lip.matrices = keep
+        lip.update_definitions()
+
+
 def test_lipm3d_c3(gpu_api):
     """C3: N=32, 3 axes, 96 unknowns, 196 inequality rows; golden at B=1, oracle
     on sampled instances of a batch."""

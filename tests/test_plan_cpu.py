@@ -33,7 +33,41 @@ def check_plan(form, given, tol=1e-12):
         block = out["PM"][r0:r0 + rows]
         assert_close(block[:, :plan.ng], PM[var][0], tol, var + " Mg")
         assert_close(block[:, plan.ng:], PM[var][1], tol, var + " Mo")
+    # the tables of the persistent kernel, when the problem fits it
+    if plan.itab[_H["RS_OK"]]:
+        res = plan_emulator.run_resident(plan, given)
+        for key, ref in (("P", Q), ("q", q.ravel()), ("G", A), ("h", h.ravel())):
+            assert_close(res[key], ref, tol, "resident " + key)
     return plan
+
+
+def test_horizon_matrices_generated_on_chip_plan(cpu_api):
+    """``lti=[name]``: the image carries (A, B) and tables built from them instead of S, U;
+    compose ops that read U above its diagonal are gone."""
+    for times in ([7, 15], [6, 14]):
+        form = problems.biped(cpu_api, problems.BipedConfig(step_samples=8))
+        form.update(step_times=np.array(times), step_count=0)
+        given = np.random.default_rng(3).standard_normal([form.given_len, 1])
+        full = compile_plan(form)
+        plan = compile_plan(form, lti=["LIP"])
+        assert plan.itab[_H["RS_OK"]] == 1 and plan.itab[_H["RS_NLTI"]] == 1
+        assert plan.itab[_H["RS_IMG"]] < full.itab[_H["RS_IMG"]] // 2
+        g = plan.lti[0]
+        assert (g["n"], g["m"], g["N"]) == (3, 1, 16)
+        lip = form.dynamics["LIP"]
+        A_sys = lip.matrices[-1][0].T.copy()
+        B_sys = lip.matrices[0][0, 0, :].reshape(3, 1).copy()
+        Sx, Ux = orc.extend_matrices(16, A_sys, B_sys)
+        assert_close(Sx, lip.matrices[-1], 1e-13)
+        assert_close(Ux[0], lip.matrices[0], 1e-13)
+        srcs = [s.array for s in plan.sources]
+        srcs[g["ids"][0]], srcs[g["ids"][1]] = A_sys, B_sys
+        res = plan_emulator.run_resident(plan, given, sources=srcs)
+        A, h, Q, q = orc.assemble(form, given)
+        for key, ref in (("P", Q), ("q", q.ravel()), ("G", A), ("h", h.ravel())):
+            assert_close(res[key], ref, 1e-12, key)
+    with pytest.raises(KeyError):
+        compile_plan(form, lti=["no such dynamics"])
 
 
 def test_body_case_plan(cpu_api):

@@ -22,7 +22,10 @@ def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     work = bench.build_workload(B, 1)
     engine, form = work["engine"], work["form"]
-    asm = engine.Assembler(form, batch=B)
+    lti = os.environ.get("MPCASM_LTI") == "1"   # horizon matrices generated on chip
+    asm = engine.Assembler(form, batch=B, lti=["LIP"] if lti else ())
+    if lti:
+        asm.bind_lti("LIP", torch.as_tensor(work["A"], device="cuda"), torch.as_tensor(work["B"], device="cuda"))
     given = torch.as_tensor(work["given"], device="cuda")
     lib = capi.load()
     for _ in range(3):
