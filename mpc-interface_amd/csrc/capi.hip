@@ -102,10 +102,10 @@ int validate_plan(const int32_t* it, const double* h_dtab, size_t n_itab, size_t
     const int64_t img = it[H_RS_IMG], unit = it[H_RS_UNIT], nchunk = it[H_RS_NCHUNK];
     if (jc < 1 || jc > RS_JC_MAX || it[H_RS_NTRIP] < 0 || it[H_RS_NSPLIT] < 0)
       return MPCASM_ERR_PLAN;
-    const int64_t dma = it[H_RS_IMG_DMA], nlti = it[H_RS_NLTI];
+    const int64_t dma = it[H_RS_IMG_DMA], nlti = it[H_RS_NLTI], nab = it[H_RS_AB];
     if ((unit != 4 && unit != 16) || dma < 128 || dma % 128 || img < dma || (img & 1) ||
         img > 65535 || nchunk * 64 * unit != dma * 8 || it[H_NPARAMS] > 65535 || nlti < 0 ||
-        nlti > RS_LTI_MAX)
+        nlti > RS_LTI_MAX || nab < 0 || nab % 32 || nab > 4096 || (nlti == 0) != (nab == 0))
       return MPCASM_ERR_PLAN;
     bool r = true;
     r = r && in_range(it[H_OFF_RS_SRC], slots, n, H_WORDS);
@@ -123,6 +123,7 @@ int validate_plan(const int32_t* it, const double* h_dtab, size_t n_itab, size_t
     r = r && in_range(it[H_RS_IMG_GIVEN], ng + 1, dma, 0);
     r = r && in_range(it[H_RS_IMG_PARAMS], (int64_t)it[H_NPARAMS] + 1, dma, 0);
     r = r && in_range(it[H_OFF_RS_LTI], nlti * RS_LTI_WORDS, n, H_WORDS);
+    r = r && in_range(it[H_OFF_RS_ABMETA], nab * 4, n, H_WORDS) && it[H_OFF_RS_ABMETA] % 2 == 0;
     if (!r) return MPCASM_ERR_PLAN;
     {
       const double* c = h_dtab + it[H_DOFF_RS_CONST];
@@ -194,24 +195,28 @@ int validate_plan(const int32_t* it, const double* h_dtab, size_t n_itab, size_t
       if (gn < 1 || gm < 1 || gN < 1 || gn > 64 || gm > 64 || gN > 4096) return MPCASM_ERR_PLAN;
       int stages = 0;
       while ((1ll << stages) < gN) ++stages;
-      // A and B inside the first chunk of the loads (the generating wave fetches it itself)
-      if (!in_range(x[LT_A], gn * gn, 8 * unit, 0) || !in_range(x[LT_B], gn * gm, 8 * unit, 0) ||
+      if (!in_range(x[LT_A], gn * gn, nab, 0) || !in_range(x[LT_B], gn * gm, nab, 0) ||
           !in_range(x[LT_TA], gN * gn * gn, img, dma) || !in_range(x[LT_TB], gN * gn * gm, img, dma) ||
           !in_range(x[LT_TP], (stages + 1) * gn * gn, img, dma))
         return MPCASM_ERR_PLAN;
     }
     // every input load stays inside its stream: sources, given, params, the constants
-    const int32_t* im = it + it[H_OFF_RS_INMETA];
-    for (int64_t i = 0; i < nchunk * 64; ++i) {
-      const int st = im[2 * i];
-      const int64_t off = im[2 * i + 1];
-      if (st < 0 || st > it[H_NSRC] + 2 || off < 0 || off % unit) return MPCASM_ERR_PLAN;
-      const int64_t lim = st < it[H_NSRC]        ? (it + it[H_OFF_ARENA])[2 * st + 1]
-                          : st == it[H_NSRC]     ? ng
-                          : st == it[H_NSRC] + 1 ? (int64_t)it[H_NPARAMS]
-                                                 : 4;
-      if (off + unit > lim * 8) return MPCASM_ERR_PLAN;
-    }
+    auto loads_ok = [&](const int32_t* im, int64_t lanes, int64_t bytes) {
+      for (int64_t i = 0; i < lanes; ++i) {
+        const int st = im[2 * i];
+        const int64_t off = im[2 * i + 1];
+        if (st < 0 || st > it[H_NSRC] + 2 || off < 0 || off % bytes) return false;
+        const int64_t lim = st < it[H_NSRC]        ? (it + it[H_OFF_ARENA])[2 * st + 1]
+                            : st == it[H_NSRC]     ? ng
+                            : st == it[H_NSRC] + 1 ? (int64_t)it[H_NPARAMS]
+                                                   : 4;
+        if (off + bytes > lim * 8) return false;
+      }
+      return true;
+    };
+    if (!loads_ok(it + it[H_OFF_RS_INMETA], nchunk * 64, unit) ||
+        !loads_ok(it + it[H_OFF_RS_ABMETA], nab * 2, 4))
+      return MPCASM_ERR_PLAN;
     for (int c = 0; c < no; ++c) {  // diagonal gterms on one column: RS_DIAG_MAX slots
       int on = 0;
       for (int g = 0; g < it[H_NGTERM]; ++g) {
@@ -412,6 +417,13 @@ int mpcasm_plan_create(const int32_t* h_itab, size_t n_itab, const double* h_dta
   d.rs_img_given = it[H_RS_IMG_GIVEN]; d.rs_img_params = it[H_RS_IMG_PARAMS];
   d.doff_rs_const = it[H_DOFF_RS_CONST];
   d.rs_nlti = it[H_RS_NLTI]; d.off_rs_lti = it[H_OFF_RS_LTI]; d.rs_img_dma = it[H_RS_IMG_DMA];
+  d.rs_ab = it[H_RS_AB]; d.off_rs_abmeta = it[H_OFF_RS_ABMETA];
+  d.rs_src16 = 0;
+  if (d.rs_ok && d.rs_unit == 16)
+    for (int64_t i = 0; i < (int64_t)d.rs_nchunk * 64; ++i) {
+      const int st = it[d.off_rs_inmeta + 2 * i];
+      if (st < d.nsrc) d.rs_src16 |= 1u << st;
+    }
   {
     hipDeviceProp_t prop;
     plan->num_cus = 256;

@@ -27,7 +27,7 @@
 namespace mpcasm {
 
 constexpr int32_t PLAN_MAGIC = 0x4D504341;  // 'MPCA'
-constexpr int32_t PLAN_VERSION = 14;
+constexpr int32_t PLAN_VERSION = 15;
 
 enum HeaderWord : int {
   H_MAGIC = 0,
@@ -102,10 +102,13 @@ enum HeaderWord : int {
   H_NDIAGCOEF,
   // source groups generated on chip (K1 fused into the persistent kernel): the horizon
   // matrices U_0..U_{m-1}, S of an LTI system are not read; its A and B arrive through the
-  // streams of the group's first two sources and the image gets tables built from them
+  // streams of the group's first two sources (4-byte loads into a ring of two slots, two
+  // instances ahead) and the image gets tables built from them
   H_RS_NLTI,
   H_OFF_RS_LTI,     // [NLTI][RS_LTI_WORDS], see LT_* below
   H_RS_IMG_DMA,     // doubles of the image that the loads fill (a multiple of 128, <= RS_IMG)
+  H_RS_AB,          // doubles of one ring slot holding every group's A and B (a multiple of 32)
+  H_OFF_RS_ABMETA,  // [RS_AB * 2][2] input stream, byte offset of every 4-byte lane of a slot
   H_WORDS = 80
 };
 
@@ -137,8 +140,8 @@ constexpr int MAX_SOURCES = 32;
 // per thread
 constexpr int RS_NW = 4, RS_NT = 512, RS_WAVES = RS_NT / 64, RS_JC_MAX = 12, RS_TRIP_WORDS = 4;
 constexpr int RS_TILES_MAX = 128;
-// generated source group: sizes; image offsets of A [n][n] and B [n][m] (loaded), of the
-// tables TA[k][i][j] = (A^{k+1})[i][j] and TB[d][i][j] = (A^d B)[i][j], k, d < N, and of
+// generated source group: sizes; offsets of A [n][n] and B [n][m] inside a ring slot; image
+// offsets of the tables TA[k][i][j] = (A^{k+1})[i][j] and TB[d][i][j] = (A^d B)[i][j], k, d < N, and of
 // the powers A^(2^s) they are built from
 enum { LT_N = 0, LT_M, LT_HORIZON, LT_A, LT_B, LT_TA, LT_TB, LT_TP, RS_LTI_WORDS = 8 };
 constexpr int RS_LTI_MAX = 4;

@@ -61,9 +61,9 @@ __host__ __device__ inline int even_up_i(int x) { return (x + 1) & ~1; }
 
 struct ResidentLayout {
   // offsets in doubles
-  int v, pl, ql, dvec, dcoef, dpar, img, streams, ints, total_doubles;
+  int v, pl, ql, dvec, dcoef, dpar, img, ab, streams, ints, total_doubles;
   int ldp;                                            // leading dimension of P in LDS
-  int i_trip, i_rr, i_meta, i_wtrip, i_split, i_lti;  // offsets in ints inside the int region
+  int i_trip, i_rr, i_meta, i_wtrip, i_split, i_lti, i_abmeta;  // offsets in ints inside the int region
 };
 
 __host__ __device__ inline ResidentLayout resident_layout(const PlanDev& p) {
@@ -79,12 +79,14 @@ __host__ __device__ inline ResidentLayout resident_layout(const PlanDev& p) {
   L.dcoef = o;  o += RS_DIAG_MAX * L.ldp;
   L.dpar = o;   o += RS_DIAG_MAX * L.ldp;
   L.img = o;    o += 2 * p.rs_img;  // two input images: this instance's, the next one's
+  L.ab = o;     o += 2 * p.rs_ab;   // ring of two slots: (A, B) of the generated systems
   L.streams = o; o += 2 * (MAX_SOURCES + 3);  // (base pointer, bytes per instance) per stream
   L.ints = o;
   int i = 0;  // the first three start 16-byte aligned
   L.i_trip = i;  i += (p.rs_ntrip + 2) * RS_TRIP_WORDS;  // two spare records: read ahead
   L.i_rr = i;    i += p.nc * RR_WORDS;
   L.i_meta = i;  i += p.rs_nchunk * 64 * 2;
+  L.i_abmeta = i; i += p.rs_ab * 2 * 2;
   L.i_wtrip = i; i += RS_WAVES * 2;
   L.i_split = i; i += p.rs_nsplit;
   L.i_lti = i;   i += p.rs_nlti * RS_LTI_WORDS;
@@ -114,6 +116,13 @@ __device__ __forceinline__ void dma4(const void* gsrc, unsigned lds_base) {
       : "=&s"(keep)
       : "v"(gsrc), "s"(lds_base)
       : "memory");
+}
+// the value of lane T of every quad, in all four lanes of the quad (DPP quad_perm)
+template <int T>
+__device__ __forceinline__ double quad_broadcast(double v) {
+  constexpr int ctl = T | (T << 2) | (T << 4) | (T << 6);
+  return __hiloint2double(__builtin_amdgcn_mov_dpp(__double2hiint(v), ctl, 0xF, 0xF, true),
+                          __builtin_amdgcn_mov_dpp(__double2loint(v), ctl, 0xF, 0xF, true));
 }
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
@@ -152,6 +161,7 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
   int* wtrip = itb + L.i_wtrip;
   int* split = itb + L.i_split;
   int* lti = itb + L.i_lti;
+  int2* abmeta = reinterpret_cast<int2*>(itb + L.i_abmeta);
   // LDS byte address of the image double buffer (the low half of a flat LDS address)
   const unsigned img_lds = (unsigned)(uintptr_t)(lds + L.img);  // (rs_img doubles each, rs_img_dma of them loaded)
   const int unit = p.rs_unit, nchunk = p.rs_nchunk;
@@ -185,7 +195,9 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
     for (int i = tid; i < p.rs_nsplit; i += NT) split[i] = t[i];
     t = p.itab + p.off_rs_lti;
     for (int i = tid; i < p.rs_nlti * RS_LTI_WORDS; i += NT) lti[i] = t[i];
-    const int2* t2 = reinterpret_cast<const int2*>(p.itab + p.off_rs_inmeta);
+    const int2* t2 = reinterpret_cast<const int2*>(p.itab + p.off_rs_abmeta);
+    for (int i = tid; i < p.rs_ab * 2; i += NT) abmeta[i] = t2[i];
+    t2 = reinterpret_cast<const int2*>(p.itab + p.off_rs_inmeta);
     for (int i = tid; i < nchunk * 64; i += NT) meta[i] = t2[i];
     double2* V2 = reinterpret_cast<double2*>(V);
     const int n2 = (even_up_i(p.rtot * ldv) + 15 * ldv + 16) / 2;
@@ -291,43 +303,54 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
   // finished blocks per pass: X_{h+d} = A^h X_d with A^h = (A^{h/2})^2 -- log2(N) dependent
   // passes instead of the N - 1 of the reference's recurrence (the rounding differs by a few
   // ulp).  LDS operations of one wavefront complete in order, so a pass sees the last one.
-  // Wave 0 does it: A and B lie in the first chunk of the image, which wave 0 fetched and
-  // waited for itself (no other wave's loads are known to have landed before barrier A).
-  auto generate_sources = [&](int buf) {
+  // The (A, B) travel apart from the image, two instances ahead, into a ring of two slots
+  // (fetch_ab, wave 0), so that the last stream wave can build the tables of instance i+1
+  // beside the assembly of instance i, off the critical path.
+  const unsigned ab_lds = (unsigned)(uintptr_t)(lds + L.ab);
+  auto fetch_ab = [&](long inst, int slot) {  // wave 0 only
+    for (int k = 0; k < p.rs_ab / 32; ++k) {
+      const int2 m = abmeta[k * 64 + lane];
+      const char* base = reinterpret_cast<const char* const*>(strm)[2 * m.x];
+      const long long stride = reinterpret_cast<const long long*>(strm)[2 * m.x + 1];
+      dma4(base + inst * stride + m.y,
+           __builtin_amdgcn_readfirstlane(ab_lds + (unsigned)((slot * p.rs_ab + k * 32) * 8)));
+    }
+  };
+  auto generate_sources = [&](int buf, int slot) {  // one wavefront
     double* im = lds + L.img + buf * p.rs_img;
-    for (int g = 0; g < p.rs_nlti && wave == 0; ++g) {
+    const double* ab = lds + L.ab + slot * p.rs_ab;
+    for (int g = 0; g < p.rs_nlti; ++g) {
       const int* rec = lti + g * RS_LTI_WORDS;
       const int n = rec[LT_N], m = rec[LT_M], N = rec[LT_HORIZON], nn = n * n, nm = n * m;
-      const double* Am = im + rec[LT_A];
-      const double* Bm = im + rec[LT_B];
+      const double* Am = ab + rec[LT_A];
+      const double* Bm = ab + rec[LT_B];
       double* TA = im + rec[LT_TA];
       double* TB = im + rec[LT_TB];
       double* TP = im + rec[LT_TP];
       if (n <= 4 && n + m <= 16) {
         // Small systems: the reference's own recurrence X_d = A X_{d-1}, X_0 = [B | A]
-        // (tools.py:21-30), on the matrix core.  One v_mfma_f64_16x16x4 computes A (padded
-        // to 16x4) times a 4x16 block; its result rows 0-3 come back in register 0 of
-        // exactly the lanes that hold the B operand of the next step (row k = lane / 16,
-        // column j = lane % 16), so the chain needs no data movement at all: N - 1
-        // dependent MFMAs, each followed by one store of the new block into the tables.
-        const bool live = lk < n && li < n + m;
-        const double a_op = li < n && lk < n ? Am[li * n + lk] : 0.0;  // A[i = li][k = lk]
-        double x = !live ? 0.0 : (li < m ? Bm[lk * m + li] : Am[lk * n + (li - m)]);
-        // element (row lk, column li) of block d: TB[d][lk][li] or TA[d][lk][li - m]
-        double* out = li < m ? TB + lk * m + li : TA + lk * n + (li - m);
-        const int step = li < m ? nm : nn;
-        // (the block is stored from a copy, so that the next MFMA, which overwrites the
-        // registers of x, need not wait for the store to have read them)
-        for (int d = 0; d < N; d += 2) {
-          double w0 = x;
-          asm volatile("" : "+v"(w0));
-          if (live) out[d * step] = w0;
-          const f64x4 y0 = mfma_f64_16x16x4(a_op, x, f64x4{0.0, 0.0, 0.0, 0.0});
-          double w1 = y0[0];
-          asm volatile("" : "+v"(w1));
-          if (live && d + 1 < N) out[(d + 1) * step] = w1;
-          const f64x4 y1 = mfma_f64_16x16x4(a_op, y0[0], f64x4{0.0, 0.0, 0.0, 0.0});
-          x = y1[0];
+        // (tools.py:21-30) in registers.  Lane 4 c + i holds element i of column c, so the
+        // n values a lane needs of its column sit in its own quad: three DPP quad
+        // broadcasts and n FMAs (in the reference's order t = 0 .. n-1) per step, no LDS
+        // round trip, nothing on the matrix core that the Hessian tiles of the other
+        // workgroup on this SIMD are using.
+        const int gi = lane & 3, gc = lane >> 2;
+        const bool live = gi < n && gc < n + m;
+        double ar[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) ar[t] = gi < n && t < n ? Am[gi * n + t] : 0.0;  // A[i][t]
+        double x = !live ? 0.0 : (gc < m ? Bm[gi * m + gc] : Am[gi * n + (gc - m)]);
+        // element (i, c) of block d: TB[d][i][c] or TA[d][i][c - m]
+        double* out = gc < m ? TB + gi * m + gc : TA + gi * n + (gc - m);
+        const int step = gc < m ? nm : nn;
+        for (int d = 0; d < N; ++d) {
+          if (live) out[d * step] = x;
+          // x[t] of this lane's column is in lane t of the quad
+          double y = ar[0] * quad_broadcast<0>(x);
+          y = fma(ar[1], quad_broadcast<1>(x), y);
+          y = fma(ar[2], quad_broadcast<2>(x), y);
+          y = fma(ar[3], quad_broadcast<3>(x), y);
+          x = y;
         }
         continue;
       }
@@ -374,8 +397,12 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
   const bool lookahead = (phases & 128) != 0;  // diagnostic: off = fetch only when needed
   if (wave < MW) {
     fetch_image(blockIdx.x, 0);
+    if (wave == 0 && p.rs_nlti != 0) {
+      fetch_ab(blockIdx.x, 0);
+      if ((long)blockIdx.x + gridDim.x < batch) fetch_ab((long)blockIdx.x + gridDim.x, 1);
+    }
     dma_wait();
-    if (p.rs_nlti != 0) generate_sources(0);
+    if (wave == 0 && p.rs_nlti != 0) generate_sources(0, 0);  // the first instance's tables
   }
 
   // ---- K4 bookkeeping of the worker threads: piece e = wt + u WT of G is the 16 bytes
@@ -441,6 +468,8 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
       MPCASM_STAMP(1)
       // the next instance's image starts its trip from HBM now
       if (lookahead && nxt < batch && (phases & 16)) fetch_image(nxt, buf ^ 1);
+      // ... and, two instances ahead, the (A, B) of the systems whose matrices are built here
+      if (wave == 0 && p.rs_nlti != 0 && nxt + gridDim.x < batch) fetch_ab(nxt + gridDim.x, buf);
       MPCASM_STAMP(7)
     } else {
       compose();
@@ -556,6 +585,9 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
           hb[R] = (prm[rec[RR_EXTREME]] + ac) - ad;
         }
       }
+      // the last stream wave builds the next instance's horizon tables (its (A, B) landed
+      // and were waited for by wave 0 a whole instance ago)
+      if (wave == RS_WAVES - 1 && p.rs_nlti != 0 && nxt < batch) generate_sources(buf ^ 1, buf ^ 1);
       MPCASM_STAMP(3)
     }
     if (P != nullptr && (phases & 2)) {
@@ -655,7 +687,6 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
       // The next image is complete before barrier A.  The wait comes before this wave's
       // P stores so that it never waits for a store, only for loads issued a phase ago.
       dma_wait();
-      if (p.rs_nlti != 0 && nxt < batch) generate_sources(buf ^ 1);
       // elements that two threads add into start the next compose from zero
       for (int i = tid; i < p.rs_nsplit; i += MW * 64) V[split[i]] = 0.0;
     }
@@ -742,7 +773,7 @@ bool resident_inputs_aligned(const PlanDev& p, const SrcTable& src, const double
     return (reinterpret_cast<uintptr_t>(base) & 15) == 0 && (stride & 1) == 0;
   };
   for (int s = 0; s < p.nsrc; ++s)
-    if (!ok(src.ptr[s], src.stride[s])) return false;
+    if (((p.rs_src16 >> s) & 1) && !ok(src.ptr[s], src.stride[s])) return false;
   return ok(given, p.ng) && ok(params, p.nparams);
 }
 

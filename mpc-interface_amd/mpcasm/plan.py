@@ -15,7 +15,7 @@ import numpy as np
 import scipy.sparse as sp
 
 PLAN_MAGIC = 0x4D504341
-PLAN_VERSION = 14
+PLAN_VERSION = 15
 
 # header words (csrc/plan_tables.h, enum HeaderWord)
 _H = {name: i for i, name in enumerate([
@@ -30,7 +30,7 @@ _H = {name: i for i, name in enumerate([
     "DOFF_RS_COEF", "OFF_RS_TRIP", "OFF_RS_WTRIP", "RS_NSPLIT", "OFF_RS_SPLIT",
     "OFF_RS_RR", "RS_UNIT", "RS_NCHUNK", "OFF_RS_INMETA", "RS_IMG", "RS_IMG_GIVEN",
     "RS_IMG_PARAMS", "DOFF_RS_CONST", "DOFF_DIAGCOEF", "NDIAGCOEF", "RS_NLTI", "OFF_RS_LTI",
-    "RS_IMG_DMA",
+    "RS_IMG_DMA", "RS_AB", "OFF_RS_ABMETA",
 ])}
 H_WORDS = 80
 assert len(_H) <= H_WORDS
@@ -480,16 +480,6 @@ def _resident_image(sources, ng, nparams, groups=()):
             slots.append((s_const, 3))
 
     push_const(0)
-    # A through the group's first stream, B through its second.  They come first: the wave
-    # that builds the tables must have fetched them itself, and chunk 0 is wave 0's.
-    for g in groups:
-        g["img_a"] = len(slots)
-        slots.extend((g["ids"][0], k) for k in range(g["n"] * g["n"]))
-        pad_even()
-        g["img_b"] = len(slots)
-        slots.extend((g["ids"][1], k) for k in range(g["n"] * g["m"]))
-        pad_even()
-    first_chunk = len(slots)
     src_off = []
     for sid, src in enumerate(sources):
         src_off.append(len(slots))
@@ -518,9 +508,22 @@ def _resident_image(sources, ng, nparams, groups=()):
         unit = 4
         meta = np.stack([np.repeat(arr[:, 0], 2),
                          (np.repeat(arr[:, 1] * 8, 2) + np.tile([0, 4], len(arr)))], axis=1)
-    if first_chunk * 8 > 64 * unit:
-        raise ValueError("the (A, B) of the systems generated on chip must fit one load "
-                         "(%d bytes), they take %d" % (64 * unit, first_chunk * 8))
+    # The (A, B) of the generated groups travel apart from the image, two instances ahead,
+    # into a ring of two slots (4-byte loads: A has n^2 doubles, no pairing to rely on): the
+    # tables of instance i+1 are built while instance i is assembled.
+    ab = []
+    for g in groups:
+        g["img_a"] = len(ab)                     # A through the group's first stream ...
+        ab.extend((g["ids"][0], k) for k in range(g["n"] * g["n"]))
+        ab.extend([(s_const, 2)] * (len(ab) & 1))
+        g["img_b"] = len(ab)                     # ... B through its second
+        ab.extend((g["ids"][1], k) for k in range(g["n"] * g["m"]))
+        ab.extend([(s_const, 2)] * (len(ab) & 1))
+    while len(ab) % 32:
+        ab.append((s_const, 2))
+    ab_arr = np.asarray(ab, dtype=np.int64).reshape(-1, 2)
+    ab_meta = np.stack([np.repeat(ab_arr[:, 0], 2),
+                        np.repeat(ab_arr[:, 1] * 8, 2) + np.tile([0, 4], len(ab_arr))], axis=1)
     total = len(slots)
     for g in groups:                             # tables behind the loaded part
         n, m, N = g["n"], g["m"], g["N"]
@@ -531,7 +534,7 @@ def _resident_image(sources, ng, nparams, groups=()):
         total += total & 1
     return dict(unit=unit, nchunk=meta.shape[0] // 64, meta=meta.astype(np.int32).reshape(-1),
                 img=total, dma=len(slots), given=given_off, params=params_off, src_off=src_off,
-                groups=list(groups))
+                groups=list(groups), ab=len(ab), ab_meta=ab_meta.astype(np.int32).reshape(-1))
 
 
 def _lti_table_offset(g, k, flat):
@@ -697,7 +700,8 @@ def _resident_program(fused, gterms, no, ldv, image, ng, nparams, nc_rows):
         else:                                      # threads of this wave own pieces e = wt + u WT
             first = (w - NW) * 64
             own = len(range(first, pieces, stream_threads))
-            loads.append((800 * own + 600, w))
+            gen = 4000 if image["groups"] and w == RS_WAVES - 1 else 0   # builds the tables
+            loads.append((800 * own + 600 + gen, w))
     heapq.heapify(loads)
     wave_tiles = [[] for _ in range(RS_WAVES)]
     for key in sorted(tile_trips, key=lambda k: -cost[k]):
@@ -894,6 +898,7 @@ def compile_plan(form, costs=None, limits=None, lti=()):
         ("OFF_RS_SPLIT", resident["split"]),
         ("OFF_RS_RR", rs_rr),
         ("OFF_RS_INMETA", image["meta"]),
+        ("OFF_RS_ABMETA", image["ab_meta"]),
         ("OFF_RS_LTI", np.asarray(
             [[g["n"], g["m"], g["N"], g["img_a"], g["img_b"], g["tab_a"], g["tab_b"], g["tab_p"]]
              for g in groups], dtype=np.int32).reshape(-1)),
@@ -904,7 +909,7 @@ def compile_plan(form, costs=None, limits=None, lti=()):
         if name == "OFF_OP" and off & 1:          # the kernels read ops as 8-byte pairs
             parts.append(np.zeros(1, dtype=np.int32))
             off += 1
-        if name in ("OFF_RS_TRIP", "OFF_RS_RR", "OFF_RS_INMETA") and off & 3:   # ... 16-byte quads
+        if name in ("OFF_RS_TRIP", "OFF_RS_RR", "OFF_RS_INMETA", "OFF_RS_ABMETA") and off & 3:   # ... 16-byte quads
             pad = 4 - (off & 3)
             parts.append(np.zeros(pad, dtype=np.int32))
             off += pad
@@ -939,6 +944,7 @@ def compile_plan(form, costs=None, limits=None, lti=()):
     header[_H["RS_IMG"]] = image["img"]
     header[_H["RS_IMG_DMA"]] = image["dma"]
     header[_H["RS_NLTI"]] = len(groups)
+    header[_H["RS_AB"]] = image["ab"]
     header[_H["RS_IMG_GIVEN"]], header[_H["RS_IMG_PARAMS"]] = image["given"], image["params"]
     if rs_rr.size != nc * RS_RR_WORDS:
         header[_H["RS_OK"]] = 0                  # a constraint with more than RS_AXMAX axes

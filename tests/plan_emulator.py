@@ -172,9 +172,16 @@ def run_resident(plan, given, params=None, sources=None):
     # horizon matrices generated on chip: tables (A^{k+1})[i][j] and (A^d B)[i][j], k, d < N,
     # from the group's A and B (which arrived through the streams of its first two sources)
     lti = _section(it, "OFF_RS_LTI", it[H["RS_NLTI"]] * P.RS_LTI_WORDS).reshape(-1, P.RS_LTI_WORDS)
+    nab = int(it[H["RS_AB"]])                    # (A, B) arrive apart, by 4-byte loads
+    abmeta = _section(it, "OFF_RS_ABMETA", nab * 4).reshape(-1, 2)
+    ab = np.full(nab * 8, 0xFF, dtype=np.uint8)
+    for lane, (st, off) in enumerate(abmeta):
+        assert 0 <= st < nsrc + 3 and off % 4 == 0 and off + 4 <= streams[st].size
+        ab[lane * 4:lane * 4 + 4] = streams[st][off:off + 4]
+    ab = ab.view(np.float64)
     for n, m, N, ia, ib, ta, tb, tp in lti:
-        Am = image[ia:ia + n * n].reshape(n, n).copy()
-        Bm = image[ib:ib + n * m].reshape(n, m).copy()
+        Am = ab[ia:ia + n * n].reshape(n, n).copy()
+        Bm = ab[ib:ib + n * m].reshape(n, m).copy()
         for k in range(N):
             image[ta + k * n * n:ta + (k + 1) * n * n] = np.linalg.matrix_power(Am, k + 1).ravel()
             image[tb + k * n * m:tb + (k + 1) * n * m] = (np.linalg.matrix_power(Am, k) @ Bm).ravel()
