@@ -201,7 +201,7 @@ def main():
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             pmc = json.load(f)
-        if pmc.get("batch_per_gpu") == B:
+        if pmc.get("batch_per_gpu") == B and pmc.get("k1_fused", False) == fused:
             traffic = pmc["traffic_bytes_per_launch"]
     except (OSError, ValueError, KeyError):
         pass

@@ -125,6 +125,16 @@ int mpcasm_workspace_bytes(const mpcasm_plan* plan, int batch, size_t* out_bytes
  *   d_work       scratch of mpcasm_workspace_bytes(plan, batch)
  *
  * Any of d_P/d_q (both) or d_G/d_h (both) may be NULL to skip that half.
+ *
+ * K1 fused (plans compiled with lti=[...], mpcasm/plan.py): for a dynamics whose
+ * horizon matrices are generated on chip, i.e. what
+ *   tools.extend_matrices(N, A, B)             python/mpc_interface/tools.py:14-33
+ * would have produced from the system's (A, B), the slot of the group's FIRST
+ * horizon matrix (U_0) carries A [n][n] and the slot of its SECOND one (U_1, or S
+ * when m = 1) carries B [n][m], each with its own per-instance stride (n*n, n*m or
+ * 0); the group's other slots are ignored.  Such a plan runs in the persistent
+ * kernel only: MPCASM_ERR_LIMIT when one instance does not fit on chip, and
+ * mpcasm_preview_matrices refuses it (there is no S, U to read).
  */
 int mpcasm_assemble(const mpcasm_plan* plan, const double* const* h_src,
                     const int64_t* h_src_stride, const double* d_params,

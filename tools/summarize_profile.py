@@ -81,12 +81,17 @@ def main():
         summary["bench_in_profiled_run"] = {
             "value": bench["stats"]["value"],
             "assemble_avg_launch_ms_hipEvent": bench["stats"]["roofline"]["avg_launch_ms"],
-            "fill_avg_launch_ms_hipEvent": bench["stats"]["fill"]["avg_launch_ms"],
+            "step": bench["stats"]["config"].get("step"),
         }
+        if "fill" in bench["stats"]:
+            summary["bench_in_profiled_run"]["fill_avg_launch_ms_hipEvent"] = \
+                bench["stats"]["fill"]["avg_launch_ms"]
     json.dump(summary, open(os.path.join(prof, tag + "_pmc.json"), "w"), indent=1)
     dominant = "resident_assemble_kernel"
     if dominant in summary["kernels"]:
+        fused = "fill" not in bench.get("stats", bench.get("fetch", {}))
         json.dump({"kernel": dominant, "batch_per_gpu": batch, "source": tag + "_pmc.json",
+                   "k1_fused": fused,
                    "traffic_bytes_per_launch": summary["kernels"][dominant]["hbm_bytes_per_launch"]},
                   open(os.path.join(prof, "pmc_traffic.json"), "w"), indent=1)
     print(json.dumps(summary, indent=1))
