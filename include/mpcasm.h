@@ -158,6 +158,20 @@ int mpcasm_preview_matrices(const mpcasm_plan* plan, const double* const* h_src,
 int mpcasm_preview(const double* d_PM, const double* d_given, const double* d_optim,
                    double* d_out, int batch, int rows, int ng, int no, void* stream);
 
+/* f3  sparse hand-off -----------------------------------------------------------
+ * Replaces the dense -> CSC conversion in front of the solver call of the walking loop
+ *   Q = scipy.sparse.csc_matrix(Q); A = scipy.sparse.csc_matrix(A)
+ *   python/use_examples/simple_functional_example/biped_mpc_loop.py:57-58
+ * for a whole batch with ONE pattern: d_index[k] is the flat offset (row * cols + col)
+ * of the k-th stored entry, in CSC order, of a structural sparsity pattern that the plan
+ * compiler derives (mpcasm/plan.py: csc_pattern); entries of the pattern that happen to
+ * be 0.0 in an instance are stored as explicit zeros, so the pattern -- indptr, indices,
+ * shared by the batch, as OSQP's update_values wants it -- never changes.
+ *   d_dst[b][k] = d_src[b * src_stride + d_index[k]]      k < nnz, b < batch
+ */
+int mpcasm_gather(const double* d_src, int64_t src_stride, const int32_t* d_index, int nnz,
+                  double* d_dst, int batch, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

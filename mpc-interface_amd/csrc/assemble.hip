@@ -552,4 +552,36 @@ int launch_preview(const double* PM, const double* given, const double* optim, d
   return *err == hipSuccess ? MPCASM_OK : MPCASM_ERR_HIP;
 }
 
+// f3: values of a fixed sparsity pattern out of a batch of dense matrices
+// (biped_mpc_loop.py:57-58 does this per instance with scipy.sparse.csc_matrix).
+// One workgroup walks the pattern of one instance: the index list is read coalesced
+// (L2-resident after the first instance), the stores are consecutive; the gathered reads
+// stay inside the instance's few KB.
+__global__ __launch_bounds__(BLOCK) void gather_kernel(const double* __restrict__ src,
+                                                       long long src_stride,
+                                                       const int32_t* __restrict__ index, int nnz,
+                                                       double* __restrict__ dst, int per_block,
+                                                       int batch) {
+  const long b0 = (long)blockIdx.x * per_block;
+  for (int s = 0; s < per_block && b0 + s < batch; ++s) {
+    const double* in = src + (b0 + s) * src_stride;
+    double* out = dst + (b0 + s) * (long)nnz;
+    for (int k = threadIdx.x; k < nnz; k += BLOCK) out[k] = in[index[k]];
+  }
+}
+
+int launch_gather(const double* src, long long src_stride, const int32_t* index, int nnz,
+                  double* dst, int batch, hipStream_t stream, hipError_t* err) {
+  // small patterns: several instances per workgroup, so that a launch has a few
+  // thousand workgroups at most and each of them a few KB to move
+  int per_block = 1;
+  while (per_block < 64 && (long)per_block * nnz < 4096 && batch / (per_block * 2) >= 2048)
+    per_block *= 2;
+  const unsigned blocks = (unsigned)((batch + per_block - 1) / per_block);
+  hipLaunchKernelGGL(gather_kernel, dim3(blocks), dim3(BLOCK), 0, stream, src, src_stride, index,
+                     nnz, dst, per_block, batch);
+  *err = hipGetLastError();
+  return *err == hipSuccess ? MPCASM_OK : MPCASM_ERR_HIP;
+}
+
 }  // namespace mpcasm

@@ -526,6 +526,18 @@ int mpcasm_preview(const double* d_PM, const double* d_given, const double* d_op
   return rc;
 }
 
+int mpcasm_gather(const double* d_src, int64_t src_stride, const int32_t* d_index, int nnz,
+                  double* d_dst, int batch, void* stream) {
+  if (nnz < 0 || batch < 0 || src_stride < 0) return MPCASM_ERR_ARG;
+  if (nnz == 0 || batch == 0) return MPCASM_OK;
+  if (!d_src || !d_index || !d_dst) return MPCASM_ERR_ARG;
+  hipError_t err;
+  const int rc = launch_gather(d_src, src_stride, d_index, nnz, d_dst, batch,
+                               static_cast<hipStream_t>(stream), &err);
+  if (rc == MPCASM_ERR_HIP) g_last_hip = (int)err;
+  return rc;
+}
+
 }  // extern "C"
 
 namespace mpcasm {

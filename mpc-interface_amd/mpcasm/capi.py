@@ -50,6 +50,8 @@ SIGNATURES = {
                                                ctypes.c_int, _void_p]),
     "mpcasm_preview": (ctypes.c_int, [_void_p, _void_p, _void_p, _void_p, ctypes.c_int,
                                       ctypes.c_int, ctypes.c_int, ctypes.c_int, _void_p]),
+    "mpcasm_gather": (ctypes.c_int, [_void_p, ctypes.c_int64, _void_p, ctypes.c_int, _void_p,
+                                     ctypes.c_int, _void_p]),
 }
 
 

@@ -154,6 +154,7 @@ class Assembler:
         self._work = torch.empty(max(nbytes.value // 8, 1), dtype=torch.float64,
                                  device=self.device)
         self._out = None
+        self._csc = {}
 
     def __del__(self):
         handle = getattr(self, "_handle", None)
@@ -273,6 +274,42 @@ class Assembler:
                 ptr(G), ptr(h), self._work.data_ptr(), n_run, _stream_handle(torch, stream))
         capi.check(rc, "mpcasm_assemble")
         return P, q, G, h
+
+    # ---- sparse hand-off (f3) ------------------------------------------------------
+    def csc_pattern(self, which, upper=False):
+        """``(indptr, indices)`` (numpy int32) of the batch-wide CSC pattern of ``"P"`` or
+        ``"G"``: every entry that can be non-zero for this structure, whatever the numbers
+        (``upper``: only the upper triangle, as OSQP wants P).  Dense when the plan is too
+        large for the structural analysis."""
+        from .plan import csc_pattern
+
+        key = (which, bool(upper))
+        if key not in self._csc:
+            mask = {"P": self.plan.P_pattern, "G": self.plan.G_pattern}[which]
+            if mask is None:
+                mask = np.ones((self.no, self.no) if which == "P" else (self.nc, self.no), dtype=bool)
+            indptr, indices, flat = csc_pattern(mask, upper)
+            self._csc[key] = (indptr, indices,
+                              self._torch.as_tensor(flat, dtype=self._torch.int32, device=self.device))
+        return self._csc[key][0], self._csc[key][1]
+
+    def export_csc(self, which, dense=None, upper=False, count=None, stream=None):
+        """``(B, nnz)`` device tensor: the ``data`` arrays of ``scipy.sparse.csc_matrix(M)`` for
+        every instance's ``M = P`` or ``G`` on the pattern of :meth:`csc_pattern`
+        (biped_mpc_loop.py:57-58, batched).  ``dense`` defaults to the last :meth:`assemble`."""
+        torch = self._torch
+        self.csc_pattern(which, upper)
+        index = self._csc[(which, bool(upper))][2]
+        if dense is None:
+            dense = self._out[0 if which == "P" else 2]
+        n = self.batch if count is None else int(count)
+        out = torch.empty((n, index.numel()), dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = capi.load().mpcasm_gather(
+                dense.data_ptr(), dense[0].numel(), index.data_ptr(), index.numel(),
+                out.data_ptr(), n, _stream_handle(torch, stream))
+        capi.check(rc, "mpcasm_gather")
+        return out
 
     def preview_matrices(self, stream=None):
         """``(B, preview_rows, ng+no)`` device tensor; rows of definition ``v`` are

@@ -723,6 +723,65 @@ def _resident_program(fused, gterms, no, ldv, image, ng, nparams, nc_rows):
     return out
 
 
+def _structural_patterns(form, b, fused, gterms, limit_recs, lax_recs, rtot, ldv, no, nc):
+    """Which entries of P (no x no) and of the stacked G (nc x no) can be non-zero at all:
+    from the structurally non-zero elements of the workspace (an element with at least one
+    op whose source is not a known zero -- ``U_j[k][l]`` above the diagonal l > k is zero
+    for every system, tools.py:27-31).  None when the op lists were not built (huge plans)."""
+    if rtot and fused["fd_idx"].size == 0:
+        return None, None
+    ops = fused["ops"].view(np.uint32).reshape(-1, 2)
+    arena = fused["arena"].reshape(-1, 2)
+    zero_src = np.zeros(int(fused["arena_total"]) + 1, dtype=bool)
+    for sid, src in enumerate(b.sources):
+        key = src.key
+        if len(key) == 2 and key[0] in form.dynamics and src.array.ndim == 3:
+            dyn = form.dynamics[key[0]]
+            m = len(getattr(dyn, "matrices", [])) - 1
+            N = src.array.shape[0]
+            if key[1] < m and src.array.shape[1] == N:          # a U_j: (N, N, n)
+                kk, ll = np.meshgrid(np.arange(N), np.arange(N), indexing="ij")
+                above = np.repeat((ll > kk).reshape(-1), src.array.shape[2])
+                off = int(arena[sid, 0])
+                zero_src[off:off + above.size] = above
+    live = ~zero_src[ops[:, 0].astype(np.int64)] if ops.size else np.zeros(0, dtype=bool)
+    Vnz = np.zeros(max(rtot, 1) * ldv, dtype=bool)
+    fd_idx, fd_ptr = fused["fd_idx"], fused["fd_ptr"]
+    for i in range(fd_idx.size):
+        Vnz[fd_idx[i]] = bool(live[fd_ptr[i]:fd_ptr[i + 1]].any())
+    Vo = Vnz.reshape(-1, ldv)[:, :no]
+    Pnz = np.zeros((no, no), dtype=bool)
+    for g in gterms:
+        if g[6] & GT_FLAG_DIAG:
+            idx = np.arange(g[0], g[0] + g[2])
+            Pnz[idx, idx] = True
+        elif g[6] & GT_FLAG_P:
+            a = Vo[g[0]:g[0] + g[2]].astype(np.int64)
+            bb = Vo[g[1]:g[1] + g[2]].astype(np.int64)
+            Pnz |= (a.T @ bb) > 0
+    Gnz = np.zeros((nc, no), dtype=bool)
+    for out0, nrows, naxes, lax0, *_ in limit_recs:
+        for r in range(nrows):
+            for ax in range(naxes):
+                off, rs = lax_recs[lax0 + ax]
+                Gnz[out0 + r] |= Vo[off + (0 if rs == 1 else r)]
+    return Pnz, Gnz
+
+
+def csc_pattern(mask, upper=False):
+    """``(indptr, indices, flat)`` of a boolean pattern in CSC order (columns, rows ascending
+    inside a column); ``flat[k] = row * ncols + col`` of the k-th stored entry.  ``upper``:
+    only ``row <= col`` (what OSQP wants of P)."""
+    mask = np.asarray(mask, dtype=bool)
+    if upper:
+        mask = np.triu(mask)
+    cols_sorted, rows_sorted = np.nonzero(mask.T)        # column by column, rows ascending
+    indptr = np.zeros(mask.shape[1] + 1, dtype=np.int32)
+    np.cumsum(np.bincount(cols_sorted, minlength=mask.shape[1]), out=indptr[1:])
+    flat = (rows_sorted.astype(np.int64) * mask.shape[1] + cols_sorted).astype(np.int32)
+    return indptr, rows_sorted.astype(np.int32), flat
+
+
 def compile_plan(form, costs=None, limits=None, lti=()):
     """Compile ``form`` (an up-to-date Formulation: sizes and IDs current).
 
@@ -970,5 +1029,7 @@ def compile_plan(form, costs=None, limits=None, lti=()):
     plan.given_ID = {v: form.given_ID[v] for v in form.given_variables}
     plan.n_gterms = len(gterms)
     plan.resident = resident
+    plan.P_pattern, plan.G_pattern = _structural_patterns(
+        form, b, fused, gterms, limit_recs, lax_recs, rtot, ldv, no, nc)
     plan.lti = [dict(name=g["name"], n=g["n"], m=g["m"], N=g["N"], ids=list(g["ids"])) for g in groups]
     return plan

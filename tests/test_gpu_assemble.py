@@ -270,6 +270,37 @@ def test_biped_batch_horizon_matrices_generated_on_chip(gpu_api, kernel_path):
         lip.update_definitions()
 
 
+def test_csc_hand_off(gpu_api):
+    """f3 (biped_mpc_loop.py:57-58): the data arrays of csc_matrix(Q), csc_matrix(A) for a
+    whole batch on one structural pattern."""
+    import scipy.sparse as sp
+    from mpcasm import engine
+
+    form = problems.biped(gpu_api, problems.BipedConfig(step_samples=8))
+    form.update(step_times=np.array([6, 14]), step_count=0)
+    batch = 130
+    rng = np.random.default_rng(8)
+    given = rng.normal(0, 0.1, [batch, form.given_len])
+    asm = engine.Assembler(form, batch=batch)
+    P, q, G, h = (t.cpu().numpy() for t in asm.assemble(given))
+    for which, dense in (("P", P), ("G", G)):
+        for upper in ((False, True) if which == "P" else (False,)):
+            indptr, indices = asm.csc_pattern(which, upper=upper)
+            data = asm.export_csc(which, upper=upper).cpu().numpy()
+            assert data.shape == (batch, indptr[-1])
+            for b in (0, 64, batch - 1):
+                mine = sp.csc_matrix((data[b], indices, indptr), shape=dense[b].shape).toarray()
+                ref = np.triu(dense[b]) if upper else dense[b]
+                assert np.array_equal(mine, ref)
+    ref = sp.csc_matrix(P[5])
+    indptr, indices = asm.csc_pattern("P")
+    assert np.array_equal(indptr, ref.indptr) and np.array_equal(indices, ref.indices)
+    assert np.array_equal(asm.export_csc("P").cpu().numpy()[5], ref.data)
+    # explicit dense input, fewer instances
+    sub = asm.export_csc("G", dense=asm.assemble(given)[2], count=7).cpu().numpy()
+    assert sub.shape[0] == 7
+
+
 def test_lipm3d_c3(gpu_api):
     """C3: N=32, 3 axes, 96 unknowns, 196 inequality rows; golden at B=1, oracle
     on sampled instances of a batch."""

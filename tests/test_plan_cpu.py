@@ -41,6 +41,39 @@ def check_plan(form, given, tol=1e-12):
     return plan
 
 
+def test_structural_csc_patterns(cpu_api):
+    """f3: the batch-wide sparsity patterns contain every numeric non-zero of the oracle's
+    P and G; with generic numbers the P pattern IS scipy's; CSC ordering as scipy's."""
+    import scipy.sparse as sp
+    from mpcasm.plan import csc_pattern
+
+    cases = [problems.biped(cpu_api, problems.BipedConfig(step_samples=8)),
+             problems.body_case(cpu_api)]
+    cases[0].update(step_times=np.array([6, 14]), step_count=0)
+    for form in cases:
+        rng = np.random.default_rng(11)
+        given = rng.standard_normal([form.given_len, 1])
+        plan = compile_plan(form)
+        A, h, Q, q = orc.assemble(form, given)
+        assert plan.P_pattern.shape == Q.shape and plan.G_pattern.shape == A.shape
+        assert ((Q != 0) <= plan.P_pattern).all() and ((A != 0) <= plan.G_pattern).all()
+        for dense, mask in ((Q, plan.P_pattern), (A, plan.G_pattern)):
+            indptr, indices, flat = csc_pattern(mask)
+            mine = sp.csc_matrix((dense.ravel()[flat], indices, indptr), shape=dense.shape)
+            assert np.array_equal(mine.toarray(), dense)
+            assert (np.diff(indptr) >= 0).all() and indptr[-1] == mask.sum() == flat.size
+            for c in range(dense.shape[1]):                      # rows ascending inside a column
+                assert (np.diff(indices[indptr[c]:indptr[c + 1]]) > 0).all()
+        up = csc_pattern(plan.P_pattern, upper=True)
+        assert (up[2] // Q.shape[1] <= up[2] % Q.shape[1]).all()
+    # the biped: U above its diagonal is a known zero, so the ZMP rows do not fill P
+    plan = compile_plan(cases[0])
+    ref = sp.csc_matrix(orc.assemble(cases[0], np.random.default_rng(1).standard_normal(
+        [cases[0].given_len, 1]))[2])
+    indptr, indices, _ = csc_pattern(plan.P_pattern)
+    assert np.array_equal(indptr, ref.indptr) and np.array_equal(indices, ref.indices)
+
+
 def test_horizon_matrices_generated_on_chip_plan(cpu_api):
     """``lti=[name]``: the image carries (A, B) and tables built from them instead of S, U;
     compose ops that read U above its diagonal are gone."""
