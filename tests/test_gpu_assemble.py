@@ -270,6 +270,41 @@ def test_biped_batch_horizon_matrices_generated_on_chip(gpu_api, kernel_path):
         lip.update_definitions()
 
 
+@pytest.mark.parametrize("nx,nu,N", [(2, 2, 6), (4, 1, 9), (5, 2, 5), (6, 3, 7)])
+def test_generated_horizon_matrices_other_systems(gpu_api, kernel_path, nx, nu, N):
+    """K1 fused for systems other than the 3-state pendulum: several inputs (U_0..U_{m-1}),
+    n = 4 (a full quad), and n > 4 (the doubling passes through LDS); horizon lengths that
+    are no powers of two.  Per-instance (A, B) against fill_su + assemble and the oracle."""
+    from mpcasm import engine
+
+    if kernel_path != "resident":
+        pytest.skip("generated sources exist in the persistent kernel only")
+    rng = np.random.default_rng(100 * nx + N)
+    form = problems.random_lti(gpu_api, rng, nx=nx, nu=nu, N=N)
+    batch = 21
+    A = np.stack([problems.random_lti_matrices(rng, nx, nu)[0] for _ in range(batch)])
+    B = np.stack([problems.random_lti_matrices(rng, nx, nu)[1] for _ in range(batch)])
+    given = rng.normal(0, 1.0, [batch, form.given_len])
+    asm = engine.Assembler(form, batch=batch, lti=["plant"])
+    assert asm.plan.resident["ok"] and asm.plan.lti[0]["n"] == nx and asm.plan.lti[0]["m"] == nu
+    asm.bind_lti("plant", A, B)
+    mine = [t.cpu().numpy() for t in asm.assemble(given)]
+    S, U = engine.fill_su(A, B, N)
+    ref = engine.Assembler(form, batch=batch)
+    for j in range(nu):
+        ref.bind_source(("plant", j), U[:, j])
+    ref.bind_source(("plant", nu), S)
+    for x, y in zip(mine, ref.assemble(given)):
+        assert_close(x, y.cpu().numpy(), RTOL_TIGHT)
+    plant = form.dynamics["plant"]
+    Sb, Ub = orc.extend_matrices(N, A[3], B[3])
+    plant.matrices = Ub + [Sb]
+    plant.update_definitions()
+    Ao, ho, Qo, qo = orc.assemble(form, given[3].reshape(-1, 1))
+    for x, y in zip(mine, (Qo, qo.ravel(), Ao, ho.ravel())):
+        assert_close(x[3], y, RTOL_TIGHT)
+
+
 def test_csc_hand_off(gpu_api):
     """f3 (biped_mpc_loop.py:57-58): the data arrays of csc_matrix(Q), csc_matrix(A) for a
     whole batch on one structural pattern."""

@@ -101,6 +101,22 @@ def test_horizon_matrices_generated_on_chip_plan(cpu_api):
             assert_close(res[key], ref, 1e-12, key)
     with pytest.raises(KeyError):
         compile_plan(form, lti=["no such dynamics"])
+    # several inputs, n > 4, a horizon that is no power of two
+    rng = np.random.default_rng(5)
+    form = problems.random_lti(cpu_api, rng, nx=5, nu=2, N=5)
+    plan = compile_plan(form, lti=["plant"])
+    g = plan.lti[0]
+    assert (g["n"], g["m"], g["N"]) == (5, 2, 5) and plan.itab[_H["RS_OK"]] == 1
+    plant = form.dynamics["plant"]
+    A_sys = plant.matrices[-1][0].T.copy()
+    B_sys = np.stack([plant.matrices[j][0, 0, :] for j in range(2)], axis=1)
+    srcs = [s.array for s in plan.sources]
+    srcs[g["ids"][0]], srcs[g["ids"][1]] = A_sys, B_sys
+    given = rng.standard_normal([form.given_len, 1])
+    res = plan_emulator.run_resident(plan, given, sources=srcs)
+    A, h, Q, q = orc.assemble(form, given)
+    for key, ref in (("P", Q), ("q", q.ravel()), ("G", A), ("h", h.ravel())):
+        assert_close(res[key], ref, 1e-12, key)
 
 
 def test_body_case_plan(cpu_api):
