@@ -166,43 +166,13 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
   const unsigned img_lds = (unsigned)(uintptr_t)(lds + L.img);  // (rs_img doubles each, rs_img_dma of them loaded)
   const int unit = p.rs_unit, nchunk = p.rs_nchunk;
 
-  // ---- once per workgroup: the compose program into registers ------------------
-  int c_sg[JC], c_dst[JC];  // c_sg: image offset of the source | of the given value << 16
-  double c_coef[JC];
+  // ---- once per workgroup, first: what the input fetch needs (stream table, per-lane load
+  // tables), so that the first instance's image is on its way while the rest is set up
   {
-    const int32_t* tsrc = p.itab + p.off_rs_src;
-    const int32_t* tg = p.itab + p.off_rs_gidx;
-    const int32_t* tdst = p.itab + p.off_rs_dst;
-    const double* tcoef = p.dtab + p.doff_rs_coef;
-#pragma unroll
-    for (int j = 0; j < JC; ++j) {
-      const bool have = j < p.rs_jc;
-      c_sg[j] = have ? (tsrc[j * NT + tid] | (tg[j * NT + tid] << 16)) : 0;
-      c_dst[j] = have ? tdst[j * NT + tid] : -1;
-      c_coef[j] = have ? tcoef[j * NT + tid] : 0.0;
-    }
-  }
-  // ---- once per workgroup: structure tables into LDS, workspace zeroed -----------
-  {
-    const int4* t4 = reinterpret_cast<const int4*>(p.itab + p.off_rs_trip);
-    for (int i = tid; i < p.rs_ntrip + 2; i += NT)
-      trips[i] = i < p.rs_ntrip ? t4[i] : int4{0, 0, 0, 0};
-    const int32_t* t = p.itab + p.off_rs_wtrip;
-    for (int i = tid; i < RS_WAVES * 2; i += NT) wtrip[i] = t[i];
-    t = p.itab + p.off_rs_rr;  // row records of G, precomputed by the plan compiler
-    for (int i = tid; i < nc * RR_WORDS; i += NT) rr[i] = t[i];
-    t = p.itab + p.off_rs_split;
-    for (int i = tid; i < p.rs_nsplit; i += NT) split[i] = t[i];
-    t = p.itab + p.off_rs_lti;
-    for (int i = tid; i < p.rs_nlti * RS_LTI_WORDS; i += NT) lti[i] = t[i];
     const int2* t2 = reinterpret_cast<const int2*>(p.itab + p.off_rs_abmeta);
     for (int i = tid; i < p.rs_ab * 2; i += NT) abmeta[i] = t2[i];
     t2 = reinterpret_cast<const int2*>(p.itab + p.off_rs_inmeta);
     for (int i = tid; i < nchunk * 64; i += NT) meta[i] = t2[i];
-    double2* V2 = reinterpret_cast<double2*>(V);
-    const int n2 = (even_up_i(p.rtot * ldv) + 15 * ldv + 16) / 2;
-    for (int i = tid; i < n2; i += NT) V2[i] = double2{0.0, 0.0};
-    for (int i = tid; i < 2 * ldp; i += NT) dvec[i] = 0.0;  // stays zero without diagonal gterms
     // input streams: the sources, then given, params, the plan's constants
     if (tid < p.nsrc + 3) {
       const int s = tid - p.nsrc;
@@ -213,35 +183,8 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
       reinterpret_cast<const double**>(strm)[2 * tid] = base;
       reinterpret_cast<long long*>(strm)[2 * tid + 1] = stride * (long long)sizeof(double);
     }
-    if (p.ndiag != 0 && tid < no) {
-      // the diagonal gterms on column tid; free slots read the 0.0 behind the parameters
-      int4 par = int4{p.nparams, p.nparams, p.nparams, p.nparams};
-      double2 co = double2{0.0, 0.0};
-      const int32_t* gt = p.itab + p.off_gterm;
-      int n = 0;
-      for (int g = 0; g < p.ngterm; ++g) {
-        const int32_t* rec = gt + g * GT_WORDS;
-        const int k = tid - rec[GT_AOFF];
-        if (!(rec[GT_FLAGS] & GT_FLAG_DIAG) || k < 0 || k >= rec[GT_NROWS] || n >= RS_DIAG_MAX)
-          continue;
-        const double cf = (p.dtab + p.doff_diagcoef)[rec[GT_BOFF] + k];
-        if (n == 0) {
-          par.x = rec[GT_WPARAM];
-          par.y = rec[GT_AIMPARAM];
-          co.x = cf;
-        } else {
-          par.z = rec[GT_WPARAM];
-          par.w = rec[GT_AIMPARAM];
-          co.y = cf;
-        }
-        ++n;
-      }
-      dpar[tid] = par;
-      dcoef[tid] = co;
-    }
   }
   lds_barrier();
-
   // The matrix waves fetch instance `inst`'s image into buffer `buf` (chunks dealt round
   // robin).  With registers to spare (FK > 0) a lane keeps the address of its piece of the
   // first FK chunks of its wave -- pointer into instance 0 and bytes per instance -- so that
@@ -394,14 +337,78 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
       }
     }
   };
-  const bool lookahead = (phases & 128) != 0;  // diagnostic: off = fetch only when needed
-  if (wave < MW) {
+  if (wave < MW) {  // the first instance's inputs start their trip now
     fetch_image(blockIdx.x, 0);
     if (wave == 0 && p.rs_nlti != 0) {
       fetch_ab(blockIdx.x, 0);
       if ((long)blockIdx.x + gridDim.x < batch) fetch_ab((long)blockIdx.x + gridDim.x, 1);
     }
-    dma_wait();
+  }
+  // ---- once per workgroup: the compose program into registers ------------------
+  int c_sg[JC], c_dst[JC];  // c_sg: image offset of the source | of the given value << 16
+  double c_coef[JC];
+  {
+    const int32_t* tsrc = p.itab + p.off_rs_src;
+    const int32_t* tg = p.itab + p.off_rs_gidx;
+    const int32_t* tdst = p.itab + p.off_rs_dst;
+    const double* tcoef = p.dtab + p.doff_rs_coef;
+#pragma unroll
+    for (int j = 0; j < JC; ++j) {
+      const bool have = j < p.rs_jc;
+      c_sg[j] = have ? (tsrc[j * NT + tid] | (tg[j * NT + tid] << 16)) : 0;
+      c_dst[j] = have ? tdst[j * NT + tid] : -1;
+      c_coef[j] = have ? tcoef[j * NT + tid] : 0.0;
+    }
+  }
+  // ---- once per workgroup: structure tables into LDS, workspace zeroed -----------
+  {
+    const int4* t4 = reinterpret_cast<const int4*>(p.itab + p.off_rs_trip);
+    for (int i = tid; i < p.rs_ntrip + 2; i += NT)
+      trips[i] = i < p.rs_ntrip ? t4[i] : int4{0, 0, 0, 0};
+    const int32_t* t = p.itab + p.off_rs_wtrip;
+    for (int i = tid; i < RS_WAVES * 2; i += NT) wtrip[i] = t[i];
+    t = p.itab + p.off_rs_rr;  // row records of G, precomputed by the plan compiler
+    for (int i = tid; i < nc * RR_WORDS; i += NT) rr[i] = t[i];
+    t = p.itab + p.off_rs_split;
+    for (int i = tid; i < p.rs_nsplit; i += NT) split[i] = t[i];
+    t = p.itab + p.off_rs_lti;
+    for (int i = tid; i < p.rs_nlti * RS_LTI_WORDS; i += NT) lti[i] = t[i];
+    double2* V2 = reinterpret_cast<double2*>(V);
+    const int n2 = (even_up_i(p.rtot * ldv) + 15 * ldv + 16) / 2;
+    for (int i = tid; i < n2; i += NT) V2[i] = double2{0.0, 0.0};
+    for (int i = tid; i < 2 * ldp; i += NT) dvec[i] = 0.0;  // stays zero without diagonal gterms
+    if (p.ndiag != 0 && tid < no) {
+      // the diagonal gterms on column tid; free slots read the 0.0 behind the parameters
+      int4 par = int4{p.nparams, p.nparams, p.nparams, p.nparams};
+      double2 co = double2{0.0, 0.0};
+      const int32_t* gt = p.itab + p.off_gterm;
+      int n = 0;
+      for (int g = 0; g < p.ngterm; ++g) {
+        const int32_t* rec = gt + g * GT_WORDS;
+        const int k = tid - rec[GT_AOFF];
+        if (!(rec[GT_FLAGS] & GT_FLAG_DIAG) || k < 0 || k >= rec[GT_NROWS] || n >= RS_DIAG_MAX)
+          continue;
+        const double cf = (p.dtab + p.doff_diagcoef)[rec[GT_BOFF] + k];
+        if (n == 0) {
+          par.x = rec[GT_WPARAM];
+          par.y = rec[GT_AIMPARAM];
+          co.x = cf;
+        } else {
+          par.z = rec[GT_WPARAM];
+          par.w = rec[GT_AIMPARAM];
+          co.y = cf;
+        }
+        ++n;
+      }
+      dpar[tid] = par;
+      dcoef[tid] = co;
+    }
+  }
+  lds_barrier();
+
+  const bool lookahead = (phases & 128) != 0;  // diagnostic: off = fetch only when needed
+  if (wave < MW) {
+    dma_wait();  // the first image (requested before the set-up above) has landed
     if (wave == 0 && p.rs_nlti != 0) generate_sources(0, 0);  // the first instance's tables
   }
 
