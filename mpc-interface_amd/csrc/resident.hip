@@ -126,7 +126,9 @@ __device__ __forceinline__ double quad_broadcast(double v) {
 }
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-template <int JC, bool STAMPS>
+// GEN: the plan has source groups generated on chip (K1 fused); without them that code is
+// not even compiled in, it costs registers
+template <int JC, bool STAMPS, bool GEN>
 __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
     PlanDev p, SrcTable src, const double* __restrict__ params, const double* __restrict__ given,
     double* __restrict__ P, double* __restrict__ q, double* __restrict__ G,
@@ -339,7 +341,7 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
   };
   if (wave < MW) {  // the first instance's inputs start their trip now
     fetch_image(blockIdx.x, 0);
-    if (wave == 0 && p.rs_nlti != 0) {
+    if (wave == 0 && (GEN && p.rs_nlti != 0)) {
       fetch_ab(blockIdx.x, 0);
       if ((long)blockIdx.x + gridDim.x < batch) fetch_ab((long)blockIdx.x + gridDim.x, 1);
     }
@@ -409,7 +411,7 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
   const bool lookahead = (phases & 128) != 0;  // diagnostic: off = fetch only when needed
   if (wave < MW) {
     dma_wait();  // the first image (requested before the set-up above) has landed
-    if (wave == 0 && p.rs_nlti != 0) generate_sources(0, 0);  // the first instance's tables
+    if (wave == 0 && (GEN && p.rs_nlti != 0)) generate_sources(0, 0);  // the first instance's tables
   }
 
   // ---- K4 bookkeeping of the worker threads: piece e = wt + u WT of G is the 16 bytes
@@ -476,7 +478,7 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
       // the next instance's image starts its trip from HBM now
       if (lookahead && nxt < batch && (phases & 16)) fetch_image(nxt, buf ^ 1);
       // ... and, two instances ahead, the (A, B) of the systems whose matrices are built here
-      if (wave == 0 && p.rs_nlti != 0 && nxt + gridDim.x < batch) fetch_ab(nxt + gridDim.x, buf);
+      if (wave == 0 && (GEN && p.rs_nlti != 0) && nxt + gridDim.x < batch) fetch_ab(nxt + gridDim.x, buf);
       MPCASM_STAMP(7)
     } else {
       compose();
@@ -594,7 +596,7 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
       }
       // the last stream wave builds the next instance's horizon tables (its (A, B) landed
       // and were waited for by wave 0 a whole instance ago)
-      if (wave == RS_WAVES - 1 && p.rs_nlti != 0 && nxt < batch) generate_sources(buf ^ 1, buf ^ 1);
+      if (wave == RS_WAVES - 1 && (GEN && p.rs_nlti != 0) && nxt < batch) generate_sources(buf ^ 1, buf ^ 1);
       MPCASM_STAMP(3)
     }
     if (P != nullptr && (phases & 2)) {
@@ -731,13 +733,15 @@ int launch_jc(const PlanDev& p, const SrcTable& src, const double* params, const
               double* P, double* q, double* G, double* h, void* work, int batch, size_t lds_bytes,
               int num_cus, hipStream_t stream, hipError_t* err) {
   // the stamped instantiation exists for the diagnostic option only
-  auto kernel = (g_phase_mask & 64) ? resident_assemble_kernel<JC, true>
-                                    : resident_assemble_kernel<JC, false>;
+  // (the stamped instantiation exists once, with everything compiled in)
+  auto kernel = (g_phase_mask & 64) ? resident_assemble_kernel<JC, true, true>
+                : p.rs_nlti != 0    ? resident_assemble_kernel<JC, false, true>
+                                    : resident_assemble_kernel<JC, false, false>;
   // residency of this instantiation at this LDS size: queried once, then cached (the
   // launch path itself makes no other runtime call, so it can be graph-captured)
-  static thread_local size_t cached_lds[2] = {0, 0};
-  static thread_local int cached_per_cu[2] = {0, 0};
-  const int slot = (g_phase_mask & 64) ? 1 : 0;
+  static thread_local size_t cached_lds[3] = {0, 0, 0};
+  static thread_local int cached_per_cu[3] = {0, 0, 0};
+  const int slot = (g_phase_mask & 64) ? 2 : (p.rs_nlti != 0 ? 1 : 0);
   if (cached_lds[slot] != lds_bytes) {
     if (lds_bytes > 64 * 1024) {
       *err = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
