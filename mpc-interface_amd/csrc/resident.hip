@@ -272,14 +272,16 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
       double* TA = im + rec[LT_TA];
       double* TB = im + rec[LT_TB];
       double* TP = im + rec[LT_TP];
-      if (n <= 4 && n + m <= 16) {
-        // Small systems: the reference's own recurrence X_d = A X_{d-1}, X_0 = [B | A]
-        // (tools.py:21-30) in registers.  Lane 4 c + i holds element i of column c, so the
-        // n values a lane needs of its column sit in its own quad: three DPP quad
-        // broadcasts and n FMAs (in the reference's order t = 0 .. n-1) per step, no LDS
-        // round trip, nothing on the matrix core that the Hessian tiles of the other
-        // workgroup on this SIMD are using.
-        const int gi = lane & 3, gc = lane >> 2;
+      if (n <= 4 && n + m <= 4) {
+        // Small systems: the recurrence X_d = A X_{d-1}, X_0 = [B | A] (tools.py:21-30) in
+        // registers.  Lane 4 c + i of a group of 16 holds element i of column c, so the n
+        // values a lane needs of its column sit in its own quad: DPP quad broadcasts and
+        // n FMAs per step, no LDS round trip, nothing on the matrix core that the Hessian
+        // tiles are using.  The chain is cut in four: group 0 makes X_0..X_3 the
+        // reference's way (three steps; the A part of X_3 is A^4), then the four groups of
+        // 16 lanes advance X_r, r = 0..3, by A^4 per step, side by side -- six dependent
+        // steps instead of fifteen for N = 16 (a few ulp from the reference's rounding).
+        const int grp = lane >> 4, gi = lane & 3, gc = (lane >> 2) & 3;
         const bool live = gi < n && gc < n + m;
         double ar[4];
 #pragma unroll
@@ -288,14 +290,27 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
         // element (i, c) of block d: TB[d][i][c] or TA[d][i][c - m]
         double* out = gc < m ? TB + gi * m + gc : TA + gi * n + (gc - m);
         const int step = gc < m ? nm : nn;
-        for (int d = 0; d < N; ++d) {
-          if (live) out[d * step] = x;
-          // x[t] of this lane's column is in lane t of the quad
+        auto advance = [&]() {  // x <- (matrix in ar) . x; x[t] of a column is in lane t of the quad
           double y = ar[0] * quad_broadcast<0>(x);
           y = fma(ar[1], quad_broadcast<1>(x), y);
           y = fma(ar[2], quad_broadcast<2>(x), y);
           y = fma(ar[3], quad_broadcast<3>(x), y);
           x = y;
+        };
+        const int head = N < 4 ? N : 4;
+        for (int d = 0; d < head; ++d) {
+          if (live && grp == 0) out[d * step] = x;
+          advance();
+        }
+        if (N > 4) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int t = 0; t < 4; ++t) ar[t] = gi < n && t < n ? TA[3 * nn + gi * n + t] : 0.0;  // A^4
+          x = live ? out[grp * step] : 0.0;  // X_grp
+          for (int d = grp + 4; d - grp < N; d += 4) {
+            advance();
+            if (live && d < N) out[d * step] = x;
+          }
         }
         continue;
       }
