@@ -676,25 +676,40 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
                 if (2 * u < rows) acc = mfma_f64_16x16x4(2 * u + krow < rows ? a[u] : 0.0, b[u], acc);
             }
             if ((word >> RT_LAST) & 1) {  // the tile is complete: into P (and q) in LDS
+              // Predicates are taken per tile, not per element: full row blocks need no row
+              // test, column validity is one mask for the four stores of a lane.
               const int ti = (word >> RT_TI) & 127, tj = (word >> RT_TJ) & 127;
               const int row0 = ti * 16 + lk, col = tj * 16 + li;
               const bool mirror = p.rs_sym && ti != tj;
-              const bool inside = ti * 16 + 16 <= no && tj * 16 + 16 <= no;
-              // the diagonal addend of this lane's column (zero unless diagonal gterms exist)
-              const double dg = ti == tj ? dvec[col < ldp ? col : 0] : 0.0;
+              const bool rows_full = ti * 16 + 16 <= no;  // wave-uniform
+              if (ti == tj) {  // the diagonal addend of this lane's column, where row == col
+                const double dg = dvec[col < ldp ? col : 0];  // (never in the lane of column `no`)
 #pragma unroll
-              for (int reg = 0; reg < 4; ++reg) {
-                const int row = row0 + 4 * reg;
-                const double v = acc[reg] + (row == col ? dg : 0.0);
-                if (inside || (row < no && col < no)) {
-                  Pl[row * ldp + col] = v;
-                  if (mirror) Pl[col * ldp + row] = v;
-                }
+                for (int reg = 0; reg < 4; ++reg) acc[reg] += lk + 4 * reg == li ? dg : 0.0;
               }
-              if (col == no) {
+              if (col < no) {
+                double* pt = Pl + row0 * ldp + col;
+                double* pm = Pl + col * ldp + row0;
+                if (rows_full) {
+#pragma unroll
+                  for (int reg = 0; reg < 4; ++reg) pt[reg * 4 * ldp] = acc[reg];
+                  if (mirror) {
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) pm[4 * reg] = acc[reg];
+                  }
+                } else {
+#pragma unroll
+                  for (int reg = 0; reg < 4; ++reg)
+                    if (row0 + 4 * reg < no) {
+                      pt[reg * 4 * ldp] = acc[reg];
+                      if (mirror) pm[4 * reg] = acc[reg];
+                    }
+                }
+              } else if (col == no) {
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg)
-                  if (row0 + 4 * reg < no) ql[row0 + 4 * reg] = acc[reg] + dvec[ldp + row0 + 4 * reg];
+                  if (rows_full || row0 + 4 * reg < no)
+                    ql[row0 + 4 * reg] = acc[reg] + dvec[ldp + row0 + 4 * reg];
               }
               acc = f64x4{0.0, 0.0, 0.0, 0.0};
             }
