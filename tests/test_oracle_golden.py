@@ -64,6 +64,47 @@ def test_extend_matrices_structure():
                 assert_close(U[j][k, l], want, 1e-12)
 
 
+@pytest.fixture(scope="module")
+def c_oracle():
+    """The compiled twin (oracle/extend_matrices.c); built here when it is not yet."""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["make", "-C", os.path.join(root, "oracle")], check=True,
+                   stdout=subprocess.DEVNULL)
+    from oracle import c_oracle as c
+
+    c.load()
+    return c
+
+
+def test_c_restatement_against_the_reference_vectors(c_oracle):
+    """oracle/extend_matrices.c: the reference's known-answer fixture, the seeded random
+    systems, the numpy oracle (same recurrence; BLAS may sum in another order),
+    and the LTV variant against its numpy counterpart."""
+    g = golden("g1_extend")
+    S, U = c_oracle.extend_matrices(36, g["lip36/A"], g["lip36/B"])
+    assert_close(S, g["lip36/S"], what="S")
+    assert_close(U[0], g["lip36/U0"], what="U")
+    for n, m, N in [(3, 1, 16), (8, 6, 20), (12, 6, 64), (1, 1, 5), (2, 3, 1)]:
+        key = "lti_n%d_m%d_N%d/" % (n, m, N)
+        A, B = g[key + "A"], g[key + "B"]
+        S, U = c_oracle.extend_matrices(N, A, B)
+        So, Uo = orc.extend_matrices(N, A, B)
+        assert_close(S, g[key + "S"], what="S")
+        assert_close(S, So, 1e-13)
+        assert_close(np.stack(U), np.stack(Uo), 1e-13)
+    rng = np.random.default_rng(9)
+    A = rng.standard_normal((3, 7, 4, 4)) / 2
+    B = rng.standard_normal((3, 7, 4, 2))
+    S, U = c_oracle.extend_matrices_batch(A, B, 7, ltv=True)
+    for b in range(3):
+        So, Uo = orc.extend_matrices_ltv(7, A[b], B[b])
+        assert_close(S[b], So, 1e-14)
+        assert_close(U[b], np.stack(Uo), 1e-14)
+
+
 # ---------------------------------------------------------------------- G2 .. G6
 def check_snapshot(form, g, prefix):
     """Index maps bit-exact; PM, per-part blocks and stacked blocks within RTOL."""
