@@ -148,3 +148,32 @@ def test_kernels_random(gpu_api, path):
                 assert_close(pm[r0:r0 + rows, asm.ng:], PM[var][1], RTOL_TIGHT, var)
     finally:
         lib.mpcasm_set_option(capi.OPT_PATH, 0)
+
+
+@pytest.mark.gpu
+def test_persistent_kernel_instance_loop(gpu_api):
+    """Several instances per workgroup (double-buffered input images, clearing of shared
+    workspace elements, P / q reuse): every instance of the persistent kernel against the
+    staged pipeline, with per-instance parameters."""
+    import torch
+
+    from mpcasm import capi
+    from mpcasm.engine import Assembler
+
+    lib = capi.load()
+    batch = 1300
+    try:
+        for seed in SEEDS[:12]:
+            form, rng = random_formulation(gpu_api, seed)
+            given = rng.standard_normal([batch, form.given_len])
+            asm = Assembler(form, batch=batch)
+            asm.params[:] = asm.params * torch.as_tensor(
+                rng.uniform(0.5, 1.5, tuple(asm.params.shape)), device=asm.params.device)
+            out = {}
+            for path in (2, 0):
+                assert lib.mpcasm_set_option(capi.OPT_PATH, path) == 0
+                out[path] = [t.cpu().numpy().copy() for t in asm.assemble(given)]
+            for a, b, name in zip(out[0], out[2], "PqGh"):
+                assert_close(a, b, 1e-12, "%s seed %d" % (name, seed))
+    finally:
+        lib.mpcasm_set_option(capi.OPT_PATH, 0)
