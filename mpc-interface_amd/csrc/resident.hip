@@ -59,11 +59,19 @@ static_assert(RS_DIAG_MAX == 2, "the per-column diagonal table holds two terms")
 
 __host__ __device__ inline int even_up_i(int x) { return (x + 1) & ~1; }
 
+// G by the fast path: every stream-wave thread owns at most GU 16-byte pieces (columns 2cp,
+// 2cp+1 of a row), rows have at most two axes, workspace offsets and parameter indices fit
+// 16 bits
+__host__ __device__ inline bool resident_g_fast(const PlanDev& p) {
+  return (p.no & 1) == 0 && p.max_axes <= 2 && (long)p.nc * (p.no >> 1) <= (long)GU * WT &&
+         (long)p.rtot * p.ldv + 15 * p.ldv + 16 < 65536 && p.nparams < 65535;
+}
+
 struct ResidentLayout {
   // offsets in doubles
   int v, pl, ql, dvec, dcoef, dpar, img, ab, streams, ints, total_doubles;
   int ldp;                                            // leading dimension of P in LDS
-  int i_trip, i_rr, i_meta, i_wtrip, i_split, i_lti, i_abmeta;  // offsets in ints inside the int region
+  int i_trip, i_rr, i_meta, i_wtrip, i_split, i_lti, i_abmeta, i_gdesc;  // offsets in ints inside the int region
 };
 
 __host__ __device__ inline ResidentLayout resident_layout(const PlanDev& p) {
@@ -87,6 +95,7 @@ __host__ __device__ inline ResidentLayout resident_layout(const PlanDev& p) {
   L.i_rr = i;    i += p.nc * RR_WORDS;
   L.i_meta = i;  i += p.rs_nchunk * 64 * 2;
   L.i_abmeta = i; i += p.rs_ab * 2 * 2;
+  L.i_gdesc = i;  i += resident_g_fast(p) ? GU * WT * 2 : 0;  // per-thread piece descriptors of G
   L.i_wtrip = i; i += RS_WAVES * 2;
   L.i_split = i; i += p.rs_nsplit;
   L.i_lti = i;   i += p.rs_nlti * RS_LTI_WORDS;
@@ -164,6 +173,7 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
   int* split = itb + L.i_split;
   int* lti = itb + L.i_lti;
   int2* abmeta = reinterpret_cast<int2*>(itb + L.i_abmeta);
+  int2* gdesc = reinterpret_cast<int2*>(itb + L.i_gdesc);  // [GU][WT]
   // LDS byte address of the image double buffer (the low half of a flat LDS address)
   const unsigned img_lds = (unsigned)(uintptr_t)(lds + L.img);  // (rs_img doubles each, rs_img_dma of them loaded)
   const int unit = p.rs_unit, nchunk = p.rs_nchunk;
@@ -394,6 +404,20 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
     const int n2 = (even_up_i(p.rtot * ldv) + 15 * ldv + 16) / 2;
     for (int i = tid; i < n2; i += NT) V2[i] = double2{0.0, 0.0};
     for (int i = tid; i < 2 * ldp; i += NT) dvec[i] = 0.0;  // stays zero without diagonal gterms
+    if (resident_g_fast(p) && tid >= MW * 64) {
+      // piece e = wt + u WT of G: columns 2cp, 2cp+1 of row R = e / npair.  What the piece
+      // needs -- the workspace offsets of its (two) source rows at those columns and the
+      // parameter slots of their arrows -- is fixed: packed once, read back as 8 bytes
+      const int wt_ = tid - MW * 64, np_ = no >> 1, gt_ = nc * np_;
+      const int32_t* rrg = p.itab + p.off_rs_rr;
+      for (int u = 0; u < GU; ++u) {
+        const int e = wt_ + u * WT;
+        const int R = e < gt_ ? e / np_ : 0, cp = e < gt_ ? e - R * np_ : 0;
+        const int32_t* rec = rrg + R * RR_WORDS;
+        gdesc[u * WT + wt_] = int2{(rec[RR_VOFF] + 2 * cp) | ((rec[RR_VOFF + 1] + 2 * cp) << 16),
+                                   rec[RR_ARROW] | (rec[RR_ARROW + 1] << 16)};
+      }
+    }
     if (p.ndiag != 0 && tid < no) {
       // the diagonal gterms on column tid; free slots read the 0.0 behind the parameters
       int4 par = int4{p.nparams, p.nparams, p.nparams, p.nparams};
@@ -434,10 +458,7 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
   const int wt = tid - MW * 64;  // index among the worker threads (negative on MFMA waves)
   const int npair = no >> 1;
   const int gtotal = nc * npair;
-  const bool g_fast = (no & 1) == 0 && p.max_axes <= 2 && (long)gtotal <= (long)GU * WT;
-  const int g_dR = npair > 0 ? WT / npair : 0, g_dcp = npair > 0 ? WT - g_dR * npair : 0;
-  const int g_R0 = npair > 0 && wt >= 0 ? wt / npair : 0;
-  const int g_cp0 = npair > 0 && wt >= 0 ? wt - g_R0 * npair : 0;
+  const bool g_fast = resident_g_fast(p);
 
   const int qli = no & 15;  // the lane column that holds d in the last tile column
 
@@ -503,42 +524,28 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
         // ---- K4: constraint rows straight to HBM ---------------------------------------
         double* Gb = G + (size_t)inst * nc * no;
         if (g_fast) {
-          // three batches of dependent LDS reads for all pieces of the thread at once:
-          // row records -> arrows and workspace rows -> arithmetic -> 16-byte stores
+          // per piece: its packed descriptor -> arrows and workspace rows -> arithmetic ->
+          // one 16-byte store; the reads of three pieces are in flight together
           double2* G2 = reinterpret_cast<double2*>(Gb);
-          int R = g_R0, cp = g_cp0;
-          // keep the compiler from hoisting the record addresses out of the instance loop
-          // (they would live in registers for the whole launch and spill)
-          asm volatile("" : "+v"(R), "+v"(cp));
+          int wt_ = wt;  // opaque copy: nothing derived from it is kept across instances
+          asm volatile("" : "+v"(wt_));
 #pragma unroll
-          for (int u0 = 0; u0 < GU; u0 += 3) {  // three pieces per trip
-            int2 vo[3], ai[3];
+          for (int u0 = 0; u0 < GU; u0 += 3) {
+            int2 ds[3];
 #pragma unroll
-            for (int u = 0; u < 3; ++u) {
-              const int* rec = rr + (R < nc ? R : 0) * RR_WORDS;
-              vo[u] = *reinterpret_cast<const int2*>(rec + RR_VOFF);
-              ai[u] = *reinterpret_cast<const int2*>(rec + RR_ARROW);
-              vo[u].x += 2 * cp;
-              vo[u].y += 2 * cp;
-              cp += g_dcp;
-              R += g_dR;
-              if (cp >= npair) {
-                cp -= npair;
-                ++R;
-              }
-            }
+            for (int u = 0; u < 3; ++u) ds[u] = gdesc[(u0 + u) * WT + wt_];
             double a0[3], a1[3];
             double2 v0[3], v1[3];
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
-              a0[u] = prm[ai[u].x];
-              a1[u] = prm[ai[u].y];
-              v0[u] = *reinterpret_cast<const double2*>(V + vo[u].x);
-              v1[u] = *reinterpret_cast<const double2*>(V + vo[u].y);
+              a0[u] = prm[ds[u].y & 0xFFFF];
+              a1[u] = prm[(unsigned)ds[u].y >> 16];
+              v0[u] = *reinterpret_cast<const double2*>(V + (ds[u].x & 0xFFFF));
+              v1[u] = *reinterpret_cast<const double2*>(V + ((unsigned)ds[u].x >> 16));
             }
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
-              const int e = wt + (u0 + u) * WT;
+              const int e = wt_ + (u0 + u) * WT;
               double2 r;
               r.x = fma(a1[u], v1[u].x, a0[u] * v0[u].x);
               r.y = fma(a1[u], v1[u].y, a0[u] * v0[u].y);
