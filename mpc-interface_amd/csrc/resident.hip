@@ -739,7 +739,10 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
     MPCASM_STAMP(5)
     if (P != nullptr && (phases & 32)) {
       double* Pb = P + (size_t)inst * no * no;
-      int t_ = tid;
+      // the thread index runs from the stream waves round to the matrix waves, so that what
+      // does not divide evenly (and q) falls to the waves that are not busy with the next
+      // image: thread t of this phase is thread (t + MW * 64) % NT of the workgroup
+      int t_ = tid >= MW * 64 ? tid - MW * 64 : tid + WT;
       asm volatile("" : "+v"(t_));
       if ((no & 1) == 0) {
         // ldp == no here, so P in LDS is dense: a flat 16-byte copy
