@@ -390,11 +390,17 @@ __global__ __launch_bounds__(BLOCK) void fill_ltv_kernel(const double* __restric
 // wavefront double-buffers the block row AND the step matrices in its own LDS slice,
 // loads (A_{k+1}, B_{k+1}) into registers while row k is being produced, and needs one
 // wave-level LDS sync per step.
-__host__ __device__ inline size_t ltv_wave_lds_doubles(int N, int n, int m) {
+// ALL: every step's (A_k, B_k) of the system sits in LDS from the start (one wait, before the
+// first store); otherwise two slots, refilled from HBM a step ahead.  A wavefront that must
+// wait for a load while its row stores are in flight waits for the stores too (one vmcnt
+// counts both), i.e. one HBM write round trip per step: ALL is several times faster whenever
+// the N (n^2 + n m) doubles fit.
+__host__ __device__ inline size_t ltv_wave_lds_doubles(int N, int n, int m, bool all = false) {
   return 2 * even_up((size_t)m * N * n) + 2 * even_up((size_t)n * n) +
-         2 * (even_up((size_t)n * n) + even_up((size_t)n * m));
+         (all ? (size_t)N : 2) * (even_up((size_t)n * n) + even_up((size_t)n * m));
 }
 
+template <bool ALL>
 __global__ __launch_bounds__(BLOCK) void fill_ltv_wave_kernel(const double* __restrict__ A,
                                                               const double* __restrict__ B,
                                                               double* __restrict__ S,
@@ -408,7 +414,7 @@ __global__ __launch_bounds__(BLOCK) void fill_ltv_wave_kernel(const double* __re
   const int rl = N * n, nn = n * n, nm = n * m;
   const size_t rstep = even_up((size_t)m * rl), pstep = even_up((size_t)nn);
   const size_t abstep = even_up((size_t)nn) + even_up((size_t)nm);
-  double* Rw = lds + (size_t)wave * ltv_wave_lds_doubles(N, n, m);  // [2][m][rl]
+  double* Rw = lds + (size_t)wave * ltv_wave_lds_doubles(N, n, m, ALL);  // [2][m][rl]
   double* Pk = Rw + 2 * rstep;                                      // [2][n][n] as [j][i]
   double* AB = Pk + 2 * pstep;                                      // [2]{A_k [n][n], B_k [n][m]}
 
@@ -424,9 +430,18 @@ __global__ __launch_bounds__(BLOCK) void fill_ltv_wave_kernel(const double* __re
 
   // both row buffers start as zeros: the blocks right of the diagonal are never written
   for (size_t e = lane; e < 2 * rstep; e += 64) Rw[e] = 0.0;
-  // step 0 matrices
-  for (int e = lane; e < nn; e += 64) AB[e] = Ab[e];
-  for (int e = lane; e < nm; e += 64) AB[even_up((size_t)nn) + e] = Bb[e];
+  // step 0 matrices (ALL: those of every step)
+  {  // (flat, coalesced copies: the steps' matrices are contiguous in HBM)
+    const int na = (ALL ? N : 1) * nn, nb = (ALL ? N : 1) * nm;
+    for (int i = lane; i < na; i += 64) {
+      const int k = i / nn;
+      AB[k * abstep + (i - k * nn)] = Ab[i];
+    }
+    for (int i = lane; i < nb; i += 64) {
+      const int k = i / nm;
+      AB[k * abstep + even_up((size_t)nn) + (i - k * nm)] = Bb[i];
+    }
+  }
   wave_lds_sync();
 
   auto stream_row = [&](const double* Rrow, int k) {
@@ -444,7 +459,7 @@ __global__ __launch_bounds__(BLOCK) void fill_ltv_wave_kernel(const double* __re
   };
 
   for (int k = 0; k < N; ++k) {
-    const double* Ak = AB + (k & 1) * abstep;
+    const double* Ak = AB + (ALL ? k : (k & 1)) * abstep;
     const double* Bk = Ak + even_up((size_t)nn);
     double* ABn = AB + ((k + 1) & 1) * abstep;
     const double* Rp = Rw + ((k + 1) & 1) * rstep;  // row k-1
@@ -455,7 +470,7 @@ __global__ __launch_bounds__(BLOCK) void fill_ltv_wave_kernel(const double* __re
     // next step's matrices leave HBM now (register staged; at most 2 + 1 values per lane
     // on the small shapes this kernel is dispatched for)
     double an[2] = {0.0, 0.0}, bn = 0.0;
-    const bool more = k + 1 < N;
+    const bool more = !ALL && k + 1 < N;
     if (more) {
       if (lane < nn) an[0] = Ab[(size_t)(k + 1) * nn + lane];
       if (lane + 64 < nn) an[1] = Ab[(size_t)(k + 1) * nn + lane + 64];
@@ -556,10 +571,19 @@ int launch_fill_su(const double* A, const double* B, double* S, double* U, int b
     const size_t per = ltv_lds_doubles(N, n, m) * sizeof(double);
     const bool small = n <= 64 && per * 4 <= 64 * 1024 && N * n <= 1024;
     const size_t wper = ltv_wave_lds_doubles(N, n, m) * sizeof(double) * 4;
-    if (n * n <= 128 && n * m <= 64 && wper <= 64 * 1024) {
+    const size_t wall = ltv_wave_lds_doubles(N, n, m, true) * sizeof(double) * 4;
+    if (n * n <= 128 && n * m <= 64 && wall <= 80 * 1024 && batch < 8192) {
+      // every step's (A_k, B_k) resident (two workgroups per CU still fit): measured faster
+      // while the batch leaves the CUs a single round of workgroups (C5: 0.43 against 0.35
+      // of HBM peak at 2 048 systems), slower beyond (0.43 against 0.53 at 16 384)
+      if ((*err = allow_lds(fill_ltv_wave_kernel<true>, wall)) != hipSuccess) return MPCASM_ERR_HIP;
       const int blocks = (batch + 3) / 4;
-      hipLaunchKernelGGL(fill_ltv_wave_kernel, dim3(blocks), dim3(BLOCK), wper, stream, A, B, S, U,
-                         batch, N, n, m);
+      hipLaunchKernelGGL(fill_ltv_wave_kernel<true>, dim3(blocks), dim3(BLOCK), wall, stream, A, B,
+                         S, U, batch, N, n, m);
+    } else if (n * n <= 128 && n * m <= 64 && wper <= 64 * 1024) {
+      const int blocks = (batch + 3) / 4;
+      hipLaunchKernelGGL(fill_ltv_wave_kernel<false>, dim3(blocks), dim3(BLOCK), wper, stream, A, B,
+                         S, U, batch, N, n, m);
     } else if (small) {
       const size_t bytes = per * 4;
       const int blocks = (batch + 3) / 4;
