@@ -386,6 +386,135 @@ __global__ __launch_bounds__(BLOCK) void fill_ltv_kernel(const double* __restric
   }
 }
 
+// LTV, one 256-thread workgroup per system, no HBM read inside the step loop: every
+// step's (A_k, B_k) is copied to LDS up front (one wait, before the first store), so the
+// loop only computes and stores and its barriers order LDS only -- a barrier or a load wait
+// that drained vmcnt would cost one HBM write round trip per step.  Step k: thread (l, i)
+// makes element i of block l <= k of row k from row k-1, while row k-1 -- complete, zeros
+// right of the diagonal included -- streams to HBM as 16-byte stores.  LDS per system: two
+// rows + N (n^2 + n m) doubles: a few KB, so eight workgroups share a CU and the store
+// stream of one hides the recurrence of the others.
+__host__ __device__ inline size_t ltv_block_lds_doubles(int N, int n, int m) {
+  return 2 * even_up((size_t)m * N * n) + 2 * even_up((size_t)n * n) +
+         (size_t)N * (even_up((size_t)n * n) + even_up((size_t)n * m));
+}
+
+__device__ __forceinline__ void block_lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+// NS: the number of states when it is small (the products unroll, A_k's row lives in
+// registers), 0 = any
+template <int NS>
+__global__ __launch_bounds__(BLOCK) void fill_ltv_block_kernel(const double* __restrict__ A,
+                                                               const double* __restrict__ B,
+                                                               double* __restrict__ S,
+                                                               double* __restrict__ U, int N,
+                                                               int n_any, int m) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int n = NS ? NS : n_any;
+  const int tid = threadIdx.x;
+  const long inst = blockIdx.x;
+  const int rl = N * n, nn = n * n, nm = n * m;
+  const size_t rstep = even_up((size_t)m * rl), pstep = even_up((size_t)nn);
+  const size_t abstep = even_up((size_t)nn) + even_up((size_t)nm);
+  double* Rw = lds;               // [2][m][rl] rows k-1 / k of every input's block row
+  double* Pk = Rw + 2 * rstep;    // [2][n][n] running product as [j][i]
+  double* AB = Pk + 2 * pstep;    // [N]{A_k [n][n], B_k [n][m]}
+
+  const double* Ab = A + (size_t)inst * N * nn;
+  const double* Bb = B + (size_t)inst * N * nm;
+  double* Sb = S + (size_t)inst * N * nn;
+  double* Ub = U + (size_t)inst * m * N * rl;
+
+  for (size_t e = tid; e < 2 * rstep; e += BLOCK) Rw[e] = 0.0;  // right of the diagonal: zeros
+  for (int i = tid; i < N * nn; i += BLOCK) {
+    const int k = i / nn;
+    AB[k * abstep + (i - k * nn)] = Ab[i];
+  }
+  for (int i = tid; i < N * nm; i += BLOCK) {
+    const int k = i / nm;
+    AB[k * abstep + even_up((size_t)nn) + (i - k * nm)] = Bb[i];
+  }
+  block_lds_barrier();
+
+  // thread <-> fixed (l-lane, i): no division inside the loops
+  const int LQ = BLOCK / n;
+  const int lq = tid / n, li = tid - lq * n;
+  const bool worker = lq < LQ;
+  const int sj = tid / n, si = tid - sj * n;  // S element (j, i) of the first pass
+
+  auto stream_row = [&](const double* Rrow, int k) {
+    for (int j = 0; j < m; ++j) {
+      const double* Rj = Rrow + (size_t)j * rl;
+      double* out = Ub + ((size_t)j * N + k) * rl;
+      if ((rl & 1) == 0) {
+        const double2* r2 = reinterpret_cast<const double2*>(Rj);
+        double2* o2 = reinterpret_cast<double2*>(out);
+        for (int q = tid; q < (rl >> 1); q += BLOCK) o2[q] = r2[q];
+      } else {
+        for (int q = tid; q < rl; q += BLOCK) out[q] = Rj[q];
+      }
+    }
+  };
+
+  for (int k = 0; k < N; ++k) {
+    const double* Ak = AB + (size_t)k * abstep;
+    const double* Bk = Ak + even_up((size_t)nn);
+    const double* Rp = Rw + ((k + 1) & 1) * rstep;  // row k-1
+    double* Rc = Rw + (k & 1) * rstep;              // row k
+    const double* Pp = Pk + ((k + 1) & 1) * pstep;
+    double* Pc = Pk + (k & 1) * pstep;
+
+    // S[k] = (A_k P_{k-1})^T, P_{-1} = I ; Pc[j][i] = P[i][j]
+    for (int e = tid; e < nn; e += BLOCK) {
+      const int j = e == tid ? sj : e / n, i = e == tid ? si : e - (e / n) * n;
+      double v;
+      if (k == 0) {
+        v = Ak[i * n + j];
+      } else {
+        v = 0.0;
+        for (int t = 0; t < n; ++t) v = fma(Ak[i * n + t], Pp[j * n + t], v);
+      }
+      Pc[e] = v;
+      Sb[(size_t)k * nn + e] = v;
+    }
+    // row k: blocks l < k are A_k times row k-1, block k is B_k, blocks l > k stay zero
+    if (worker) {
+      double arow[NS ? NS : 1];
+      if (NS) {
+#pragma unroll
+        for (int t = 0; t < NS; ++t) arow[t] = Ak[li * NS + t];
+      }
+      for (int j = 0; j < m; ++j) {
+        const double* Rpj = Rp + (size_t)j * rl;
+        double* Rcj = Rc + (size_t)j * rl;
+        for (int l = lq; l <= k; l += LQ) {
+          double v;
+          if (l < k) {
+            v = 0.0;
+            if (NS) {
+#pragma unroll
+              for (int t = 0; t < NS; ++t) v = fma(arow[t], Rpj[l * NS + t], v);
+            } else {
+              for (int t = 0; t < n; ++t) v = fma(Ak[li * n + t], Rpj[l * n + t], v);
+            }
+          } else {
+            v = Bk[li * m + j];
+          }
+          Rcj[l * n + li] = v;
+        }
+      }
+    }
+    // row k-1 (complete since the last barrier) goes to HBM while row k is being made
+    if (k > 0) stream_row(Rp, k - 1);
+    block_lds_barrier();
+  }
+  stream_row(Rw + ((N - 1) & 1) * rstep, N - 1);
+}
+
 // LTV, one wavefront per system (n <= 64, N n <= 1024): no workgroup barrier -- the
 // wavefront double-buffers the block row AND the step matrices in its own LDS slice,
 // loads (A_{k+1}, B_{k+1}) into registers while row k is being produced, and needs one
@@ -572,7 +701,15 @@ int launch_fill_su(const double* A, const double* B, double* S, double* U, int b
     const bool small = n <= 64 && per * 4 <= 64 * 1024 && N * n <= 1024;
     const size_t wper = ltv_wave_lds_doubles(N, n, m) * sizeof(double) * 4;
     const size_t wall = ltv_wave_lds_doubles(N, n, m, true) * sizeof(double) * 4;
-    if (n * n <= 128 && n * m <= 64 && wall <= 80 * 1024 && batch < 8192) {
+    const size_t bper = ltv_block_lds_doubles(N, n, m) * sizeof(double);
+    if (n <= BLOCK && bper <= 20 * 1024) {
+      // a workgroup per system, all step matrices resident, eight workgroups per CU
+      auto kernel = n == 2   ? fill_ltv_block_kernel<2>
+                    : n == 3 ? fill_ltv_block_kernel<3>
+                    : n == 4 ? fill_ltv_block_kernel<4>
+                             : fill_ltv_block_kernel<0>;
+      hipLaunchKernelGGL(kernel, dim3(batch), dim3(BLOCK), bper, stream, A, B, S, U, N, n, m);
+    } else if (n * n <= 128 && n * m <= 64 && wall <= 80 * 1024 && batch < 8192) {
       // every step's (A_k, B_k) resident (two workgroups per CU still fit): measured faster
       // while the batch leaves the CUs a single round of workgroups (C5: 0.43 against 0.35
       // of HBM peak at 2 048 systems), slower beyond (0.43 against 0.53 at 16 384)
