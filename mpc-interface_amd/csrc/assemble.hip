@@ -400,13 +400,20 @@ __global__ __launch_bounds__(BLOCK) void constraints_kernel(PlanDev p,
                                                             const double* __restrict__ params,
                                                             const double* __restrict__ V,
                                                             double* __restrict__ G,
-                                                            double* __restrict__ h, int nrb) {
+                                                            double* __restrict__ h, int nrb,
+                                                            int batch) {
   __shared__ double s_arrow[K4_ROWS][K4_AXMAX];
   __shared__ int s_voff[K4_ROWS][K4_AXMAX];
   __shared__ int s_nax[K4_ROWS];
   const int tid = threadIdx.x;
-  const long inst = blockIdx.x / nrb;
-  const int rb = blockIdx.x - inst * nrb;
+  // Workgroups go to the 8 XCDs round robin and every XCD has its own L2.  The row blocks
+  // of one instance read the same workspace rows several times over (every facet of a box
+  // reads the rows of its variable), so they are dealt to ONE XCD, one after the other:
+  // workgroups x, x + 8, x + 16 ... walk the row blocks of instance 8 s + x.
+  const unsigned xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const long inst = (long)(slot / nrb) * 8 + xcd;
+  const int rb = slot % nrb;
+  if (inst >= batch) return;
   const int no = p.no, ldv = p.ldv;
   const double* Vb = V + (size_t)inst * p.rtot * ldv;
   const double* pb = params + (size_t)inst * p.nparams;
@@ -524,8 +531,9 @@ int launch_assemble_staged(const PlanDev& p, const SrcTable& src, const double* 
   if (G && p.nc > 0) {
     if (p.max_axes > K4_AXMAX) return MPCASM_ERR_LIMIT;
     const unsigned nrb = ceil_div(p.nc, K4_ROWS);
-    hipLaunchKernelGGL(constraints_kernel, dim3(nrb * batch), dim3(BLOCK), 0, stream, p, params, V,
-                       G, h, (int)nrb);
+    const unsigned groups = ceil_div((unsigned)batch, 8u);
+    hipLaunchKernelGGL(constraints_kernel, dim3(nrb * groups * 8), dim3(BLOCK), 0, stream, p, params,
+                       V, G, h, (int)nrb, batch);
   }
   *err = hipGetLastError();
   return *err == hipSuccess ? MPCASM_OK : MPCASM_ERR_HIP;
