@@ -172,6 +172,28 @@ int mpcasm_preview(const double* d_PM, const double* d_given, const double* d_op
 int mpcasm_gather(const double* d_src, int64_t src_stride, const int32_t* d_index, int nnz,
                   double* d_dst, int batch, void* stream);
 
+/* f4  batched box transforms ---------------------------------------------------
+ * Replaces, for every instance of a batch at once, the per-tick geometry updates of a
+ *   Box                                     python/mpc_interface/restrictions.py:380-486
+ * on the facets' parameters inside d_params [batch][n_params] (the arrow, center and
+ * extreme fields of the box's Constraints, restrictions.py:201-219 incl. normalize()):
+ *   MPCASM_BOX_RECENTER   center  = arg[axes]                 recenter_in_TS   :380-388
+ *   MPCASM_BOX_TRANSLATE  center += arg[axes]                 translate_in_TS  :411-415
+ *   MPCASM_BOX_ROTATE     arrow_r = arrow_r . R^T, R = arg[axes][axes]   rotate_in_TS :436-455
+ *   MPCASM_BOX_SCALE      extreme *= arg[0]  (new factor / old factor)   scale_box :474-478
+ *   MPCASM_BOX_MARGIN     extreme -= arg[0] * ||arrow||_F     set_safety_margin :480-486
+ * After ROTATE, SCALE and MARGIN rows whose extreme turned negative are flipped
+ * (extreme, arrow -> -extreme, -arrow), as Constraint.normalize() does (:180-194).
+ * d_facets: nfacets records of 7 int32 -- arrow offset, arrow rows, center offset, center
+ * rows, extreme offset, extreme rows, axes -- offsets into one instance's parameters.
+ * d_arg [batch][arg_stride] (arg_stride 0: one argument for all instances).
+ */
+enum { MPCASM_BOX_RECENTER = 0, MPCASM_BOX_TRANSLATE, MPCASM_BOX_ROTATE, MPCASM_BOX_SCALE,
+       MPCASM_BOX_MARGIN };
+int mpcasm_box_transform(double* d_params, int64_t n_params, int batch, const int32_t* d_facets,
+                         int nfacets, int op, const double* d_arg, int64_t arg_stride,
+                         void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -592,4 +592,65 @@ int launch_gather(const double* src, long long src_stride, const int32_t* index,
   return *err == hipSuccess ? MPCASM_OK : MPCASM_ERR_HIP;
 }
 
+// f4: the geometry updates of a Box (restrictions.py:380-486) on the facets' parameters of
+// every instance.  One thread per (instance, facet): a facet is a handful of rows and axes.
+__global__ __launch_bounds__(BLOCK) void box_transform_kernel(double* __restrict__ params,
+                                                              long long nparams, int batch,
+                                                              const int32_t* __restrict__ facets,
+                                                              int nfacets, int op,
+                                                              const double* __restrict__ arg,
+                                                              long long arg_stride) {
+  const long t = (long)blockIdx.x * BLOCK + threadIdx.x;
+  if (t >= (long)batch * nfacets) return;
+  const long inst = t / nfacets;
+  const int32_t* f = facets + (t - inst * nfacets) * 7;
+  double* p = params + inst * nparams;
+  double* arrow = p + f[0];
+  double* center = p + f[2];
+  double* extreme = p + f[4];
+  const int arows = f[1], crows = f[3], erows = f[5], axes = f[6];
+  const double* a = arg + inst * arg_stride;
+  if (op == MPCASM_BOX_RECENTER || op == MPCASM_BOX_TRANSLATE) {
+    for (int r = 0; r < crows; ++r)
+      for (int x = 0; x < axes; ++x)
+        center[r * axes + x] = (op == MPCASM_BOX_TRANSLATE ? center[r * axes + x] : 0.0) + a[x];
+    return;
+  }
+  if (op == MPCASM_BOX_ROTATE) {  // arrow_r <- arrow_r . R^T (axes <= 4 per facet row)
+    for (int r = 0; r < arows; ++r) {
+      double old[4];
+      for (int x = 0; x < axes; ++x) old[x] = arrow[r * axes + x];
+      for (int x = 0; x < axes; ++x) {
+        double v = 0.0;
+        for (int y = 0; y < axes; ++y) v += old[y] * a[x * axes + y];
+        arrow[r * axes + x] = v;
+      }
+    }
+  } else if (op == MPCASM_BOX_SCALE) {
+    for (int r = 0; r < erows; ++r) extreme[r] *= a[0];
+  } else {  // MPCASM_BOX_MARGIN: the Frobenius norm of the whole arrow field, as numpy's norm
+    double s = 0.0;
+    for (int i = 0; i < arows * axes; ++i) s += arrow[i] * arrow[i];
+    const double nrm = sqrt(s);
+    for (int r = 0; r < erows; ++r) extreme[r] -= a[0] * nrm;
+  }
+  // Constraint.normalize(): a negative extreme flips its row (rows match, or both are single)
+  for (int r = 0; r < erows; ++r)
+    if (extreme[r] < 0.0) {
+      extreme[r] = -extreme[r];
+      const int ar = arows == 1 ? 0 : r;
+      for (int x = 0; x < axes; ++x) arrow[ar * axes + x] = -arrow[ar * axes + x];
+    }
+}
+
+int launch_box_transform(double* params, long long nparams, int batch, const int32_t* facets,
+                         int nfacets, int op, const double* arg, long long arg_stride,
+                         hipStream_t stream, hipError_t* err) {
+  const long total = (long)batch * nfacets;
+  hipLaunchKernelGGL(box_transform_kernel, dim3((unsigned)((total + BLOCK - 1) / BLOCK)), dim3(BLOCK),
+                     0, stream, params, nparams, batch, facets, nfacets, op, arg, arg_stride);
+  *err = hipGetLastError();
+  return *err == hipSuccess ? MPCASM_OK : MPCASM_ERR_HIP;
+}
+
 }  // namespace mpcasm

@@ -52,7 +52,11 @@ SIGNATURES = {
                                       ctypes.c_int, ctypes.c_int, ctypes.c_int, _void_p]),
     "mpcasm_gather": (ctypes.c_int, [_void_p, ctypes.c_int64, _void_p, ctypes.c_int, _void_p,
                                      ctypes.c_int, _void_p]),
+    "mpcasm_box_transform": (ctypes.c_int, [_void_p, ctypes.c_int64, ctypes.c_int, _void_p,
+                                            ctypes.c_int, ctypes.c_int, _void_p, ctypes.c_int64,
+                                            _void_p]),
 }
+BOX_RECENTER, BOX_TRANSLATE, BOX_ROTATE, BOX_SCALE, BOX_MARGIN = range(5)
 
 
 class MpcasmError(RuntimeError):

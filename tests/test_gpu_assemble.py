@@ -305,6 +305,60 @@ def test_generated_horizon_matrices_other_systems(gpu_api, kernel_path, nx, nu, 
         assert_close(x[3], y, RTOL_TIGHT)
 
 
+def test_batched_box_transforms(gpu_api, kernel_path):
+    """f4 (restrictions.py:380-486): recenter, translate, rotate, scale and safety margin of a
+    box for every instance at once on the device, against the same calls made instance by
+    instance on this repository's host Box and assembled by the oracle."""
+    import copy
+
+    from mpcasm import engine
+    from mpcasm.boxes import BoxBatch
+
+    if kernel_path != "resident":
+        pytest.skip("the transforms act on the parameters, one assembly path is enough")
+    form = problems.biped(gpu_api, problems.BipedConfig(step_samples=8))
+    form.update(step_times=np.array([6, 14]), step_count=0)
+    batch = 9
+    rng = np.random.default_rng(21)
+    given = rng.normal(0, 0.1, [batch, form.given_len])
+    asm = engine.Assembler(form, batch=batch)
+    support = BoxBatch(asm, form, "support_polygon")
+    stepping = BoxBatch(asm, form, "stepping area")
+    with pytest.raises(KeyError):
+        BoxBatch(asm, form, "no such box")
+
+    centers = rng.normal(0, 0.05, [batch, 2])
+    shifts = rng.normal(0, 0.02, [batch, 2])
+    angles = rng.uniform(-0.5, 0.5, batch)
+    rot = np.stack([[[np.cos(t), -np.sin(t)], [np.sin(t), np.cos(t)]] for t in angles])
+    scales = rng.uniform(0.6, 1.4, batch)
+    margins = rng.uniform(0.0, 0.01, batch)
+    stepping.recenter_in_TS(centers)
+    stepping.translate_in_TS(shifts)
+    support.scale_box(scales)
+    support.scale_box(scales * 0.9)          # relative to the factor set before
+    # (the margin before the rotation: the host's rotate_in_TS spreads a single arrow over the
+    # rows of the facet, after which np.linalg.norm(arrow) is another number)
+    support.set_safety_margin(margins)
+    support.rotate_in_TS(rot)
+    stepping.set_safety_margin(0.002)        # one margin for all
+    G, h = (t.cpu().numpy() for t in asm.assemble(given)[2:])
+
+    for b in (0, 4, batch - 1):
+        ref = copy.deepcopy(form)
+        rs, rp = ref.constraint_boxes["stepping area"], ref.constraint_boxes["support_polygon"]
+        rs.recenter_in_TS(centers[b])
+        rs.translate_in_TS(shifts[b])
+        rp.scale_box(scales[b])
+        rp.scale_box(scales[b] * 0.9)
+        rp.set_safety_margin(margins[b])
+        rp.rotate_in_TS(rot[b])
+        rs.set_safety_margin(0.002)
+        Ao, ho, _, _ = orc.assemble(ref, given[b].reshape(-1, 1))
+        assert_close(G[b], Ao, RTOL_TIGHT, "G of instance %d" % b)
+        assert_close(h[b], ho.ravel(), RTOL_TIGHT, "h of instance %d" % b)
+
+
 def test_csc_hand_off(gpu_api):
     """f3 (biped_mpc_loop.py:57-58): the data arrays of csc_matrix(Q), csc_matrix(A) for a
     whole batch on one structural pattern."""
