@@ -82,6 +82,7 @@ class WalkerFleet:
         phases = np.arange(self.batch) % n if phases is None else np.asarray(phases)
         self.clock = FleetClock(n, self.conf.num_steps, phases)
         self.device = device
+        self._ticks, self._cache = 0, {}
 
         # one template formulation + assembler per structure bucket (steps in preview)
         self.buckets = {}
@@ -109,32 +110,50 @@ class WalkerFleet:
         """Steps in the preview of every walker right now (its structure bucket)."""
         return steps_in_preview(self.clock.step_times, self.N).sum(axis=1)
 
+    def _bucket_inputs(self):
+        """This tick's per-bucket inputs on the device: walker ids, step indicator matrices,
+        stepping-area centres.  The fleet advances in lock step, so they repeat with period
+        ``2 * step_samples`` (the step cycle times the left/right alternation): each of those
+        ticks is worked out once on the host (tools.plan_steps / find_step_centers semantics)
+        and kept on the device."""
+        key = self._ticks % (2 * self.conf.step_samples)
+        if key not in self._cache:
+            torch = self._torch
+            p_of = self.structure_of()
+            entry = []
+            for p, bucket in self.buckets.items():
+                idx = np.nonzero(p_of == p)[0]
+                if idx.size == 0:
+                    continue
+                dev = bucket["asm"].device
+                times = self.clock.step_times[idx]
+                kept = times[steps_in_preview(times, self.N)].reshape(idx.size, p)
+                E = torch.as_tensor(step_indicator(kept, self.N), device=dev)
+                centers = stepping_centers(self.clock.step_count[idx], p, self.conf.stepping_center)
+                entry.append(dict(p=p, idx=idx, index=torch.as_tensor(idx, device=dev), E=E,
+                                  centers=torch.as_tensor(centers.reshape(idx.size, -1), device=dev)))
+            self._cache[key] = entry
+        return self._cache[key]
+
     def tick(self, given):
         """Assemble this tick's QPs (``given``: ``(batch, ng)`` tensor or array), then
         advance every walker's clock."""
         torch = self._torch
-        p_of = self.structure_of()
         out = []
-        for p, bucket in self.buckets.items():
-            idx = np.nonzero(p_of == p)[0]
-            if idx.size == 0:
-                continue
+        for item in self._bucket_inputs():
+            p, idx = item["p"], item["idx"]
+            bucket = self.buckets[p]
             asm = bucket["asm"]
-            times = self.clock.step_times[idx]
-            kept = times[steps_in_preview(times, self.N)].reshape(idx.size, p)
-            bucket["E"][:idx.size, :, :, 0] = torch.as_tensor(step_indicator(kept, self.N),
-                                                              device=asm.device)
-            centers = stepping_centers(self.clock.step_count[idx], p, self.conf.stepping_center)
+            bucket["E"][:idx.size, :, :, 0] = item["E"]
             for k in bucket["facets"]:
                 sl, (rows, cols) = asm.param_slice("limit", k, "center")
-                asm.params[:idx.size, sl] = torch.as_tensor(
-                    centers.reshape(idx.size, rows * cols), device=asm.device)
-            index = torch.as_tensor(idx, device=asm.device)
+                asm.params[:idx.size, sl] = item["centers"]
             g = given if isinstance(given, torch.Tensor) else torch.as_tensor(
                 np.asarray(given, dtype=np.float64), device=asm.device)
-            g = g.to(asm.device).index_select(0, index)
+            g = g.to(asm.device).index_select(0, item["index"])
             P, q, G, h = asm.assemble(g, count=idx.size)
             out.append({"p": p, "index": idx, "P": P[:idx.size], "q": q[:idx.size],
                         "G": G[:idx.size], "h": h[:idx.size]})
         self.clock.tick()
+        self._ticks += 1
         return out

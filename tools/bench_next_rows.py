@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Rates of the rows SURVEY.md section 8 marks "next" (f1-f4) on one GPU: the walker fleet's
+ticks, the batched preview, the CSC hand-off and the box transforms, on the C2 biped."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "mpc-interface_amd"))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from mpcasm import engine, problems  # noqa: E402
+from mpcasm.boxes import BoxBatch  # noqa: E402
+from mpcasm.walkers import WalkerFleet  # noqa: E402
+
+
+def timed(fn, reps):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+    work = bench.build_workload(B, 3)
+    form = work["form"]
+    given = torch.as_tensor(work["given"], device="cuda")
+    asm = engine.Assembler(form, batch=B)
+    P, q, G, h = asm.assemble(given)
+
+    # f1: a fleet of walkers in all phases of the step cycle, one tick = clocks, step
+    # indicator matrices, stepping centres, one assembly per structure bucket
+    fleet = WalkerFleet(B, conf=problems.BipedConfig(step_samples=8))
+    g_fleet = torch.zeros((B, fleet.given_len), dtype=torch.float64, device="cuda")
+    t = timed(lambda: fleet.tick(g_fleet), 40)
+    print("f1 walker fleet   %6d walkers  %8.3f ms per tick  %10.0f walker-ticks/s" % (B, t * 1e3, B / t))
+
+    # f2: Mg.given + Mo.optim for every definition (body.py:209-219)
+    PM = asm.preview_matrices()
+    optim = torch.zeros((B, asm.no), dtype=torch.float64, device="cuda")
+    t = timed(lambda: asm.preview(PM, given, optim), 50)
+    nbytes = PM.numel() * 8
+    print("f2 preview        %6d x %d rows  %8.3f ms  %7.0f GB/s read" % (B, asm.plan.pmrows, t * 1e3, nbytes / t / 1e9))
+    t = timed(lambda: asm.preview_matrices(), 20)
+    print("   preview matrices (K2 alone)   %8.3f ms  %7.0f GB/s written" % (t * 1e3, nbytes / t / 1e9))
+
+    # f3: data arrays of csc_matrix(P), csc_matrix(G) on the structural patterns
+    for which, dense in (("P", P), ("G", G)):
+        indptr, _ = asm.csc_pattern(which)
+        t = timed(lambda: asm.export_csc(which), 50)
+        print("f3 csc %s          nnz %5d of %6d  %8.3f ms  %7.0f GB/s written"
+              % (which, indptr[-1], dense[0].numel(), t * 1e3, B * int(indptr[-1]) * 8 / t / 1e9))
+
+    # f4: box transforms on the per-instance parameters
+    box = BoxBatch(asm, form, "support_polygon")
+    rot = torch.eye(2, dtype=torch.float64, device="cuda").repeat(B, 1, 1)
+    shift = torch.zeros((B, 2), dtype=torch.float64, device="cuda")
+    for name, fn in (("rotate", lambda: box.rotate_in_TS(rot)), ("translate", lambda: box.translate_in_TS(shift))):
+        t = timed(fn, 50)
+        print("f4 box %-9s  %6d boxes x %d facets  %8.3f ms  %10.0f boxes/s" % (name, B, box.nfacets, t * 1e3, B / t))
+
+
+if __name__ == "__main__":
+    main()
