@@ -55,14 +55,16 @@ const char* mpcasm_status_string(int status);
  * the persistent kernel (per-instance fused kernel if it fits), 2 = always the
  * staged K2 -> K3 -> K4 pipeline with the workspace in HBM.  The parity tests use
  * it to exercise every path; all paths give the same results. */
-enum { MPCASM_OPT_PATH = 1, MPCASM_OPT_PHASE_MASK = 2 };
+enum { MPCASM_OPT_PATH = 1, MPCASM_OPT_PHASE_MASK = 2, MPCASM_OPT_RESIDENT_PER_CU = 3 };
 /* MPCASM_OPT_PHASE_MASK is a profiling aid (timing-only ablation of the fused
  * kernels: bit 0 compose, 1 Hessian, 2 gradient, 3 constraints, 4 input staging
  * after the first instance, 5 P/q stores, 7 register prefetch of the next instance's
  * inputs; bit 6, off by default, makes the persistent kernel also write per-wavefront
  * cycle sums of its phases into d_work, which mpcasm_workspace_bytes sizes for it;
  * default 0xBF).  Results are WRONG with any of bits 0-5 cleared -- never use it
- * outside a profile. */
+ * outside a profile.
+ * MPCASM_OPT_RESIDENT_PER_CU (tuning aid): workgroups of the persistent kernel per CU;
+ * 0 (default) = chosen from the batch size, never more than are resident at once. */
 int mpcasm_set_option(int option, int value);
 
 /* K1  horizon extension ---------------------------------------------------

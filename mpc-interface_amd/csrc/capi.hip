@@ -15,6 +15,7 @@ using namespace mpcasm;
 namespace mpcasm {
 extern int g_path;
 extern int g_phase_mask;
+extern int g_resident_per_cu;
 }
 
 struct mpcasm_plan {
@@ -112,7 +113,8 @@ int validate_plan(const int32_t* it, const double* h_dtab, size_t n_itab, size_t
     r = r && in_range(it[H_OFF_RS_GIDX], slots, n, H_WORDS);
     r = r && in_range(it[H_OFF_RS_DST], slots, n, H_WORDS);
     r = r && in_range(it[H_DOFF_RS_COEF], slots, nd, 0);
-    r = r && in_range(it[H_OFF_RS_TRIP], (int64_t)it[H_RS_NTRIP] * RS_TRIP_WORDS, n, H_WORDS);
+    // (two spare records behind the table: the kernel reads that far ahead)
+    r = r && in_range(it[H_OFF_RS_TRIP], ((int64_t)it[H_RS_NTRIP] + 2) * RS_TRIP_WORDS, n, H_WORDS);
     r = r && in_range(it[H_OFF_RS_WTRIP], RS_WAVES * 2, n, H_WORDS);
     r = r && in_range(it[H_OFF_RS_SPLIT], it[H_RS_NSPLIT], n, H_WORDS);
     r = r && (it[H_OFF_RS_TRIP] % 4 == 0);
@@ -140,40 +142,52 @@ int validate_plan(const int32_t* it, const double* h_dtab, size_t n_itab, size_t
     const int32_t* sp = it + it[H_OFF_RS_SPLIT];
     for (int i = 0; i < it[H_RS_NSPLIT]; ++i)
       if (sp[i] < 0 || sp[i] >= vsize) return MPCASM_ERR_PLAN;
-    const int nt = ((int)no + 15) / 16, ntb = (int)no / 16 + 1;
+    const int nb = ((int)no + 3) / 4;  // 4-column blocks of the unknowns
+    if (nb > RS_BLOCKS_MAX) return MPCASM_ERR_PLAN;
     const int32_t* tr = it + it[H_OFF_RS_TRIP];
+    for (int i = 0; i < 2 * RS_TRIP_WORDS; ++i)
+      if (tr[it[H_RS_NTRIP] * RS_TRIP_WORDS + i] != 0) return MPCASM_ERR_PLAN;
     for (int i = 0; i < it[H_RS_NTRIP]; ++i) {
       const int32_t* x = tr + i * RS_TRIP_WORDS;
-      const int rows = x[RT_WORD] & 31, mode = (x[RT_WORD] >> RT_MODE) & 3;
-      const int ti = (x[RT_WORD] >> RT_TI) & 127, tj = (x[RT_WORD] >> RT_TJ) & 127;
-      if (x[RT_WORD] < 0 || (x[RT_WORD] >> 24) != 0 || rows > 16 || ti >= nt || tj >= ntb ||
-          (mode != RI_MODE_PLAIN && tj != ntb - 1) || x[RT_PARAMS] < 0 ||
-          (x[RT_PARAMS] & 0xFFFF) >= it[H_NPARAMS] || (x[RT_PARAMS] >> 16) >= it[H_NPARAMS])
+      const int word = x[RT_WORD], rows = word & 31;
+      const int live = (word >> RT_LIVE) & 15, qmask = (word >> RT_QMASK) & 15;
+      if (word < 0 || (word >> 18) != 0 || (word & 0x80) || rows > 16 || (qmask & ~live) ||
+          x[RT_W] < 0 || x[RT_W] % 8 || x[RT_W] / 8 >= it[H_NPARAMS] || x[RT_AIM] < 0 ||
+          x[RT_AIM] % 8 || x[RT_AIM] / 8 >= it[H_NPARAMS])
         return MPCASM_ERR_PLAN;
-      for (int k = 0; k < 2; ++k)  // 16 columns from the offset: the slack behind V covers them
-        if (x[k] < 0 || (rows > 0 && x[k] / it[H_LDV] + rows > it[H_RTOT]) ||
-            (rows == 0 && x[k] != 0))
+      for (int g = 0; g < 4; ++g)  // (all four groups load, live or not)
+        if (((x[RT_BI] >> (8 * g)) & 255) >= nb || ((x[RT_BJ] >> (8 * g)) & 255) >= nb)
+          return MPCASM_ERR_PLAN;
+      // a trip reads 16 rows from its offsets, up to column 4 nb - 1 <= no + 2: the slack
+      // behind V covers what lies past the last row
+      const int offs[3] = {x[RT_A], x[RT_B], x[RT_D]};
+      for (int k = 0; k < 3; ++k)
+        if (offs[k] < 0 || offs[k] % 8 || (rows > 0 && offs[k] / 8 / it[H_LDV] + rows > it[H_RTOT]) ||
+            (rows == 0 && offs[k] != 0))
           return MPCASM_ERR_PLAN;
     }
-    {  // every wavefront's trips: consecutive, whole tiles (first ... last)
+    {  // every wavefront's trips: consecutive, whole packs (first ... last)
       const int32_t* wt = it + it[H_OFF_RS_WTRIP];
       int next = 0;
       for (int w = 0; w < RS_WAVES; ++w) {
         if (wt[2 * w] != next || wt[2 * w + 1] < 0 || (wt[2 * w + 1] & 1)) return MPCASM_ERR_PLAN;
         next += wt[2 * w + 1];
         if (next > it[H_RS_NTRIP]) return MPCASM_ERR_PLAN;
-        int open = -1;
+        const int32_t* open = nullptr;
         for (int i = wt[2 * w]; i < next; ++i) {
-          const int word = tr[i * RS_TRIP_WORDS + RT_WORD], tile = word >> RT_TI;
-          if (word == 0 && open == -1) continue;  // padding between tiles
+          const int32_t* x = tr + i * RS_TRIP_WORDS;
+          const int word = x[RT_WORD];
+          if (word == 0 && open == nullptr) continue;  // padding between packs
           if ((word >> RT_FIRST) & 1) {
-            if (open != -1) return MPCASM_ERR_PLAN;
-            open = tile;
+            if (open != nullptr) return MPCASM_ERR_PLAN;
+            open = x;
           }
-          if (open != tile) return MPCASM_ERR_PLAN;
-          if ((word >> RT_LAST) & 1) open = -1;
+          if (open == nullptr || open[RT_BI] != x[RT_BI] || open[RT_BJ] != x[RT_BJ] ||
+              (open[RT_WORD] >> RT_LIVE) != (word >> RT_LIVE))
+            return MPCASM_ERR_PLAN;
+          if ((word >> RT_LAST) & 1) open = nullptr;
         }
-        if (open != -1) return MPCASM_ERR_PLAN;
+        if (open != nullptr) return MPCASM_ERR_PLAN;
       }
       if (next != it[H_RS_NTRIP]) return MPCASM_ERR_PLAN;
     }
@@ -188,7 +202,15 @@ int validate_plan(const int32_t* it, const double* h_dtab, size_t n_itab, size_t
             x[RR_ARROW + a] > it[H_NPARAMS] || x[RR_CENTER + a] < 0 ||
             x[RR_CENTER + a] > it[H_NPARAMS])
           return MPCASM_ERR_PLAN;
+      // the packed words the 16-byte-piece path of G reads instead of the fields above
+      if (it[H_RR_PACKED] &&
+          (x[RR_NAXES] > 2 || x[RR_VOFF] > 65535 || x[RR_VOFF + 1] > 65535 ||
+           x[RR_ARROW] > 65535 || x[RR_ARROW + 1] > 65535 ||
+           (uint32_t)x[RR_PACKED] != ((uint32_t)x[RR_VOFF] | ((uint32_t)x[RR_VOFF + 1] << 16)) ||
+           (uint32_t)x[RR_PACKED + 1] != ((uint32_t)x[RR_ARROW] | ((uint32_t)x[RR_ARROW + 1] << 16))))
+        return MPCASM_ERR_PLAN;
     }
+    if (it[H_RR_PACKED] != 0 && (it[H_RR_PACKED] != 1 || (no & 1) || nc < 1)) return MPCASM_ERR_PLAN;
     for (int64_t g = 0; g < nlti; ++g) {  // generated groups: loaded A, B and the tables
       const int32_t* x = it + it[H_OFF_RS_LTI] + g * RS_LTI_WORDS;
       const int64_t gn = x[LT_N], gm = x[LT_M], gN = x[LT_HORIZON];
@@ -332,6 +354,11 @@ int mpcasm_set_option(int option, int value) {
     g_phase_mask = value;
     return MPCASM_OK;
   }
+  if (option == MPCASM_OPT_RESIDENT_PER_CU) {
+    if (value < 0 || value > 16) return MPCASM_ERR_ARG;
+    g_resident_per_cu = value;
+    return MPCASM_OK;
+  }
   return MPCASM_ERR_ARG;
 }
 
@@ -418,6 +445,7 @@ int mpcasm_plan_create(const int32_t* h_itab, size_t n_itab, const double* h_dta
   d.doff_rs_const = it[H_DOFF_RS_CONST];
   d.rs_nlti = it[H_RS_NLTI]; d.off_rs_lti = it[H_OFF_RS_LTI]; d.rs_img_dma = it[H_RS_IMG_DMA];
   d.rs_ab = it[H_RS_AB]; d.off_rs_abmeta = it[H_OFF_RS_ABMETA];
+  d.rr_packed = it[H_RR_PACKED];
   d.rs_src16 = 0;
   if (d.rs_ok && d.rs_unit == 16)
     for (int64_t i = 0; i < (int64_t)d.rs_nchunk * 64; ++i) {
@@ -558,6 +586,7 @@ int mpcasm_gather(const double* d_src, int64_t src_stride, const int32_t* d_inde
 namespace mpcasm {
 
 int g_path = 0;  // test hook (MPCASM_OPT_PATH): 0 best, 1 no resident kernel, 2 staged only
+int g_resident_per_cu = 0;  // tuning aid (MPCASM_OPT_RESIDENT_PER_CU): 0 = automatic
 
 // dispatch: fused single launch when the problem fits on chip, else staged
 int launch_assemble(const PlanDev& p, const SrcTable& src, const double* params,

@@ -15,6 +15,11 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f64x4 mfma_f64_16x16x4(double a, double b, f64x4 c) {
   return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
+// four independent 4x4x4 products: lane l feeds A[x][k] / B[k][x] and receives D[k][x] of
+// block g, where x = l & 3, g = (l >> 2) & 3, k = l >> 4 (tools/microbench/mfma4x4_layout.hip)
+__device__ __forceinline__ double mfma_f64_4x4x4(double a, double b, double c) {
+  return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
+}
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains
 // the vector-memory counter (s_waitcnt vmcnt(0)), i.e. it waits for every global

@@ -27,7 +27,7 @@
 namespace mpcasm {
 
 constexpr int32_t PLAN_MAGIC = 0x4D504341;  // 'MPCA'
-constexpr int32_t PLAN_VERSION = 15;
+constexpr int32_t PLAN_VERSION = 16;
 
 enum HeaderWord : int {
   H_MAGIC = 0,
@@ -84,7 +84,8 @@ enum HeaderWord : int {
   H_OFF_RS_DST,     // [JC][RS_NT] workspace index the running sum goes to (| RS_DST_ACC: added
                     //             to it, the element is shared by two threads), or -1
   H_DOFF_RS_COEF,   // [JC][RS_NT]
-  H_OFF_RS_TRIP,    // [NTRIP][4]: up to 16 rows of one gterm into one tile, see RT_* below
+  H_OFF_RS_TRIP,    // [NTRIP + 2][8]: up to 16 rows of one gterm into one pack of blocks, see RT_* below;
+                    //    two all-zero records behind the last (read ahead)
   H_OFF_RS_WTRIP,   // [RS_WAVES][2] first trip, trip count of every wavefront
   H_RS_NSPLIT,      // workspace elements composed by two threads
   H_OFF_RS_SPLIT,   // [NSPLIT] their workspace indices (zeroed before every compose)
@@ -109,6 +110,8 @@ enum HeaderWord : int {
   H_RS_IMG_DMA,     // doubles of the image that the loads fill (a multiple of 128, <= RS_IMG)
   H_RS_AB,          // doubles of one ring slot holding every group's A and B (a multiple of 32)
   H_OFF_RS_ABMETA,  // [RS_AB * 2][2] input stream, byte offset of every 4-byte lane of a slot
+  H_RR_PACKED,      // 1: every row record of G carries its RR_PACKED words (no is even, rows
+                    //    have at most two axes, offsets and parameter slots fit 16 bits)
   H_WORDS = 80
 };
 
@@ -138,29 +141,35 @@ constexpr int MAX_SOURCES = 32;
 // RS_NT threads per instance = RS_WAVES wavefronts; the first RS_NW ("matrix waves") fetch
 // the inputs, the others stream G; all of them run Hessian tiles; RS_JC_MAX compose ops
 // per thread
-constexpr int RS_NW = 4, RS_NT = 512, RS_WAVES = RS_NT / 64, RS_JC_MAX = 12, RS_TRIP_WORDS = 4;
-constexpr int RS_TILES_MAX = 128;
+constexpr int RS_NW = 4, RS_NT = 512, RS_WAVES = RS_NT / 64, RS_JC_MAX = 12, RS_TRIP_WORDS = 8;
+constexpr int RS_BLOCKS_MAX = 255;  // 4-column blocks of the unknowns (one byte each): no <= 1020
 // generated source group: sizes; offsets of A [n][n] and B [n][m] inside a ring slot; image
 // offsets of the tables TA[k][i][j] = (A^{k+1})[i][j] and TB[d][i][j] = (A^d B)[i][j], k, d < N, and of
 // the powers A^(2^s) they are built from
 enum { LT_N = 0, LT_M, LT_HORIZON, LT_A, LT_B, LT_TA, LT_TB, LT_TP, RS_LTI_WORDS = 8 };
 constexpr int RS_LTI_MAX = 4;
-// row record of G: voff[4], arrow param[4], center param[4], naxes, extreme param, 2 pad
+// row record of G: voff[4], arrow param[4], center param[4], naxes, extreme param, the first
+// two axes packed once more: voff0 | voff1 << 16, arrow0 | arrow1 << 16
 constexpr int RS_AXMAX = 4, RS_RR_WORDS = 16;
 constexpr int32_t RS_DST_ACC = 1 << 30;
-// trip record: up to 16 workspace rows of one gterm into one 16x16 tile (four MFMA
-// k-steps).  RT_A / RT_B: workspace offset of the first A / B row, tile column included;
-// RT_WORD: rows | mode << 5 | (1 << 7 when the term is halved) | first trip of its tile << 8
-// | last << 9 | ti << 10 | tj << 17; RT_PARAMS: weight param | aim param << 16.  A
-// wavefront's trips of one tile are consecutive.  Column `no` of a workspace row holds d,
-// so the tile column no / 16 of the B operand carries the gradient: mode 0 tile outside
-// that column; 1 B rows == d rows, P and q from one product (b[no] <- s (d - aim)); 2 P
-// only (b[no] <- 0); 3 q only (the B rows are the d rows, every other column <- 0)
-enum { RT_A = 0, RT_B, RT_WORD, RT_PARAMS };
-enum { RT_MODE = 5, RT_HALF = 7, RT_FIRST = 8, RT_LAST = 9, RT_TI = 10, RT_TJ = 17 };
-enum { RI_MODE_PLAIN = 0, RI_MODE_PQ = 1, RI_MODE_P = 2, RI_MODE_Q = 3 };
+// The Hessian and the gradient are accumulated in 4x4 blocks (v_mfma_f64_4x4x4_4b_f64: four
+// independent 4x4 blocks per instruction, 4 rows of the workspace per k-step): block (bi, bj)
+// of P is columns 4bi.. of the A rows times columns 4bj.. of the B rows, block bi of q is
+// the same A columns times s (d - aim), d = column `no` of the d rows.  Only blocks some term
+// reaches structurally exist (plus the diagonal of P and all of q, which the diagonal gterms
+// add into); four of them form a *pack*, one accumulator register: lane group j of the
+// instruction works on the pack's block j.  Trip record: up to 16 workspace rows of one
+// gterm into one pack (four k-steps).  RT_A / RT_B / RT_D: BYTE offset in the workspace of
+// the first A / B / d row, column 0; RT_WORD: rows | (1 << 5 when the term is halved) | (1 << 6 when the
+// term has no Hessian part: blocks of P get nothing) | first trip of its pack << 8 | last
+// << 9 | live lane groups << 10 | lane groups that hold a block of q << 14; RT_W / RT_AIM:
+// BYTE offset of the weight / aim among the parameters; RT_BI / RT_BJ: block row / block column of the four lane
+// groups, a byte each (groups that are not live repeat a live one's; the column of a block
+// of q is not used).  A wavefront's trips of one pack are consecutive.
+enum { RT_A = 0, RT_B, RT_WORD, RT_W, RT_BI, RT_BJ, RT_D, RT_AIM };
+enum { RT_HALF = 5, RT_NOP = 6, RT_FIRST = 8, RT_LAST = 9, RT_LIVE = 10, RT_QMASK = 14 };
 // diagonal gterms the persistent kernel takes on one column of the unknowns
 constexpr int RS_DIAG_MAX = 2;
-enum { RR_VOFF = 0, RR_ARROW = 4, RR_CENTER = 8, RR_NAXES = 12, RR_EXTREME = 13 };
+enum { RR_VOFF = 0, RR_ARROW = 4, RR_CENTER = 8, RR_NAXES = 12, RR_EXTREME = 13, RR_PACKED = 14 };
 
 }  // namespace mpcasm

@@ -46,6 +46,7 @@
 namespace mpcasm {
 
 extern int g_phase_mask;  // diagnostic (timing-only ablation), fused.hip
+extern int g_resident_per_cu;  // tuning aid, capi.hip
 
 namespace {
 
@@ -54,24 +55,26 @@ constexpr int MW = RS_NW;         // wavefronts that run the matrix core
 constexpr int WT = NT - MW * 64;  // threads of the worker wavefronts
 constexpr int AXMAX = RS_AXMAX;
 constexpr int RR_WORDS = RS_RR_WORDS;
-constexpr int GU = 6;  // 16-byte pieces of G a worker thread may own
 static_assert(RS_DIAG_MAX == 2, "the per-column diagonal table holds two terms");
 
 __host__ __device__ inline int even_up_i(int x) { return (x + 1) & ~1; }
 
-// G by the fast path: every stream-wave thread owns at most GU 16-byte pieces (columns 2cp,
-// 2cp+1 of a row), rows have at most two axes, workspace offsets and parameter indices fit
-// 16 bits
-__host__ __device__ inline bool resident_g_fast(const PlanDev& p) {
-  return (p.no & 1) == 0 && p.max_axes <= 2 && (long)p.nc * (p.no >> 1) <= (long)GU * WT &&
-         (long)p.rtot * p.ldv + 15 * p.ldv + 16 < 65536 && p.nparams < 65535;
+constexpr int GU = 6;  // 16-byte pieces of G a worker thread may own a descriptor for
+// G by 16-byte pieces (columns 2cp, 2cp+1 of a row) from the row's two source rows and
+// arrows packed in the RR_PACKED words of its record (rows have at most two axes, workspace
+// offsets and parameter indices fit 16 bits): mode 1.  Mode 2: a small problem (every
+// stream-wave thread owns at most GU pieces) keeps a ready-made descriptor per piece in
+// LDS -- 12 KB that buy back the row/column bookkeeping; 0: the general path.
+__host__ __device__ inline int resident_g_mode(const PlanDev& p) {
+  if (!p.rr_packed) return 0;
+  return (long)p.nc * (p.no >> 1) <= (long)GU * WT ? 2 : 1;
 }
 
 struct ResidentLayout {
   // offsets in doubles
   int v, pl, ql, dvec, dcoef, dpar, img, ab, streams, ints, total_doubles;
   int ldp;                                            // leading dimension of P in LDS
-  int i_trip, i_rr, i_meta, i_wtrip, i_split, i_lti, i_abmeta, i_gdesc;  // offsets in ints inside the int region
+  int i_rr, i_meta, i_wtrip, i_split, i_lti, i_abmeta, i_gdesc;  // offsets in ints inside the int region
 };
 
 __host__ __device__ inline ResidentLayout resident_layout(const PlanDev& p) {
@@ -90,12 +93,11 @@ __host__ __device__ inline ResidentLayout resident_layout(const PlanDev& p) {
   L.ab = o;     o += 2 * p.rs_ab;   // ring of two slots: (A, B) of the generated systems
   L.streams = o; o += 2 * (MAX_SOURCES + 3);  // (base pointer, bytes per instance) per stream
   L.ints = o;
-  int i = 0;  // the first three start 16-byte aligned
-  L.i_trip = i;  i += (p.rs_ntrip + 2) * RS_TRIP_WORDS;  // two spare records: read ahead
+  int i = 0;  // the first two start 16-byte aligned
   L.i_rr = i;    i += p.nc * RR_WORDS;
   L.i_meta = i;  i += p.rs_nchunk * 64 * 2;
   L.i_abmeta = i; i += p.rs_ab * 2 * 2;
-  L.i_gdesc = i;  i += resident_g_fast(p) ? GU * WT * 2 : 0;  // per-thread piece descriptors of G
+  L.i_gdesc = i;  i += resident_g_mode(p) == 2 ? GU * WT * 2 : 0;  // per-thread piece descriptors of G
   L.i_wtrip = i; i += RS_WAVES * 2;
   L.i_split = i; i += p.rs_nsplit;
   L.i_lti = i;   i += p.rs_nlti * RS_LTI_WORDS;
@@ -166,7 +168,6 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
   int4* dpar = reinterpret_cast<int4*>(lds + L.dpar);
   double* strm = lds + L.streams;  // [nsrc + 3] pairs: base pointer, bytes per instance (raw)
   int* itb = reinterpret_cast<int*>(lds + L.ints);
-  int4* trips = reinterpret_cast<int4*>(itb + L.i_trip);
   int* rr = itb + L.i_rr;
   int2* meta = reinterpret_cast<int2*>(itb + L.i_meta);
   int* wtrip = itb + L.i_wtrip;
@@ -247,10 +248,10 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
         dma4(a, dst);
     }
   };
-  const int li = lane & 15, lk = lane >> 4;
+  const int lx = lane & 3, lg = (lane >> 2) & 3, lk = lane >> 4;
   // Row of a trip this lane feeds to MFMA k-step 0 (the step u adds 2u).  Lanes 0-31 and
   // 32-63 are the two groups an 8-byte LDS read is served in; inside a group the rows of
-  // lk and lk+1 lie 8 apart, which with ldv = 2 (mod 4) is half the banks: no conflicts.
+  // lk and lk+1 lie 8 apart, which with ldv = 2 (mod 4) is half the banks.
   const int krow = (lk >> 1) + 8 * (lk & 1);
   // K1 on chip: the horizon matrices of an LTI system, as the tables the compose ops read
   // (TA[k][i][j] = (A^{k+1})[i][j], TB[d][i][j] = (A^d B)[i][j]; tools.py:14-33), from the
@@ -389,9 +390,8 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
   }
   // ---- once per workgroup: structure tables into LDS, workspace zeroed -----------
   {
-    const int4* t4 = reinterpret_cast<const int4*>(p.itab + p.off_rs_trip);
-    for (int i = tid; i < p.rs_ntrip + 2; i += NT)
-      trips[i] = i < p.rs_ntrip ? t4[i] : int4{0, 0, 0, 0};
+    // blocks of P no term reaches stay zero for the whole launch
+    for (int i = tid; i < no * ldp; i += NT) Pl[i] = 0.0;
     const int32_t* t = p.itab + p.off_rs_wtrip;
     for (int i = tid; i < RS_WAVES * 2; i += NT) wtrip[i] = t[i];
     t = p.itab + p.off_rs_rr;  // row records of G, precomputed by the plan compiler
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
     const int n2 = (even_up_i(p.rtot * ldv) + 15 * ldv + 16) / 2;
     for (int i = tid; i < n2; i += NT) V2[i] = double2{0.0, 0.0};
     for (int i = tid; i < 2 * ldp; i += NT) dvec[i] = 0.0;  // stays zero without diagonal gterms
-    if (resident_g_fast(p) && tid >= MW * 64) {
+    if (resident_g_mode(p) == 2 && tid >= MW * 64) {
       // piece e = wt + u WT of G: columns 2cp, 2cp+1 of row R = e / npair.  What the piece
       // needs -- the workspace offsets of its (two) source rows at those columns and the
       // parameter slots of their arrows -- is fixed: packed once, read back as 8 bytes
@@ -458,9 +458,11 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
   const int wt = tid - MW * 64;  // index among the worker threads (negative on MFMA waves)
   const int npair = no >> 1;
   const int gtotal = nc * npair;
-  const bool g_fast = resident_g_fast(p);
+  const int g_mode = resident_g_mode(p);
+  // (row, column pair) of this thread's first piece, and the step from piece to piece
+  const int g_first = wt >= 0 && npair > 0 ? ((wt / npair) << 16) | (wt % npair) : 0;
+  const int g_dR = npair > 0 ? WT / npair : 0, g_dcp = npair > 0 ? WT % npair : 0;
 
-  const int qli = no & 15;  // the lane column that holds d in the last tile column
 
   if (STAMPS && stamping) t_prev = __builtin_amdgcn_s_memtime();
   int buf = 0;
@@ -523,7 +525,7 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
       if (G != nullptr && (phases & 8)) {
         // ---- K4: constraint rows straight to HBM ---------------------------------------
         double* Gb = G + (size_t)inst * nc * no;
-        if (g_fast) {
+        if (g_mode == 2) {
           // per piece: its packed descriptor -> arrows and workspace rows -> arithmetic ->
           // one 16-byte store; the reads of three pieces are in flight together
           double2* G2 = reinterpret_cast<double2*>(Gb);
@@ -546,6 +548,47 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
               const int e = wt_ + (u0 + u) * WT;
+              double2 r;
+              r.x = fma(a1[u], v1[u].x, a0[u] * v0[u].x);
+              r.y = fma(a1[u], v1[u].y, a0[u] * v0[u].y);
+              if (e < gtotal) G2[e] = r;
+            }
+          }
+        } else if (g_mode == 1) {
+          // piece e = wt + u WT of G: columns 2cp, 2cp+1 of row R.  Per piece: the packed
+          // words of the row record -> arrows and workspace rows -> arithmetic -> one
+          // 16-byte store; the reads of three pieces are in flight together
+          double2* G2 = reinterpret_cast<double2*>(Gb);
+          int first = g_first;  // opaque copy: nothing derived from it is kept across instances
+          asm volatile("" : "+v"(first));
+          int R = first >> 16, cp = first & 0xFFFF;
+          for (int e0 = wt; e0 < gtotal; e0 += 3 * WT) {
+            int2 ds[3];
+            int c2[3];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+              const int Rr = e0 + u * WT < gtotal ? R : 0;
+              ds[u] = *reinterpret_cast<const int2*>(rr + Rr * RR_WORDS + RR_PACKED);
+              c2[u] = 2 * cp;
+              cp += g_dcp;
+              R += g_dR;
+              if (cp >= npair) {
+                cp -= npair;
+                ++R;
+              }
+            }
+            double a0[3], a1[3];
+            double2 v0[3], v1[3];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+              a0[u] = prm[ds[u].y & 0xFFFF];
+              a1[u] = prm[(unsigned)ds[u].y >> 16];
+              v0[u] = *reinterpret_cast<const double2*>(V + (ds[u].x & 0xFFFF) + c2[u]);
+              v1[u] = *reinterpret_cast<const double2*>(V + ((unsigned)ds[u].x >> 16) + c2[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+              const int e = e0 + u * WT;
               double2 r;
               r.x = fma(a1[u], v1[u].x, a0[u] * v0[u].x);
               r.y = fma(a1[u], v1[u].y, a0[u] * v0[u].y);
@@ -622,104 +665,88 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
       MPCASM_STAMP(3)
     }
     if (P != nullptr && (phases & 2)) {
-      // ---- K3: this wavefront's Hessian and gradient tiles on the matrix core -> P, q in
-      // LDS.  The operands of trip t+1 are loaded while the MFMAs of trip t run; two
-      // operand register sets take turns (the plan pads every list to an even length).
+      // ---- K3: this wavefront's packs of Hessian and gradient blocks on the matrix core
+      // -> P, q in LDS.  v_mfma_f64_4x4x4_4b_f64: lane l feeds element x = l & 3 of block
+      // g = (l >> 2) & 3 in k-step row l >> 4 and receives D[l >> 4][l & 3] of block g.  The
+      // operands of trip t+1 are loaded while the MFMAs of trip t run; two operand register
+      // sets take turns (the plan pads every list to an even length).
       const int t0 = __builtin_amdgcn_readfirstlane(wtrip[2 * wave]);
       const int tn = __builtin_amdgcn_readfirstlane(wtrip[2 * wave + 1]);
+      // The records are the same for every instance and wave-uniform: read from the plan
+      // in global memory through the scalar cache, they cost no LDS traffic and no vector
+      // instruction.
+      typedef int i32x4 __attribute__((ext_vector_type(4)));
+      typedef const __attribute__((address_space(4))) i32x4* const_i32x4_ptr;  // -> s_load
+      const const_i32x4_ptr tg = (const_i32x4_ptr)(uintptr_t)(p.itab + p.off_rs_trip);
       if (tn > 0) {
-        double opa[2][4], opb[2][4], opw[2], opaim[2];
-        int opword[2];
-        int4 rec = trips[t0 + 1];  // the record after the one being loaded
-        auto load_operands = [&](const int4& r, int set) {  // rows past the trip are read too
-          const double* ap = V + __builtin_amdgcn_readfirstlane(r.x) + li;
-          const double* bp = V + __builtin_amdgcn_readfirstlane(r.y) + li;
-          const int par = __builtin_amdgcn_readfirstlane(r.w);
+        // One trip at a time: loads, products, next.  Overlapping the next trip's loads with
+        // this trip's MFMAs (two operand register sets) bought nothing -- the other
+        // wavefronts of the SIMD fill the gaps -- and the registers are worth more as a third
+        // resident workgroup per CU.  The record of the next trip is on its way meanwhile.
+        const char* Vc = reinterpret_cast<const char*>(V);
+        const char* prc = reinterpret_cast<const char*>(prm);
+        const int stride = 2 * ldv * (int)sizeof(double);  // k-step to k-step
+        int a_lane = 0, b_lane = 0, bi = 0, bj = 0;  // of the current pack
+        bool isq = false, live = false;
+        i32x4 rn = tg[2 * t0], kn = tg[2 * t0 + 1];
+        double acc = 0.0;
+        for (int t = 0; t < tn; ++t) {
+          const i32x4 r = rn, k = kn;
+          rn = tg[2 * (t0 + t) + 2];
+          kn = tg[2 * (t0 + t) + 3];
+          const int word = r.z, rows = word & 31;
+          if (word == 0) continue;  // padding
+          if ((word >> RT_FIRST) & 1) {  // a new pack: what this lane reads and owns
+            bi = (k.x >> (8 * lg)) & 255;
+            bj = (k.y >> (8 * lg)) & 255;
+            isq = (word >> (RT_QMASK + lg)) & 1;
+            live = (word >> (RT_LIVE + lg)) & 1;
+            a_lane = (krow * ldv + 4 * bi + lx) * (int)sizeof(double);
+            b_lane = (krow * ldv + (isq ? no : 4 * bj + lx)) * (int)sizeof(double);
+          }
+          const char* ap = Vc + (r.x + a_lane);
+          const char* bp = Vc + ((isq ? k.z : r.y) + b_lane);
+          double a[4], b[4];
 #pragma unroll
           for (int u = 0; u < 4; ++u) {  // k-step u takes rows 2u, 2u+1, 2u+8, 2u+9 (see krow)
-            opa[set][u] = ap[(2 * u + krow) * ldv];
-            opb[set][u] = bp[(2 * u + krow) * ldv];
+            a[u] = *reinterpret_cast<const double*>(ap + u * stride);
+            b[u] = *reinterpret_cast<const double*>(bp + u * stride);
           }
-          opw[set] = prm[par & 0xFFFF];
-          opaim[set] = prm[par >> 16];
-          opword[set] = __builtin_amdgcn_readfirstlane(r.z);
-        };
-        load_operands(trips[t0], 0);
-        f64x4 acc = f64x4{0.0, 0.0, 0.0, 0.0};
-        for (int t = 0; t < tn; t += 2) {
+          // a weight of 0 contributes exact zeros through the products (body.py:292)
+          const double w = *reinterpret_cast<const double*>(prc + r.w);
+          if (word & ((15 << RT_QMASK) | (1 << RT_NOP))) {
+            // lanes of a block of q: b <- s (d - aim); lanes of a block of P keep b, or get 0
+            // from a term without a Hessian part
+            const double aim = *reinterpret_cast<const double*>(prc + k.w);
+            const double sc = (word >> RT_HALF) & 1 ? 0.5 : 1.0;
+            const double m1 = isq ? sc : ((word >> RT_NOP) & 1 ? 0.0 : 1.0);
+            const double m2 = isq ? sc * aim : 0.0;
 #pragma unroll
-          for (int set = 0; set < 2; ++set) {
-            // the next trip's operands (after the last trip: a spare record's)
-            const int4 nrec = rec;
-            rec = trips[t0 + t + set + 2];
-            load_operands(nrec, set ^ 1);
-            const int word = opword[set];
-            const int rows = word & 31, mode = (word >> RT_MODE) & 3;
-            double a[4], b[4];
-            // a weight of 0 contributes exact zeros through the products (body.py:292)
-            const double w = opw[set];
+            for (int u = 0; u < 4; ++u) b[u] = fma(m1, b[u], -m2);
+          }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              a[u] = w * opa[set][u];
-              b[u] = opb[set][u];
-            }
-            if (mode != RI_MODE_PLAIN) {
-              // the B operand becomes m1 b - m2: in the lane that holds column `no`,
-              // s (d - aim) (modes PQ, Q) or 0 (mode P); elsewhere b, or 0 (mode Q)
-              const double sc = (word >> RT_HALF) & 1 ? 0.5 : 1.0;
-              const bool ql_ = li == qli;
-              const double m1 =
-                  ql_ ? (mode == RI_MODE_P ? 0.0 : sc) : (mode == RI_MODE_Q ? 0.0 : 1.0);
-              const double m2 = ql_ && mode != RI_MODE_P ? sc * opaim[set] : 0.0;
+          for (int u = 0; u < 4; ++u) a[u] *= w;
+          if (rows == 16) {
 #pragma unroll
-              for (int u = 0; u < 4; ++u) b[u] = fma(m1, b[u], -m2);
-            }
-            if (rows == 16) {
+            for (int u = 0; u < 4; ++u) acc = mfma_f64_4x4x4(a[u], b[u], acc);
+          } else {
 #pragma unroll
-              for (int u = 0; u < 4; ++u) acc = mfma_f64_16x16x4(a[u], b[u], acc);
-            } else {
-#pragma unroll
-              for (int u = 0; u < 4; ++u)
-                if (2 * u < rows) acc = mfma_f64_16x16x4(2 * u + krow < rows ? a[u] : 0.0, b[u], acc);
-            }
-            if ((word >> RT_LAST) & 1) {  // the tile is complete: into P (and q) in LDS
-              // Predicates are taken per tile, not per element: full row blocks need no row
-              // test, column validity is one mask for the four stores of a lane.
-              const int ti = (word >> RT_TI) & 127, tj = (word >> RT_TJ) & 127;
-              const int row0 = ti * 16 + lk, col = tj * 16 + li;
-              const bool mirror = p.rs_sym && ti != tj;
-              const bool rows_full = ti * 16 + 16 <= no;  // wave-uniform
-              if (ti == tj) {  // the diagonal addend of this lane's column, where row == col
-                const double dg = dvec[col < ldp ? col : 0];  // (never in the lane of column `no`)
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) acc[reg] += lk + 4 * reg == li ? dg : 0.0;
+            for (int u = 0; u < 4; ++u)
+              if (2 * u < rows) acc = mfma_f64_4x4x4(2 * u + krow < rows ? a[u] : 0.0, b[u], acc);
+          }
+          if ((word >> RT_LAST) & 1) {  // the pack is complete: into P and q in LDS
+            const int row = 4 * bi + lk, col = 4 * bj + lx;
+            if (live && row < no) {
+              if (isq) {
+                if (lx == 0) ql[row] = acc + dvec[ldp + row];
+              } else if (col < no) {
+                // the diagonal gterms' addend where row == col
+                const double val = acc + (row == col ? dvec[col] : 0.0);
+                Pl[row * ldp + col] = val;
+                if (p.rs_sym && bi != bj) Pl[col * ldp + row] = val;
               }
-              if (col < no) {
-                double* pt = Pl + row0 * ldp + col;
-                double* pm = Pl + col * ldp + row0;
-                if (rows_full) {
-#pragma unroll
-                  for (int reg = 0; reg < 4; ++reg) pt[reg * 4 * ldp] = acc[reg];
-                  if (mirror) {
-#pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) pm[4 * reg] = acc[reg];
-                  }
-                } else {
-#pragma unroll
-                  for (int reg = 0; reg < 4; ++reg)
-                    if (row0 + 4 * reg < no) {
-                      pt[reg * 4 * ldp] = acc[reg];
-                      if (mirror) pm[4 * reg] = acc[reg];
-                    }
-                }
-              } else if (col == no) {
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg)
-                  if (rows_full || row0 + 4 * reg < no)
-                    ql[row0 + 4 * reg] = acc[reg] + dvec[ldp + row0 + 4 * reg];
-              }
-              acc = f64x4{0.0, 0.0, 0.0, 0.0};
             }
+            acc = 0.0;
           }
         }
       }
@@ -796,8 +823,9 @@ int launch_jc(const PlanDev& p, const SrcTable& src, const double* params, const
   }
   // persistent grid: exactly the workgroups that are resident at once, never more
   // than there are instances
-  const int per_cu = cached_per_cu[slot];
+  int per_cu = cached_per_cu[slot];
   if (per_cu < 1) return MPCASM_ERR_LIMIT;
+  if (g_resident_per_cu > 0 && g_resident_per_cu < per_cu) per_cu = g_resident_per_cu;
   long grid = (long)num_cus * per_cu;
   if (grid > batch) grid = batch;
   hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(NT), lds_bytes, stream, p, src, params,

@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libmpcasm.so")
 OK = 0
 OPT_PATH = 1
 OPT_PHASE_MASK = 2
+OPT_RESIDENT_PER_CU = 3
 PHASE_DEFAULT = 0xBF   # every phase on, cycle stamps (bit 6) off
 PHASE_STAMPS = 0x40
 STATUS = {

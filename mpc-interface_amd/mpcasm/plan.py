@@ -15,7 +15,7 @@ import numpy as np
 import scipy.sparse as sp
 
 PLAN_MAGIC = 0x4D504341
-PLAN_VERSION = 15
+PLAN_VERSION = 16
 
 # header words (csrc/plan_tables.h, enum HeaderWord)
 _H = {name: i for i, name in enumerate([
@@ -30,22 +30,22 @@ _H = {name: i for i, name in enumerate([
     "DOFF_RS_COEF", "OFF_RS_TRIP", "OFF_RS_WTRIP", "RS_NSPLIT", "OFF_RS_SPLIT",
     "OFF_RS_RR", "RS_UNIT", "RS_NCHUNK", "OFF_RS_INMETA", "RS_IMG", "RS_IMG_GIVEN",
     "RS_IMG_PARAMS", "DOFF_RS_CONST", "DOFF_DIAGCOEF", "NDIAGCOEF", "RS_NLTI", "OFF_RS_LTI",
-    "RS_IMG_DMA", "RS_AB", "OFF_RS_ABMETA",
+    "RS_IMG_DMA", "RS_AB", "OFF_RS_ABMETA", "RR_PACKED",
 ])}
 H_WORDS = 80
 assert len(_H) <= H_WORDS
 RS_NW, RS_NT = 4, 512                     # matrix wavefronts (they fetch the inputs), threads per instance
 RS_WAVES = RS_NT // 64
-RS_TILES_MAX = 128                        # 7-bit tile coordinates; no <= 256 anyway
+RS_BLOCKS_MAX = 255                       # 4-column blocks of the unknowns, a byte each
 RS_LTI_WORDS, RS_LTI_MAX = 8, 4           # record of a source group generated on chip; groups per plan
 RS_JC_MAX = 12                            # compose ops a thread can keep in registers
-RS_TRIP_WORDS = 4
+RS_TRIP_WORDS = 8
+TRIP_COST, TRIP_STEP_COST, G_PIECE_COST = 800, 50, 750   # wavefront assignment, see _resident_program
 # trip record, word 2: rows | mode << 5 | half << 7 | first << 8 | last << 9 | ti << 10 | tj << 17
-RT_MODE, RT_HALF, RT_FIRST, RT_LAST, RT_TI, RT_TJ = 5, 7, 8, 9, 10, 17
+RT_HALF, RT_NOP, RT_FIRST, RT_LAST, RT_LIVE, RT_QMASK = 5, 6, 8, 9, 10, 14
 RS_DIAG_MAX = 2                           # diagonal gterms per column (persistent kernel)
 RS_AXMAX = 4                              # axes per constraint row record
 RS_DST_ACC = 1 << 30                      # compose destination shared by two threads
-RI_MODE_PLAIN, RI_MODE_PQ, RI_MODE_P, RI_MODE_Q = 0, 1, 2, 3
 RS_RR_WORDS = 16                          # row record: voff[4], arrow param[4], center param[4], naxes, extreme param, pad
 SEG_WORDS, GT_WORDS, LM_WORDS, LX_WORDS = 8, 10, 12, 2
 FUSED_MAX_OPS = 1 << 18           # beyond this the staged pipeline is used
@@ -404,9 +404,10 @@ def _fused_program(b, rowptr, entbase, entk, entcoef, rtot, ldv):
 
 def _resident_rows(limit_recs, lax_recs, nparams, ldv):
     """Per row of the stacked G, 16 words: workspace offset of every axis' row [4], arrow
-    param of every axis [4], center param of every axis [4], naxes, extreme param, 2 pad;
-    a missing axis points at workspace row 0 with the always-zero parameter slot
-    ``nparams``."""
+    param of every axis [4], center param of every axis [4], naxes, extreme param, then
+    the first two axes once more, packed: voff0 | voff1 << 16, arrow0 | arrow1 << 16 (zero
+    where that does not fit); a missing axis points at workspace row 0 with the always-zero
+    parameter slot ``nparams``."""
     rows = []
     for out0, nrows, naxes, lax0, p_a, a_rows, p_c, c_rows, p_e, e_rows, _, _ in limit_recs:
         for r in range(nrows):
@@ -422,8 +423,10 @@ def _resident_rows(limit_recs, lax_recs, nparams, ldv):
                     voff.append(0)
                     ap.append(nparams)
                     cp.append(nparams)
+            if naxes <= 2 and max(voff) < 65536 and nparams < 65536:
+                tail[2:] = [voff[0] | (voff[1] << 16), ap[0] | (ap[1] << 16)]
             rows.append(voff + ap + cp + tail)
-    return np.asarray(rows, dtype=np.int32).reshape(-1)
+    return np.asarray(rows, dtype=np.int64).astype(np.uint32).view(np.int32).reshape(-1)
 
 
 def _lti_groups(form, sources, names):
@@ -560,7 +563,7 @@ def _resident_program(fused, gterms, no, ldv, image, ng, nparams, nc_rows):
 
     NT, NW = RS_NT, RS_NW
     z = np.zeros(0, dtype=np.int32)
-    out = dict(ok=0, jc=0, sym=0, src=z, gidx=z, dst=z, coef=np.zeros(0), trips=z, split=z,
+    out = dict(ok=0, jc=0, sym=0, src=z, gidx=z, dst=z, coef=np.zeros(0), trips=z, ntrip=0, split=z,
                wtrip=np.zeros(RS_WAVES * 2, dtype=np.int32))
     if not fused["ok"] or image["img"] > 65535 or nparams > 65535:
         return out
@@ -635,62 +638,94 @@ def _resident_program(fused, gterms, no, ldv, image, ng, nparams, nc_rows):
                 coef[j, t] = pool[int(ops[o, 1]) & 0xFFFF]
                 j += 1
             dst[j - 1, t] = int(fd_idx[i]) | (RS_DST_ACC if shared else 0)
-    # ---- Hessian and gradient on the matrix core.  A *trip* is up to 16 rows of one gterm
-    # into one 16x16 tile (four MFMA k-steps); every wavefront walks its own list of trips,
-    # tile by tile.  Column `no` of a workspace row is d, so tile column tq = no // 16 of
-    # the B operand yields q[c] = sum_k w a[k][c] s (d[k] - aim) next to (or instead of)
-    # the P columns.
-    nt, tq = (no + 15) // 16, no // 16
-    ntb = tq + 1
+    # ---- Hessian and gradient on the matrix core, in 4x4 blocks (plan_tables.h RT_*).
+    # Block (bi, bj) of P exists when some term has structural non-zeros in columns 4bi.. of
+    # its A rows and 4bj.. of its B rows; block bi of q when a term's A rows reach columns
+    # 4bi...  Diagonal blocks and all blocks of q always exist (the diagonal gterms add into
+    # them).  Four blocks with (nearly) the same set of terms share a pack = an accumulator;
+    # a *trip* is up to 16 rows of one term into one pack.
+    nb = (no + 3) // 4
+    if nb > RS_BLOCKS_MAX:
+        return out
     terms = [g for g in gterms if not g[6] & GT_FLAG_DIAG]
     pterms = [g for g in terms if g[6] & GT_FLAG_P]
     sym = int(all(g[0] == g[1] for g in pterms))
-    tile_trips = {}
-    for ti in range(nt):
-        for tj in range(ti if sym else 0, ntb):
-            tile_trips[(ti, tj)] = []
-    if ntb > RS_TILES_MAX:
-        return out
-
-    def bit(mask, t):
-        return (mask >> min(t, 30)) & 1
-
-    def trips_of(a, b, nrows, mode, half, par):
-        flags = (mode << RT_MODE) | (half << RT_HALF)
-        return [[a + k0 * ldv, b + k0 * ldv, min(16, nrows - k0) | flags, par]
-                for k0 in range(0, nrows, 16)]
-
-    for g in terms:
-        aoff, boff, nrows, wparam, doff, aimparam, flags = g[:7]
-        half = 1 if flags & GT_FLAG_HALF else 0
-        par = wparam | (aimparam << 16)
-        for (ti, tj), lst in tile_trips.items():
-            if not bit(g[7], ti):
-                continue
-            p_part = bool(flags & GT_FLAG_P) and tj < nt and bool(bit(g[8], tj))
-            q_part = tj == tq
-            a = aoff * ldv + ti * 16
-            if p_part and q_part and boff == doff:
-                lst += trips_of(a, boff * ldv + tj * 16, nrows, RI_MODE_PQ, half, par)
-                continue
-            if p_part:
-                mode = RI_MODE_P if q_part else RI_MODE_PLAIN
-                lst += trips_of(a, boff * ldv + tj * 16, nrows, mode, half, par)
-            if q_part:
-                lst += trips_of(a, doff * ldv + tj * 16, nrows, RI_MODE_Q, half, par)
-    for (ti, tj), lst in tile_trips.items():
-        if not lst:
-            lst.append([0, 0, 0, 0])               # nothing to add up: the tile is still written
+    rtot_rows = max([g[0] + g[2] for g in terms] + [max(g[1], g[4]) + g[2] for g in terms] + [1])
+    reach = np.zeros((rtot_rows, nb), dtype=bool)    # structural non-zeros of V by block column
+    el_row, el_col = fd_idx // ldv, fd_idx % ldv
+    keep = (el_col < no) & (el_row < rtot_rows) & (counts > 0)   # (no kept op: an exact zero)
+    reach[el_row[keep], el_col[keep] // 4] = True
+    p_blocks = {(bi, bi): [] for bi in range(nb)}
+    q_blocks = {bi: [] for bi in range(nb)}
+    for gi, g in enumerate(terms):
+        aoff, boff, nrows, flags = g[0], g[1], g[2], g[6]
+        ablk = np.flatnonzero(reach[aoff:aoff + nrows].any(axis=0))
+        for bi in ablk:
+            q_blocks[int(bi)].append(gi)
+        if flags & GT_FLAG_P:
+            bblk = np.flatnonzero(reach[boff:boff + nrows].any(axis=0))
+            for bi in ablk:
+                for bj in bblk:
+                    if not sym or bi <= bj:
+                        p_blocks.setdefault((int(bi), int(bj)), []).append(gi)
+    # Blocks with the same set of terms fill packs of four; what is left over is merged
+    # where it costs the fewest extra trips (a pack is visited by every term of its blocks).
+    # A block of q is (bi, -1).
+    blocks = dict(p_blocks)
+    blocks.update({(bi, -1): v for bi, v in q_blocks.items()})
+    by_sig = {}
+    for key in sorted(blocks):
+        by_sig.setdefault(tuple(blocks[key]), []).append(key)
+    packs, partial = [], []                          # ([block] * <= 4, set of term ids)
+    for sig in sorted(by_sig):
+        keys = by_sig[sig]
+        for i in range(0, len(keys), 4):
+            (packs if len(keys) - i >= 4 else partial).append((keys[i:i + 4], set(sig)))
+    merged = []
+    for keys, sig in sorted(partial, key=lambda p: (-len(p[0]), sorted(p[1]))):
+        best = None
+        for m in merged:
+            if len(m[0]) + len(keys) <= 4:
+                extra = len(m[1] | sig) * 2 - len(m[1]) - len(sig)
+                if best is None or extra < best[0]:
+                    best = (extra, m)
+        if best is None:
+            merged.append((list(keys), set(sig)))
+        else:
+            best[1][0].extend(keys)
+            best[1][1].update(sig)
+    packs += merged
+    pack_trips = []
+    for grp, tids in packs:
+        live = (1 << len(grp)) - 1
+        qmask = sum(1 << j for j, k in enumerate(grp) if k[1] < 0)
+        grp = [(k[0], max(k[1], 0)) for k in grp]
+        grp = grp + [grp[0]] * (4 - len(grp))
+        bi_bytes = sum(k[0] << (8 * j) for j, k in enumerate(grp))
+        bj_bytes = sum(k[1] << (8 * j) for j, k in enumerate(grp))
+        lst = []
+        for gi in sorted(tids):
+            aoff, boff, nrows, wparam, doff, aimparam, flags = terms[gi][:7]
+            half = 1 if flags & GT_FLAG_HALF else 0
+            brow = boff if flags & GT_FLAG_P else doff   # (a term without P only meets q lanes)
+            for k0 in range(0, nrows, 16):
+                lst.append([(aoff + k0) * ldv * 8, (brow + k0) * ldv * 8,
+                            min(16, nrows - k0) | (half << RT_HALF)
+                            | (0 if flags & GT_FLAG_P else 1 << RT_NOP), wparam * 8,
+                            bi_bytes, bj_bytes, (doff + k0) * ldv * 8, aimparam * 8])
+        if not lst:                                  # nothing to add up: the pack is still written
+            lst.append([0, 0, 0, 0, bi_bytes, bj_bytes, 0, 0])
+        for trip in lst:
+            trip[2] |= (live << RT_LIVE) | (qmask << RT_QMASK)
         lst[0][2] |= 1 << RT_FIRST
         lst[-1][2] |= 1 << RT_LAST
-        for trip in lst:
-            trip[2] |= (ti << RT_TI) | (tj << RT_TJ)
-    # tiles to wavefronts, heaviest first onto the least loaded.  Costs in (measured,
-    # rounded) cycles of one wavefront: a trip, a tile store, a 16-byte piece of G, a
+        pack_trips.append(lst)
+    # packs to wavefronts, heaviest first onto the least loaded.  Costs in (measured,
+    # rounded) cycles of one wavefront: a trip, a pack store, a 16-byte piece of G, a
     # chunk of the input fetch.  The matrix waves start with the fetch on their account,
     # the stream waves with their share of G.
-    cost = {key: 400 + sum(900 + 70 * (((trip[2] & 31) + 3) // 4) for trip in lst)
-            for key, lst in tile_trips.items()}
+    cost = [200 + sum(TRIP_COST + TRIP_STEP_COST * (((trip[2] & 31) + 3) // 4) for trip in lst)
+            for lst in pack_trips]
     stream_threads = NT - NW * 64
     pieces = nc_rows * max(no // 2, 1)
     loads = []
@@ -701,24 +736,26 @@ def _resident_program(fused, gterms, no, ldv, image, ng, nparams, nc_rows):
             first = (w - NW) * 64
             own = len(range(first, pieces, stream_threads))
             gen = 4000 if image["groups"] and w == RS_WAVES - 1 else 0   # builds the tables
-            loads.append((800 * own + 600 + gen, w))
+            loads.append((G_PIECE_COST * own + 600 + gen, w))
     heapq.heapify(loads)
-    wave_tiles = [[] for _ in range(RS_WAVES)]
-    for key in sorted(tile_trips, key=lambda k: -cost[k]):
+    wave_packs = [[] for _ in range(RS_WAVES)]
+    for k in sorted(range(len(pack_trips)), key=lambda k: -cost[k]):
         load, w = heapq.heappop(loads)
-        wave_tiles[w].append(key)
-        heapq.heappush(loads, (load + cost[key], w))
+        wave_packs[w].append(k)
+        heapq.heappush(loads, (load + cost[k], w))
     trips, wtrip = [], np.zeros(RS_WAVES * 2, dtype=np.int32)
     for w in range(RS_WAVES):
         wtrip[2 * w] = len(trips)
-        for key in wave_tiles[w]:
-            trips.extend(tile_trips[key])
+        for k in wave_packs[w]:
+            trips.extend(pack_trips[k])
         if (len(trips) - wtrip[2 * w]) & 1:
-            trips.append([0, 0, 0, 0])             # the kernel walks trips in pairs
+            trips.append([0] * RS_TRIP_WORDS)      # the kernel walks trips in pairs
         wtrip[2 * w + 1] = len(trips) - wtrip[2 * w]
+    ntrip = len(trips)
+    trips += [[0] * RS_TRIP_WORDS] * 2             # the kernel reads two records ahead
     out.update(ok=1, jc=jc, sym=sym, src=src.reshape(-1), gidx=gidx.reshape(-1),
                dst=dst.reshape(-1), coef=coef.reshape(-1),
-               trips=np.asarray(trips, dtype=np.int32).reshape(-1), wtrip=wtrip,
+               trips=np.asarray(trips, dtype=np.int32).reshape(-1), ntrip=ntrip, wtrip=wtrip,
                split=np.asarray(split, dtype=np.int32))
     return out
 
@@ -997,7 +1034,7 @@ def compile_plan(form, costs=None, limits=None, lti=()):
     header[_H["DOFF_COEFPOOL"]] = entcoef.size + pm_entcoef.size
     header[_H["RS_OK"]], header[_H["RS_JC"]] = resident["ok"], resident["jc"]
     header[_H["RS_SYM"]] = resident["sym"]
-    header[_H["RS_NTRIP"]] = resident["trips"].size // RS_TRIP_WORDS
+    header[_H["RS_NTRIP"]] = resident["ntrip"]
     header[_H["RS_NSPLIT"]] = resident["split"].size
     header[_H["RS_UNIT"]], header[_H["RS_NCHUNK"]] = image["unit"], image["nchunk"]
     header[_H["RS_IMG"]] = image["img"]
@@ -1007,6 +1044,11 @@ def compile_plan(form, costs=None, limits=None, lti=()):
     header[_H["RS_IMG_GIVEN"]], header[_H["RS_IMG_PARAMS"]] = image["given"], image["params"]
     if rs_rr.size != nc * RS_RR_WORDS:
         header[_H["RS_OK"]] = 0                  # a constraint with more than RS_AXMAX axes
+    else:                                        # G by 16-byte pieces from the packed words
+        recs = rs_rr.reshape(nc, RS_RR_WORDS)
+        header[_H["RR_PACKED"]] = int(
+            no % 2 == 0 and nc > 0 and (b.rtot + 15) * ldv + 16 < 65536 and len(b.params) < 65535
+            and bool((recs[:, 12] <= 2).all()))
     header[_H["DOFF_RS_COEF"]] = entcoef.size + pm_entcoef.size + fused["coefpool"].size
     header[_H["DOFF_DIAGCOEF"]] = (entcoef.size + pm_entcoef.size + fused["coefpool"].size
                                    + resident["coef"].size)

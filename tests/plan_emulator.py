@@ -214,10 +214,12 @@ def run_resident(plan, given, params=None, sources=None):
                     written[d] = 99
                 acc = 0.0
     assert all(written[d] in (1, 2) for d in split)
-    # ---- Hessian and gradient tiles
-    tq = no // 16
-    ntb, nt, qli = tq + 1, (no + 15) // 16, no % 16
-    trips = _section(it, "OFF_RS_TRIP", it[H["RS_NTRIP"]] * 4).reshape(-1, 4)
+    # ---- Hessian and gradient: packs of four 4x4 blocks (plan_tables.h RT_*)
+    nb = (no + 3) // 4
+    TW = P.RS_TRIP_WORDS
+    trips = _section(it, "OFF_RS_TRIP", (it[H["RS_NTRIP"]] + 2) * TW).reshape(-1, TW)
+    assert not trips[-2:].any()                              # read ahead by the kernel
+    trips = trips[:-2]
     wtrip = _section(it, "OFF_RS_WTRIP", P.RS_WAVES * 2).reshape(-1, 2)
     dP, dq = np.zeros(no), np.zeros(no)
     gt = _section(it, "OFF_GTERM", it[H["NGTERM"]] * P.GT_WORDS).reshape(-1, P.GT_WORDS)
@@ -228,51 +230,63 @@ def run_resident(plan, given, params=None, sources=None):
             dP[idx] += (prm[pw] * c) * c
             dq[idx] += prm[pw] * (c * (0.0 - prm[pa]))
     Pm, q = np.full((no, no), np.nan), np.full(no, np.nan)
-    lanes = np.arange(16)
+    four = np.arange(4)
     assert wtrip[:, 1].sum() == len(trips)
     for first_trip, count in wtrip:
         assert count % 2 == 0
-        acc, open_tile = None, None
+        acc, open_pack = None, None
         for x in trips[first_trip:first_trip + count]:
             word = int(x[2])
-            if word == 0 and open_tile is None:
+            if word == 0 and open_pack is None:
                 continue                                  # padding to an even count
-            rows, mode, half = word & 31, (word >> P.RT_MODE) & 3, (word >> P.RT_HALF) & 1
-            ti, tj = (word >> P.RT_TI) & 127, (word >> P.RT_TJ) & 127
-            assert rows <= 16 and ti < nt and tj < ntb
+            rows, half, nop = word & 31, (word >> P.RT_HALF) & 1, (word >> P.RT_NOP) & 1
+            live, qmask = (word >> P.RT_LIVE) & 15, (word >> P.RT_QMASK) & 15
+            pack = (int(x[4]), int(x[5]), live, qmask)
+            assert rows <= 16 and live and not qmask & ~live
             if (word >> P.RT_FIRST) & 1:
-                assert open_tile is None
-                acc, open_tile = np.zeros((16, 16)), (ti, tj)
-            assert open_tile == (ti, tj)
-            w, aim = prm[x[3] & 0xFFFF], prm[x[3] >> 16]
-            assert mode == P.RI_MODE_PLAIN or tj == tq
+                assert open_pack is None
+                acc, open_pack = np.zeros((4, 4, 4)), pack
+            assert open_pack == pack
+            w, aim = prm[x[3] // 8], prm[x[7] // 8]
+            xa, xb, xd = x[0] // 8, x[1] // 8, x[6] // 8
             s = 0.5 if half else 1.0
-            for k in range(rows):
-                av = w * V[x[0] + k * ldv + lanes]
-                bv = V[x[1] + k * ldv + lanes].copy()
-                if mode != P.RI_MODE_PLAIN:
-                    dval = s * (bv[qli] - aim)
-                    if mode == P.RI_MODE_Q:
-                        bv[:] = 0.0
-                    bv[qli] = 0.0 if mode == P.RI_MODE_P else dval
-                acc += np.outer(av, bv)
+            for g in range(4):
+                bi, bj = (pack[0] >> (8 * g)) & 255, (pack[1] >> (8 * g)) & 255
+                assert bi < nb and bj < nb
+                for k in range(rows):
+                    av = w * V[xa + k * ldv + 4 * bi + four]
+                    if (qmask >> g) & 1:
+                        bv = np.full(4, s * (V[xd + k * ldv + no] - aim))
+                    elif nop:
+                        bv = np.zeros(4)
+                    else:
+                        bv = V[xb + k * ldv + 4 * bj + four]
+                    acc[g] += np.outer(av, bv)
             if (word >> P.RT_LAST) & 1:
-                for i in range(16):
-                    row = ti * 16 + i
-                    if row >= no:
+                for g in range(4):
+                    if not (live >> g) & 1:
                         continue
-                    for jx in range(16):
-                        col = tj * 16 + jx
-                        if col < no:
-                            assert np.isnan(Pm[row, col])
-                            Pm[row, col] = acc[i, jx] + (dP[row] if row == col else 0.0)
-                            if it[H["RS_SYM"]] and ti != tj:
-                                Pm[col, row] = Pm[row, col]
-                        elif col == no:
+                    bi, bj = (pack[0] >> (8 * g)) & 255, (pack[1] >> (8 * g)) & 255
+                    for i in range(4):
+                        row = 4 * bi + i
+                        if row >= no:
+                            continue
+                        if (qmask >> g) & 1:
                             assert np.isnan(q[row])
-                            q[row] = acc[i, jx] + dq[row]
-                open_tile = None
-        assert open_tile is None
+                            q[row] = acc[g][i, 0] + dq[row]
+                            continue
+                        for jx in range(4):
+                            col = 4 * bj + jx
+                            if col < no:
+                                assert np.isnan(Pm[row, col])
+                                Pm[row, col] = acc[g][i, jx] + (dP[row] if row == col else 0.0)
+                                if it[H["RS_SYM"]] and bi != bj:
+                                    assert np.isnan(Pm[col, row])
+                                    Pm[col, row] = Pm[row, col]
+                open_pack = None
+        assert open_pack is None
+    assert not np.isnan(q).any()
+    Pm[np.isnan(Pm)] = 0.0        # blocks no term reaches: zeroed once per workgroup, never written
     # ---- constraint rows
     rr = _section(it, "OFF_RS_RR", nc * P.RS_RR_WORDS).reshape(nc, P.RS_RR_WORDS)
     G, h = np.zeros((nc, no)), np.zeros(nc)

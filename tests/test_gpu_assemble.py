@@ -275,6 +275,37 @@ def test_biped_batch_horizon_matrices_generated_on_chip(gpu_api, kernel_path):
         assert np.array_equal(Pc.cpu().numpy(), P) and np.array_equal(qc.cpu().numpy(), q)
 
 
+def test_biped_long_horizon_persistent_kernel(gpu_api):
+    """N = 24 (no = 52, nc = 108): more 16-byte pieces of G than the per-thread descriptor
+    table of the persistent kernel holds, so G goes by the packed words of the row records
+    (plan_tables.h RR_PACKED); 13 block columns of P and q.  Horizon matrices built on chip,
+    against the staged pipeline fed by fill_su."""
+    from mpcasm import capi, engine
+
+    conf = problems.BipedConfig(step_samples=12)
+    form = problems.biped(gpu_api, conf)
+    clock = problems.StepClock(conf.step_samples, form.domain["Ds_x"])
+    form.update(step_times=clock.step_times, step_count=clock.step_count)
+    batch = 70
+    rng = np.random.default_rng(24)
+    given = rng.normal(0, 0.1, [batch, form.given_len])
+    asm = engine.Assembler(form, batch=batch, lti=["LIP"])
+    assert asm.plan.resident["ok"] and asm.nc * (asm.no // 2) > 6 * 256
+    mine = [t.cpu().numpy() for t in asm.assemble(given)]
+    ref = engine.Assembler(form, batch=batch)
+    lib = capi.load()
+    lib.mpcasm_set_option(capi.OPT_PATH, 2)
+    try:
+        theirs = [t.cpu().numpy() for t in ref.assemble(given)]
+    finally:
+        lib.mpcasm_set_option(capi.OPT_PATH, 0)
+    for m, t in zip(mine, theirs):
+        assert_close(m, t, RTOL_TIGHT)
+    Ao, ho, Qo, qo = orc.assemble(form, given[5].reshape(-1, 1))
+    assert_close(mine[0][5], Qo, RTOL_TIGHT)
+    assert_close(mine[2][5], Ao, RTOL_TIGHT)
+
+
 @pytest.mark.parametrize("nx,nu,N", [(2, 2, 6), (4, 1, 9), (5, 2, 5), (6, 3, 7)])
 def test_generated_horizon_matrices_other_systems(gpu_api, kernel_path, nx, nu, N):
     """K1 fused for systems other than the 3-state pendulum: several inputs (U_0..U_{m-1}),

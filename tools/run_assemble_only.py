@@ -13,7 +13,10 @@ import bench  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 work = bench.build_workload(B, 1)
-asm = work["engine"].Assembler(work["form"], batch=B)
+lti = os.environ.get("MPCASM_LTI") == "1"      # horizon matrices generated on chip
+asm = work["engine"].Assembler(work["form"], batch=B, lti=["LIP"] if lti else ())
+if lti:
+    asm.bind_lti("LIP", torch.as_tensor(work["A"], device="cuda"), torch.as_tensor(work["B"], device="cuda"))
 given = torch.as_tensor(work["given"], device="cuda")
 for _ in range(6):
     asm.assemble(given)
