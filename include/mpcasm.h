@@ -126,7 +126,8 @@ int mpcasm_workspace_bytes(const mpcasm_plan* plan, int batch, size_t* out_bytes
  *                (the reference returns them as A=G, h, Q=P, q).
  *   d_work       scratch of mpcasm_workspace_bytes(plan, batch)
  *
- * Any of d_P/d_q (both) or d_G/d_h (both) may be NULL to skip that half.
+ * Any of d_P/d_q (both) or d_G/d_h (both) may be NULL to skip that half.  The result
+ * buffers are 16-byte aligned (MPCASM_ERR_ARG otherwise).
  *
  * K1 fused (plans compiled with lti=[...], mpcasm/plan.py): for a dynamics whose
  * horizon matrices are generated on chip, i.e. what

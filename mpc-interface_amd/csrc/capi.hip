@@ -516,7 +516,10 @@ int mpcasm_assemble(const mpcasm_plan* plan, const double* const* h_src,
   if ((d_P == nullptr) != (d_q == nullptr) || (d_G == nullptr) != (d_h == nullptr))
     return MPCASM_ERR_ARG;
   if (d.rtot && !d_work) return MPCASM_ERR_ARG;
-  if (batch == 0) return MPCASM_OK;
+  // results leave the chip in 16-byte stores
+  if ((reinterpret_cast<uintptr_t>(d_P) | reinterpret_cast<uintptr_t>(d_q) |
+       reinterpret_cast<uintptr_t>(d_G) | reinterpret_cast<uintptr_t>(d_h)) & 15)
+    return MPCASM_ERR_ARG;
   SrcTable src;
   int rc = make_src_table(plan, h_src, h_src_stride, &src);
   if (rc != MPCASM_OK) return rc;

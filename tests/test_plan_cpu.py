@@ -222,6 +222,25 @@ def test_invalid_problems_raise(cpu_api):
         compile_plan(form)
 
 
+def test_header_slots_agree_with_the_kernels_enum():
+    """The table header is written by mpcasm/plan.py and read by csrc/plan_tables.h: same
+    slots in the same order, same constants."""
+    import os
+    import re
+
+    import mpcasm.plan as P
+
+    text = open(os.path.join(os.path.dirname(__file__), "..", "mpc-interface_amd", "csrc",
+                             "plan_tables.h")).read()
+    body = text[text.index("H_MAGIC = 0"):text.index("H_WORDS =")]
+    names = re.findall(r"^\s*H_([A-Z0-9_]+)\s*(?:=\s*\d+\s*)?,", body, flags=re.M)
+    assert names == [n for n, _ in sorted(P._H.items(), key=lambda kv: kv[1])]
+    for const in ("PLAN_VERSION", "H_WORDS", "RS_TRIP_WORDS", "RS_RR_WORDS", "RS_LTI_WORDS",
+                  "RS_BLOCKS_MAX"):
+        m = re.search(r"\b%s\s*=\s*(\d+)" % const, text)
+        assert m and int(m.group(1)) == getattr(P, const), const
+
+
 def test_plan_tables_rejected_or_accepted_by_the_library(cpu_api):
     """mpcasm_plan_create validates the tables on the host before touching the
     device: a corrupted plan is MPCASM_ERR_PLAN everywhere, a good one reaches the
