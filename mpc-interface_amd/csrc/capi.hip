@@ -165,6 +165,21 @@ int validate_plan(const int32_t* it, const double* h_dtab, size_t n_itab, size_t
         if (offs[k] < 0 || offs[k] % 8 || (rows > 0 && offs[k] / 8 / it[H_LDV] + rows > it[H_RTOT]) ||
             (rows == 0 && offs[k] != 0))
           return MPCASM_ERR_PLAN;
+      // the tail k-step: at most four rows of its own
+      const int tword = x[RT_TAIL_WORD], trows = tword & 31;
+      if (tword != 0) {
+        if (rows == 0 || (tword & ~(31 | (1 << RT_HALF) | (1 << RT_NOP))) || trows < 1 || trows > 4 ||
+            x[RT_TAIL_W] < 0 || x[RT_TAIL_W] % 8 || x[RT_TAIL_W] / 8 >= it[H_NPARAMS] ||
+            x[RT_TAIL_AIM] < 0 || x[RT_TAIL_AIM] % 8 || x[RT_TAIL_AIM] / 8 >= it[H_NPARAMS])
+          return MPCASM_ERR_PLAN;
+        const int toffs[3] = {x[RT_TAIL_A], x[RT_TAIL_B], x[RT_TAIL_D]};
+        for (int k = 0; k < 3; ++k)  // (reads four rows from the offset: the slack covers them)
+          if (toffs[k] < 0 || toffs[k] % 8 || toffs[k] / 8 / it[H_LDV] + trows > it[H_RTOT])
+            return MPCASM_ERR_PLAN;
+      } else {
+        for (int k = RT_TAIL_A; k < RS_TRIP_WORDS; ++k)
+          if (x[k] != 0) return MPCASM_ERR_PLAN;
+      }
     }
     {  // every wavefront's trips: consecutive, whole packs (first ... last)
       const int32_t* wt = it + it[H_OFF_RS_WTRIP];

@@ -27,7 +27,7 @@
 namespace mpcasm {
 
 constexpr int32_t PLAN_MAGIC = 0x4D504341;  // 'MPCA'
-constexpr int32_t PLAN_VERSION = 16;
+constexpr int32_t PLAN_VERSION = 17;
 
 enum HeaderWord : int {
   H_MAGIC = 0,
@@ -84,7 +84,7 @@ enum HeaderWord : int {
   H_OFF_RS_DST,     // [JC][RS_NT] workspace index the running sum goes to (| RS_DST_ACC: added
                     //             to it, the element is shared by two threads), or -1
   H_DOFF_RS_COEF,   // [JC][RS_NT]
-  H_OFF_RS_TRIP,    // [NTRIP + 2][8]: up to 16 rows of one gterm into one pack of blocks, see RT_* below;
+  H_OFF_RS_TRIP,    // [NTRIP + 2][16]: up to 16 rows of one gterm into one pack of blocks, see RT_* below;
                     //    two all-zero records behind the last (read ahead)
   H_OFF_RS_WTRIP,   // [RS_WAVES][2] first trip, trip count of every wavefront
   H_RS_NSPLIT,      // workspace elements composed by two threads
@@ -141,7 +141,7 @@ constexpr int MAX_SOURCES = 32;
 // RS_NT threads per instance = RS_WAVES wavefronts; the first RS_NW ("matrix waves") fetch
 // the inputs, the others stream G; all of them run Hessian tiles; RS_JC_MAX compose ops
 // per thread
-constexpr int RS_NW = 4, RS_NT = 512, RS_WAVES = RS_NT / 64, RS_JC_MAX = 12, RS_TRIP_WORDS = 8;
+constexpr int RS_NW = 4, RS_NT = 512, RS_WAVES = RS_NT / 64, RS_JC_MAX = 12, RS_TRIP_WORDS = 16;
 constexpr int RS_BLOCKS_MAX = 255;  // 4-column blocks of the unknowns (one byte each): no <= 1020
 // generated source group: sizes; offsets of A [n][n] and B [n][m] inside a ring slot; image
 // offsets of the tables TA[k][i][j] = (A^{k+1})[i][j] and TB[d][i][j] = (A^d B)[i][j], k, d < N, and of
@@ -165,8 +165,13 @@ constexpr int32_t RS_DST_ACC = 1 << 30;
 // << 9 | live lane groups << 10 | lane groups that hold a block of q << 14; RT_W / RT_AIM:
 // BYTE offset of the weight / aim among the parameters; RT_BI / RT_BJ: block row / block column of the four lane
 // groups, a byte each (groups that are not live repeat a live one's; the column of a block
-// of q is not used).  A wavefront's trips of one pack are consecutive.
-enum { RT_A = 0, RT_B, RT_WORD, RT_W, RT_BI, RT_BJ, RT_D, RT_AIM };
+// of q is not used).  A wavefront's trips of one pack are consecutive.  A term (or the rest
+// of one) of at most four rows does not get a trip of its own: it rides as the *tail* of the
+// trip before it in the pack, a fifth k-step over the rows RT_TAIL_A.. (consecutive rows,
+// one per k-step lane row) with its own weight: RT_TAIL_WORD = rows | half << 5 | no
+// Hessian part << 6, 0 = no tail.
+enum { RT_A = 0, RT_B, RT_WORD, RT_W, RT_BI, RT_BJ, RT_D, RT_AIM,
+       RT_TAIL_A, RT_TAIL_B, RT_TAIL_WORD, RT_TAIL_W, RT_TAIL_D, RT_TAIL_AIM };
 enum { RT_HALF = 5, RT_NOP = 6, RT_FIRST = 8, RT_LAST = 9, RT_LIVE = 10, RT_QMASK = 14 };
 // diagonal gterms the persistent kernel takes on one column of the unknowns
 constexpr int RS_DIAG_MAX = 2;

@@ -688,12 +688,16 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
         const int stride = 2 * ldv * (int)sizeof(double);  // k-step to k-step
         int a_lane = 0, b_lane = 0, bi = 0, bj = 0;  // of the current pack
         bool isq = false, live = false;
-        i32x4 rn = tg[2 * t0], kn = tg[2 * t0 + 1];
+        // the tail k-step of a trip reads consecutive rows: lane row lk instead of krow
+        const int tail_shift = (lk - krow) * ldv * (int)sizeof(double);
+        i32x4 rn = tg[4 * t0], kn = tg[4 * t0 + 1], xn = tg[4 * t0 + 2], yn = tg[4 * t0 + 3];
         double acc = 0.0;
         for (int t = 0; t < tn; ++t) {
-          const i32x4 r = rn, k = kn;
-          rn = tg[2 * (t0 + t) + 2];
-          kn = tg[2 * (t0 + t) + 3];
+          const i32x4 r = rn, k = kn, x = xn, y = yn;  // y: tail d offset, tail aim
+          rn = tg[4 * (t0 + t) + 4];
+          kn = tg[4 * (t0 + t) + 5];
+          xn = tg[4 * (t0 + t) + 6];
+          yn = tg[4 * (t0 + t) + 7];
           const int word = r.z, rows = word & 31;
           if (word == 0) continue;  // padding
           if ((word >> RT_FIRST) & 1) {  // a new pack: what this lane reads and owns
@@ -711,6 +715,23 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
           for (int u = 0; u < 4; ++u) {  // k-step u takes rows 2u, 2u+1, 2u+8, 2u+9 (see krow)
             a[u] = *reinterpret_cast<const double*>(ap + u * stride);
             b[u] = *reinterpret_cast<const double*>(bp + u * stride);
+          }
+          // the tail: at most four rows of another term (or the rest of this one), one more
+          // k-step with a weight of its own
+          const int tword = x.z;
+          double ta = 0.0, tb = 0.0;
+          if (tword != 0) {
+            const double tw = *reinterpret_cast<const double*>(prc + x.w);
+            ta = *reinterpret_cast<const double*>(Vc + (x.x + a_lane + tail_shift));
+            tb = *reinterpret_cast<const double*>(Vc + ((isq ? y.x : x.y) + b_lane + tail_shift));
+            ta = lk < (tword & 31) ? tw * ta : 0.0;
+            if ((word & (15 << RT_QMASK)) | (tword & (1 << RT_NOP))) {
+              const double taim = *reinterpret_cast<const double*>(prc + y.y);
+              const double sc = (tword >> RT_HALF) & 1 ? 0.5 : 1.0;
+              const double m1 = isq ? sc : ((tword >> RT_NOP) & 1 ? 0.0 : 1.0);
+              const double m2 = isq ? sc * taim : 0.0;
+              tb = fma(m1, tb, -m2);
+            }
           }
           // a weight of 0 contributes exact zeros through the products (body.py:292)
           const double w = *reinterpret_cast<const double*>(prc + r.w);
@@ -734,6 +755,7 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
             for (int u = 0; u < 4; ++u)
               if (2 * u < rows) acc = mfma_f64_4x4x4(2 * u + krow < rows ? a[u] : 0.0, b[u], acc);
           }
+          if (tword != 0) acc = mfma_f64_4x4x4(ta, tb, acc);
           if ((word >> RT_LAST) & 1) {  // the pack is complete: into P and q in LDS
             const int row = 4 * bi + lk, col = 4 * bj + lx;
             if (live && row < no) {

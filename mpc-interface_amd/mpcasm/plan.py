@@ -15,7 +15,7 @@ import numpy as np
 import scipy.sparse as sp
 
 PLAN_MAGIC = 0x4D504341
-PLAN_VERSION = 16
+PLAN_VERSION = 17
 
 # header words (csrc/plan_tables.h, enum HeaderWord)
 _H = {name: i for i, name in enumerate([
@@ -39,10 +39,11 @@ RS_WAVES = RS_NT // 64
 RS_BLOCKS_MAX = 255                       # 4-column blocks of the unknowns, a byte each
 RS_LTI_WORDS, RS_LTI_MAX = 8, 4           # record of a source group generated on chip; groups per plan
 RS_JC_MAX = 12                            # compose ops a thread can keep in registers
-RS_TRIP_WORDS = 8
-TRIP_COST, TRIP_STEP_COST, G_PIECE_COST = 800, 50, 750   # wavefront assignment, see _resident_program
+RS_TRIP_WORDS = 16
+TRIP_COST, TRIP_STEP_COST, TRIP_TAIL_COST, G_PIECE_COST = 1100, 50, 250, 550   # wavefront assignment, see _resident_program
 # trip record, word 2: rows | mode << 5 | half << 7 | first << 8 | last << 9 | ti << 10 | tj << 17
 RT_HALF, RT_NOP, RT_FIRST, RT_LAST, RT_LIVE, RT_QMASK = 5, 6, 8, 9, 10, 14
+RT_TAIL = 8                               # words 8..13 of a trip record: its tail k-step
 RS_DIAG_MAX = 2                           # diagonal gterms per column (persistent kernel)
 RS_AXMAX = 4                              # axes per constraint row record
 RS_DST_ACC = 1 << 30                      # compose destination shared by two threads
@@ -709,12 +710,18 @@ def _resident_program(fused, gterms, no, ldv, image, ng, nparams, nc_rows):
             half = 1 if flags & GT_FLAG_HALF else 0
             brow = boff if flags & GT_FLAG_P else doff   # (a term without P only meets q lanes)
             for k0 in range(0, nrows, 16):
-                lst.append([(aoff + k0) * ldv * 8, (brow + k0) * ldv * 8,
-                            min(16, nrows - k0) | (half << RT_HALF)
-                            | (0 if flags & GT_FLAG_P else 1 << RT_NOP), wparam * 8,
-                            bi_bytes, bj_bytes, (doff + k0) * ldv * 8, aimparam * 8])
+                rec = [(aoff + k0) * ldv * 8, (brow + k0) * ldv * 8,
+                       min(16, nrows - k0) | (half << RT_HALF)
+                       | (0 if flags & GT_FLAG_P else 1 << RT_NOP), wparam * 8,
+                       bi_bytes, bj_bytes, (doff + k0) * ldv * 8, aimparam * 8] + [0] * 8
+                if (rec[2] & 31) <= 4 and lst and lst[-1][RT_TAIL + 2] == 0:
+                    # at most four rows: one more k-step at the tail of the trip before,
+                    # with its own rows and weight, instead of a trip of its own
+                    lst[-1][RT_TAIL:RT_TAIL + 6] = [rec[0], rec[1], rec[2], rec[3], rec[6], rec[7]]
+                else:
+                    lst.append(rec)
         if not lst:                                  # nothing to add up: the pack is still written
-            lst.append([0, 0, 0, 0, bi_bytes, bj_bytes, 0, 0])
+            lst.append([0, 0, 0, 0, bi_bytes, bj_bytes, 0, 0] + [0] * 8)
         for trip in lst:
             trip[2] |= (live << RT_LIVE) | (qmask << RT_QMASK)
         lst[0][2] |= 1 << RT_FIRST
@@ -724,7 +731,8 @@ def _resident_program(fused, gterms, no, ldv, image, ng, nparams, nc_rows):
     # rounded) cycles of one wavefront: a trip, a pack store, a 16-byte piece of G, a
     # chunk of the input fetch.  The matrix waves start with the fetch on their account,
     # the stream waves with their share of G.
-    cost = [200 + sum(TRIP_COST + TRIP_STEP_COST * (((trip[2] & 31) + 3) // 4) for trip in lst)
+    cost = [200 + sum(TRIP_COST + TRIP_STEP_COST * (((trip[2] & 31) + 3) // 4)
+                      + TRIP_TAIL_COST * (trip[RT_TAIL + 2] != 0) for trip in lst)
             for lst in pack_trips]
     stream_threads = NT - NW * 64
     pieces = nc_rows * max(no // 2, 1)
@@ -735,8 +743,8 @@ def _resident_program(fused, gterms, no, ldv, image, ng, nparams, nc_rows):
         else:                                      # threads of this wave own pieces e = wt + u WT
             first = (w - NW) * 64
             own = len(range(first, pieces, stream_threads))
-            gen = 4000 if image["groups"] and w == RS_WAVES - 1 else 0   # builds the tables
-            loads.append((G_PIECE_COST * own + 600 + gen, w))
+            gen = 2000 if image["groups"] and w == RS_WAVES - 1 else 0   # builds the tables
+            loads.append((G_PIECE_COST * own + 500 + gen, w))
     heapq.heapify(loads)
     wave_packs = [[] for _ in range(RS_WAVES)]
     for k in sorted(range(len(pack_trips)), key=lambda k: -cost[k]):

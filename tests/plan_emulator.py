@@ -249,19 +249,29 @@ def run_resident(plan, given, params=None, sources=None):
             assert open_pack == pack
             w, aim = prm[x[3] // 8], prm[x[7] // 8]
             xa, xb, xd = x[0] // 8, x[1] // 8, x[6] // 8
-            s = 0.5 if half else 1.0
-            for g in range(4):
-                bi, bj = (pack[0] >> (8 * g)) & 255, (pack[1] >> (8 * g)) & 255
-                assert bi < nb and bj < nb
-                for k in range(rows):
-                    av = w * V[xa + k * ldv + 4 * bi + four]
-                    if (qmask >> g) & 1:
-                        bv = np.full(4, s * (V[xd + k * ldv + no] - aim))
-                    elif nop:
-                        bv = np.zeros(4)
-                    else:
-                        bv = V[xb + k * ldv + 4 * bj + four]
-                    acc[g] += np.outer(av, bv)
+            parts = [(rows, half, nop, w, aim, xa, xb, xd)]
+            tword = int(x[P.RT_TAIL + 2])
+            if tword:                                     # the tail k-step: rows of its own
+                assert 1 <= (tword & 31) <= 4 and rows > 0
+                parts.append((tword & 31, (tword >> P.RT_HALF) & 1, (tword >> P.RT_NOP) & 1,
+                              prm[x[P.RT_TAIL + 3] // 8], prm[x[P.RT_TAIL + 5] // 8],
+                              x[P.RT_TAIL] // 8, x[P.RT_TAIL + 1] // 8, x[P.RT_TAIL + 4] // 8))
+            else:
+                assert not x[P.RT_TAIL:].any()
+            for rows_, half_, nop_, w_, aim_, ya, yb, yd in parts:
+                s = 0.5 if half_ else 1.0
+                for g in range(4):
+                    bi, bj = (pack[0] >> (8 * g)) & 255, (pack[1] >> (8 * g)) & 255
+                    assert bi < nb and bj < nb
+                    for k in range(rows_):
+                        av = w_ * V[ya + k * ldv + 4 * bi + four]
+                        if (qmask >> g) & 1:
+                            bv = np.full(4, s * (V[yd + k * ldv + no] - aim_))
+                        elif nop_:
+                            bv = np.zeros(4)
+                        else:
+                            bv = V[yb + k * ldv + 4 * bj + four]
+                        acc[g] += np.outer(av, bv)
             if (word >> P.RT_LAST) & 1:
                 for g in range(4):
                     if not (live >> g) & 1:
