@@ -226,6 +226,29 @@ int validate_plan(const int32_t* it, const double* h_dtab, size_t n_itab, size_t
         return MPCASM_ERR_PLAN;
     }
     if (it[H_RR_PACKED] != 0 && (it[H_RR_PACKED] != 1 || (no & 1) || nc < 1)) return MPCASM_ERR_PLAN;
+    {  // the per-column tables of the diagonal gterms and the piece descriptors of G
+      if (!in_range(it[H_OFF_RS_DPAR], no * 2 * RS_DIAG_MAX, n, H_WORDS) || it[H_OFF_RS_DPAR] % 4 ||
+          !in_range(it[H_DOFF_RS_DCOEF], no * RS_DIAG_MAX, nd, 0) || it[H_DOFF_RS_DCOEF] % 2)
+        return MPCASM_ERR_PLAN;
+      const int32_t* dp = it + it[H_OFF_RS_DPAR];
+      for (int64_t i = 0; i < no * 2 * RS_DIAG_MAX; ++i)
+        if (dp[i] < 0 || dp[i] > it[H_NPARAMS]) return MPCASM_ERR_PLAN;
+      const int64_t ngd = it[H_RS_NGDESC];
+      if (ngd != 0) {
+        const int64_t pieces = nc * (no / 2);
+        if (!it[H_RR_PACKED] || ngd != (int64_t)RS_GDESC_PIECES * RS_GDESC_THREADS || pieces > ngd ||
+            !in_range(it[H_OFF_RS_GDESC], ngd * 2, n, H_WORDS) || it[H_OFF_RS_GDESC] % 2)
+          return MPCASM_ERR_PLAN;
+        const int32_t* gd = it + it[H_OFF_RS_GDESC];
+        for (int64_t e = 0; e < ngd; ++e) {  // the same numbers as the row record of the piece
+          const int64_t R = e < pieces ? e / (no / 2) : 0, cp = e < pieces ? e % (no / 2) : 0;
+          const int32_t* x = rrw + R * RS_RR_WORDS;
+          if ((uint32_t)gd[2 * e] != (((uint32_t)x[RR_VOFF] + 2 * cp) | (((uint32_t)x[RR_VOFF + 1] + 2 * cp) << 16)) ||
+              (uint32_t)gd[2 * e + 1] != (uint32_t)x[RR_PACKED + 1])
+            return MPCASM_ERR_PLAN;
+        }
+      }
+    }
     for (int64_t g = 0; g < nlti; ++g) {  // generated groups: loaded A, B and the tables
       const int32_t* x = it + it[H_OFF_RS_LTI] + g * RS_LTI_WORDS;
       const int64_t gn = x[LT_N], gm = x[LT_M], gN = x[LT_HORIZON];
@@ -461,6 +484,8 @@ int mpcasm_plan_create(const int32_t* h_itab, size_t n_itab, const double* h_dta
   d.rs_nlti = it[H_RS_NLTI]; d.off_rs_lti = it[H_OFF_RS_LTI]; d.rs_img_dma = it[H_RS_IMG_DMA];
   d.rs_ab = it[H_RS_AB]; d.off_rs_abmeta = it[H_OFF_RS_ABMETA];
   d.rr_packed = it[H_RR_PACKED];
+  d.off_rs_dpar = it[H_OFF_RS_DPAR]; d.doff_rs_dcoef = it[H_DOFF_RS_DCOEF];
+  d.rs_ngdesc = it[H_RS_NGDESC]; d.off_rs_gdesc = it[H_OFF_RS_GDESC];
   d.rs_src16 = 0;
   if (d.rs_ok && d.rs_unit == 16)
     for (int64_t i = 0; i < (int64_t)d.rs_nchunk * 64; ++i) {
@@ -513,9 +538,10 @@ int mpcasm_plan_sizes(const mpcasm_plan* plan, int64_t out[8]) {
 int mpcasm_workspace_bytes(const mpcasm_plan* plan, int batch, size_t* out_bytes) {
   if (!plan || !out_bytes || batch < 0) return MPCASM_ERR_ARG;
   // the staged pipeline's workspace; never less than the cycle stamps of the diagnostic
-  // persistent kernel take (8 wavefronts x 8 counters per resident workgroup)
+  // persistent kernel take (8 wavefronts x 8 counters per resident workgroup for the phases
+  // of the instance loop, as many again for the set-up)
   const size_t groups = (size_t)std::min<long>(batch, (long)plan->num_cus * 8);
-  *out_bytes = std::max(assemble_workspace_bytes(plan->dev, batch), groups * 8 * 8 * sizeof(uint64_t));
+  *out_bytes = std::max(assemble_workspace_bytes(plan->dev, batch), 2 * groups * 8 * 8 * sizeof(uint64_t));
   return MPCASM_OK;
 }
 

@@ -24,7 +24,8 @@ struct PlanDev {
   int rs_ok, rs_jc, rs_sym, rs_ntrip, off_rs_src, off_rs_gidx, off_rs_dst, doff_rs_coef,
       off_rs_trip, off_rs_wtrip, rs_nsplit, off_rs_split, off_rs_rr, rs_unit,
       rs_nchunk, off_rs_inmeta, rs_img, rs_img_given, rs_img_params, doff_rs_const, rs_nlti,
-      off_rs_lti, rs_img_dma, rs_ab, off_rs_abmeta, rr_packed;
+      off_rs_lti, rs_img_dma, rs_ab, off_rs_abmeta, rr_packed, off_rs_dpar, doff_rs_dcoef,
+      rs_ngdesc, off_rs_gdesc;
   unsigned rs_src16;  // sources that the 16-byte image loads read (bit per source)
   int doff_diagcoef, ndiag;  // diagonal gterms: coefficient list, number of such terms
 };

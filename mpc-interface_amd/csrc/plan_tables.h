@@ -27,7 +27,7 @@
 namespace mpcasm {
 
 constexpr int32_t PLAN_MAGIC = 0x4D504341;  // 'MPCA'
-constexpr int32_t PLAN_VERSION = 17;
+constexpr int32_t PLAN_VERSION = 18;
 
 enum HeaderWord : int {
   H_MAGIC = 0,
@@ -112,6 +112,13 @@ enum HeaderWord : int {
   H_OFF_RS_ABMETA,  // [RS_AB * 2][2] input stream, byte offset of every 4-byte lane of a slot
   H_RR_PACKED,      // 1: every row record of G carries its RR_PACKED words (no is even, rows
                     //    have at most two axes, offsets and parameter slots fit 16 bits)
+  H_OFF_RS_DPAR,    // [NO][4] per column of the unknowns: weight, aim parameter slots of the (at most
+                    //    RS_DIAG_MAX = 2) diagonal gterms on it (free: slot NPARAMS, always 0.0)
+  H_DOFF_RS_DCOEF,  // [NO][2] their coefficients (free: 0.0)
+  H_RS_NGDESC,      // RS_GDESC_PIECES * RS_GDESC_THREADS when the table below exists, else 0
+  H_OFF_RS_GDESC,   // [RS_NGDESC][2] small problems: a ready-made descriptor of every 16-byte piece of
+                    //    G; piece e = columns 2cp, 2cp+1 of row R = e / (no/2):
+                    //    (voff0 + 2cp) | (voff1 + 2cp) << 16, arrow0 | arrow1 << 16
   H_WORDS = 80
 };
 
@@ -151,6 +158,7 @@ constexpr int RS_LTI_MAX = 4;
 // row record of G: voff[4], arrow param[4], center param[4], naxes, extreme param, the first
 // two axes packed once more: voff0 | voff1 << 16, arrow0 | arrow1 << 16
 constexpr int RS_AXMAX = 4, RS_RR_WORDS = 16;
+constexpr int RS_GDESC_PIECES = 6, RS_GDESC_THREADS = RS_NT - RS_NW * 64;  // pieces per stream-wave thread
 constexpr int32_t RS_DST_ACC = 1 << 30;
 // The Hessian and the gradient are accumulated in 4x4 blocks (v_mfma_f64_4x4x4_4b_f64: four
 // independent 4x4 blocks per instruction, 4 rows of the workspace per k-step): block (bi, bj)

@@ -67,8 +67,9 @@ constexpr int GU = 6;  // 16-byte pieces of G a worker thread may own a descript
 // LDS -- 12 KB that buy back the row/column bookkeeping; 0: the general path.
 __host__ __device__ inline int resident_g_mode(const PlanDev& p) {
   if (!p.rr_packed) return 0;
-  return (long)p.nc * (p.no >> 1) <= (long)GU * WT ? 2 : 1;
+  return p.rs_ngdesc != 0 ? 2 : 1;
 }
+static_assert(GU == RS_GDESC_PIECES && WT == RS_GDESC_THREADS, "descriptor table of G");
 
 struct ResidentLayout {
   // offsets in doubles
@@ -150,6 +151,14 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
   // diagnostic build only (MPCASM_OPT_PHASE_MASK bit 6): per-wave cycle sums of the phases,
   // written to the otherwise unused workspace; no result depends on them
   unsigned long long t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0;
+  // ... and, behind those of all workgroups, cycles since the kernel's start at the stations
+  // of the set-up (0 stream tables in LDS, 1 first barrier, 2 compose program in registers,
+  // 3 first tables generated, 4 structure tables copied, 5 barrier, 6 first image landed)
+  const unsigned long long t_begin = STAMPS ? __builtin_amdgcn_s_memtime() : 0;
+#define SETUP_STAMP(k)                                                                  \
+  if (STAMPS && stamps != nullptr && lane == 0)                                         \
+    stamps[((size_t)gridDim.x + blockIdx.x) * (NT / 64) * 8 + wave * 8 + (k)] =         \
+        __builtin_amdgcn_s_memtime() - t_begin;
   const bool stamping = STAMPS && stamps != nullptr;
 #define MPCASM_STAMP(slot)                                         \
   if (STAMPS && stamping) {                                        \
@@ -186,6 +195,7 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
     for (int i = tid; i < p.rs_ab * 2; i += NT) abmeta[i] = t2[i];
     t2 = reinterpret_cast<const int2*>(p.itab + p.off_rs_inmeta);
     for (int i = tid; i < nchunk * 64; i += NT) meta[i] = t2[i];
+    for (int i = tid; i < p.rs_nlti * RS_LTI_WORDS; i += NT) lti[i] = (p.itab + p.off_rs_lti)[i];
     // input streams: the sources, then given, params, the plan's constants
     if (tid < p.nsrc + 3) {
       const int s = tid - p.nsrc;
@@ -197,7 +207,9 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
       reinterpret_cast<long long*>(strm)[2 * tid + 1] = stride * (long long)sizeof(double);
     }
   }
+  SETUP_STAMP(0)
   lds_barrier();
+  SETUP_STAMP(1)
   // The matrix waves fetch instance `inst`'s image into buffer `buf` (chunks dealt round
   // robin).  With registers to spare (FK > 0) a lane keeps the address of its piece of the
   // first FK chunks of its wave -- pointer into instance 0 and bytes per instance -- so that
@@ -388,70 +400,82 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
       c_coef[j] = have ? tcoef[j * NT + tid] : 0.0;
     }
   }
+  SETUP_STAMP(2)
+  if (wave == 0 && (GEN && p.rs_nlti != 0)) {
+    // wave 0 builds the first instance's tables as soon as its (A, B) are there, while the
+    // other waves copy the structure tables
+    dma_wait();
+    generate_sources(0, 0);
+  }
+  const bool w0_busy = GEN && p.rs_nlti != 0;  // wave 0 takes no part in the table copies
+  const int ct = w0_busy ? tid - 64 : tid, CT = w0_busy ? NT - 64 : NT;
+  SETUP_STAMP(3)
   // ---- once per workgroup: structure tables into LDS, workspace zeroed -----------
   {
-    // blocks of P no term reaches stay zero for the whole launch
-    for (int i = tid; i < no * ldp; i += NT) Pl[i] = 0.0;
-    const int32_t* t = p.itab + p.off_rs_wtrip;
-    for (int i = tid; i < RS_WAVES * 2; i += NT) wtrip[i] = t[i];
-    t = p.itab + p.off_rs_rr;  // row records of G, precomputed by the plan compiler
-    for (int i = tid; i < nc * RR_WORDS; i += NT) rr[i] = t[i];
-    t = p.itab + p.off_rs_split;
-    for (int i = tid; i < p.rs_nsplit; i += NT) split[i] = t[i];
-    t = p.itab + p.off_rs_lti;
-    for (int i = tid; i < p.rs_nlti * RS_LTI_WORDS; i += NT) lti[i] = t[i];
-    double2* V2 = reinterpret_cast<double2*>(V);
-    const int n2 = (even_up_i(p.rtot * ldv) + 15 * ldv + 16) / 2;
-    for (int i = tid; i < n2; i += NT) V2[i] = double2{0.0, 0.0};
-    for (int i = tid; i < 2 * ldp; i += NT) dvec[i] = 0.0;  // stays zero without diagonal gterms
-    if (resident_g_mode(p) == 2 && tid >= MW * 64) {
-      // piece e = wt + u WT of G: columns 2cp, 2cp+1 of row R = e / npair.  What the piece
-      // needs -- the workspace offsets of its (two) source rows at those columns and the
-      // parameter slots of their arrows -- is fixed: packed once, read back as 8 bytes
-      const int wt_ = tid - MW * 64, np_ = no >> 1, gt_ = nc * np_;
-      const int32_t* rrg = p.itab + p.off_rs_rr;
-      for (int u = 0; u < GU; ++u) {
-        const int e = wt_ + u * WT;
-        const int R = e < gt_ ? e / np_ : 0, cp = e < gt_ ? e - R * np_ : 0;
-        const int32_t* rec = rrg + R * RR_WORDS;
-        gdesc[u * WT + wt_] = int2{(rec[RR_VOFF] + 2 * cp) | ((rec[RR_VOFF + 1] + 2 * cp) << 16),
-                                   rec[RR_ARROW] | (rec[RR_ARROW + 1] << 16)};
-      }
+    // All loads from the plan first (every one a trip to L2), then the LDS stores: table
+    // by table the latencies would add up.
+    constexpr int RRK = 3;  // row-record words per thread in the first batch
+    const int32_t* trr = p.itab + p.off_rs_rr;  // row records of G, precomputed by the plan compiler
+    const int nrr = nc * RR_WORDS;
+    int v_rr[RRK], v_wtrip = 0, v_split = 0;
+    int2 v_gd[GU];
+    int4 v_dpar = int4{0, 0, 0, 0};
+    double2 v_dcoef = double2{0.0, 0.0};
+    const bool own_gd = resident_g_mode(p) == 2 && tid >= MW * 64;
+    const bool own_diag = p.ndiag != 0 && ct >= 0 && ct < no;
+    const int wt_ = tid - MW * 64;
+    if (ct >= 0) {
+#pragma unroll
+      for (int k = 0; k < RRK; ++k) v_rr[k] = ct + k * CT < nrr ? trr[ct + k * CT] : 0;
+      if (ct < RS_WAVES * 2) v_wtrip = (p.itab + p.off_rs_wtrip)[ct];
+      if (ct < p.rs_nsplit) v_split = (p.itab + p.off_rs_split)[ct];
     }
-    if (p.ndiag != 0 && tid < no) {
-      // the diagonal gterms on column tid; free slots read the 0.0 behind the parameters
-      int4 par = int4{p.nparams, p.nparams, p.nparams, p.nparams};
-      double2 co = double2{0.0, 0.0};
-      const int32_t* gt = p.itab + p.off_gterm;
-      int n = 0;
-      for (int g = 0; g < p.ngterm; ++g) {
-        const int32_t* rec = gt + g * GT_WORDS;
-        const int k = tid - rec[GT_AOFF];
-        if (!(rec[GT_FLAGS] & GT_FLAG_DIAG) || k < 0 || k >= rec[GT_NROWS] || n >= RS_DIAG_MAX)
-          continue;
-        const double cf = (p.dtab + p.doff_diagcoef)[rec[GT_BOFF] + k];
-        if (n == 0) {
-          par.x = rec[GT_WPARAM];
-          par.y = rec[GT_AIMPARAM];
-          co.x = cf;
-        } else {
-          par.z = rec[GT_WPARAM];
-          par.w = rec[GT_AIMPARAM];
-          co.y = cf;
-        }
-        ++n;
-      }
-      dpar[tid] = par;
-      dcoef[tid] = co;
+    if (own_gd) {
+      // the descriptors of this thread's pieces of G (made by the plan compiler): piece
+      // e = wt + u WT, packed, read back as 8 bytes
+      const int2* gd = reinterpret_cast<const int2*>(p.itab + p.off_rs_gdesc);
+#pragma unroll
+      for (int u = 0; u < GU; ++u) v_gd[u] = gd[u * WT + wt_];
+    }
+    if (own_diag) {
+      // the diagonal gterms on column ct; free slots read the 0.0 behind the parameters
+      v_dpar = reinterpret_cast<const int4*>(p.itab + p.off_rs_dpar)[ct];
+      v_dcoef = reinterpret_cast<const double2*>(p.dtab + p.doff_rs_dcoef)[ct];
+    }
+    if (ct >= 0) {
+      // blocks of P no term reaches stay zero for the whole launch
+      for (int i = ct; i < no * ldp; i += CT) Pl[i] = 0.0;
+      double2* V2 = reinterpret_cast<double2*>(V);
+      const int n2 = (even_up_i(p.rtot * ldv) + 15 * ldv + 16) / 2;
+      for (int i = ct; i < n2; i += CT) V2[i] = double2{0.0, 0.0};
+      for (int i = ct; i < 2 * ldp; i += CT) dvec[i] = 0.0;  // stays zero without diagonal gterms
+#pragma unroll
+      for (int k = 0; k < RRK; ++k)
+        if (ct + k * CT < nrr) rr[ct + k * CT] = v_rr[k];
+      for (int i = ct + RRK * CT; i < nrr; i += CT) rr[i] = trr[i];
+      if (ct < RS_WAVES * 2) wtrip[ct] = v_wtrip;
+      if (ct < p.rs_nsplit) split[ct] = v_split;
+      for (int i = ct + CT; i < p.rs_nsplit; i += CT) split[i] = (p.itab + p.off_rs_split)[i];
+    }
+    if (own_gd) {
+#pragma unroll
+      for (int u = 0; u < GU; ++u) gdesc[u * WT + wt_] = v_gd[u];
+    }
+    if (own_diag) {
+      dpar[ct] = v_dpar;
+      dcoef[ct] = v_dcoef;
     }
   }
+  SETUP_STAMP(4)
   lds_barrier();
+  SETUP_STAMP(5)
 
   const bool lookahead = (phases & 128) != 0;  // diagnostic: off = fetch only when needed
   if (wave < MW) {
     dma_wait();  // the first image (requested before the set-up above) has landed
-    if (wave == 0 && (GEN && p.rs_nlti != 0)) generate_sources(0, 0);  // the first instance's tables
+    SETUP_STAMP(6)
   }
+  SETUP_STAMP(7)
 
   // ---- K4 bookkeeping of the worker threads: piece e = wt + u WT of G is the 16 bytes
   // (columns 2cp, 2cp+1) of row R; (R, cp) of the first piece and the step between pieces
@@ -815,6 +839,7 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
     for (int i = 0; i < 8; ++i) stamps[((size_t)blockIdx.x * (NT / 64) + wave) * 8 + i] = t_acc[i];
   }
 #undef MPCASM_STAMP
+#undef SETUP_STAMP
 }
 
 template <int JC>

@@ -15,7 +15,7 @@ import numpy as np
 import scipy.sparse as sp
 
 PLAN_MAGIC = 0x4D504341
-PLAN_VERSION = 17
+PLAN_VERSION = 18
 
 # header words (csrc/plan_tables.h, enum HeaderWord)
 _H = {name: i for i, name in enumerate([
@@ -30,7 +30,8 @@ _H = {name: i for i, name in enumerate([
     "DOFF_RS_COEF", "OFF_RS_TRIP", "OFF_RS_WTRIP", "RS_NSPLIT", "OFF_RS_SPLIT",
     "OFF_RS_RR", "RS_UNIT", "RS_NCHUNK", "OFF_RS_INMETA", "RS_IMG", "RS_IMG_GIVEN",
     "RS_IMG_PARAMS", "DOFF_RS_CONST", "DOFF_DIAGCOEF", "NDIAGCOEF", "RS_NLTI", "OFF_RS_LTI",
-    "RS_IMG_DMA", "RS_AB", "OFF_RS_ABMETA", "RR_PACKED",
+    "RS_IMG_DMA", "RS_AB", "OFF_RS_ABMETA", "RR_PACKED", "OFF_RS_DPAR", "DOFF_RS_DCOEF",
+    "RS_NGDESC", "OFF_RS_GDESC",
 ])}
 H_WORDS = 80
 assert len(_H) <= H_WORDS
@@ -47,6 +48,7 @@ RT_TAIL = 8                               # words 8..13 of a trip record: its ta
 RS_DIAG_MAX = 2                           # diagonal gterms per column (persistent kernel)
 RS_AXMAX = 4                              # axes per constraint row record
 RS_DST_ACC = 1 << 30                      # compose destination shared by two threads
+RS_GDESC_PIECES, RS_GDESC_THREADS = 6, 256   # descriptor table of G: pieces per stream-wave thread
 RS_RR_WORDS = 16                          # row record: voff[4], arrow param[4], center param[4], naxes, extreme param, pad
 SEG_WORDS, GT_WORDS, LM_WORDS, LX_WORDS = 8, 10, 12, 2
 FUSED_MAX_OPS = 1 << 18           # beyond this the staged pipeline is used
@@ -1007,13 +1009,46 @@ def compile_plan(form, costs=None, limits=None, lti=()):
             [[g["n"], g["m"], g["N"], g["img_a"], g["img_b"], g["tab_a"], g["tab_b"], g["tab_p"]]
              for g in groups], dtype=np.int32).reshape(-1)),
     ]
+    # what the persistent kernel would otherwise derive once per workgroup, ready to copy:
+    # per column of the unknowns the (weight, aim) slots and coefficients of the (at most
+    # RS_DIAG_MAX = 2) diagonal gterms on it (free slots: the always-zero parameter), ...
+    rs_dpar = np.full((no, 2 * RS_DIAG_MAX), len(b.params), dtype=np.int32)
+    rs_dcoef = np.zeros((no, RS_DIAG_MAX))
+    taken = np.zeros(no, dtype=np.int64)
+    for g in gterms:
+        if g[6] & GT_FLAG_DIAG:
+            for k in range(g[2]):
+                c, j = g[0] + k, int(taken[g[0] + k])
+                if j < RS_DIAG_MAX:
+                    rs_dpar[c, 2 * j:2 * j + 2] = [g[3], g[5]]
+                    rs_dcoef[c, j] = diag_coefs[g[1] + k]
+                taken[c] += 1
+    # ... and, for small problems, the descriptor of every 16-byte piece of G a stream-wave
+    # thread owns: piece e = t + u RS_GDESC_THREADS, columns 2cp, 2cp+1 of row R = e // (no/2):
+    # (voff0 + 2cp) | (voff1 + 2cp) << 16, arrow0 | arrow1 << 16
+    rs_gdesc = np.zeros(0, dtype=np.int32)
+    rr_ok = rs_rr.size == nc * RS_RR_WORDS
+    packed_ok = (rr_ok and no % 2 == 0 and nc > 0 and (b.rtot + 15) * ldv + 16 < 65536
+                 and len(b.params) < 65535
+                 and bool((rs_rr.reshape(nc, RS_RR_WORDS)[:, 12] <= 2).all()))
+    if packed_ok and nc * (no // 2) <= RS_GDESC_PIECES * RS_GDESC_THREADS:
+        recs = rs_rr.reshape(nc, RS_RR_WORDS).astype(np.int64)
+        e = np.arange(RS_GDESC_PIECES * RS_GDESC_THREADS)
+        live = e < nc * (no // 2)
+        R = np.where(live, e // (no // 2), 0)
+        cp = np.where(live, e % (no // 2), 0)
+        word0 = (recs[R, 0] + 2 * cp) | ((recs[R, 1] + 2 * cp) << 16)
+        word1 = recs[R, 4] | (recs[R, 5] << 16)
+        rs_gdesc = np.stack([word0, word1], axis=1).astype(np.uint32).view(np.int32).reshape(-1)
+    sections += [("OFF_RS_DPAR", rs_dpar.reshape(-1)), ("OFF_RS_GDESC", rs_gdesc)]
     header = np.zeros(H_WORDS, dtype=np.int32)
     parts, off = [header], H_WORDS
     for name, arr in sections:
         if name == "OFF_OP" and off & 1:          # the kernels read ops as 8-byte pairs
             parts.append(np.zeros(1, dtype=np.int32))
             off += 1
-        if name in ("OFF_RS_TRIP", "OFF_RS_RR", "OFF_RS_INMETA", "OFF_RS_ABMETA") and off & 3:   # ... 16-byte quads
+        if name in ("OFF_RS_TRIP", "OFF_RS_RR", "OFF_RS_INMETA", "OFF_RS_ABMETA", "OFF_RS_DPAR",
+                    "OFF_RS_GDESC") and off & 3:   # ... 16-byte quads
             pad = 4 - (off & 3)
             parts.append(np.zeros(pad, dtype=np.int32))
             off += pad
@@ -1025,6 +1060,9 @@ def compile_plan(form, costs=None, limits=None, lti=()):
     dparts.append(np.zeros(ndt & 1))             # the constant stream starts 16-byte aligned
     header[_H["DOFF_RS_CONST"]] = ndt + (ndt & 1)
     dparts.append(np.array([1.0, 1.0, 0.0, 0.0]))
+    header[_H["DOFF_RS_DCOEF"]] = ndt + (ndt & 1) + 4
+    dparts.append(rs_dcoef.reshape(-1))
+    header[_H["RS_NGDESC"]] = rs_gdesc.size // 2
     dtab = np.concatenate(dparts).astype(np.float64)
     params = np.asarray(b.params, dtype=np.float64)
     header[_H["MAGIC"]], header[_H["VERSION"]] = PLAN_MAGIC, PLAN_VERSION
@@ -1053,10 +1091,7 @@ def compile_plan(form, costs=None, limits=None, lti=()):
     if rs_rr.size != nc * RS_RR_WORDS:
         header[_H["RS_OK"]] = 0                  # a constraint with more than RS_AXMAX axes
     else:                                        # G by 16-byte pieces from the packed words
-        recs = rs_rr.reshape(nc, RS_RR_WORDS)
-        header[_H["RR_PACKED"]] = int(
-            no % 2 == 0 and nc > 0 and (b.rtot + 15) * ldv + 16 < 65536 and len(b.params) < 65535
-            and bool((recs[:, 12] <= 2).all()))
+        header[_H["RR_PACKED"]] = int(packed_ok)
     header[_H["DOFF_RS_COEF"]] = entcoef.size + pm_entcoef.size + fused["coefpool"].size
     header[_H["DOFF_DIAGCOEF"]] = (entcoef.size + pm_entcoef.size + fused["coefpool"].size
                                    + resident["coef"].size)

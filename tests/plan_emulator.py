@@ -221,14 +221,23 @@ def run_resident(plan, given, params=None, sources=None):
     assert not trips[-2:].any()                              # read ahead by the kernel
     trips = trips[:-2]
     wtrip = _section(it, "OFF_RS_WTRIP", P.RS_WAVES * 2).reshape(-1, 2)
-    dP, dq = np.zeros(no), np.zeros(no)
+    # diagonal gterms: the per-column tables (weight, aim slots and coefficients of at most two
+    # terms; slot NPARAMS is the 0.0 behind the parameters), checked against the gterm records
+    dpar = _section(it, "OFF_RS_DPAR", no * 4).reshape(no, 4)
+    dcoef = dt[it[H["DOFF_RS_DCOEF"]]:it[H["DOFF_RS_DCOEF"]] + 2 * no].reshape(no, 2)
+    prm0 = np.append(prm, 0.0)
+    dP = (prm0[dpar[:, 0]] * dcoef[:, 0]) * dcoef[:, 0] + (prm0[dpar[:, 2]] * dcoef[:, 1]) * dcoef[:, 1]
+    dq = (prm0[dpar[:, 0]] * (dcoef[:, 0] * (0.0 - prm0[dpar[:, 1]]))
+          + prm0[dpar[:, 2]] * (dcoef[:, 1] * (0.0 - prm0[dpar[:, 3]])))
+    dP_ref, dq_ref = np.zeros(no), np.zeros(no)
     gt = _section(it, "OFF_GTERM", it[H["NGTERM"]] * P.GT_WORDS).reshape(-1, P.GT_WORDS)
     for a, b, n, pw, d, pa, flags, _ma, _mb, _pad in gt:
         if flags & P.GT_FLAG_DIAG:
             c = dt[it[H["DOFF_DIAGCOEF"]] + b:it[H["DOFF_DIAGCOEF"]] + b + n]
             idx = np.arange(a, a + n)
-            dP[idx] += (prm[pw] * c) * c
-            dq[idx] += prm[pw] * (c * (0.0 - prm[pa]))
+            dP_ref[idx] += (prm[pw] * c) * c
+            dq_ref[idx] += prm[pw] * (c * (0.0 - prm[pa]))
+    assert np.allclose(dP, dP_ref, rtol=1e-15, atol=0) and np.allclose(dq, dq_ref, rtol=1e-15, atol=0)
     Pm, q = np.full((no, no), np.nan), np.full(no, np.nan)
     four = np.arange(4)
     assert wtrip[:, 1].sum() == len(trips)
@@ -300,6 +309,13 @@ def run_resident(plan, given, params=None, sources=None):
     # ---- constraint rows
     rr = _section(it, "OFF_RS_RR", nc * P.RS_RR_WORDS).reshape(nc, P.RS_RR_WORDS)
     G, h = np.zeros((nc, no)), np.zeros(nc)
+    if it[H["RS_NGDESC"]]:                              # descriptors of the 16-byte pieces of G
+        gd = _section(it, "OFF_RS_GDESC", it[H["RS_NGDESC"]] * 2).view(np.uint32).reshape(-1, 2)
+        assert it[H["RR_PACKED"]] and len(gd) >= nc * (no // 2)
+        for e in range(nc * (no // 2)):
+            R, cp = divmod(e, no // 2)
+            assert gd[e, 0] == (rr[R, 0] + 2 * cp) | ((rr[R, 1] + 2 * cp) << 16)
+            assert gd[e, 1] == rr[R, 4] | (rr[R, 5] << 16)
     for R in range(nc):
         rec = rr[R]
         ac = ad = 0.0

@@ -37,16 +37,27 @@ def main():
     lib.mpcasm_set_option(capi.OPT_PHASE_MASK, capi.PHASE_DEFAULT)
     raw = asm._work.view(torch.int64).cpu().numpy()
     n64 = (raw.size // 64) * 64
-    used = int((raw[:n64].reshape(-1, 64)[: 256 * 8].sum(axis=1) != 0).sum())  # workgroups that stamped
+    # workgroups that stamped (phase sums, then as many rows of set-up stations)
+    used = int((raw[:n64].reshape(-1, 64)[: 2 * 256 * 8].sum(axis=1) != 0).sum()) // 2
     grid = max(1, min(B, used))
     t = raw[:grid * 8 * 8].reshape(grid, 8, 8).astype(np.float64)
     per_wg = B / grid
     print("B=%d grid=%d  instances per workgroup %.2f; cycles per instance (100 MHz ticks x?)"
           % (B, grid, per_wg))
+    setup_stamps(raw, grid)
     for w in range(8):
         row = t[:, w, :].mean(axis=0) / per_wg
         print("wave %d: " % w + "  ".join("%s %7.0f" % (n, v) for n, v in zip(NAMES, row))
               + "   total %8.0f" % row.sum())
+
+
+def setup_stamps(raw, grid):
+    """Cycles since kernel start at the stations of the once-per-workgroup set-up."""
+    s = raw[grid * 64:2 * grid * 64].reshape(grid, 8, 8).astype(np.float64)
+    names = ["stream tables", "barrier", "compose regs", "first tables", "tables copied", "barrier",
+             "first image", "loop"]
+    for w in (0, 1, 4, 7):
+        print("set-up, wave %d: " % w + "  ".join("%s %6.0f" % (n, v) for n, v in zip(names, s[:, w, :].mean(axis=0))))
 
 
 if __name__ == "__main__":
