@@ -555,11 +555,28 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
           double2* G2 = reinterpret_cast<double2*>(Gb);
           int wt_ = wt;  // opaque copy: nothing derived from it is kept across instances
           asm volatile("" : "+v"(wt_));
+          // h of row wt_ rides with the first batch of pieces: its chain of dependent LDS
+          // reads (record -> parameters, d -> arithmetic) costs a wave as much as a whole
+          // batch when it runs on its own after G
+          const bool h_mine = wt_ < nc;
+          const int* hrec = rr + (h_mine ? wt_ : 0) * RR_WORDS;
+          const int4 hr = *reinterpret_cast<const int4*>(hrec + RR_NAXES);  // naxes, extreme, packed
+          const int2 hc = *reinterpret_cast<const int2*>(hrec + RR_CENTER);
+          double ha0 = 0.0, ha1 = 0.0, hc0 = 0.0, hc1 = 0.0, hd0 = 0.0, hd1 = 0.0, hext = 0.0;
 #pragma unroll
           for (int u0 = 0; u0 < GU; u0 += 3) {
             int2 ds[3];
 #pragma unroll
             for (int u = 0; u < 3; ++u) ds[u] = gdesc[(u0 + u) * WT + wt_];
+            if (u0 == 0) {
+              ha0 = prm[hr.w & 0xFFFF];
+              ha1 = prm[(unsigned)hr.w >> 16];
+              hc0 = prm[hc.x];
+              hc1 = prm[hc.y];
+              hd0 = V[(hr.z & 0xFFFF) + no];
+              hd1 = V[((unsigned)hr.z >> 16) + no];
+              hext = prm[hr.y];
+            }
             double a0[3], a1[3];
             double2 v0[3], v1[3];
 #pragma unroll
@@ -576,6 +593,12 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
               r.x = fma(a1[u], v1[u].x, a0[u] * v0[u].x);
               r.y = fma(a1[u], v1[u].y, a0[u] * v0[u].y);
               if (e < gtotal) G2[e] = r;
+            }
+            if (u0 == 0 && h_mine) {  // h = (extreme + arrow . center) - arrow . d   (body.py:264)
+              double ac = ha0 * hc0, ad = ha0 * hd0;
+              ac += ha1 * hc1;
+              ad = fma(ha1, hd1, ad);
+              (h + (size_t)inst * nc)[wt_] = (hext + ac) - ad;
             }
           }
         } else if (g_mode == 1) {
@@ -669,7 +692,7 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
           }
         }
         double* hb = h + (size_t)inst * nc;
-        int Rh = wt;
+        int Rh = g_mode == 2 ? wt + WT : wt;  // (the descriptor path has done row wt already)
         asm volatile("" : "+v"(Rh));
         for (int R = Rh; R < nc; R += WT) {
           const int* rec = rr + R * RR_WORDS;
