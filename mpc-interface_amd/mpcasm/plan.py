@@ -41,7 +41,7 @@ RS_BLOCKS_MAX = 255                       # 4-column blocks of the unknowns, a b
 RS_LTI_WORDS, RS_LTI_MAX = 8, 4           # record of a source group generated on chip; groups per plan
 RS_JC_MAX = 12                            # compose ops a thread can keep in registers
 RS_TRIP_WORDS = 16
-TRIP_COST, TRIP_STEP_COST, TRIP_TAIL_COST, G_PIECE_COST = 1100, 50, 250, 550   # wavefront assignment, see _resident_program
+TRIP_COST, TRIP_STEP_COST, TRIP_TAIL_COST, G_PIECE_COST = 1100, 50, 250, 420   # wavefront assignment, see _resident_program
 # trip record, word 2: rows | mode << 5 | half << 7 | first << 8 | last << 9 | ti << 10 | tj << 17
 RT_HALF, RT_NOP, RT_FIRST, RT_LAST, RT_LIVE, RT_QMASK = 5, 6, 8, 9, 10, 14
 RT_TAIL = 8                               # words 8..13 of a trip record: its tail k-step
@@ -745,7 +745,7 @@ def _resident_program(fused, gterms, no, ldv, image, ng, nparams, nc_rows):
         else:                                      # threads of this wave own pieces e = wt + u WT
             first = (w - NW) * 64
             own = len(range(first, pieces, stream_threads))
-            gen = 2000 if image["groups"] and w == RS_WAVES - 1 else 0   # builds the tables
+            gen = 3300 if image["groups"] and w == RS_WAVES - 1 else 0   # builds the tables
             loads.append((G_PIECE_COST * own + 500 + gen, w))
     heapq.heapify(loads)
     wave_packs = [[] for _ in range(RS_WAVES)]
