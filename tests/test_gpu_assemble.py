@@ -275,6 +275,35 @@ def test_biped_batch_horizon_matrices_generated_on_chip(gpu_api, kernel_path):
         assert np.array_equal(Pc.cpu().numpy(), P) and np.array_equal(qc.cpu().numpy(), q)
 
 
+def test_result_buffers_must_be_16_byte_aligned(gpu_api):
+    """The kernels store results 16 bytes at a time: a result buffer that starts 8 bytes off
+    is refused (MPCASM_ERR_ARG), not written through a misaligned pointer."""
+    import torch
+
+    from mpcasm import capi, engine
+
+    form = problems.biped(gpu_api, problems.BipedConfig(step_samples=8))
+    batch = 4
+    asm = engine.Assembler(form, batch=batch)
+    given = np.random.default_rng(3).normal(0, 0.1, [batch, form.given_len])
+    no, nc = asm.no, asm.nc
+    f = dict(dtype=torch.float64, device="cuda")
+    sizes = (batch * no * no, batch * no, batch * nc * no, batch * nc)
+    shapes = ((batch, no, no), (batch, no), (batch, nc, no), (batch, nc))
+    ref = [t.cpu().numpy() for t in asm.assemble(given)]
+    for bad in range(4):
+        bufs = [torch.empty(n + 1, **f) for n in sizes]
+        out = [b[1:].view(shape) if i == bad else b[:-1].view(shape)
+               for i, (b, shape) in enumerate(zip(bufs, shapes))]
+        with pytest.raises(capi.MpcasmError) as err:
+            asm.assemble(given, out=tuple(out))
+        assert err.value.status == -1          # MPCASM_ERR_ARG
+    bufs = [torch.empty(n + 2, **f) for n in sizes]             # 16 bytes off: fine
+    out = tuple(b[2:].view(shape) for b, shape in zip(bufs, shapes))
+    for mine, theirs in zip(asm.assemble(given, out=out), ref):
+        assert np.array_equal(mine.cpu().numpy(), theirs)
+
+
 def test_biped_long_horizon_persistent_kernel(gpu_api):
     """N = 24 (no = 52, nc = 108): more 16-byte pieces of G than the per-thread descriptor
     table of the persistent kernel holds, so G goes by the packed words of the row records
