@@ -932,6 +932,7 @@ int launch_assemble_resident(const PlanDev& p, const SrcTable& src, const double
                              hipStream_t stream, hipError_t* err) {
 #define MPCASM_RS_ARGS p, src, params, given, P, q, G, h, work, batch, lds_bytes, num_cus, stream, err
   if (p.rs_jc <= 3) return launch_jc<3>(MPCASM_RS_ARGS);
+  if (p.rs_jc <= 4) return launch_jc<4>(MPCASM_RS_ARGS);
   if (p.rs_jc <= 5) return launch_jc<5>(MPCASM_RS_ARGS);
   if (p.rs_jc <= 8) return launch_jc<8>(MPCASM_RS_ARGS);
   return launch_jc<RS_JC_MAX>(MPCASM_RS_ARGS);
