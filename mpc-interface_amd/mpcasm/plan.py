@@ -716,10 +716,12 @@ def _resident_program(fused, gterms, no, ldv, image, ng, nparams, nc_rows):
                        min(16, nrows - k0) | (half << RT_HALF)
                        | (0 if flags & GT_FLAG_P else 1 << RT_NOP), wparam * 8,
                        bi_bytes, bj_bytes, (doff + k0) * ldv * 8, aimparam * 8] + [0] * 8
-                if (rec[2] & 31) <= 4 and lst and lst[-1][RT_TAIL + 2] == 0:
-                    # at most four rows: one more k-step at the tail of the trip before,
-                    # with its own rows and weight, instead of a trip of its own
-                    lst[-1][RT_TAIL:RT_TAIL + 6] = [rec[0], rec[1], rec[2], rec[3], rec[6], rec[7]]
+                free = [t for t in lst if t[RT_TAIL + 2] == 0]
+                if (rec[2] & 31) <= 4 and free:
+                    # at most four rows: one more k-step at the tail of a trip of the pack
+                    # that has none yet, with its own rows and weight, instead of a trip of
+                    # its own (the order of the sum inside a pack is free)
+                    free[-1][RT_TAIL:RT_TAIL + 6] = [rec[0], rec[1], rec[2], rec[3], rec[6], rec[7]]
                 else:
                     lst.append(rec)
         if not lst:                                  # nothing to add up: the pack is still written
