@@ -100,7 +100,14 @@ class WalkerFleet:
             # the stepping area is the first box: its facets are the first limits
             n_facets = len(form.constraint_boxes["stepping area"].constraints)
             first = sum(len(group) for group in form.constraints.values())
-            self.buckets[p] = dict(form=form, asm=asm, E=E, facets=range(first, first + n_facets))
+            facets = range(first, first + n_facets)
+            # parameter columns of the centres of all facets of the stepping area, side by side
+            cols = []
+            for k in facets:
+                sl, _ = asm.param_slice("limit", k, "center")
+                cols.extend(range(sl.start, sl.stop))
+            self.buckets[p] = dict(form=form, asm=asm, E=E, facets=facets,
+                                   center_cols=torch.as_tensor(cols, dtype=torch.int64, device=asm.device))
 
     @property
     def given_len(self):
@@ -115,7 +122,9 @@ class WalkerFleet:
         stepping-area centres.  The fleet advances in lock step, so they repeat with period
         ``2 * step_samples`` (the step cycle times the left/right alternation): each of those
         ticks is worked out once on the host (tools.plan_steps / find_step_centers semantics)
-        and kept on the device."""
+        and kept on the device in the shape the assembler takes as it is -- the indicator
+        matrices as a full source tensor (bound per tick, no copy), the centres of all facets
+        side by side (one indexed copy into the parameters)."""
         key = self._ticks % (2 * self.conf.step_samples)
         if key not in self._cache:
             torch = self._torch
@@ -125,13 +134,16 @@ class WalkerFleet:
                 idx = np.nonzero(p_of == p)[0]
                 if idx.size == 0:
                     continue
-                dev = bucket["asm"].device
+                asm = bucket["asm"]
+                dev = asm.device
                 times = self.clock.step_times[idx]
                 kept = times[steps_in_preview(times, self.N)].reshape(idx.size, p)
-                E = torch.as_tensor(step_indicator(kept, self.N), device=dev)
+                E = torch.zeros((self.batch, self.N, p, 1), dtype=torch.float64, device=dev)
+                E[:idx.size, :, :, 0] = torch.as_tensor(step_indicator(kept, self.N), device=dev)
                 centers = stepping_centers(self.clock.step_count[idx], p, self.conf.stepping_center)
+                centers = torch.as_tensor(centers.reshape(idx.size, -1), device=dev)
                 entry.append(dict(p=p, idx=idx, index=torch.as_tensor(idx, device=dev), E=E,
-                                  centers=torch.as_tensor(centers.reshape(idx.size, -1), device=dev)))
+                                  centers=centers.repeat(1, len(bucket["facets"]))))
             self._cache[key] = entry
         return self._cache[key]
 
@@ -144,10 +156,8 @@ class WalkerFleet:
             p, idx = item["p"], item["idx"]
             bucket = self.buckets[p]
             asm = bucket["asm"]
-            bucket["E"][:idx.size, :, :, 0] = item["E"]
-            for k in bucket["facets"]:
-                sl, (rows, cols) = asm.param_slice("limit", k, "center")
-                asm.params[:idx.size, sl] = item["centers"]
+            asm.bind_source(("steps", 0), item["E"])
+            asm.params[:idx.size].index_copy_(1, bucket["center_cols"], item["centers"])
             g = given if isinstance(given, torch.Tensor) else torch.as_tensor(
                 np.asarray(given, dtype=np.float64), device=asm.device)
             g = g.to(asm.device).index_select(0, item["index"])

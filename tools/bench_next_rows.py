@@ -19,8 +19,8 @@ from mpcasm.boxes import BoxBatch  # noqa: E402
 from mpcasm.walkers import WalkerFleet  # noqa: E402
 
 
-def timed(fn, reps):
-    for _ in range(3):
+def timed(fn, reps, warm=3):
+    for _ in range(warm):
         fn()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -42,7 +42,9 @@ def main():
     # indicator matrices, stepping centres, one assembly per structure bucket
     fleet = WalkerFleet(B, conf=problems.BipedConfig(step_samples=8))
     g_fleet = torch.zeros((B, fleet.given_len), dtype=torch.float64, device="cuda")
-    t = timed(lambda: fleet.tick(g_fleet), 40)
+    # (the fleet keeps the inputs of the 2 * step_samples ticks of its cycle on the device: warm
+    # all of them up, the rate is that of the steady state)
+    t = timed(lambda: fleet.tick(g_fleet), 64, warm=2 * fleet.conf.step_samples + 4)
     print("f1 walker fleet   %6d walkers  %8.3f ms per tick  %10.0f walker-ticks/s" % (B, t * 1e3, B / t))
 
     # f2: Mg.given + Mo.optim for every definition (body.py:209-219)
