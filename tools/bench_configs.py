@@ -16,9 +16,11 @@ import torch  # noqa: E402
 from mpcasm import engine, problems  # noqa: E402
 
 
-def run(name, form, batch, reps=10):
+def run(name, form, batch, reps=10, lti=None):
     rng = np.random.default_rng(0)
-    asm = engine.Assembler(form, batch=batch)
+    asm = engine.Assembler(form, batch=batch, lti=[lti[0]] if lti else ())
+    if lti:     # horizon matrices built on chip from per-instance (A, B)
+        asm.bind_lti(lti[0], torch.as_tensor(lti[1], device="cuda"), torch.as_tensor(lti[2], device="cuda"))
     given = torch.as_tensor(rng.normal(0, 0.1, [batch, form.given_len]), device="cuda")
     for _ in range(2):
         asm.assemble(given)
@@ -45,6 +47,11 @@ def main():
     form = problems.biped(api, problems.BipedConfig(step_samples=12))
     form.update(step_times=np.array([10, 22]), step_count=0)
     run("biped N=24 (as shipped)", form, 16384)
+    get_A, get_B, _ = api.tools.get_system_matrices("J->CCC")
+    taus = np.random.default_rng(1).uniform(0.08, 0.12, 16384)
+    A = np.stack([get_A(tau=t) for t in taus])
+    B = np.stack([get_B(tau=t) for t in taus])
+    run("biped N=24, K1 fused", form, 16384, lti=("LIP", A, B))
     run("C3 lipm3d N=32", problems.lipm3d(api, N=32), 16384)
     run("C4 random LTI N=64", problems.random_lti(api, np.random.default_rng(20262), N=64), 256, 3)
 
