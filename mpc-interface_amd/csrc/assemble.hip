@@ -81,6 +81,55 @@ __global__ __launch_bounds__(BLOCK) void compose_preview_kernel(PlanDev p, SrcTa
   }
 }
 
+// The same matrices from the element program (plan_tables.h H_PM_*): a thread per element
+// of [Mg | Mo]; most are structural zeros -- one 4-byte read of the map, one coalesced store
+// -- and a non-zero one is a short list of coef * source value.  One workgroup takes
+// PM_CHUNK consecutive elements of one instance; the source table goes through LDS once
+// (a by-value table indexed per lane would travel through scratch memory).
+constexpr int PM_CHUNK = 4 * BLOCK;
+__global__ __launch_bounds__(BLOCK) void preview_elements_kernel(PlanDev p, SrcTable src,
+                                                                 double* __restrict__ PM,
+                                                                 int chunks) {
+  __shared__ const double* s_ptr[MAX_SOURCES];
+  __shared__ long long s_stride[MAX_SOURCES];
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+#pragma unroll
+    for (int k = 0; k < MAX_SOURCES; ++k) {
+      s_ptr[k] = src.ptr[k];
+      s_stride[k] = src.stride[k];
+    }
+  }
+  __syncthreads();
+  const long inst = blockIdx.x / chunks;
+  const int chunk = blockIdx.x - inst * chunks;
+  const int elems = p.pmrows * (p.ng + p.no);
+  const int32_t* map = p.itab + p.off_pm_map;
+  const int32_t* fdp = p.itab + p.off_pm_fdptr;
+  const uint2* ops = reinterpret_cast<const uint2*>(p.itab + p.off_pm_op);
+  const double* pool = p.dtab + p.doff_pm_pool;
+  double* out = PM + (size_t)inst * elems;
+  auto element = [&](int m) {
+    double acc = 0.0;
+    if (m >= 0) {
+      for (int o = fdp[m]; o < fdp[m + 1]; ++o) {
+        const uint2 op = ops[o];
+        const unsigned sid = op.y & 255u;
+        const double val = sid == 255u ? 1.0 : s_ptr[sid][inst * s_stride[sid] + op.x];
+        acc = fma(pool[op.y >> 8], val, acc);
+      }
+    }
+    return acc;
+  };
+  // (pairs of elements per thread with 16-byte stores were no faster)
+#pragma unroll
+  for (int k = 0; k < PM_CHUNK / BLOCK; ++k) {
+    const int e = chunk * PM_CHUNK + k * BLOCK + tid;
+    if (e >= elems) break;
+    out[e] = element(map[e]);
+  }
+}
+
 // ---------------------------------------------------------------------------
 // K3: [P | q] = sum_gterms  (w A)^T [B | r]   with v_mfma_f64_16x16x4_f64.
 // One wavefront owns a 32x32 block of [P | q] (2x2 MFMA tiles) and walks every
@@ -567,7 +616,12 @@ int launch_assemble_staged(const PlanDev& p, const SrcTable& src, const double* 
 int launch_preview_matrices(const PlanDev& p, const SrcTable& src, double* PM, int batch,
                             hipStream_t stream, hipError_t* err) {
   *err = hipSuccess;
-  if (p.pmrows > 0) {
+  if (p.pmrows > 0 && p.pm_nfd > 0) {
+    const unsigned chunks = ceil_div((unsigned)(p.pmrows * (p.ng + p.no)), (unsigned)PM_CHUNK);
+    hipLaunchKernelGGL(preview_elements_kernel, dim3(chunks * batch), dim3(BLOCK), 0, stream, p, src,
+                       PM, (int)chunks);
+    *err = hipGetLastError();
+  } else if (p.pmrows > 0) {
     const unsigned nrb = ceil_div(p.pmrows, WAVES * K2_ROWS_PER_WAVE);
     hipLaunchKernelGGL(compose_preview_kernel, dim3(nrb * batch), dim3(BLOCK), 0, stream, p, src,
                        PM, (int)nrb);

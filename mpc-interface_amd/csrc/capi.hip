@@ -96,6 +96,37 @@ int validate_plan(const int32_t* it, const double* h_dtab, size_t n_itab, size_t
     }
   }
 
+  if (it[H_PM_NFD] < 0) return MPCASM_ERR_PLAN;
+  if (it[H_PM_NFD] > 0) {  // the element program of the preview matrices
+    const int64_t nfd = it[H_PM_NFD], nops = it[H_PM_NOPS], npool = it[H_PM_NPOOL];
+    const int64_t elems = (int64_t)it[H_PMROWS] * (ng + no);
+    if (nops < nfd || npool < 1 || elems < nfd ||
+        !in_range(it[H_OFF_PM_MAP], elems, n, H_WORDS) ||
+        !in_range(it[H_OFF_PM_FDPTR], nfd + 1, n, H_WORDS) ||
+        !in_range(it[H_OFF_PM_OP], nops * 2, n, H_WORDS) || it[H_OFF_PM_OP] % 2 ||
+        !in_range(it[H_DOFF_PM_POOL], npool, nd, 0) ||
+        !in_range(it[H_OFF_ARENA], (int64_t)it[H_NSRC] * 2, n, H_WORDS) || it[H_NSRC] > 254)
+      return MPCASM_ERR_PLAN;
+    const int32_t* mp = it + it[H_OFF_PM_MAP];
+    for (int64_t e = 0; e < elems; ++e)
+      if (mp[e] < -1 || mp[e] >= nfd) return MPCASM_ERR_PLAN;
+    const int32_t* fp = it + it[H_OFF_PM_FDPTR];
+    if (fp[0] != 0 || fp[nfd] != nops) return MPCASM_ERR_PLAN;
+    for (int64_t i = 0; i < nfd; ++i)
+      if (fp[i + 1] < fp[i]) return MPCASM_ERR_PLAN;
+    const uint32_t* op = reinterpret_cast<const uint32_t*>(it + it[H_OFF_PM_OP]);
+    const int32_t* ar = it + it[H_OFF_ARENA];
+    for (int64_t o = 0; o < nops; ++o) {
+      const uint32_t sid = op[2 * o + 1] & 255u, cid = op[2 * o + 1] >> 8;
+      if (cid >= (uint64_t)npool) return MPCASM_ERR_PLAN;
+      if (sid == 255u) {
+        if (op[2 * o] != 0) return MPCASM_ERR_PLAN;
+      } else if (sid >= (uint32_t)it[H_NSRC] || ar[2 * sid + 1] < 0 ||
+                 op[2 * o] >= (uint32_t)ar[2 * sid + 1]) {
+        return MPCASM_ERR_PLAN;
+      }
+    }
+  }
   if (it[H_RS_OK] != 0 && it[H_RS_OK] != 1) return MPCASM_ERR_PLAN;
   if (it[H_RS_OK]) {
     if (!it[H_FUSED_OK]) return MPCASM_ERR_PLAN;
@@ -486,6 +517,8 @@ int mpcasm_plan_create(const int32_t* h_itab, size_t n_itab, const double* h_dta
   d.rr_packed = it[H_RR_PACKED];
   d.off_rs_dpar = it[H_OFF_RS_DPAR]; d.doff_rs_dcoef = it[H_DOFF_RS_DCOEF];
   d.rs_ngdesc = it[H_RS_NGDESC]; d.off_rs_gdesc = it[H_OFF_RS_GDESC];
+  d.pm_nfd = it[H_PM_NFD]; d.off_pm_map = it[H_OFF_PM_MAP]; d.off_pm_fdptr = it[H_OFF_PM_FDPTR];
+  d.off_pm_op = it[H_OFF_PM_OP]; d.doff_pm_pool = it[H_DOFF_PM_POOL];
   d.rs_src16 = 0;
   if (d.rs_ok && d.rs_unit == 16)
     for (int64_t i = 0; i < (int64_t)d.rs_nchunk * 64; ++i) {

@@ -25,7 +25,7 @@ struct PlanDev {
       off_rs_trip, off_rs_wtrip, rs_nsplit, off_rs_split, off_rs_rr, rs_unit,
       rs_nchunk, off_rs_inmeta, rs_img, rs_img_given, rs_img_params, doff_rs_const, rs_nlti,
       off_rs_lti, rs_img_dma, rs_ab, off_rs_abmeta, rr_packed, off_rs_dpar, doff_rs_dcoef,
-      rs_ngdesc, off_rs_gdesc;
+      rs_ngdesc, off_rs_gdesc, pm_nfd, off_pm_map, off_pm_fdptr, off_pm_op, doff_pm_pool;
   unsigned rs_src16;  // sources that the 16-byte image loads read (bit per source)
   int doff_diagcoef, ndiag;  // diagonal gterms: coefficient list, number of such terms
 };

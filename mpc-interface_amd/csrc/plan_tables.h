@@ -27,7 +27,7 @@
 namespace mpcasm {
 
 constexpr int32_t PLAN_MAGIC = 0x4D504341;  // 'MPCA'
-constexpr int32_t PLAN_VERSION = 18;
+constexpr int32_t PLAN_VERSION = 19;
 
 enum HeaderWord : int {
   H_MAGIC = 0,
@@ -119,7 +119,19 @@ enum HeaderWord : int {
   H_OFF_RS_GDESC,   // [RS_NGDESC][2] small problems: a ready-made descriptor of every 16-byte piece of
                     //    G; piece e = columns 2cp, 2cp+1 of row R = e / (no/2):
                     //    (voff0 + 2cp) | (voff1 + 2cp) << 16, arrow0 | arrow1 << 16
-  H_WORDS = 80
+  // the preview matrices [Mg | Mo] element by element (0 elements: the tables are absent and
+  // K2 alone walks the row program): H_OFF_PM_MAP [PMROWS * (NG + NO)] index of the element's
+  // op list or -1 (structural zero); element i = sum over ops H_OFF_PM_FDPTR[i] .. [i+1] of
+  // pool[cid] * source[sid][offset]; an op is two words: offset inside the source, sid | cid << 8
+  // (sid 255: the constant 1)
+  H_PM_NFD,
+  H_OFF_PM_MAP,
+  H_OFF_PM_FDPTR,   // [PM_NFD + 1]
+  H_OFF_PM_OP,      // [PM_NOPS][2]
+  H_PM_NOPS,
+  H_DOFF_PM_POOL,   // [PM_NPOOL] distinct coefficients
+  H_PM_NPOOL,
+  H_WORDS = 96
 };
 
 // segment record

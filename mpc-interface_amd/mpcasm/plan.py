@@ -15,7 +15,7 @@ import numpy as np
 import scipy.sparse as sp
 
 PLAN_MAGIC = 0x4D504341
-PLAN_VERSION = 18
+PLAN_VERSION = 19
 
 # header words (csrc/plan_tables.h, enum HeaderWord)
 _H = {name: i for i, name in enumerate([
@@ -31,9 +31,10 @@ _H = {name: i for i, name in enumerate([
     "OFF_RS_RR", "RS_UNIT", "RS_NCHUNK", "OFF_RS_INMETA", "RS_IMG", "RS_IMG_GIVEN",
     "RS_IMG_PARAMS", "DOFF_RS_CONST", "DOFF_DIAGCOEF", "NDIAGCOEF", "RS_NLTI", "OFF_RS_LTI",
     "RS_IMG_DMA", "RS_AB", "OFF_RS_ABMETA", "RR_PACKED", "OFF_RS_DPAR", "DOFF_RS_DCOEF",
-    "RS_NGDESC", "OFF_RS_GDESC",
+    "RS_NGDESC", "OFF_RS_GDESC", "PM_NFD", "OFF_PM_MAP", "OFF_PM_FDPTR", "OFF_PM_OP", "PM_NOPS",
+    "DOFF_PM_POOL", "PM_NPOOL",
 ])}
-H_WORDS = 80
+H_WORDS = 96
 assert len(_H) <= H_WORDS
 RS_NW, RS_NT = 4, 512                     # matrix wavefronts (they fetch the inputs), threads per instance
 RS_WAVES = RS_NT // 64
@@ -339,6 +340,64 @@ def _csr_tables(blocks, base_row0, base_rows, total):
     k = idx - starts[base] if idx.size else idx
     return (M.indptr.astype(np.int32), base.astype(np.int32), k.astype(np.int32),
             M.data.astype(np.float64), M.shape[0])
+
+
+PM_MAX_OPS = 1 << 20                      # element program of the preview matrices: table limits
+PM_MAX_MAP = 1 << 22
+
+
+def _preview_program(b, rowptr, entbase, entk, entcoef, pmrows):
+    """The preview matrices [Mg | Mo] element by element: ``pm_map[r * W + c]`` is the index of
+    the element's op list or -1 for a structural zero; element ``i`` is the sum of
+    ``pool[cid] * source[sid][offset]`` over ops ``fd_ptr[i] .. fd_ptr[i+1]`` (``sid`` 255: the
+    constant 1).  An op is two words: offset inside the source, ``sid | cid << 8``."""
+    W = b.ng + b.no
+    z = np.zeros(0, dtype=np.int32)
+    empty = dict(nfd=0, map=z, fd_ptr=z, ops=z, pool=np.zeros(0))
+    if pmrows * W > PM_MAX_MAP or pmrows == 0 or len(b.sources) > 254:
+        return empty
+    segs_of_base = [[] for _ in b.base_rows]
+    for bid, colseg in enumerate(b.colseg):
+        for sg in sorted(set(int(x) for x in colseg if x >= 0)):
+            segs_of_base[bid].append(b.segments[sg])
+    dst, sid_l, off_l, coef = [], [], [], []
+    nops = 0
+    for r in range(pmrows):
+        for e in range(rowptr[r], rowptr[r + 1]):
+            u, k, cf = int(entbase[e]), int(entk[e]), float(entcoef[e])
+            for sid, off0, rs, es, dst0, length, kind, _ in segs_of_base[u]:
+                if kind == SEG_IDENTITY:
+                    if k >= length:
+                        continue
+                    cols = np.array([dst0 + k])
+                    sids, offs = np.full(1, 255), np.zeros(1, dtype=np.int64)
+                else:
+                    cols = dst0 + np.arange(length)
+                    sids = np.full(length, sid)
+                    offs = off0 + k * rs + np.arange(length, dtype=np.int64) * es
+                dst.append(r * W + cols)
+                sid_l.append(sids)
+                off_l.append(offs)
+                coef.append(np.full(cols.size, cf))
+                nops += cols.size
+        if nops > PM_MAX_OPS:
+            return empty
+    if not dst:
+        return empty
+    dst, sids = np.concatenate(dst), np.concatenate(sid_l)
+    offs, coef = np.concatenate(off_l), np.concatenate(coef)
+    order = np.argsort(dst, kind="stable")          # keeps the entry order inside an element
+    dst, sids, offs, coef = dst[order], sids[order], offs[order], coef[order]
+    fd_idx, first = np.unique(dst, return_index=True)
+    fd_ptr = np.append(first, dst.size).astype(np.int32)
+    pool, cid = np.unique(coef, return_inverse=True)
+    if pool.size >= 1 << 23 or offs.max(initial=0) >= 1 << 31:
+        return empty
+    pm_map = np.full(pmrows * W, -1, dtype=np.int32)
+    pm_map[fd_idx] = np.arange(fd_idx.size, dtype=np.int32)
+    word1 = (sids.astype(np.int64) | (cid.astype(np.int64) << 8)).astype(np.uint32)
+    ops = np.stack([offs.astype(np.uint32), word1], axis=1).view(np.int32).reshape(-1)
+    return dict(nfd=int(fd_idx.size), map=pm_map, fd_ptr=fd_ptr, ops=ops, pool=pool.astype(np.float64))
 
 
 def _fused_program(b, rowptr, entbase, entk, entcoef, rtot, ldv):
@@ -1042,11 +1101,17 @@ def compile_plan(form, costs=None, limits=None, lti=()):
         word0 = (recs[R, 0] + 2 * cp) | ((recs[R, 1] + 2 * cp) << 16)
         word1 = recs[R, 4] | (recs[R, 5] << 16)
         rs_gdesc = np.stack([word0, word1], axis=1).astype(np.uint32).view(np.int32).reshape(-1)
-    sections += [("OFF_RS_DPAR", rs_dpar.reshape(-1)), ("OFF_RS_GDESC", rs_gdesc)]
+    pmprog = _preview_program(b, pm_rowptr, pm_entbase, pm_entk, pm_entcoef, pmrows)
+    sections += [("OFF_RS_DPAR", rs_dpar.reshape(-1)), ("OFF_RS_GDESC", rs_gdesc),
+                 ("OFF_PM_MAP", pmprog["map"]), ("OFF_PM_FDPTR", pmprog["fd_ptr"]),
+                 ("OFF_PM_OP", pmprog["ops"])]
     header = np.zeros(H_WORDS, dtype=np.int32)
     parts, off = [header], H_WORDS
     for name, arr in sections:
         if name == "OFF_OP" and off & 1:          # the kernels read ops as 8-byte pairs
+            parts.append(np.zeros(1, dtype=np.int32))
+            off += 1
+        if name == "OFF_PM_OP" and off & 1:       # ... 8-byte pairs
             parts.append(np.zeros(1, dtype=np.int32))
             off += 1
         if name in ("OFF_RS_TRIP", "OFF_RS_RR", "OFF_RS_INMETA", "OFF_RS_ABMETA", "OFF_RS_DPAR",
@@ -1065,6 +1130,10 @@ def compile_plan(form, costs=None, limits=None, lti=()):
     header[_H["DOFF_RS_DCOEF"]] = ndt + (ndt & 1) + 4
     dparts.append(rs_dcoef.reshape(-1))
     header[_H["RS_NGDESC"]] = rs_gdesc.size // 2
+    header[_H["DOFF_PM_POOL"]] = ndt + (ndt & 1) + 4 + rs_dcoef.size
+    dparts.append(pmprog["pool"])
+    header[_H["PM_NFD"]], header[_H["PM_NOPS"]] = pmprog["nfd"], pmprog["ops"].size // 2
+    header[_H["PM_NPOOL"]] = pmprog["pool"].size
     dtab = np.concatenate(dparts).astype(np.float64)
     params = np.asarray(b.params, dtype=np.float64)
     header[_H["MAGIC"]], header[_H["VERSION"]] = PLAN_MAGIC, PLAN_VERSION

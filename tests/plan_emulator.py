@@ -99,6 +99,24 @@ def run(plan, given, params=None, sources=None):
     pcoef = dt[it[H["DOFF_PM_ENTCOEF"]]:it[H["DOFF_PM_ENTCOEF"]] + pm_nent]
     PM = np.stack([_row(plan, srcs, prp, peb, pek, pcoef, r, W) for r in range(pmrows)]) \
         if pmrows else np.zeros((0, W))
+    if it[H["PM_NFD"]]:                   # the same matrices from the element program
+        nfd, nops = int(it[H["PM_NFD"]]), int(it[H["PM_NOPS"]])
+        pmap = _section(it, "OFF_PM_MAP", pmrows * W)
+        fdp = _section(it, "OFF_PM_FDPTR", nfd + 1)
+        ops = _section(it, "OFF_PM_OP", nops * 2).view(np.uint32).reshape(-1, 2)
+        pool = dt[it[H["DOFF_PM_POOL"]]:it[H["DOFF_PM_POOL"]] + it[H["PM_NPOOL"]]]
+        flat = [np.asarray(s_, dtype=np.float64).reshape(-1) for s_ in srcs]
+        PM2 = np.zeros(pmrows * W)
+        for e in range(pmrows * W):
+            m = pmap[e]
+            if m < 0:
+                continue
+            acc = 0.0
+            for off, word in ops[fdp[m]:fdp[m + 1]]:
+                sid, cid = int(word) & 255, int(word) >> 8
+                acc += pool[cid] * (1.0 if sid == 255 else flat[sid][off])
+            PM2[e] = acc
+        assert np.allclose(PM2.reshape(pmrows, W), PM, rtol=1e-14, atol=0)
     return {"V": V, "P": Pm, "q": q, "G": G, "h": h, "PM": PM}
 
 
