@@ -59,28 +59,11 @@ def main():
 
 
 def cpu_lines(rng):
-    """The same fill on one host core: the compiled C restatement (oracle/extend_matrices.c)
-    and the numpy oracle -- the CPU baselines beside K1."""
+    """The same fill on one host core -- the CPU baselines beside K1.
+    The oracle is test infrastructure: its timing lives under tests/ and runs as a child."""
     import subprocess
-    import time
 
-    sys.path.insert(0, ROOT)
-    subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True, stdout=subprocess.DEVNULL)
-    from oracle import c_oracle, qp_oracle
-
-    print("%-22s %8s %14s %14s" % ("CPU, one core", "systems", "C  systems/s", "numpy systems/s"))
-    for name, n, m, N, count in (("C2 biped LIPM", 3, 1, 16, 20000), ("C4 nx=12 nu=6 N=64", 12, 6, 64, 60)):
-        A = rng.standard_normal((count, n, n)) / np.sqrt(n) * 0.9
-        B = rng.standard_normal((count, n, m))
-        t0 = time.perf_counter()
-        c_oracle.extend_matrices_batch(A, B, N)
-        tc = time.perf_counter() - t0
-        k = max(1, count // 20)
-        t0 = time.perf_counter()
-        for b in range(k):
-            qp_oracle.extend_matrices(N, A[b], B[b])
-        tn = (time.perf_counter() - t0) / k * count
-        print("%-22s %8d %14.0f %14.0f" % (name, count, count / tc, count / tn))
+    subprocess.run([sys.executable, os.path.join(ROOT, "tests", "cpu_fill_baseline.py")], check=True)
 
 
 if __name__ == "__main__":
