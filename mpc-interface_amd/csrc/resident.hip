@@ -217,6 +217,10 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
   constexpr int FK = JC <= 5 ? 3 : 0;
   const char* f_base[FK > 0 ? FK : 1];
   int f_stride[FK > 0 ? FK : 1];
+  // A chunk whose every lane reads a stream shared by the whole batch (stride 0: one model
+  // for all instances, the constants) holds the same bytes for every instance: once both
+  // halves of the double buffer have it, it is not fetched again.
+  bool f_shared[FK > 0 ? FK : 1];
   bool f_fast = FK > 0;
   if (FK > 0 && wave < MW) {
 #pragma unroll
@@ -226,18 +230,20 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
       const long long stride = reinterpret_cast<const long long*>(strm)[2 * m.x + 1];
       f_base[j] = reinterpret_cast<const char* const*>(strm)[2 * m.x] + m.y;
       f_stride[j] = (int)stride;
+      f_shared[j] = __all(stride == 0);
       f_fast = f_fast && stride >= 0 && stride < (1ll << 31);
     }
   }
   f_fast = __builtin_amdgcn_readfirstlane(__all(f_fast));
-  auto fetch_image = [&](long inst, int buf) {
+  // `settled`: both image buffers have been filled once by this workgroup
+  auto fetch_image = [&](long inst, int buf, bool settled) {
     const unsigned dst0 = img_lds + (unsigned)buf * (unsigned)p.rs_img * 8u;
     int kfirst = wave;
     if (FK > 0 && f_fast) {
 #pragma unroll
       for (int j = 0; j < FK; ++j) {
         const int k = wave + j * MW;
-        if (k < nchunk) {
+        if (k < nchunk && !(settled && f_shared[j])) {
           const char* a = f_base[j] + (unsigned long long)inst * (unsigned)f_stride[j];
           const unsigned dst = __builtin_amdgcn_readfirstlane(dst0 + (unsigned)(k * 64 * unit));
           if (unit == 16)
@@ -252,6 +258,7 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
       const int2 m = meta[k * 64 + lane];
       const char* base = reinterpret_cast<const char* const*>(strm)[2 * m.x];
       const long long stride = reinterpret_cast<const long long*>(strm)[2 * m.x + 1];
+      if (settled && __all(stride == 0)) continue;
       const char* a = base + inst * stride + m.y;
       const unsigned dst = __builtin_amdgcn_readfirstlane(dst0 + (unsigned)(k * 64 * unit));
       if (unit == 16)
@@ -378,7 +385,7 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
     }
   };
   if (wave < MW) {  // the first instance's inputs start their trip now
-    fetch_image(blockIdx.x, 0);
+    fetch_image(blockIdx.x, 0, false);
     if (wave == 0 && (GEN && p.rs_nlti != 0)) {
       fetch_ab(blockIdx.x, 0);
       if ((long)blockIdx.x + gridDim.x < batch) fetch_ab((long)blockIdx.x + gridDim.x, 1);
@@ -489,8 +496,8 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
 
 
   if (STAMPS && stamping) t_prev = __builtin_amdgcn_s_memtime();
-  int buf = 0;
-  for (long inst = blockIdx.x; inst < batch; inst += gridDim.x, buf ^= 1) {
+  int buf = 0, iter = 0;  // iter: instances this workgroup has started
+  for (long inst = blockIdx.x; inst < batch; inst += gridDim.x, buf ^= 1, ++iter) {
     const double* img = lds + L.img + buf * p.rs_img;
     const double* prm = img + p.rs_img_params;
     lds_barrier();  // A: this instance's image landed, P and q of the previous one read out
@@ -538,7 +545,7 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
       lds_barrier();  // B: workspace complete
       MPCASM_STAMP(1)
       // the next instance's image starts its trip from HBM now
-      if (lookahead && nxt < batch && (phases & 16)) fetch_image(nxt, buf ^ 1);
+      if (lookahead && nxt < batch && (phases & 16)) fetch_image(nxt, buf ^ 1, iter >= 1);
       // ... and, two instances ahead, the (A, B) of the systems whose matrices are built here
       if (wave == 0 && (GEN && p.rs_nlti != 0) && nxt + gridDim.x < batch) fetch_ab(nxt + gridDim.x, buf);
       MPCASM_STAMP(7)
@@ -830,7 +837,7 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
     MPCASM_STAMP(4)
 
     if (wave < MW) {
-      if (!lookahead && nxt < batch && (phases & 16)) fetch_image(nxt, buf ^ 1);
+      if (!lookahead && nxt < batch && (phases & 16)) fetch_image(nxt, buf ^ 1, iter >= 1);
       // The next image is complete before barrier A.  The wait comes before this wave's
       // P stores so that it never waits for a store, only for loads issued a phase ago.
       dma_wait();
