@@ -304,6 +304,28 @@ def test_result_buffers_must_be_16_byte_aligned(gpu_api):
         assert np.array_equal(mine.cpu().numpy(), theirs)
 
 
+def test_workgroups_per_cu_option_changes_nothing_but_the_grid(gpu_api):
+    """MPCASM_OPT_RESIDENT_PER_CU (tuning aid): one persistent workgroup per CU walks more
+    instances each; same bits out (every instance is assembled by one workgroup alone)."""
+    from mpcasm import capi, engine
+
+    form = problems.biped(gpu_api, problems.BipedConfig(step_samples=8))
+    form.update(step_times=np.array([6, 14]), step_count=0)
+    batch = 700
+    asm = engine.Assembler(form, batch=batch)
+    given = np.random.default_rng(11).normal(0, 0.1, [batch, form.given_len])
+    ref = [t.cpu().numpy().copy() for t in asm.assemble(given)]
+    lib = capi.load()
+    try:
+        for per_cu in (1, 2):
+            assert lib.mpcasm_set_option(capi.OPT_RESIDENT_PER_CU, per_cu) == 0
+            for mine, theirs in zip(asm.assemble(given), ref):
+                assert np.array_equal(mine.cpu().numpy(), theirs)
+        assert lib.mpcasm_set_option(capi.OPT_RESIDENT_PER_CU, -1) == -1
+    finally:
+        lib.mpcasm_set_option(capi.OPT_RESIDENT_PER_CU, 0)
+
+
 def test_biped_long_horizon_persistent_kernel(gpu_api):
     """N = 24 (no = 52, nc = 108): more 16-byte pieces of G than the per-thread descriptor
     table of the persistent kernel holds, so G goes by the packed words of the row records

@@ -266,3 +266,51 @@ def test_plan_tables_rejected_or_accepted_by_the_library(cpu_api):
     bad[bad[_H["OFF_ENTBASE"]]] = 10 ** 6          # base id out of range
     assert create(bad, plan.dtab) == -2
     assert create(plan.itab[:-1].copy(), plan.dtab) == -2
+
+
+def test_persistent_kernel_tables_are_validated(cpu_api):
+    """The tables only the persistent kernel reads -- trips with their tails, packed row
+    records, piece descriptors of G, per-column diagonal terms, the element program of the
+    preview matrices -- are checked on the host like the rest: one corrupted word each."""
+    import mpcasm.plan as P
+
+    lib = capi.load()
+    form = problems.biped(cpu_api, problems.BipedConfig(step_samples=8))
+    form.update(step_times=np.array([6, 14]), step_count=0)
+    plan = compile_plan(form)
+    handle = ctypes.c_void_p()
+
+    def create(itab):
+        return lib.mpcasm_plan_create(itab.ctypes.data, itab.size, plan.dtab.ctypes.data,
+                                      plan.dtab.size, ctypes.byref(handle))
+
+    rc = create(plan.itab)
+    assert rc in (0, -4), rc
+    if rc == 0:
+        assert lib.mpcasm_plan_destroy(handle) == 0
+    it = plan.itab
+    assert it[_H["RS_OK"]] == 1 and it[_H["RS_NGDESC"]] > 0 and it[_H["PM_NFD"]] > 0
+    trip0 = it[_H["OFF_RS_TRIP"]]
+    tails = [t for t in range(it[_H["RS_NTRIP"]]) if it[trip0 + t * P.RS_TRIP_WORDS + P.RT_TAIL + 2]]
+    assert tails                                        # the one-row terminal terms ride as tails
+    tail = trip0 + tails[0] * P.RS_TRIP_WORDS + P.RT_TAIL
+    corruptions = {
+        "trip: 17 rows": (trip0 + 2, (it[trip0 + 2] & ~31) | 17),
+        "trip: A offset off the workspace": (trip0 + 0, 8 * it[_H["RTOT"]] * it[_H["LDV"]]),
+        "trip: weight slot": (trip0 + 3, 8 * int(it[_H["NPARAMS"]])),
+        "trip: block column": (trip0 + 5, 0x7F7F7F7F),
+        "tail: 5 rows": (tail + 2, 5),
+        "tail: misaligned offset": (tail + 0, it[tail + 0] + 4),
+        "wave list": (it[_H["OFF_RS_WTRIP"]] + 1, it[it[_H["OFF_RS_WTRIP"]] + 1] + 2),
+        "row record: packed words": (it[_H["OFF_RS_RR"]] + P.RS_RR_WORDS - 2, 0x12340000),
+        "piece descriptor of G": (it[_H["OFF_RS_GDESC"]] + 2, it[it[_H["OFF_RS_GDESC"]] + 2] + 2),
+        "diagonal term slot": (it[_H["OFF_RS_DPAR"]], int(it[_H["NPARAMS"]]) + 1),
+        "preview map": (it[_H["OFF_PM_MAP"]], int(it[_H["PM_NFD"]])),
+        "preview op source": (it[_H["OFF_PM_OP"]] + 1, 200),
+        "preview op list ends": (it[_H["OFF_PM_FDPTR"]] + int(it[_H["PM_NFD"]]), int(it[_H["PM_NOPS"]]) + 1),
+    }
+    for what, (word, value) in corruptions.items():
+        bad = it.copy()
+        assert bad[word] != value, what
+        bad[word] = value
+        assert create(bad) == -2, what
