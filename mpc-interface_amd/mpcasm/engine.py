@@ -37,8 +37,12 @@ def require_device():
 
 
 def _stream_handle(torch, stream):
-    s = torch.cuda.current_stream() if stream is None else stream
-    return ctypes.c_void_p(s.cuda_stream)
+    if stream is None:      # (the raw handle of the current stream: no Stream object per launch)
+        try:
+            return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
+        except AttributeError:
+            stream = torch.cuda.current_stream()
+    return ctypes.c_void_p(stream.cuda_stream)
 
 
 def _as_device(torch, x, device):
@@ -232,10 +236,14 @@ class Assembler:
 
     # ---- launches ---------------------------------------------------------------
     def _src_args(self):
-        n = len(self._src)
-        ptrs = (ctypes.c_void_p * max(n, 1))(*[t.data_ptr() for t in self._src])
-        strides = (ctypes.c_int64 * max(n, 1))(*self._src_stride)
-        return ptrs, strides
+        # (rebuilt only when a source has been bound to another tensor since the last launch)
+        key = tuple(t.data_ptr() for t in self._src) + tuple(self._src_stride)
+        if getattr(self, "_src_key", None) != key:
+            n = len(self._src)
+            ptrs = (ctypes.c_void_p * max(n, 1))(*key[:n])
+            strides = (ctypes.c_int64 * max(n, 1))(*self._src_stride)
+            self._src_key, self._src_ctypes = key, (ptrs, strides)
+        return self._src_ctypes
 
     def assemble(self, given=None, out=None, stream=None, want_cost=True, want_constraints=True,
                  count=None):
