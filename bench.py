@@ -8,26 +8,38 @@ formulation, N=16, 2 axes, 6 costs, 3 boxes (36 unknowns, 76 inequality rows in
 the headline phase), B independent instances per GPU in fp64, synthetic inputs
 resident in HBM.  One *step* is one pass of the hot path over one batch:
 
-    K1  mpcasm_fill_su     per-instance (A, B) -> horizon matrices S, U
-    K2-K4 mpcasm_assemble  S, U, given, parameters -> P, q, G, h  for every instance
+    K1  horizon matrices S, U from the per-instance (A, B)          (tools.py:14-33)
+    K2-K4  S, U, given, parameters -> P, q, G, h for every instance (body.py:142-348)
+
+by default ONE launch of mpcasm_assemble that builds the horizon matrices on chip
+(--two-kernels: mpcasm_fill_su + mpcasm_assemble through S, U in HBM).  The outputs
+rotate over --rotate buffer sets so that at B=4096 (140 MB per step) consecutive steps
+do not rewrite lines that still sit in the 256 MiB Infinity Cache.
 
 Prints ONE JSON line (rank 0): whole-job assemblies/s, the roofline object of the
-dominant kernel (hipEvent-timed inside the timed region) and, at N=1, the CPU
-baseline (the numpy oracle -- a port of the reference algorithm -- timed on this
-box's host cores for a bounded sample of the same workload).
+dominant kernel (one pair of hipEvents on the launch stream around the timed region: the
+same clock as ms_per_step), `fill` sub-records (K1 alone, timed after the main region, on
+the north-star shapes), an `extra` record at B=65536 (a working set far beyond the
+Infinity Cache), for N>1 a separately timed `gather` record (all-gather of the assembled
+QPs over RCCL, never part of `value`) and, at N=1, the CPU baseline (the numpy oracle --
+a port of the reference algorithm -- on this box's host cores, bounded sample).
 
-Multi-GPU: one process per GPU (torch.distributed, backend nccl = RCCL); the batch
-is sharded with no collective on the data path (weak scaling: B per GPU is fixed);
-the only collectives are the barriers around the timed region and the MAX of the
-elapsed time.
+Multi-GPU: one process per GPU (torch.distributed, backend nccl = RCCL); the batch is
+sharded with no collective on the data path (weak scaling: B per GPU is fixed); the only
+collectives inside the measurement are the barriers around the timed region and the MAX
+of the elapsed time.  `python bench.py --gpus N` without a launcher starts the N ranks
+itself (child processes, before this process has touched the GPU); under
+`python -m torch.distributed.run` the ranks come from the environment.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
-# the CPU baseline is quoted for one core: keep BLAS single-threaded
+# the CPU baseline is quoted for one core per process: keep BLAS single-threaded
 os.environ.setdefault("OMP_NUM_THREADS", "1")
 os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
 
@@ -39,8 +51,82 @@ for path in (os.path.join(ROOT, "mpc-interface_amd"), ROOT):
         sys.path.insert(0, path)
 
 HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md, chip-level parameters)
+METRIC = "QP assemblies/sec (P,q,G,h), biped N=16 batched"
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=4096, help="instances per GPU")
+    ap.add_argument("--rotate", type=int, default=3, help="output buffer sets the steps cycle over")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the fill / B=65536 / gather sub-records (main line only)")
+    ap.add_argument("--two-kernels", action="store_true",
+                    help="step = mpcasm_fill_su (S, U through HBM) + mpcasm_assemble instead of the "
+                         "default single launch that builds the horizon matrices on chip")
+    ap.add_argument("--fused", action="store_true", help="(the default; kept for scripts)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--stub-fail-rank", type=int, default=-1, help="TEST ONLY: this rank exits 3")
+    ap.add_argument("--stub-kernels", action="store_true",
+                    help="TEST ONLY (tests/test_bench_launcher.py): no GPU, no kernels -- exercises "
+                         "the rank launcher, sharding, gather and record plumbing on CPU tensors")
+    return ap.parse_args(argv)
+
+
+# --------------------------------------------------------------------------
+# rank launcher
+# --------------------------------------------------------------------------
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args, argv):
+    """Start ``args.gpus`` ranks of this script as child processes (one per GPU) and wait.
+    The parent never initialises the GPU; rank 0's stdout (the JSON line) passes through.
+    Returns the exit code: non-zero if any rank failed (the others are stopped)."""
+    n = args.gpus
+    if not args.stub_kernels:
+        import torch
+
+        have = torch.cuda.device_count()        # (counting devices does not initialise HIP)
+        if have < n and args.backend == "nccl":
+            print("bench.py: --gpus %d but only %d HIP device(s) visible" % (n, have),
+                  file=sys.stderr)
+            return 2
+    port = _free_port()
+    procs = []
+    for rank in range(n):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if rank == 0 else subprocess.DEVNULL))
+    rc = 0
+    pending = set(range(n))
+    while pending:
+        for r in sorted(pending):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            pending.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print("bench.py: rank %d exited with %d; stopping the others" % (r, code),
+                      file=sys.stderr)
+                for o in pending:
+                    procs[o].terminate()
+        time.sleep(0.05)
+    return rc
+
+
+# --------------------------------------------------------------------------
+# workload
+# --------------------------------------------------------------------------
 def build_workload(batch, seed):
     """The biped formulation in its 36-wide phase + per-instance synthetic inputs."""
     from mpcasm import engine, problems
@@ -124,63 +210,170 @@ def cpu_baseline_all_cores(budget_s=10.0):
     return sum(r[0] / r[1] for r in results), done, procs
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=4096, help="instances per GPU")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--two-kernels", action="store_true",
-                    help="step = mpcasm_fill_su (S, U through HBM) + mpcasm_assemble instead of the "
-                         "default single launch that builds the horizon matrices on chip")
-    ap.add_argument("--fused", action="store_true", help="(the default; kept for scripts)")
-    ap.add_argument("--event-every", type=int, default=8,
-                    help="bracket the calls of every n-th timed step with hipEvents")
-    args = ap.parse_args()
+# --------------------------------------------------------------------------
+# sub-records (timed after the main region; never part of `value`)
+# --------------------------------------------------------------------------
+def _event_ms(torch, fn, reps, warm=3):
+    """Average duration of ``fn`` over ``reps`` back-to-back calls, hipEvents on the launch stream."""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
 
+
+FILL_CASES = [  # name, n, m, N, ltv, systems per GPU (north star: global batch / 8 GPUs)
+    ("C2 biped LIPM n=3 m=1 N=16", 3, 1, 16, False, None),           # None: --batch
+    ("C2 biped LIPM n=3 m=1 N=16", 3, 1, 16, False, 8192),
+    ("C4 random LTI n=12 m=6 N=64", 12, 6, 64, False, 1024),
+    ("C5 LTV LIPM n=3 m=1 N=100", 3, 1, 100, True, 2048),
+]
+
+
+def fill_bytes(n, m, N, ltv):
+    """Algorithmic bytes of K1 per system: written + read."""
+    return 8 * (N * n * n + m * N * N * n) + 8 * (n * n + n * m) * (N if ltv else 1)
+
+
+def fill_records(torch, engine, dev, batch, reps=30):
+    """K1 alone (mpcasm_fill_su) on the north-star shapes: fraction of the HBM roofline."""
+    out = []
+    rng = np.random.default_rng(5)
+    for name, n, m, N, ltv, systems in FILL_CASES:
+        systems = systems or batch
+        shapeA = (systems, N, n, n) if ltv else (systems, n, n)
+        shapeB = (systems, N, n, m) if ltv else (systems, n, m)
+        A = torch.as_tensor(rng.standard_normal(shapeA) / np.sqrt(n) * 0.9, device=dev)
+        Bm = torch.as_tensor(rng.standard_normal(shapeB), device=dev)
+        S = torch.empty((systems, N, n, n), dtype=torch.float64, device=dev)
+        U = torch.empty((systems, m, N, N, n), dtype=torch.float64, device=dev)
+        ms = _event_ms(torch, lambda: engine.fill_su(A, Bm, N, ltv=ltv, out=(S, U)), reps)
+        nbytes = fill_bytes(n, m, N, ltv) * systems
+        gbps = nbytes / (ms * 1e-3) / 1e9
+        out.append({"kernel": "mpcasm_fill_su (K1 toeplitz_fill%s)" % (", LTV" if ltv else ""),
+                    "shape": name, "systems": systems, "bound": "hbm",
+                    "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": ms,
+                    "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": gbps / HBM_PEAK_GBPS, "systems_per_s": systems / (ms * 1e-3)})
+        del A, Bm, S, U
+    torch.cuda.empty_cache()
+    return out
+
+
+def tiled(x, times):
+    return np.concatenate([x] * times) if times > 1 else x
+
+
+# --------------------------------------------------------------------------
+# one rank
+# --------------------------------------------------------------------------
+def run_stub(args, world, rank):
+    """TEST ONLY: the launcher / sharding / gather / record plumbing without a GPU."""
     import torch
+    import torch.distributed as dist
 
+    from mpcasm import dist as mdist
+
+    if rank == args.stub_fail_rank:
+        sys.exit(3)
+    if world > 1:
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
+    B, no, nc = args.batch, 36, 76
+    lo, hi = mdist.shard_bounds(world * B, world, rank)
+    P = torch.full((hi - lo, no, no), float(rank), dtype=torch.float64)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        P.add_(0.0)
+    elapsed = time.perf_counter() - t0
+    record = {"metric": METRIC, "unit": "assemblies/s", "n_gpus": world, "steps": args.steps,
+              "warmup": args.warmup, "stub": True,
+              "config": {"batch_per_gpu": B, "global_batch": B * world}}
+    if world > 1:
+        elapsed = mdist.max_over_ranks(elapsed)
+        allP = mdist.gather_batch(P, world * B)
+        assert allP.shape[0] == world * B
+        assert all(float(allP[r * B, 0, 0]) == float(r) for r in range(world))
+        record["gather"] = {"instances": int(allP.shape[0])}
+        dist.destroy_process_group()
+    record["value"] = world * B * args.steps / elapsed
+    record["ms_per_step"] = elapsed / args.steps * 1e3
+    if rank == 0:
+        print(json.dumps(record), flush=True)
+
+
+def run_rank(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE %d" % (args.gpus, world))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if args.stub_kernels:
+        return run_stub(args, world, rank)
+
+    import torch
+
+    from mpcasm import dist as mdist
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the assembly path has no CPU fallback)")
+    if args.backend == "gloo":      # rehearsal: the ranks may share a GPU (RCCL would refuse that)
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-    if args.gpus != world and rank == 0 and world > 1:
-        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     B = args.batch
-    work = build_workload(B, 20260 + rank)          # each rank owns its own shard of instances
+    lo, hi = mdist.shard_bounds(world * B, world, rank)   # this rank's slice of the global batch
+    assert hi - lo == B
+    work = build_workload(B, 20260 + rank)                # its own instances
     engine, form, N = work["engine"], work["form"], work["N"]
     dev = torch.device("cuda", local_rank)
     A = torch.as_tensor(work["A"], device=dev)
     Bm = torch.as_tensor(work["B"], device=dev)
     given = torch.as_tensor(work["given"], device=dev)
     fused = not args.two_kernels
-    if fused:
-        # K1 inside the assembly: per-instance (A, B) in, the kernel builds what it needs of
-        # S, U in LDS (SURVEY.md section 8d counts exactly these bytes for an assembly)
-        asm = engine.Assembler(form, batch=B, device=dev, lti=["LIP"])
-        asm.bind_lti("LIP", A, Bm)
-    else:
-        S = torch.empty((B, N, 3, 3), dtype=torch.float64, device=dev)
-        U = torch.empty((B, 1, N, N, 3), dtype=torch.float64, device=dev)
-        asm = engine.Assembler(form, batch=B, device=dev)
-        asm.bind_source(("LIP", 0), U[:, 0])
-        asm.bind_source(("LIP", 1), S)
-    asm.set_param("cost", "track vel_x", "aim", work["aims"])
 
-    def step():
+    def make_assembler(batch, A, Bm, aims):
+        if fused:
+            # K1 inside the assembly: per-instance (A, B) in, the kernel builds what it needs of
+            # S, U in LDS (SURVEY.md section 8d counts exactly these bytes for an assembly)
+            asm = engine.Assembler(form, batch=batch, device=dev, lti=["LIP"])
+            asm.bind_lti("LIP", A, Bm)
+            SU = None
+        else:
+            S = torch.empty((batch, N, 3, 3), dtype=torch.float64, device=dev)
+            U = torch.empty((batch, 1, N, N, 3), dtype=torch.float64, device=dev)
+            asm = engine.Assembler(form, batch=batch, device=dev)
+            asm.bind_source(("LIP", 0), U[:, 0])
+            asm.bind_source(("LIP", 1), S)
+            SU = (S, U)
+        asm.set_param("cost", "track vel_x", "aim", aims)
+        return asm, SU
+
+    def output_sets(asm, batch, count):
+        f = dict(dtype=torch.float64, device=dev)
+        return [(torch.empty((batch, asm.no, asm.no), **f), torch.empty((batch, asm.no), **f),
+                 torch.empty((batch, asm.nc, asm.no), **f), torch.empty((batch, asm.nc), **f))
+                for _ in range(max(1, count))]
+
+    asm, SU = make_assembler(B, A, Bm, work["aims"])
+    outs = output_sets(asm, B, args.rotate)
+
+    def step(k):
         if not fused:
-            engine.fill_su(A, Bm, N, out=(S, U))
-        return asm.assemble(given)
+            engine.fill_su(A, Bm, N, out=SU)
+        return asm.assemble(given, out=outs[k % len(outs)])
 
     def sync_all():
         torch.cuda.synchronize()
@@ -188,46 +381,47 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    for k in range(args.warmup):
+        step(k)
     sync_all()
 
-    # timed region: exactly K steps; hipEvents (on the launch stream) bracket the C-ABI
-    # calls of every EVERY-th step, so that the kernels' own durations come from the same
-    # run without an event pair between every two launches
-    sampled = range(0, args.steps, args.event_every)
-    ev = {k: [torch.cuda.Event(enable_timing=True) for _ in range(3)] for k in sampled}
+    # timed region: exactly K steps.  One pair of hipEvents on the launch stream brackets the
+    # K launches (K1-fused: a step IS one kernel, so event time / K = average launch duration,
+    # launch gaps included -- the conservative reading); --two-kernels adds a pair around the
+    # fill of every 8th step.
+    e_begin, e_end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    fill_ev = []
     t0 = time.perf_counter()
+    e_begin.record()
     for k in range(args.steps):
-        e = ev.get(k)
-        if e:
-            e[0].record()
         if not fused:
-            engine.fill_su(A, Bm, N, out=(S, U))
-        if e:
-            e[1].record()
-        asm.assemble(given)
-        if e:
-            e[2].record()
+            if k % 8 == 0:
+                pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                pair[0].record()
+                engine.fill_su(A, Bm, N, out=SU)
+                pair[1].record()
+                fill_ev.append(pair)
+            else:
+                engine.fill_su(A, Bm, N, out=SU)
+        asm.assemble(given, out=outs[k % len(outs)])
+    e_end.record()
     sync_all()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = mdist.max_over_ranks(elapsed, device=dev)
 
-    fill_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev.values()]))
-    asm_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev.values()]))
+    step_ms = e_begin.elapsed_time(e_end) / args.steps
+    fill_ms = float(np.mean([a.elapsed_time(b) for a, b in fill_ev])) if fill_ev else 0.0
+    asm_ms = step_ms - fill_ms
 
     no, ng, nc = asm.no, asm.ng, asm.nc
     nparams = int(asm.params.shape[1])
-    bytes_fill = 8 * (N * 9 + N * N * 3) + 8 * (9 + 3)                    # written + read
+    bytes_fill = fill_bytes(3, 1, N, False)
     bytes_out = 8 * (no * no + no + nc * no + nc)
     bytes_asm = bytes_out + 8 * (ng + nparams) + (8 * (9 + 3) if fused else 8 * (N * 9 + N * N * 3))
-    total = world * B * args.steps
-    value = total / elapsed
+    value = world * B * args.steps / elapsed
 
-    # dominant kernel = the assembly (K2-K4); HBM-bound
+    # dominant kernel = the assembly (K2-K4, K1 inside when fused); HBM-bound
     achieved = bytes_asm * B / (asm_ms * 1e-3) / 1e9
     # HBM bytes per launch from the PMC passes of the same command (rocprofv3 --pmc
     # FETCH_SIZE / WRITE_SIZE in separate runs, tools/summarize_profile.py); only
@@ -240,8 +434,11 @@ def main():
             traffic = pmc["traffic_bytes_per_launch"]
     except (OSError, ValueError, KeyError):
         pass
+    kernel_name = "mpcasm_assemble -> resident_assemble_kernel (%sK2 compose + K3 hessian_mfma + " \
+                  "K4 constraint_stack fused in one persistent launch)" \
+                  % ("K1 horizon tables + " if fused else "")
     record = {
-        "metric": "QP assemblies/sec (P,q,G,h), biped N=16 batched",
+        "metric": METRIC,
         "value": value,
         "unit": "assemblies/s",
         "n_gpus": world,
@@ -259,13 +456,12 @@ def main():
             "batch_per_gpu": B,
             "global_batch": B * world,
             "horizon": N,
+            "output_buffer_sets": len(outs),
             "step": "mpcasm_assemble, horizon matrices built on chip from per-instance (A,B) "
                     "(K1 fused)" if fused else "mpcasm_fill_su + mpcasm_assemble",
         },
         "roofline": {
-            "kernel": "mpcasm_assemble -> resident_assemble_kernel (%sK2 compose + K3 hessian_mfma "
-                      "+ K4 constraint_stack fused in one persistent launch)"
-                      % ("K1 horizon tables + " if fused else ""),
+            "kernel": kernel_name,
             "bound": "hbm",
             "achieved": achieved,
             "peak": HBM_PEAK_GBPS,
@@ -275,16 +471,74 @@ def main():
             "algorithmic_bytes_per_launch": bytes_asm * B,
             "algorithmic_bytes_per_assembly": bytes_asm,
             "avg_launch_ms": asm_ms,
+            "clock": "hipEvents on the launch stream around the %d timed launches" % args.steps,
         },
         "hbm_GBps_end_to_end": (bytes_asm + (0 if fused else bytes_fill)) * value / 1e9,
     }
     if not fused:
-        record["fill"] = {
+        record["fill_in_step"] = {
             "kernel": "mpcasm_fill_su (K1 toeplitz_fill)",
             "algorithmic_bytes_per_system": bytes_fill,
             "avg_launch_ms": fill_ms,
             "achieved_GBps": bytes_fill * B / (fill_ms * 1e-3) / 1e9,
         }
+
+    if not args.no_extras:
+        # optional final gather of the assembled QPs: all-gather over RCCL/xGMI
+        if dist is not None:
+            P, q, G, h = outs[(args.steps - 1) % len(outs)]
+            gathered = [None]
+
+            def gather():
+                gathered[0] = [mdist.gather_batch(t, world * B) for t in (P, q, G, h)]
+
+            for _ in range(2):
+                gather()
+            sync_all()
+            reps = 5
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                gather()
+            sync_all()
+            g_ms = mdist.max_over_ranks((time.perf_counter() - t0) / reps * 1e3, device=dev)
+            recv = bytes_out * B * (world - 1)
+            record["gather"] = {
+                "what": "all-gather of P,q,G,h of every rank onto every rank (mpcasm.dist.gather_batch), "
+                        "after the assembly; not part of `value`",
+                "backend": args.backend, "ms": g_ms, "bytes_received_per_gpu": recv,
+                "GBps_received_per_gpu": recv / (g_ms * 1e-3) / 1e9,
+                "instances_per_gpu_after": int(gathered[0][0].shape[0]),
+            }
+            del gathered
+            torch.cuda.empty_cache()
+        # K1 alone on the north-star shapes
+        record["fill"] = fill_records(torch, engine, dev, B)
+        # the same step at B=65536: 2.2 GB of outputs per step, no cache can hold it
+        big = 65536
+        times = (big + B - 1) // B
+        if big > B:
+            Ab = torch.as_tensor(tiled(work["A"], times)[:big], device=dev)
+            Bb = torch.as_tensor(tiled(work["B"], times)[:big], device=dev)
+            gb = torch.as_tensor(tiled(work["given"], times)[:big], device=dev)
+            asm_big, SU_big = make_assembler(big, Ab, Bb, tiled(work["aims"], times)[:big])
+            out_big = output_sets(asm_big, big, 1)[0]
+
+            def big_step():
+                if not fused:
+                    engine.fill_su(Ab, Bb, N, out=SU_big)
+                asm_big.assemble(gb, out=out_big)
+
+            ms = _event_ms(torch, big_step, 20)
+            gbps = (bytes_asm + (0 if fused else bytes_fill)) * big / (ms * 1e-3) / 1e9
+            record["extra"] = {
+                "what": "the same step at B=%d per GPU (outputs %.2f GB per step: HBM traffic for sure)"
+                        % (big, bytes_out * big / 1e9),
+                "batch_per_gpu": big, "ms_per_step": ms, "assemblies_per_s": big / (ms * 1e-3),
+                "achieved": gbps, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
+            }
+            del asm_big, SU_big, out_big, Ab, Bb, gb
+            torch.cuda.empty_cache()
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         rate1, count1, secs1 = cpu_baseline(work, 6.0)
         rate, count, procs = cpu_baseline_all_cores(10.0)
@@ -296,13 +550,23 @@ def main():
             "single_core_value": rate1,
             "sample": "%d assemblies of the same workload in 10 s on %d processes (one formulation "
                       "each): oracle/qp_oracle.py (extend_matrices + preview matrices + all QP "
-                      "blocks per instance); one process alone: %d in %.1f s; host has %d cores"
+                      "blocks per instance; the per-tick update() callback of the reference's "
+                      "979/s figure is not in it); one process alone: %d in %.1f s; host has %d cores"
                       % (count, procs, count1, secs1, os.cpu_count() or 0),
         }
     if rank == 0:
-        print(json.dumps(record))
+        print(json.dumps(record), flush=True)
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args, argv))
+    run_rank(args)
 
 
 if __name__ == "__main__":

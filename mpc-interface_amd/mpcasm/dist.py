@@ -41,8 +41,16 @@ def gather_batch(local, batch, group=None):
         pad = torch.zeros((longest - local.shape[0],) + tuple(local.shape[1:]),
                           dtype=local.dtype, device=local.device)
         padded = torch.cat([local, pad])
+    padded = padded.contiguous()
+    if padded.is_cuda and dist.get_backend(group) == "gloo":
+        # gloo has no all-gather of device tensors: stage through the host (rehearsals of the
+        # multi-rank path on a box whose ranks share one GPU; RCCL takes the branch below)
+        host = padded.cpu()
+        parts = [torch.empty_like(host) for _ in range(world)]
+        dist.all_gather(parts, host, group=group)
+        return torch.cat([p[:n] for p, n in zip(parts, sizes)]).to(local.device)
     parts = [torch.empty_like(padded) for _ in range(world)]
-    dist.all_gather(parts, padded.contiguous(), group=group)
+    dist.all_gather(parts, padded, group=group)
     return torch.cat([p[:n] for p, n in zip(parts, sizes)])
 
 
@@ -51,6 +59,8 @@ def max_over_ranks(value, device=None, group=None):
     import torch
     import torch.distributed as dist
 
+    if device is not None and dist.get_backend(group) == "gloo":
+        device = None           # (host tensor: every gloo build reduces those)
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return float(t.item())
