@@ -34,6 +34,14 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("" ::: "memory");
 }
 
+// the value of lane T of every quad, in all four lanes of the quad (DPP quad_perm)
+template <int T>
+__device__ __forceinline__ double quad_broadcast(double v) {
+  constexpr int ctl = T | (T << 2) | (T << 4) | (T << 6);
+  return __hiloint2double(__builtin_amdgcn_mov_dpp(__double2hiint(v), ctl, 0xF, 0xF, true),
+                          __builtin_amdgcn_mov_dpp(__double2loint(v), ctl, 0xF, 0xF, true));
+}
+
 // sum over the 64 lanes of a wavefront, result in every lane
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll

@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "device_common.h"
 #include "kernels.h"
 
 namespace mpcasm {
@@ -650,6 +651,354 @@ __global__ __launch_bounds__(BLOCK) void fill_ltv_wave_kernel(const double* __re
   stream_row(Rw + ((N - 1) & 1) * rstep, N - 1);
 }
 
+// ---------------------------------------------------------------------------------------
+// Few states (n <= 4, n + m <= 16: the LIPM family of C2 / C3 / C5), one wavefront per
+// workgroup.  Both kernels below are written against ONE budget: vector instructions per
+// stored kilobyte.  A wave64 instruction occupies its SIMD for ~4 cycles whatever it does, so
+// a write loop that spends 40 instructions of index arithmetic per 1 KiB store (the kernels
+// above: running (row, position) counters, clamps, selects) is bound by instruction issue,
+// not by HBM, as soon as every CU holds a few waves.  Here the per-lane part of every address
+// is a constant computed once per wave and the per-row part is wave-uniform (scalar unit):
+// a store costs one LDS read (ds_read2_b64) and the store itself.
+//
+// LTI: the recurrence runs in registers -- a system occupies m + n quads of lanes, lane
+// (c, i) holds X[i][c] of X_d = [A^d B | A^{d+1}], A's row i sits in registers and the n
+// values X[t][c] come from the lane's own quad with DPP quad broadcasts: no LDS round trip in
+// the dependent chain (~40 cycles a step instead of ~150).  Every step drops its values into
+// LDS: the state columns in S's own order, the input columns into a block-reversed table
+// R_j[(N-1-d) n + i] that is FOLLOWED BY N n ZEROS -- row k of U_j is then the window
+// T_j[(N-1-k) n ...][0 .. N n), structural zeros included, with no select and no clamp.
+// Rows shorter than a wavefront (N n / 2 sixteen-byte words <= 32) go out 64 / L rows per
+// instruction, L the next power of two.
+__host__ __device__ inline size_t quad_lds_doubles(int N, int n, int m, int spw) {
+  return (size_t)spw * ((size_t)N * n * n + (size_t)m * 2 * N * n) + 64;   // + idle lanes' scratch
+}
+
+// `count2` sixteen-byte words from LDS (8-byte aligned: ds_read2_b64) to HBM, lane q handles
+// words q, q + 64, ...; UNR reads go out before the first store waits for them.  `src` and `dst`
+// already carry the lane's own offset (2 lane doubles / lane words).
+template <int UNR>
+__device__ __forceinline__ void stream_words(const double* __restrict__ src,
+                                             double2* __restrict__ dst, int count2, int lane) {
+  const int last = count2 - 1 - lane;   // (clamped reads stay inside the run; stores are masked)
+  for (int base = 0; base < count2; base += 64 * UNR) {
+    double2 v[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int q = min(base + 64 * u, last);
+      v[u].x = src[2 * q];
+      v[u].y = src[2 * q + 1];
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u)
+      if (base + 64 * u <= last) dst[base + 64 * u] = v[u];
+  }
+}
+
+template <int NS>
+__global__ __launch_bounds__(64) void fill_lti_quad_kernel(const double* __restrict__ A,
+                                                           const double* __restrict__ B,
+                                                           double* __restrict__ S,
+                                                           double* __restrict__ U, int batch, int N,
+                                                           int m, int spw, int lshift) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  constexpr int n = NS, nn = NS * NS;
+  const int lane = threadIdx.x;
+  const int rl = N * n, rl2 = rl >> 1;
+  const long sys0 = (long)blockIdx.x * spw;
+  const int nsys = (int)min((long)spw, (long)batch - sys0);
+  double* Sl = lds;                          // [spw][N][n][n], S's own layout
+  double* T = lds + (size_t)spw * N * nn;    // [spw][m]{R_j (rl) | zeros (rl)}
+
+  // recurrence role: quad c of system `sub`, row i
+  const int lps = 4 * (m + n);               // lanes per system
+  const int sub = lane / lps, within = lane - sub * lps;
+  const int c = within >> 2, i = within & 3;
+  const bool worker = sub < nsys && i < n;
+  double a[NS], x = 0.0;
+#pragma unroll
+  for (int t = 0; t < NS; ++t) a[t] = 0.0;
+  if (worker) {
+    const double* Ab = A + (size_t)(sys0 + sub) * nn;
+    const double* Bb = B + (size_t)(sys0 + sub) * n * m;
+#pragma unroll
+    for (int t = 0; t < NS; ++t) a[t] = Ab[i * n + t];
+    x = c < m ? Bb[i * m + c] : Ab[i * n + (c - m)];
+  }
+  {  // the tables start as zeros (the upper halves stay that way); the loads are in flight
+    double2* T2 = reinterpret_cast<double2*>(T);
+    const int count2 = spw * m * rl;         // (2 rl doubles per table = rl sixteen-byte words)
+    const double2 zero = {0.0, 0.0};
+    for (int e = lane; e < count2; e += 64) T2[e] = zero;
+  }
+  // where this lane's values go, step after step; idle lanes write their own scratch word
+  double* w = T + (size_t)spw * m * 2 * rl + lane;
+  int wstep = 0;
+  if (worker) {
+    if (c < m) {
+      w = T + (size_t)(sub * m + c) * 2 * rl + (size_t)(N - 1) * n + i;
+      wstep = -n;
+    } else {
+      w = Sl + (size_t)sub * N * nn + (c - m) * n + i;
+      wstep = nn;
+    }
+  }
+  // X_d = A X_{d-1}  (tools.py:24-29: left-multiply the previous block row)
+  for (int d = 0; d < N; ++d) {
+    *w = x;
+    w += wstep;
+    double y = a[0] * quad_broadcast<0>(x);
+    if (NS > 1) y = fma(a[NS > 1 ? 1 : 0], quad_broadcast<1>(x), y);
+    if (NS > 2) y = fma(a[NS > 2 ? 2 : 0], quad_broadcast<2>(x), y);
+    if (NS > 3) y = fma(a[NS > 3 ? 3 : 0], quad_broadcast<3>(x), y);
+    x = y;
+  }
+  wave_lds_sync();
+
+  // S of the wave's systems: contiguous in HBM and in LDS, one flat copy
+  stream_words<4>(Sl + 2 * lane, reinterpret_cast<double2*>(S + (size_t)sys0 * N * nn) + lane,
+                  (nsys * N * nn) >> 1, lane);
+  if (rl2 > 64) {  // long rows: a row is ceil(rl2 / 64) instructions
+    for (int sj = 0; sj < nsys * m; ++sj) {
+      const double* Tj = T + (size_t)sj * 2 * rl + 2 * lane;
+      double2* out = reinterpret_cast<double2*>(U + ((size_t)sys0 * m + sj) * N * rl) + lane;
+      for (int k = 0; k < N; ++k)
+        stream_words<4>(Tj + (N - 1 - k) * n, out + (size_t)k * rl2, rl2, lane);
+    }
+  } else {
+    // short rows: R = 64 >> lshift rows per instruction, lane = (row r, word p) -- constants
+    const int L = 1 << lshift, R = 64 >> lshift;
+    const int r = lane >> lshift, p = lane & (L - 1);
+    const int full = N / R;                    // row groups with R valid rows
+    const bool tail = full * R + r < N;        // this lane's row of the last, partial group
+    const int lds_step = R * n, out_step = R * rl2;
+    for (int sj = 0; sj < nsys * m; ++sj) {
+      // group g: row k = g R + r, window T_j[(N-1-k) n + 2 p ...]
+      const double* win = T + (size_t)sj * 2 * rl + (N - 1 - r) * n + 2 * p;
+      double2* dst = reinterpret_cast<double2*>(U + ((size_t)sys0 * m + sj) * N * rl) +
+                     (size_t)r * rl2 + p;
+      if (p < rl2) {
+        int g = 0;
+        for (; g + 4 <= full; g += 4) {
+          double2 v[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            v[u].x = win[-(g + u) * lds_step];
+            v[u].y = win[-(g + u) * lds_step + 1];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) dst[(size_t)(g + u) * out_step] = v[u];
+        }
+        for (; g < full; ++g) {
+          double2 v;
+          v.x = win[-g * lds_step];
+          v.y = win[-g * lds_step + 1];
+          dst[(size_t)g * out_step] = v;
+        }
+        if (tail) {
+          double2 v;
+          v.x = win[-full * lds_step];
+          v.y = win[-full * lds_step + 1];
+          dst[(size_t)full * out_step] = v;
+        }
+      }
+    }
+  }
+}
+
+// `count` doubles from HBM to LDS, eight loads per lane in flight (16-byte loads when the
+// source allows)
+__device__ __forceinline__ void copy_to_lds(double* __restrict__ dst, const double* __restrict__ src,
+                                            int count, int lane) {
+  if (((count & 1) == 0) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
+    const double2* s2 = reinterpret_cast<const double2*>(src);
+    double2* d2 = reinterpret_cast<double2*>(dst);
+    const int c2 = count >> 1;
+    for (int base = 0; base < c2; base += 64 * 8) {
+      double2 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = s2[min(base + 64 * u + lane, c2 - 1)];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (base + 64 * u + lane < c2) d2[base + 64 * u + lane] = v[u];
+    }
+  } else {
+    for (int base = 0; base < count; base += 64 * 8) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = src[min(base + 64 * u + lane, count - 1)];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (base + 64 * u + lane < count) dst[base + 64 * u + lane] = v[u];
+    }
+  }
+}
+
+// LTV, one wavefront per system, the whole block row advanced in place of the reference's
+// per-block products: the row buffer holds [P_k (n columns of the running product) | block
+// l = 0 .. N-1 of every input], every block is "A_k times the same block one step ago", so
+// ONE unrolled pass structure serves S and U, lanes are (block, i) with 64 / n blocks per
+// pass, and blocks right of the diagonal are zeros times A_k: computed like the others, no
+// select; the diagonal block B_k is written after the passes (LDS operations of a wavefront
+// complete in order).  A pass is two LDS reads, n FMAs with A_k's row in registers and one LDS
+// write at immediate offsets.  Row k-1 streams to HBM (ds_read2_b64 + 16-byte stores) while
+// row k is being made.  Every step's (A_k, B_k) is copied to LDS before the first store (a
+// load inside the step loop would wait for the row stores in flight: one vmcnt counts both).
+template <int NS>
+struct LtvRow {
+  static constexpr int LQ = 64 / NS;            // blocks per pass
+  static constexpr int PASS = LQ * NS;          // doubles per pass
+  __host__ __device__ static int passes(int N, int m) { return (NS + m * N + LQ - 1) / LQ; }
+  __host__ __device__ static size_t row_doubles(int N, int m) {
+    return even_up((size_t)passes(N, m) * PASS + 2);
+  }
+  __host__ __device__ static size_t a_doubles(int N) { return even_up((size_t)N * NS * NS); }
+  __host__ __device__ static size_t lds_doubles(int N, int m) {
+    return 2 * row_doubles(N, m) + a_doubles(N) + even_up((size_t)N * NS * m);
+  }
+};
+
+template <int NS, int P>
+__device__ __forceinline__ void ltv_passes(const double* __restrict__ rd, double* __restrict__ wr,
+                                           const double (&a)[NS], bool worker) {
+  constexpr int PASS = LtvRow<NS>::PASS;
+  double x[P][NS];
+#pragma unroll
+  for (int q = 0; q < P; ++q)
+#pragma unroll
+    for (int t = 0; t < NS; ++t) x[q][t] = rd[q * PASS + t];
+#pragma unroll
+  for (int q = 0; q < P; ++q) {
+    double y = a[0] * x[q][0];
+#pragma unroll
+    for (int t = 1; t < NS; ++t) y = fma(a[t], x[q][t], y);
+    if (worker) wr[q * PASS] = y;
+  }
+}
+
+template <int NS>
+__global__ __launch_bounds__(64) void fill_ltv_row_kernel(const double* __restrict__ A,
+                                                          const double* __restrict__ B,
+                                                          double* __restrict__ S,
+                                                          double* __restrict__ U, int N, int m) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  using Lay = LtvRow<NS>;
+  constexpr int n = NS, nn = NS * NS, LQ = Lay::LQ, PASS = Lay::PASS;
+  const int lane = threadIdx.x;
+  const long inst = blockIdx.x;
+  const int rl = N * n, rl2 = rl >> 1, nm = n * m;
+  const size_t rstep = Lay::row_doubles(N, m);
+  double* Row = lds;                     // [2][rstep]
+  double* At = lds + 2 * rstep;          // [N][n][n], as in HBM
+  double* Bt = At + Lay::a_doubles(N);   // [N][n][m], as in HBM
+
+  const double* Ab = A + (size_t)inst * N * nn;
+  const double* Bb = B + (size_t)inst * N * nm;
+  double* Sb = S + (size_t)inst * N * nn;
+  double* Ub = U + (size_t)inst * m * N * rl;
+
+  // every step's matrices: flat copies, all loads in flight before the first LDS write waits
+  // for one (a load-wait-write loop would pay one HBM latency per 64 elements)
+  copy_to_lds(At, Ab, N * nn, lane);
+  copy_to_lds(Bt, Bb, N * nm, lane);
+  {  // zeros in both rows, P_{-1} = I in row "-1"
+    double2* Z = reinterpret_cast<double2*>(Row);
+    const double2 zero = {0.0, 0.0};
+    for (int e = lane; e < (int)rstep; e += 64) Z[e] = zero;
+    wave_lds_sync();
+    if (lane < n) Row[rstep + lane * n + lane] = 1.0;
+  }
+
+  const int lq = lane / n, li = lane - lq * n;
+  const bool worker = lq < LQ;
+  const int rd_off = worker ? lq * n : 0, wr_off = worker ? lq * n + li : 0;
+  const int arow = worker ? li * n : 0;
+  const int bj = lane / n, bi = lane - bj * n;   // B_k element (i, j) of lane < n m
+  const int boff = lane < nm ? bi * m + bj : 0;
+  const int bdiag = nn + bj * N * n + bi;        // (+ k n) where B_k[i][j] lands in row k
+
+  auto stream_row = [&](const double* Rrow, int k) {
+    const double sv = Rrow[lane < nn ? lane : 0];
+    for (int j = 0; j < m; ++j)
+      stream_words<4>(Rrow + nn + (size_t)j * rl + 2 * lane,
+                      reinterpret_cast<double2*>(Ub + ((size_t)j * N + k) * rl) + lane, rl2, lane);
+    if (lane < nn) Sb[(size_t)k * nn + lane] = sv;
+  };
+
+  // One LDS round trip per step: everything step k reads -- the NEXT step's A row and B element,
+  // row k-1 for the stream (S and up to four 1 KiB store instructions of U) and row k-1 for
+  // the passes -- is issued before the first result is waited for; then FMAs, LDS writes and
+  // the global stores, none of which anything waits for.
+  const bool fast = m == 1 && rl2 <= 256;
+  const int last = rl2 - 1 - lane;
+  const double* ak = At + arow;    // A_k's row of this lane
+  const double* bp = Bt + boff;    // B_k's element of this lane
+  double a[NS], bk = *bp;
+#pragma unroll
+  for (int t = 0; t < NS; ++t) a[t] = ak[t];
+  int cur = 0;
+  double* sdst = Sb + (lane < nn ? lane : 0) - nn;            // S[k-1]
+  double2* udst = reinterpret_cast<double2*>(Ub) + lane - rl2;  // U_0[k-1]
+  for (int k = 0; k < N; ++k) {
+    const double* Rp = Row + (cur ^ 1) * rstep;  // row k-1
+    double* Rc = Row + cur * rstep;              // row k
+    if (k + 1 < N) {
+      ak += nn;
+      bp += nm;
+    }
+    double an[NS];
+#pragma unroll
+    for (int t = 0; t < NS; ++t) an[t] = ak[t];
+    const double bn = *bp;
+    const double sv = Rp[lane < nn ? lane : 0];
+    double2 v[4];
+    if (fast) {
+      const double* src = Rp + nn + 2 * lane;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int q = min(64 * u, last);
+        v[u].x = src[2 * q];
+        v[u].y = src[2 * q + 1];
+      }
+    }
+    // blocks that can be non-zero in row k-1: P and, of the LAST input, l < k
+    const int live = n + (m - 1) * N + k;
+    const int np = (live + LQ - 1) / LQ;
+    const double* rd = Rp + rd_off;
+    double* wr = Rc + wr_off;
+    int done = 0;
+    while (np - done >= 4) {
+      ltv_passes<NS, 4>(rd + done * PASS, wr + done * PASS, a, worker);
+      done += 4;
+    }
+    switch (np - done) {
+      case 3: ltv_passes<NS, 3>(rd + done * PASS, wr + done * PASS, a, worker); break;
+      case 2: ltv_passes<NS, 2>(rd + done * PASS, wr + done * PASS, a, worker); break;
+      case 1: ltv_passes<NS, 1>(rd + done * PASS, wr + done * PASS, a, worker); break;
+      default: break;
+    }
+    if (lane < nm) Rc[bdiag + k * n] = bk;
+    // row k-1 (complete, zeros right of the diagonal included) goes to HBM meanwhile
+    if (k > 0) {
+      if (fast) {
+        if (lane < nn) *sdst = sv;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (64 * u <= last) udst[64 * u] = v[u];
+      } else {
+        stream_row(Rp, k - 1);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < NS; ++t) a[t] = an[t];
+    bk = bn;
+    cur ^= 1;
+    sdst += nn;
+    udst += rl2;
+  }
+  stream_row(Row + (cur ^ 1) * rstep, N - 1);
+}
+
 template <typename K>
 hipError_t allow_lds(K kernel, size_t bytes) {
   if (bytes <= 64 * 1024) return hipSuccess;
@@ -663,6 +1012,43 @@ int launch_fill_su(const double* A, const double* B, double* S, double* U, int b
                    int m, int ltv, hipStream_t stream, hipError_t* err) {
   *err = hipSuccess;
   constexpr size_t LDS_MAX = 160 * 1024;
+  const bool aligned16 = (((uintptr_t)S | (uintptr_t)U) & 15) == 0;
+  const bool pairs = ((N * n) & 1) == 0 && aligned16;   // rows of U are whole 16-byte words
+  if (!ltv && n <= 4 && m + n <= 16 && pairs && ((N * n * n) & 1) == 0) {
+    // few states: registers + DPP recurrence, constant-address write loop
+    int spw = 16 / (m + n);
+    while (spw > 1 && quad_lds_doubles(N, n, m, spw) * sizeof(double) > 40 * 1024) --spw;
+    while (spw > 1 && (batch + spw - 1) / spw < 2048) --spw;
+    const size_t bytes = quad_lds_doubles(N, n, m, spw) * sizeof(double);
+    if (bytes <= LDS_MAX) {
+      auto kernel = n == 1   ? fill_lti_quad_kernel<1>
+                    : n == 2 ? fill_lti_quad_kernel<2>
+                    : n == 3 ? fill_lti_quad_kernel<3>
+                             : fill_lti_quad_kernel<4>;
+      if ((*err = allow_lds(kernel, bytes)) != hipSuccess) return MPCASM_ERR_HIP;
+      int lshift = 0;
+      while (lshift < 6 && (1 << lshift) < (N * n) / 2) ++lshift;
+      hipLaunchKernelGGL(kernel, dim3((batch + spw - 1) / spw), dim3(64), bytes, stream, A, B, S, U,
+                         batch, N, m, spw, lshift);
+      *err = hipGetLastError();
+      return *err == hipSuccess ? MPCASM_OK : MPCASM_ERR_HIP;
+    }
+  }
+  if (ltv && n <= 4 && n * m <= 64 && pairs) {
+    const size_t bytes = (n == 1   ? LtvRow<1>::lds_doubles(N, m)
+                          : n == 2 ? LtvRow<2>::lds_doubles(N, m)
+                          : n == 3 ? LtvRow<3>::lds_doubles(N, m)
+                                   : LtvRow<4>::lds_doubles(N, m)) * sizeof(double);
+    if (bytes <= 64 * 1024) {
+      auto kernel = n == 1   ? fill_ltv_row_kernel<1>
+                    : n == 2 ? fill_ltv_row_kernel<2>
+                    : n == 3 ? fill_ltv_row_kernel<3>
+                             : fill_ltv_row_kernel<4>;
+      hipLaunchKernelGGL(kernel, dim3(batch), dim3(64), bytes, stream, A, B, S, U, N, m);
+      *err = hipGetLastError();
+      return *err == hipSuccess ? MPCASM_OK : MPCASM_ERR_HIP;
+    }
+  }
   if (!ltv) {
     const size_t per = lti_lds_doubles(N, n, m) * sizeof(double);
     const int xsz = n * (m + n);

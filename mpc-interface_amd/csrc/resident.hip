@@ -129,13 +129,6 @@ __device__ __forceinline__ void dma4(const void* gsrc, unsigned lds_base) {
       : "v"(gsrc), "s"(lds_base)
       : "memory");
 }
-// the value of lane T of every quad, in all four lanes of the quad (DPP quad_perm)
-template <int T>
-__device__ __forceinline__ double quad_broadcast(double v) {
-  constexpr int ctl = T | (T << 2) | (T << 4) | (T << 6);
-  return __hiloint2double(__builtin_amdgcn_mov_dpp(__double2hiint(v), ctl, 0xF, 0xF, true),
-                          __builtin_amdgcn_mov_dpp(__double2loint(v), ctl, 0xF, 0xF, true));
-}
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // GEN: the plan has source groups generated on chip (K1 fused); without them that code is

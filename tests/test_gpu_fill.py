@@ -36,7 +36,11 @@ def test_reference_fixture_through_the_drop_in_api(gpu_api):
 
 @pytest.mark.parametrize("n,m,N", [(3, 1, 16), (3, 1, 32), (3, 1, 100), (8, 6, 20),
                                    (12, 6, 64), (1, 1, 5), (2, 3, 1), (1, 1, 1), (5, 2, 7),
-                                   (17, 3, 9), (24, 18, 4)])
+                                   (17, 3, 9), (24, 18, 4),
+                                   # few states: the register/DPP kernel (rows per store 1 ... 64,
+                                   # rows longer than a wavefront, several inputs) and its fall-backs
+                                   (4, 2, 12), (2, 1, 8), (1, 3, 6), (3, 2, 10), (4, 12, 6), (3, 1, 2),
+                                   (2, 2, 64), (4, 1, 40), (3, 1, 15), (4, 1, 1), (3, 13, 4)])
 def test_lti_against_golden_and_oracle(eng, gpu_api, n, m, N):
     g = golden("g1_extend")
     key = "lti_n%d_m%d_N%d/" % (n, m, N)
@@ -80,7 +84,39 @@ def test_batched_lti_per_instance_systems(eng):
             assert_close(U[b], np.stack(Uo), RTOL_TIGHT)
 
 
-@pytest.mark.parametrize("n,m,N", [(3, 1, 100), (3, 1, 7), (4, 2, 12), (12, 6, 16), (70, 2, 3)])
+def test_batched_lti_several_systems_per_wavefront(eng):
+    """Batches large enough for the few-state kernel to put 2 ... 5 systems on one wavefront,
+    ragged at the end; every system against a vectorised restatement of the recurrence, a
+    sample against the oracle."""
+    import torch
+
+    rng = np.random.default_rng(78)
+    for batch, n, m, N in ((8195, 3, 1, 16), (4097, 3, 1, 16), (10241, 2, 1, 8), (6151, 4, 3, 6),
+                           (6145, 3, 1, 100), (9001, 1, 2, 4)):
+        A = rng.standard_normal((batch, n, n)) / np.sqrt(n)
+        B = rng.standard_normal((batch, n, m))
+        S, U = eng.fill_su(torch.as_tensor(A, device="cuda"), torch.as_tensor(B, device="cuda"), N)
+        S, U = S.cpu().numpy(), U.cpu().numpy()
+        X, Sref, col = B.copy(), [], []
+        P = A.copy()
+        for k in range(N):
+            col.append(X)                               # A^k B
+            Sref.append(P.transpose(0, 2, 1))           # S[k][j][i] = (A^{k+1})[i][j]
+            X, P = A @ X, A @ P
+        assert_close(S, np.stack(Sref, axis=1), RTOL_TIGHT, "S")
+        Uref = np.zeros_like(U)
+        for k in range(N):
+            for l in range(k + 1):
+                Uref[:, :, k, l, :] = col[k - l].transpose(0, 2, 1)
+        assert_close(U, Uref, RTOL_TIGHT, "U")
+        for b in (0, batch // 3, batch - 1):
+            So, Uo = orc.extend_matrices(N, A[b], B[b])
+            assert_close(S[b], So, RTOL_TIGHT)
+            assert_close(U[b], np.stack(Uo), RTOL_TIGHT)
+
+
+@pytest.mark.parametrize("n,m,N", [(3, 1, 100), (3, 1, 7), (4, 2, 12), (12, 6, 16), (70, 2, 3),
+                                   (2, 1, 64), (1, 1, 10), (4, 3, 30), (3, 2, 101), (3, 1, 16)])
 def test_ltv_against_oracle(eng, n, m, N):
     """Per-step (A_k, B_k): parity unpinned beyond the degenerate LTI case (the
     reference has no such path); checked against the oracle's

@@ -17,6 +17,7 @@ from mpcasm import engine  # noqa: E402
 
 CASES = [  # name, n, m, N, ltv, batch
     ("C2 biped LIPM", 3, 1, 16, False, 4096),
+    ("C2 biped LIPM", 3, 1, 16, False, 8192),
     ("C2 biped LIPM", 3, 1, 16, False, 65536),
     ("C2 biped LIPM", 3, 1, 16, False, 524288),
     ("C3 N=32", 3, 1, 32, False, 131072),
@@ -29,9 +30,12 @@ CASES = [  # name, n, m, N, ltv, batch
 
 
 def main():
+    only = sys.argv[1] if len(sys.argv) > 1 else ""          # substring of the case names to run
     rng = np.random.default_rng(0)
     print("%-22s %8s %10s %10s %9s %7s" % ("case", "batch", "MB/launch", "us/launch", "GB/s", "frac"))
     for name, n, m, N, ltv, batch in CASES:
+        if only not in name:
+            continue
         shapeA = (batch, N, n, n) if ltv else (batch, n, n)
         shapeB = (batch, N, n, m) if ltv else (batch, n, m)
         A = torch.as_tensor(rng.standard_normal(shapeA) / np.sqrt(n) * 0.9, device="cuda")
@@ -55,7 +59,8 @@ def main():
                                                       gbs / 8000.0))
         del A, B, S, U
         torch.cuda.empty_cache()
-    cpu_lines(rng)
+    if not only:
+        cpu_lines(rng)
 
 
 def cpu_lines(rng):
