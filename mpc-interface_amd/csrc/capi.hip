@@ -82,7 +82,8 @@ int validate_plan(const int32_t* it, const double* h_dtab, size_t n_itab, size_t
       if (ar[2 * s] < 1 || ar[2 * s + 1] < 0 ||
           (int64_t)ar[2 * s] + ar[2 * s + 1] > it[H_ARENA_TOTAL])
         return MPCASM_ERR_PLAN;
-    const int64_t vsize = (int64_t)it[H_RTOT] * it[H_LDV];
+    // (indices of the persistent kernel's workspace layout: whole groups of four rows)
+    const int64_t vsize = (int64_t)((it[H_RTOT] + 3) / 4) * 4 * it[H_LDV];
     const int32_t* fi = it + it[H_OFF_FD_IDX];
     const int32_t* fp = it + it[H_OFF_FD_PTR];
     if (fp[0] != 0 || fp[it[H_NFD]] != it[H_NOPS]) return MPCASM_ERR_PLAN;
@@ -148,7 +149,7 @@ int validate_plan(const int32_t* it, const double* h_dtab, size_t n_itab, size_t
     r = r && in_range(it[H_OFF_RS_TRIP], ((int64_t)it[H_RS_NTRIP] + 2) * RS_TRIP_WORDS, n, H_WORDS);
     r = r && in_range(it[H_OFF_RS_WTRIP], RS_WAVES * 2, n, H_WORDS);
     r = r && in_range(it[H_OFF_RS_SPLIT], it[H_RS_NSPLIT], n, H_WORDS);
-    r = r && (it[H_OFF_RS_TRIP] % 4 == 0);
+    r = r && (it[H_OFF_RS_TRIP] % 8 == 0);
     r = r && in_range(it[H_OFF_RS_RR], nc * RS_RR_WORDS, n, H_WORDS) && it[H_OFF_RS_RR] % 4 == 0;
     r = r && in_range(it[H_OFF_RS_INMETA], nchunk * 64 * 2, n, H_WORDS) &&
         it[H_OFF_RS_INMETA] % 2 == 0;
@@ -162,7 +163,8 @@ int validate_plan(const int32_t* it, const double* h_dtab, size_t n_itab, size_t
       const double* c = h_dtab + it[H_DOFF_RS_CONST];
       if (c[0] != 1.0 || c[1] != 1.0 || c[2] != 0.0 || c[3] != 0.0) return MPCASM_ERR_PLAN;
     }
-    const int64_t vsize = (int64_t)it[H_RTOT] * it[H_LDV];
+    // (indices of the persistent kernel's workspace layout: whole groups of four rows)
+    const int64_t vsize = (int64_t)((it[H_RTOT] + 3) / 4) * 4 * it[H_LDV];
     const int32_t* ts = it + it[H_OFF_RS_SRC];
     const int32_t* tg = it + it[H_OFF_RS_GIDX];
     const int32_t* td = it + it[H_OFF_RS_DST];
@@ -178,58 +180,46 @@ int validate_plan(const int32_t* it, const double* h_dtab, size_t n_itab, size_t
     const int32_t* tr = it + it[H_OFF_RS_TRIP];
     for (int i = 0; i < 2 * RS_TRIP_WORDS; ++i)
       if (tr[it[H_RS_NTRIP] * RS_TRIP_WORDS + i] != 0) return MPCASM_ERR_PLAN;
+    const int64_t group_bytes = 4 * (int64_t)it[H_LDV] * 8, ngroups = (it[H_RTOT] + 3) / 4;
+    if (it[H_LDV] < no + 2) return MPCASM_ERR_PLAN;  // columns: unknowns, d, ones
     for (int i = 0; i < it[H_RS_NTRIP]; ++i) {
       const int32_t* x = tr + i * RS_TRIP_WORDS;
       const int word = x[RT_WORD], rows = word & 31;
       const int live = (word >> RT_LIVE) & 15, qmask = (word >> RT_QMASK) & 15;
-      if (word < 0 || (word >> 18) != 0 || (word & 0x80) || rows > 16 || (qmask & ~live) ||
+      const bool is_short = (word >> RT_SHORT) & 1;
+      if (word < 0 || (word >> 19) != 0 || (rows != 0 && rows != 4 && rows != 16) ||
+          (qmask & ~live) || live == 0 || (is_short != (rows == 4)) ||
+          (rows == 0 && ((word >> RT_TERM_END) & 1)) ||
           x[RT_W] < 0 || x[RT_W] % 8 || x[RT_W] / 8 >= it[H_NPARAMS] || x[RT_AIM] < 0 ||
           x[RT_AIM] % 8 || x[RT_AIM] / 8 >= it[H_NPARAMS])
         return MPCASM_ERR_PLAN;
       for (int g = 0; g < 4; ++g)  // (all four groups load, live or not)
         if (((x[RT_BI] >> (8 * g)) & 255) >= nb || ((x[RT_BJ] >> (8 * g)) & 255) >= nb)
           return MPCASM_ERR_PLAN;
-      // a trip reads 16 rows from its offsets, up to column 4 nb - 1 <= no + 2: the slack
-      // behind V covers what lies past the last row
-      const int offs[3] = {x[RT_A], x[RT_B], x[RT_D]};
+      // offsets: whole row groups (the d offset: column `no` of its group); a full trip reads
+      // four groups, a short one a single group
+      const int64_t offs[3] = {x[RT_A], x[RT_B], (int64_t)x[RT_D] - (rows > 0 ? no * 32 : 0)};
       for (int k = 0; k < 3; ++k)
-        if (offs[k] < 0 || offs[k] % 8 || (rows > 0 && offs[k] / 8 / it[H_LDV] + rows > it[H_RTOT]) ||
-            (rows == 0 && offs[k] != 0))
+        if (offs[k] < 0 || offs[k] % group_bytes || offs[k] / group_bytes + rows / 4 > ngroups)
           return MPCASM_ERR_PLAN;
-      // the tail k-step: at most four rows of its own
-      const int tword = x[RT_TAIL_WORD], trows = tword & 31;
-      if (tword != 0) {
-        if (rows == 0 || (tword & ~(31 | (1 << RT_HALF) | (1 << RT_NOP))) || trows < 1 || trows > 4 ||
-            x[RT_TAIL_W] < 0 || x[RT_TAIL_W] % 8 || x[RT_TAIL_W] / 8 >= it[H_NPARAMS] ||
-            x[RT_TAIL_AIM] < 0 || x[RT_TAIL_AIM] % 8 || x[RT_TAIL_AIM] / 8 >= it[H_NPARAMS])
-          return MPCASM_ERR_PLAN;
-        const int toffs[3] = {x[RT_TAIL_A], x[RT_TAIL_B], x[RT_TAIL_D]};
-        for (int k = 0; k < 3; ++k)  // (reads four rows from the offset: the slack covers them)
-          if (toffs[k] < 0 || toffs[k] % 8 || toffs[k] / 8 / it[H_LDV] + trows > it[H_RTOT])
-            return MPCASM_ERR_PLAN;
-      } else {
-        for (int k = RT_TAIL_A; k < RS_TRIP_WORDS; ++k)
-          if (x[k] != 0) return MPCASM_ERR_PLAN;
-      }
     }
     {  // every wavefront's trips: consecutive, whole packs (first ... last)
       const int32_t* wt = it + it[H_OFF_RS_WTRIP];
       int next = 0;
       for (int w = 0; w < RS_WAVES; ++w) {
-        if (wt[2 * w] != next || wt[2 * w + 1] < 0 || (wt[2 * w + 1] & 1)) return MPCASM_ERR_PLAN;
+        if (wt[2 * w] != next || wt[2 * w + 1] < 0) return MPCASM_ERR_PLAN;
         next += wt[2 * w + 1];
         if (next > it[H_RS_NTRIP]) return MPCASM_ERR_PLAN;
         const int32_t* open = nullptr;
         for (int i = wt[2 * w]; i < next; ++i) {
           const int32_t* x = tr + i * RS_TRIP_WORDS;
           const int word = x[RT_WORD];
-          if (word == 0 && open == nullptr) continue;  // padding between packs
           if ((word >> RT_FIRST) & 1) {
             if (open != nullptr) return MPCASM_ERR_PLAN;
             open = x;
           }
           if (open == nullptr || open[RT_BI] != x[RT_BI] || open[RT_BJ] != x[RT_BJ] ||
-              (open[RT_WORD] >> RT_LIVE) != (word >> RT_LIVE))
+              (((open[RT_WORD] ^ word) >> RT_LIVE) & 0xFF) != 0)   // live groups, groups of q
             return MPCASM_ERR_PLAN;
           if ((word >> RT_LAST) & 1) open = nullptr;
         }
@@ -244,7 +234,8 @@ int validate_plan(const int32_t* it, const double* h_dtab, size_t n_itab, size_t
           x[RR_EXTREME] >= it[H_NPARAMS])
         return MPCASM_ERR_PLAN;
       for (int a = 0; a < RS_AXMAX; ++a)
-        if (x[RR_VOFF + a] < 0 || x[RR_VOFF + a] + no >= vsize + 1 || x[RR_ARROW + a] < 0 ||
+        if (x[RR_VOFF + a] < 0 || x[RR_VOFF + a] % (4 * it[H_LDV]) >= 4 ||
+            x[RR_VOFF + a] / (4 * it[H_LDV]) >= (it[H_RTOT] + 3) / 4 || x[RR_ARROW + a] < 0 ||
             x[RR_ARROW + a] > it[H_NPARAMS] || x[RR_CENTER + a] < 0 ||
             x[RR_CENTER + a] > it[H_NPARAMS])
           return MPCASM_ERR_PLAN;
@@ -274,7 +265,7 @@ int validate_plan(const int32_t* it, const double* h_dtab, size_t n_itab, size_t
         for (int64_t e = 0; e < ngd; ++e) {  // the same numbers as the row record of the piece
           const int64_t R = e < pieces ? e / (no / 2) : 0, cp = e < pieces ? e % (no / 2) : 0;
           const int32_t* x = rrw + R * RS_RR_WORDS;
-          if ((uint32_t)gd[2 * e] != (((uint32_t)x[RR_VOFF] + 2 * cp) | (((uint32_t)x[RR_VOFF + 1] + 2 * cp) << 16)) ||
+          if ((uint32_t)gd[2 * e] != (((uint32_t)x[RR_VOFF] + 8 * cp) | (((uint32_t)x[RR_VOFF + 1] + 8 * cp) << 16)) ||
               (uint32_t)gd[2 * e + 1] != (uint32_t)x[RR_PACKED + 1])
             return MPCASM_ERR_PLAN;
         }

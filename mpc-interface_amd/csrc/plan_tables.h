@@ -27,7 +27,7 @@
 namespace mpcasm {
 
 constexpr int32_t PLAN_MAGIC = 0x4D504341;  // 'MPCA'
-constexpr int32_t PLAN_VERSION = 19;
+constexpr int32_t PLAN_VERSION = 20;
 
 enum HeaderWord : int {
   H_MAGIC = 0,
@@ -46,7 +46,7 @@ enum HeaderWord : int {
   H_NLAX,          // limit-axis records
   H_PMROWS,        // rows of the preview program (all definitions)
   H_PM_NENT,
-  H_LDV,           // workspace leading dimension (>= no + 1, even)
+  H_LDV,           // workspace leading dimension (>= no + 2, even)
   H_OFF_SEG,
   H_OFF_COLSEG,    // [nbase][ng+no] segment id or -1
   H_OFF_ROWPTR,    // [RTOT+1]
@@ -84,7 +84,7 @@ enum HeaderWord : int {
   H_OFF_RS_DST,     // [JC][RS_NT] workspace index the running sum goes to (| RS_DST_ACC: added
                     //             to it, the element is shared by two threads), or -1
   H_DOFF_RS_COEF,   // [JC][RS_NT]
-  H_OFF_RS_TRIP,    // [NTRIP + 2][16]: up to 16 rows of one gterm into one pack of blocks, see RT_* below;
+  H_OFF_RS_TRIP,    // [NTRIP + 2][8]: up to 16 rows of one gterm into one pack of blocks, see RT_* below;
                     //    two all-zero records behind the last (read ahead)
   H_OFF_RS_WTRIP,   // [RS_WAVES][2] first trip, trip count of every wavefront
   H_RS_NSPLIT,      // workspace elements composed by two threads
@@ -118,7 +118,7 @@ enum HeaderWord : int {
   H_RS_NGDESC,      // RS_GDESC_PIECES * RS_GDESC_THREADS when the table below exists, else 0
   H_OFF_RS_GDESC,   // [RS_NGDESC][2] small problems: a ready-made descriptor of every 16-byte piece of
                     //    G; piece e = columns 2cp, 2cp+1 of row R = e / (no/2):
-                    //    (voff0 + 2cp) | (voff1 + 2cp) << 16, arrow0 | arrow1 << 16
+                    //    (voff0 + 8cp) | (voff1 + 8cp) << 16, arrow0 | arrow1 << 16
   // the preview matrices [Mg | Mo] element by element (0 elements: the tables are absent and
   // K2 alone walks the row program): H_OFF_PM_MAP [PMROWS * (NG + NO)] index of the element's
   // op list or -1 (structural zero); element i = sum over ops H_OFF_PM_FDPTR[i] .. [i+1] of
@@ -160,15 +160,16 @@ constexpr int MAX_SOURCES = 32;
 // RS_NT threads per instance = RS_WAVES wavefronts; the first RS_NW ("matrix waves") fetch
 // the inputs, the others stream G; all of them run Hessian tiles; RS_JC_MAX compose ops
 // per thread
-constexpr int RS_NW = 4, RS_NT = 512, RS_WAVES = RS_NT / 64, RS_JC_MAX = 12, RS_TRIP_WORDS = 16;
+constexpr int RS_NW = 4, RS_NT = 512, RS_WAVES = RS_NT / 64, RS_JC_MAX = 12, RS_TRIP_WORDS = 8;
 constexpr int RS_BLOCKS_MAX = 255;  // 4-column blocks of the unknowns (one byte each): no <= 1020
 // generated source group: sizes; offsets of A [n][n] and B [n][m] inside a ring slot; image
 // offsets of the tables TA[k][i][j] = (A^{k+1})[i][j] and TB[d][i][j] = (A^d B)[i][j], k, d < N, and of
 // the powers A^(2^s) they are built from
 enum { LT_N = 0, LT_M, LT_HORIZON, LT_A, LT_B, LT_TA, LT_TB, LT_TP, RS_LTI_WORDS = 8 };
 constexpr int RS_LTI_MAX = 4;
-// row record of G: voff[4], arrow param[4], center param[4], naxes, extreme param, the first
-// two axes packed once more: voff0 | voff1 << 16, arrow0 | arrow1 << 16
+// row record of G: voff[4] (index of column 0 of the axis' row in the persistent kernel's
+// workspace layout, see RT_* below), arrow param[4], center param[4], naxes, extreme param, the
+// first two axes packed once more: voff0 | voff1 << 16, arrow0 | arrow1 << 16
 constexpr int RS_AXMAX = 4, RS_RR_WORDS = 16;
 constexpr int RS_GDESC_PIECES = 6, RS_GDESC_THREADS = RS_NT - RS_NW * 64;  // pieces per stream-wave thread
 constexpr int32_t RS_DST_ACC = 1 << 30;
@@ -178,21 +179,28 @@ constexpr int32_t RS_DST_ACC = 1 << 30;
 // the same A columns times s (d - aim), d = column `no` of the d rows.  Only blocks some term
 // reaches structurally exist (plus the diagonal of P and all of q, which the diagonal gterms
 // add into); four of them form a *pack*, one accumulator register: lane group j of the
-// instruction works on the pack's block j.  Trip record: up to 16 workspace rows of one
-// gterm into one pack (four k-steps).  RT_A / RT_B / RT_D: BYTE offset in the workspace of
-// the first A / B / d row, column 0; RT_WORD: rows | (1 << 5 when the term is halved) | (1 << 6 when the
-// term has no Hessian part: blocks of P get nothing) | first trip of its pack << 8 | last
-// << 9 | live lane groups << 10 | lane groups that hold a block of q << 14; RT_W / RT_AIM:
-// BYTE offset of the weight / aim among the parameters; RT_BI / RT_BJ: block row / block column of the four lane
-// groups, a byte each (groups that are not live repeat a live one's; the column of a block
-// of q is not used).  A wavefront's trips of one pack are consecutive.  A term (or the rest
-// of one) of at most four rows does not get a trip of its own: it rides as the *tail* of the
-// trip before it in the pack, a fifth k-step over the rows RT_TAIL_A.. (consecutive rows,
-// one per k-step lane row) with its own weight: RT_TAIL_WORD = rows | half << 5 | no
-// Hessian part << 6, 0 = no tail.
-enum { RT_A = 0, RT_B, RT_WORD, RT_W, RT_BI, RT_BJ, RT_D, RT_AIM,
-       RT_TAIL_A, RT_TAIL_B, RT_TAIL_WORD, RT_TAIL_W, RT_TAIL_D, RT_TAIL_AIM };
-enum { RT_HALF = 5, RT_NOP = 6, RT_FIRST = 8, RT_LAST = 9, RT_LIVE = 10, RT_QMASK = 14 };
+// instruction works on the pack's block j.
+// The persistent kernel keeps the workspace in LDS in groups of four rows, a group column by
+// column: element (r, c) at (r / 4) (4 LDV) + 4 c + r % 4 (columns: the unknowns, d = Mg.given in
+// column `no`, ones in column no + 1), row-sets start on group boundaries and are followed by
+// zero rows up to the next one.  Trip record (8 words = one s_load_dwordx8): 16 rows (four
+// groups, four k-steps: the lanes of k-step row l >> 4 own group l >> 4, its four rows are their
+// A / B operands of the four k-steps -- 32 contiguous bytes) or, *short*, 4 rows (one group,
+// one k-step, k-step row l >> 4 owns row l >> 4) of one gterm into one pack.  RT_A / RT_B: BYTE
+// offset of the first group of the A / B rows; RT_D: BYTE offset of column `no` in the first
+// group of the d rows -- what the lanes of a block of q read as their B operand: element 0 of
+// the block row is d, element 1 the ones, so that D[.][0] = sum a d and D[.][1] = sum a;
+// RT_W / RT_AIM: BYTE offset of the weight / aim among the parameters; RT_WORD: rows (16, 4;
+// 0: a pack nothing adds into -- it is still written) | short << 5 | half << 6 (the term is
+// halved) | nop << 7 (no Hessian part: blocks of P get nothing) | first trip of its pack << 8
+// | last << 9 | live lane groups << 10 | lane groups that hold a block of q << 14 | last
+// trip of its term in the pack << 18: there the term's sum S enters the pack as w S (blocks of
+// P) or (w s) (S[.][0] - aim S[.][1]) (blocks of q).  RT_BI / RT_BJ: block row / block column
+// of the four lane groups, a byte each (groups that are not live repeat a live one's; the
+// column of a block of q is not used).  A wavefront's trips of one pack are consecutive.
+enum { RT_A = 0, RT_B, RT_D, RT_W, RT_AIM, RT_WORD, RT_BI, RT_BJ };
+enum { RT_SHORT = 5, RT_HALF = 6, RT_NOP = 7, RT_FIRST = 8, RT_LAST = 9, RT_LIVE = 10, RT_QMASK = 14,
+       RT_TERM_END = 18 };
 // diagonal gterms the persistent kernel takes on one column of the unknowns
 constexpr int RS_DIAG_MAX = 2;
 enum { RR_VOFF = 0, RR_ARROW = 4, RR_CENTER = 8, RR_NAXES = 12, RR_EXTREME = 13, RR_PACKED = 14 };

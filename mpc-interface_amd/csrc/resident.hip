@@ -71,6 +71,12 @@ __host__ __device__ inline int resident_g_mode(const PlanDev& p) {
 }
 static_assert(GU == RS_GDESC_PIECES && WT == RS_GDESC_THREADS, "descriptor table of G");
 
+// doubles of the workspace: row groups of four, column by column (plan_tables.h RT_*), one
+// spare group behind the last (the lanes of a block of q read two columns past the ones)
+__host__ __device__ inline int resident_v_doubles(const PlanDev& p) {
+  return ((p.rtot + 3) / 4 + 1) * 4 * p.ldv;
+}
+
 struct ResidentLayout {
   // offsets in doubles
   int v, pl, ql, dvec, dcoef, dpar, img, ab, streams, ints, total_doubles;
@@ -82,7 +88,7 @@ __host__ __device__ inline ResidentLayout resident_layout(const PlanDev& p) {
   ResidentLayout L;
   L.ldp = even_up_i(p.no);
   int o = 0;
-  L.v = o;      o += even_up_i(p.rtot * p.ldv) + 15 * p.ldv + 16;  // a trip reads 16 rows x 16 columns
+  L.v = o;      o += resident_v_doubles(p);
   L.pl = o;     o += p.no * L.ldp;
   L.ql = o;     o += L.ldp;
   // diagonal gterms: addends of P[c][c] and q[c] of this instance, then per column the
@@ -261,10 +267,6 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
     }
   };
   const int lx = lane & 3, lg = (lane >> 2) & 3, lk = lane >> 4;
-  // Row of a trip this lane feeds to MFMA k-step 0 (the step u adds 2u).  Lanes 0-31 and
-  // 32-63 are the two groups an 8-byte LDS read is served in; inside a group the rows of
-  // lk and lk+1 lie 8 apart, which with ldv = 2 (mod 4) is half the banks.
-  const int krow = (lk >> 1) + 8 * (lk & 1);
   // K1 on chip: the horizon matrices of an LTI system, as the tables the compose ops read
   // (TA[k][i][j] = (A^{k+1})[i][j], TB[d][i][j] = (A^d B)[i][j]; tools.py:14-33), from the
   // A and B that arrived with the image.  One wavefront per system, doubling the number of
@@ -446,7 +448,7 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
       // blocks of P no term reaches stay zero for the whole launch
       for (int i = ct; i < no * ldp; i += CT) Pl[i] = 0.0;
       double2* V2 = reinterpret_cast<double2*>(V);
-      const int n2 = (even_up_i(p.rtot * ldv) + 15 * ldv + 16) / 2;
+      const int n2 = resident_v_doubles(p) / 2;
       for (int i = ct; i < n2; i += CT) V2[i] = double2{0.0, 0.0};
       for (int i = ct; i < 2 * ldp; i += CT) dvec[i] = 0.0;  // stays zero without diagonal gterms
 #pragma unroll
@@ -469,6 +471,8 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
   SETUP_STAMP(4)
   lds_barrier();
   SETUP_STAMP(5)
+  // column no + 1 of the workspace: ones, for the whole launch (nothing composes into it)
+  for (int r = tid; r < ((p.rtot + 3) & ~3); r += NT) V[(r >> 2) * 4 * ldv + 4 * (no + 1) + (r & 3)] = 1.0;
 
   const bool lookahead = (phases & 128) != 0;  // diagnostic: off = fetch only when needed
   if (wave < MW) {
@@ -576,8 +580,8 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
               ha1 = prm[(unsigned)hr.w >> 16];
               hc0 = prm[hc.x];
               hc1 = prm[hc.y];
-              hd0 = V[(hr.z & 0xFFFF) + no];
-              hd1 = V[((unsigned)hr.z >> 16) + no];
+              hd0 = V[(hr.z & 0xFFFF) + 4 * no];
+              hd1 = V[((unsigned)hr.z >> 16) + 4 * no];
               hext = prm[hr.y];
             }
             double a0[3], a1[3];
@@ -586,8 +590,9 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
             for (int u = 0; u < 3; ++u) {
               a0[u] = prm[ds[u].y & 0xFFFF];
               a1[u] = prm[(unsigned)ds[u].y >> 16];
-              v0[u] = *reinterpret_cast<const double2*>(V + (ds[u].x & 0xFFFF));
-              v1[u] = *reinterpret_cast<const double2*>(V + ((unsigned)ds[u].x >> 16));
+              // (columns 2cp, 2cp+1 of a row lie four doubles apart: one ds_read2_b64)
+              v0[u] = double2{V[ds[u].x & 0xFFFF], V[(ds[u].x & 0xFFFF) + 4]};
+              v1[u] = double2{V[(unsigned)ds[u].x >> 16], V[((unsigned)ds[u].x >> 16) + 4]};
             }
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
@@ -619,7 +624,7 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
             for (int u = 0; u < 3; ++u) {
               const int Rr = e0 + u * WT < gtotal ? R : 0;
               ds[u] = *reinterpret_cast<const int2*>(rr + Rr * RR_WORDS + RR_PACKED);
-              c2[u] = 2 * cp;
+              c2[u] = 8 * cp;
               cp += g_dcp;
               R += g_dR;
               if (cp >= npair) {
@@ -633,8 +638,8 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
             for (int u = 0; u < 3; ++u) {
               a0[u] = prm[ds[u].y & 0xFFFF];
               a1[u] = prm[(unsigned)ds[u].y >> 16];
-              v0[u] = *reinterpret_cast<const double2*>(V + (ds[u].x & 0xFFFF) + c2[u]);
-              v1[u] = *reinterpret_cast<const double2*>(V + ((unsigned)ds[u].x >> 16) + c2[u]);
+              v0[u] = double2{V[(ds[u].x & 0xFFFF) + c2[u]], V[(ds[u].x & 0xFFFF) + c2[u] + 4]};
+              v1[u] = double2{V[((unsigned)ds[u].x >> 16) + c2[u]], V[((unsigned)ds[u].x >> 16) + c2[u] + 4]};
             }
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
@@ -659,7 +664,7 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
             double2 accv{0.0, 0.0};
             for (int ax = 0; ax < naxes; ++ax) {
               const double a = prm[rec[RR_ARROW + ax]];
-              const double2 v = *reinterpret_cast<const double2*>(V + rec[RR_VOFF + ax] + 2 * cp);
+              const double2 v = double2{V[rec[RR_VOFF + ax] + 8 * cp], V[rec[RR_VOFF + ax] + 8 * cp + 4]};
               accv.x = fma(a, v.x, accv.x);
               accv.y = fma(a, v.y, accv.y);
             }
@@ -683,7 +688,7 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
             const int naxes = rec[RR_NAXES];
             double accv = 0.0;
             for (int ax = 0; ax < naxes; ++ax)
-              accv = fma(prm[rec[RR_ARROW + ax]], V[rec[RR_VOFF + ax] + c], accv);
+              accv = fma(prm[rec[RR_ARROW + ax]], V[rec[RR_VOFF + ax] + 4 * c], accv);
             Gb[e] = accv;
             e += WT;
             c += dc;
@@ -704,7 +709,7 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
           for (int ax = 0; ax < naxes; ++ax) {
             const double a = prm[rec[RR_ARROW + ax]];
             ac += a * prm[rec[RR_CENTER + ax]];
-            ad = fma(a, V[rec[RR_VOFF + ax] + no], ad);
+            ad = fma(a, V[rec[RR_VOFF + ax] + 4 * no], ad);
           }
           hb[R] = (prm[rec[RR_EXTREME]] + ac) - ad;
         }
@@ -718,95 +723,73 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
     if (P != nullptr && (phases & 2)) {
       // ---- K3: this wavefront's packs of Hessian and gradient blocks on the matrix core
       // -> P, q in LDS.  v_mfma_f64_4x4x4_4b_f64: lane l feeds element x = l & 3 of block
-      // g = (l >> 2) & 3 in k-step row l >> 4 and receives D[l >> 4][l & 3] of block g.  The
-      // operands of trip t+1 are loaded while the MFMAs of trip t run; two operand register
-      // sets take turns (the plan pads every list to an even length).
+      // g = (l >> 2) & 3 in k-step row l >> 4 and receives D[l >> 4][l & 3] of block g.
+      // A trip is one 32-byte record (wave-uniform, the same for every instance: read from
+      // the plan through the scalar cache, the next one on its way), two address adds, four
+      // 16-byte operand reads (the workspace keeps the four rows a lane feeds to the four
+      // k-steps side by side) and four MFMAs into the TERM's sum; nothing is scaled on the
+      // way.  The weight comes in once per term and pack: acc += w S, the lanes of a block of
+      // q (B operand: d in element 0, ones in element 1) acc += (w s) (S[.][0] - aim S[.][1]).
       const int t0 = __builtin_amdgcn_readfirstlane(wtrip[2 * wave]);
       const int tn = __builtin_amdgcn_readfirstlane(wtrip[2 * wave + 1]);
-      // The records are the same for every instance and wave-uniform: read from the plan
-      // in global memory through the scalar cache, they cost no LDS traffic and no vector
-      // instruction.
-      typedef int i32x4 __attribute__((ext_vector_type(4)));
-      typedef const __attribute__((address_space(4))) i32x4* const_i32x4_ptr;  // -> s_load
-      const const_i32x4_ptr tg = (const_i32x4_ptr)(uintptr_t)(p.itab + p.off_rs_trip);
+      typedef int i32x8 __attribute__((ext_vector_type(8)));
+      typedef const __attribute__((address_space(4))) i32x8* const_i32x8_ptr;  // -> s_load
+      const_i32x8_ptr tg = (const_i32x8_ptr)(uintptr_t)(p.itab + p.off_rs_trip) + t0;
       if (tn > 0) {
-        // One trip at a time: loads, products, next.  Overlapping the next trip's loads with
-        // this trip's MFMAs (two operand register sets) bought nothing -- the other
-        // wavefronts of the SIMD fill the gaps -- and the registers are worth more as a third
-        // resident workgroup per CU.  The record of the next trip is on its way meanwhile.
-        const char* Vc = reinterpret_cast<const char*>(V);
         const char* prc = reinterpret_cast<const char*>(prm);
-        const int stride = 2 * ldv * (int)sizeof(double);  // k-step to k-step
-        int a_lane = 0, b_lane = 0, bi = 0, bj = 0;  // of the current pack
+        const int group_bytes = 4 * ldv * (int)sizeof(double);
+        // full trip: k-step row lk owns row group lk of the trip; short trip: row lk of the
+        // one group -- `short_shift` moves a lane's address from the one to the other
+        const int short_shift = lk * (int)sizeof(double) - lk * group_bytes;
+        const char* Vlane = reinterpret_cast<const char*>(V) + lk * group_bytes + lx * 32;
+        const char *ap = Vlane, *bp = Vlane;  // of the current pack
+        int bi = 0, bj = 0;
         bool isq = false, live = false;
-        // the tail k-step of a trip reads consecutive rows: lane row lk instead of krow
-        const int tail_shift = (lk - krow) * ldv * (int)sizeof(double);
-        i32x4 rn = tg[4 * t0], kn = tg[4 * t0 + 1], xn = tg[4 * t0 + 2], yn = tg[4 * t0 + 3];
-        double acc = 0.0;
+        i32x8 rn = tg[0];
+        double acc = 0.0, sum = 0.0;
         for (int t = 0; t < tn; ++t) {
-          const i32x4 r = rn, k = kn, x = xn, y = yn;  // y: tail d offset, tail aim
-          rn = tg[4 * (t0 + t) + 4];
-          kn = tg[4 * (t0 + t) + 5];
-          xn = tg[4 * (t0 + t) + 6];
-          yn = tg[4 * (t0 + t) + 7];
-          const int word = r.z, rows = word & 31;
-          if (word == 0) continue;  // padding
+          const i32x8 r = rn;
+          rn = tg[t + 1];
+          const int word = r[RT_WORD];
           if ((word >> RT_FIRST) & 1) {  // a new pack: what this lane reads and owns
-            bi = (k.x >> (8 * lg)) & 255;
-            bj = (k.y >> (8 * lg)) & 255;
+            bi = (r[RT_BI] >> (8 * lg)) & 255;
+            bj = (r[RT_BJ] >> (8 * lg)) & 255;
             isq = (word >> (RT_QMASK + lg)) & 1;
             live = (word >> (RT_LIVE + lg)) & 1;
-            a_lane = (krow * ldv + 4 * bi + lx) * (int)sizeof(double);
-            b_lane = (krow * ldv + (isq ? no : 4 * bj + lx)) * (int)sizeof(double);
+            ap = Vlane + bi * 128;
+            bp = Vlane + (isq ? 0 : bj * 128);  // (the d offset of a record points at column `no`)
+            acc = 0.0;
           }
-          const char* ap = Vc + (r.x + a_lane);
-          const char* bp = Vc + ((isq ? k.z : r.y) + b_lane);
-          double a[4], b[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {  // k-step u takes rows 2u, 2u+1, 2u+8, 2u+9 (see krow)
-            a[u] = *reinterpret_cast<const double*>(ap + u * stride);
-            b[u] = *reinterpret_cast<const double*>(bp + u * stride);
-          }
-          // the tail: at most four rows of another term (or the rest of this one), one more
-          // k-step with a weight of its own
-          const int tword = x.z;
-          double ta = 0.0, tb = 0.0;
-          if (tword != 0) {
-            const double tw = *reinterpret_cast<const double*>(prc + x.w);
-            ta = *reinterpret_cast<const double*>(Vc + (x.x + a_lane + tail_shift));
-            tb = *reinterpret_cast<const double*>(Vc + ((isq ? y.x : x.y) + b_lane + tail_shift));
-            ta = lk < (tword & 31) ? tw * ta : 0.0;
-            if ((word & (15 << RT_QMASK)) | (tword & (1 << RT_NOP))) {
-              const double taim = *reinterpret_cast<const double*>(prc + y.y);
-              const double sc = (tword >> RT_HALF) & 1 ? 0.5 : 1.0;
-              const double m1 = isq ? sc : ((tword >> RT_NOP) & 1 ? 0.0 : 1.0);
-              const double m2 = isq ? sc * taim : 0.0;
-              tb = fma(m1, tb, -m2);
+          if (word & 31) {
+            const int boff = isq ? r[RT_D] : r[RT_B];
+            if (!((word >> RT_SHORT) & 1)) {
+              const double2* a2 = reinterpret_cast<const double2*>(ap + r[RT_A]);
+              const double2* b2 = reinterpret_cast<const double2*>(bp + boff);
+              const double2 a01 = a2[0], a23 = a2[1], b01 = b2[0], b23 = b2[1];
+              sum = mfma_f64_4x4x4(a01.x, b01.x, sum);
+              sum = mfma_f64_4x4x4(a01.y, b01.y, sum);
+              sum = mfma_f64_4x4x4(a23.x, b23.x, sum);
+              sum = mfma_f64_4x4x4(a23.y, b23.y, sum);
+            } else {
+              const double a = *reinterpret_cast<const double*>(ap + (r[RT_A] + short_shift));
+              const double b = *reinterpret_cast<const double*>(bp + (boff + short_shift));
+              sum = mfma_f64_4x4x4(a, b, sum);
+            }
+            if ((word >> RT_TERM_END) & 1) {
+              // a weight of 0 contributes exact zeros (body.py:292)
+              const double w = *reinterpret_cast<const double*>(prc + r[RT_W]);
+              if (word & ((15 << RT_QMASK) | (1 << RT_NOP))) {
+                const double aim = *reinterpret_cast<const double*>(prc + r[RT_AIM]);
+                const double ws = (word >> RT_HALF) & 1 ? 0.5 * w : w;
+                const double ones = quad_broadcast<1>(sum);  // (blocks of q: sum of the A rows)
+                const double m = isq ? ws : ((word >> RT_NOP) & 1 ? 0.0 : w);
+                acc = fma(m, fma(-(isq ? aim : 0.0), ones, sum), acc);
+              } else {
+                acc = fma(w, sum, acc);
+              }
+              sum = 0.0;
             }
           }
-          // a weight of 0 contributes exact zeros through the products (body.py:292)
-          const double w = *reinterpret_cast<const double*>(prc + r.w);
-          if (word & ((15 << RT_QMASK) | (1 << RT_NOP))) {
-            // lanes of a block of q: b <- s (d - aim); lanes of a block of P keep b, or get 0
-            // from a term without a Hessian part
-            const double aim = *reinterpret_cast<const double*>(prc + k.w);
-            const double sc = (word >> RT_HALF) & 1 ? 0.5 : 1.0;
-            const double m1 = isq ? sc : ((word >> RT_NOP) & 1 ? 0.0 : 1.0);
-            const double m2 = isq ? sc * aim : 0.0;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) b[u] = fma(m1, b[u], -m2);
-          }
-#pragma unroll
-          for (int u = 0; u < 4; ++u) a[u] *= w;
-          if (rows == 16) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) acc = mfma_f64_4x4x4(a[u], b[u], acc);
-          } else {
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-              if (2 * u < rows) acc = mfma_f64_4x4x4(2 * u + krow < rows ? a[u] : 0.0, b[u], acc);
-          }
-          if (tword != 0) acc = mfma_f64_4x4x4(ta, tb, acc);
           if ((word >> RT_LAST) & 1) {  // the pack is complete: into P and q in LDS
             const int row = 4 * bi + lk, col = 4 * bj + lx;
             if (live && row < no) {
@@ -819,7 +802,6 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
                 if (p.rs_sym && bi != bj) Pl[col * ldp + row] = val;
               }
             }
-            acc = 0.0;
           }
         }
       }

@@ -15,7 +15,7 @@ import numpy as np
 import scipy.sparse as sp
 
 PLAN_MAGIC = 0x4D504341
-PLAN_VERSION = 19
+PLAN_VERSION = 20
 
 # header words (csrc/plan_tables.h, enum HeaderWord)
 _H = {name: i for i, name in enumerate([
@@ -41,11 +41,14 @@ RS_WAVES = RS_NT // 64
 RS_BLOCKS_MAX = 255                       # 4-column blocks of the unknowns, a byte each
 RS_LTI_WORDS, RS_LTI_MAX = 8, 4           # record of a source group generated on chip; groups per plan
 RS_JC_MAX = 12                            # compose ops a thread can keep in registers
-RS_TRIP_WORDS = 16
-TRIP_COST, TRIP_STEP_COST, TRIP_TAIL_COST, G_PIECE_COST = 1100, 50, 250, 420   # wavefront assignment, see _resident_program
-# trip record, word 2: rows | mode << 5 | half << 7 | first << 8 | last << 9 | ti << 10 | tj << 17
-RT_HALF, RT_NOP, RT_FIRST, RT_LAST, RT_LIVE, RT_QMASK = 5, 6, 8, 9, 10, 14
-RT_TAIL = 8                               # words 8..13 of a trip record: its tail k-step
+RS_TRIP_WORDS = 8
+# cost model of the wavefront assignment (rounded cycles of one wavefront), see _resident_program
+TRIP_COST, TRIP_STEP_COST, TERM_COST, TRIP_Q_COST, PACK_COST, G_PIECE_COST = 250, 40, 80, 80, 350, 420
+# trip record (csrc/plan_tables.h RT_*): words A, B, D, W, AIM, WORD, BI, BJ;
+# WORD = rows (16 or 4) | short << 5 | half << 6 | nop << 7 | first << 8 | last << 9 | live << 10
+#        | qmask << 14 | last trip of its term in the pack << 18
+RT_A, RT_B, RT_D, RT_W, RT_AIM, RT_WORD, RT_BI, RT_BJ = range(8)
+RT_SHORT, RT_HALF, RT_NOP, RT_FIRST, RT_LAST, RT_LIVE, RT_QMASK, RT_TERM_END = 5, 6, 7, 8, 9, 10, 14, 18
 RS_DIAG_MAX = 2                           # diagonal gterms per column (persistent kernel)
 RS_AXMAX = 4                              # axes per constraint row record
 RS_DST_ACC = 1 << 30                      # compose destination shared by two threads
@@ -284,8 +287,8 @@ class _Builder:
         return cols[0], np.asarray(coefs)
 
     def place_rowsets(self, needed):
-        """Workspace row offset of every needed row-set (id order); the others are never
-        materialised."""
+        """Workspace row offset of every needed row-set (id order, each a multiple of four);
+        the others are never materialised."""
         offsets, blocks = {}, []
         self.rtot = 0
         for rid, block in enumerate(self.rowset_rows):
@@ -293,6 +296,13 @@ class _Builder:
                 offsets[rid] = self.rtot
                 self.rtot += block.shape[0]
                 blocks.append(block)
+                pad = -block.shape[0] % 4
+                if pad:
+                    # every row-set starts a group of four rows and is followed by zero rows up
+                    # to the next one: the matrix core then takes the rows of a term four at a
+                    # time without masking (rows nothing composes stay exact zeros)
+                    blocks.append(sp.csr_matrix((pad, block.shape[1])))
+                    self.rtot += pad
         self.placed_blocks = blocks
         return offsets
 
@@ -464,8 +474,16 @@ def _fused_program(b, rowptr, entbase, entk, entcoef, rtot, ldv):
                 row_tiles=row_tiles)
 
 
+def rs_index(r, c, ldv):
+    """Where the persistent kernel keeps element (r, c) of the workspace in LDS: rows in
+    groups of four, a group column by column -- V[r // 4][c][r % 4] -- so that the four rows a
+    lane feeds to four k-steps of the matrix core are 32 contiguous bytes (two ds_read_b128)
+    and the two columns of a 16-byte piece of G lie 32 bytes apart (one ds_read2_b64)."""
+    return (r // 4) * (4 * ldv) + 4 * c + (r % 4)
+
+
 def _resident_rows(limit_recs, lax_recs, nparams, ldv):
-    """Per row of the stacked G, 16 words: workspace offset of every axis' row [4], arrow
+    """Per row of the stacked G, 16 words: workspace index (:func:`rs_index`, column 0) of every axis' row [4], arrow
     param of every axis [4], center param of every axis [4], naxes, extreme param, then
     the first two axes once more, packed: voff0 | voff1 << 16, arrow0 | arrow1 << 16 (zero
     where that does not fit); a missing axis points at workspace row 0 with the always-zero
@@ -478,7 +496,7 @@ def _resident_rows(limit_recs, lax_recs, nparams, ldv):
             for ax in range(RS_AXMAX):
                 if ax < naxes:
                     off, rs = lax_recs[lax0 + ax]
-                    voff.append((off + (0 if rs == 1 else r)) * ldv)
+                    voff.append(rs_index(off + (0 if rs == 1 else r), 0, ldv))
                     ap.append(p_a + (0 if a_rows == 1 else r) * naxes + ax)
                     cp.append(p_c + (0 if c_rows == 1 else r) * naxes + ax)
                 else:
@@ -680,7 +698,7 @@ def _resident_program(fused, gterms, no, ldv, image, ng, nparams, nc_rows):
             heapq.heappush(heap, (load + pc[1] - pc[0], t))
         if max((sum(pc[1] - pc[0] for pc in own) for own in trial), default=0) <= cap:
             owner = trial
-            split = sorted({int(fd_idx[pc[2]]) for pc in pieces if pc[3]})
+            split = sorted({rs_index(*divmod(int(fd_idx[pc[2]]), ldv), ldv) for pc in pieces if pc[3]})
             break
     if owner is None:
         return out
@@ -699,7 +717,7 @@ def _resident_program(fused, gterms, no, ldv, image, ng, nparams, nc_rows):
                     gidx[j, t] = image["given"] + gi
                 coef[j, t] = pool[int(ops[o, 1]) & 0xFFFF]
                 j += 1
-            dst[j - 1, t] = int(fd_idx[i]) | (RS_DST_ACC if shared else 0)
+            dst[j - 1, t] = rs_index(*divmod(int(fd_idx[i]), ldv), ldv) | (RS_DST_ACC if shared else 0)
     # ---- Hessian and gradient on the matrix core, in 4x4 blocks (plan_tables.h RT_*).
     # Block (bi, bj) of P exists when some term has structural non-zeros in columns 4bi.. of
     # its A rows and 4bj.. of its B rows; block bi of q when a term's A rows reach columns
@@ -766,37 +784,46 @@ def _resident_program(fused, gterms, no, ldv, image, ng, nparams, nc_rows):
         bi_bytes = sum(k[0] << (8 * j) for j, k in enumerate(grp))
         bj_bytes = sum(k[1] << (8 * j) for j, k in enumerate(grp))
         lst = []
+        group_bytes = 4 * ldv * 8
         for gi in sorted(tids):
             aoff, boff, nrows, wparam, doff, aimparam, flags = terms[gi][:7]
             half = 1 if flags & GT_FLAG_HALF else 0
-            brow = boff if flags & GT_FLAG_P else doff   # (a term without P only meets q lanes)
-            for k0 in range(0, nrows, 16):
-                rec = [(aoff + k0) * ldv * 8, (brow + k0) * ldv * 8,
-                       min(16, nrows - k0) | (half << RT_HALF)
-                       | (0 if flags & GT_FLAG_P else 1 << RT_NOP), wparam * 8,
-                       bi_bytes, bj_bytes, (doff + k0) * ldv * 8, aimparam * 8] + [0] * 8
-                free = [t for t in lst if t[RT_TAIL + 2] == 0]
-                if (rec[2] & 31) <= 4 and free:
-                    # at most four rows: one more k-step at the tail of a trip of the pack
-                    # that has none yet, with its own rows and weight, instead of a trip of
-                    # its own (the order of the sum inside a pack is free)
-                    free[-1][RT_TAIL:RT_TAIL + 6] = [rec[0], rec[1], rec[2], rec[3], rec[6], rec[7]]
-                else:
-                    lst.append(rec)
+            nop = 0 if flags & GT_FLAG_P else 1
+            brow = aoff if nop else boff                 # (a term without P only meets q lanes)
+            assert aoff % 4 == 0 and brow % 4 == 0 and doff % 4 == 0
+            n4 = nrows + (-nrows % 4)                    # the zero rows behind the row-set included
+            k0, mine = 0, []
+            while k0 < n4:
+                # full trips of 16 rows (four groups, four k-steps); what is left goes group by
+                # group: *short* trips, one k-step each
+                rows = 16 if n4 - k0 >= 16 else 4
+                mine.append([(aoff + k0) // 4 * group_bytes, (brow + k0) // 4 * group_bytes,
+                             (doff + k0) // 4 * group_bytes + no * 32, wparam * 8, aimparam * 8,
+                             rows | ((rows == 4) << RT_SHORT) | (half << RT_HALF) | (nop << RT_NOP),
+                             bi_bytes, bj_bytes])
+                k0 += rows
+            mine[-1][RT_WORD] |= 1 << RT_TERM_END        # the term's sum gets its weight here
+            lst += mine
         if not lst:                                  # nothing to add up: the pack is still written
-            lst.append([0, 0, 0, 0, bi_bytes, bj_bytes, 0, 0] + [0] * 8)
+            lst.append([0, 0, 0, 0, 0, 0, bi_bytes, bj_bytes])
         for trip in lst:
-            trip[2] |= (live << RT_LIVE) | (qmask << RT_QMASK)
-        lst[0][2] |= 1 << RT_FIRST
-        lst[-1][2] |= 1 << RT_LAST
+            trip[RT_WORD] |= (live << RT_LIVE) | (qmask << RT_QMASK)
+        lst[0][RT_WORD] |= 1 << RT_FIRST
+        lst[-1][RT_WORD] |= 1 << RT_LAST
         pack_trips.append(lst)
     # packs to wavefronts, heaviest first onto the least loaded.  Costs in (measured,
     # rounded) cycles of one wavefront: a trip, a pack store, a 16-byte piece of G, a
     # chunk of the input fetch.  The matrix waves start with the fetch on their account,
     # the stream waves with their share of G.
-    cost = [200 + sum(TRIP_COST + TRIP_STEP_COST * (((trip[2] & 31) + 3) // 4)
-                      + TRIP_TAIL_COST * (trip[RT_TAIL + 2] != 0) for trip in lst)
-            for lst in pack_trips]
+    def trip_cost(trip):
+        word = trip[RT_WORD]
+        if not word & 31:
+            return 0
+        return (TRIP_COST + (TRIP_STEP_COST if (word >> RT_SHORT) & 1 else 4 * TRIP_STEP_COST)
+                + (TERM_COST + (TRIP_Q_COST if (word >> RT_QMASK) & 15 else 0)
+                   if (word >> RT_TERM_END) & 1 else 0))
+
+    cost = [PACK_COST + sum(trip_cost(trip) for trip in lst) for lst in pack_trips]
     stream_threads = NT - NW * 64
     pieces = nc_rows * max(no // 2, 1)
     loads = []
@@ -819,8 +846,6 @@ def _resident_program(fused, gterms, no, ldv, image, ng, nparams, nc_rows):
         wtrip[2 * w] = len(trips)
         for k in wave_packs[w]:
             trips.extend(pack_trips[k])
-        if (len(trips) - wtrip[2 * w]) & 1:
-            trips.append([0] * RS_TRIP_WORDS)      # the kernel walks trips in pairs
         wtrip[2 * w + 1] = len(trips) - wtrip[2 * w]
     ntrip = len(trips)
     trips += [[0] * RS_TRIP_WORDS] * 2             # the kernel reads two records ahead
@@ -1009,8 +1034,8 @@ def compile_plan(form, costs=None, limits=None, lti=()):
     rowptr, entbase, entk, entcoef, rtot = _csr_tables(
         b.placed_blocks, b.base_row0, b.base_rows, b.total_base_rows)
     assert rtot == b.rtot
-    ldv = no + 1
-    ldv += (2 - ldv) % 4      # = 2 mod 4: rows 8 apart fall into opposite halves of the LDS banks
+    ldv = no + 2              # columns: the unknowns, d = Mg . given, a column of ones (persistent kernel)
+    ldv += (2 - ldv) % 4      # = 2 mod 4
     fused = _fused_program(b, rowptr, entbase, entk, entcoef, rtot, ldv)
     # structural tile masks of the gterm operands (exact zeros of the workspace)
     tiles = fused["row_tiles"]
@@ -1086,10 +1111,10 @@ def compile_plan(form, costs=None, limits=None, lti=()):
                 taken[c] += 1
     # ... and, for small problems, the descriptor of every 16-byte piece of G a stream-wave
     # thread owns: piece e = t + u RS_GDESC_THREADS, columns 2cp, 2cp+1 of row R = e // (no/2):
-    # (voff0 + 2cp) | (voff1 + 2cp) << 16, arrow0 | arrow1 << 16
+    # rs_index(row0, 2cp) | rs_index(row1, 2cp) << 16, arrow0 | arrow1 << 16
     rs_gdesc = np.zeros(0, dtype=np.int32)
     rr_ok = rs_rr.size == nc * RS_RR_WORDS
-    packed_ok = (rr_ok and no % 2 == 0 and nc > 0 and (b.rtot + 15) * ldv + 16 < 65536
+    packed_ok = (rr_ok and no % 2 == 0 and nc > 0 and (b.rtot + 8) * ldv < 65536
                  and len(b.params) < 65535
                  and bool((rs_rr.reshape(nc, RS_RR_WORDS)[:, 12] <= 2).all()))
     if packed_ok and nc * (no // 2) <= RS_GDESC_PIECES * RS_GDESC_THREADS:
@@ -1098,7 +1123,7 @@ def compile_plan(form, costs=None, limits=None, lti=()):
         live = e < nc * (no // 2)
         R = np.where(live, e // (no // 2), 0)
         cp = np.where(live, e % (no // 2), 0)
-        word0 = (recs[R, 0] + 2 * cp) | ((recs[R, 1] + 2 * cp) << 16)
+        word0 = (recs[R, 0] + 8 * cp) | ((recs[R, 1] + 8 * cp) << 16)    # rs_index(row, 2 cp)
         word1 = recs[R, 4] | (recs[R, 5] << 16)
         rs_gdesc = np.stack([word0, word1], axis=1).astype(np.uint32).view(np.int32).reshape(-1)
     pmprog = _preview_program(b, pm_rowptr, pm_entbase, pm_entk, pm_entcoef, pmrows)
@@ -1114,9 +1139,13 @@ def compile_plan(form, costs=None, limits=None, lti=()):
         if name == "OFF_PM_OP" and off & 1:       # ... 8-byte pairs
             parts.append(np.zeros(1, dtype=np.int32))
             off += 1
-        if name in ("OFF_RS_TRIP", "OFF_RS_RR", "OFF_RS_INMETA", "OFF_RS_ABMETA", "OFF_RS_DPAR",
+        if name in ("OFF_RS_RR", "OFF_RS_INMETA", "OFF_RS_ABMETA", "OFF_RS_DPAR",
                     "OFF_RS_GDESC") and off & 3:   # ... 16-byte quads
             pad = 4 - (off & 3)
+            parts.append(np.zeros(pad, dtype=np.int32))
+            off += pad
+        if name == "OFF_RS_TRIP" and off & 7:     # ... 32-byte records (one scalar load each)
+            pad = 8 - (off & 7)
             parts.append(np.zeros(pad, dtype=np.int32))
             off += pad
         header[_H[name]] = off

@@ -212,7 +212,8 @@ def run_resident(plan, given, params=None, sources=None):
     gix = _section(it, "OFF_RS_GIDX", jc * P.RS_NT).reshape(jc, P.RS_NT)
     dst = _section(it, "OFF_RS_DST", jc * P.RS_NT).reshape(jc, P.RS_NT)
     cf = dt[it[H["DOFF_RS_COEF"]]:it[H["DOFF_RS_COEF"]] + jc * P.RS_NT].reshape(jc, P.RS_NT)
-    V = np.zeros(plan.rtot * ldv + 15 * ldv + 32)
+    ngroups, gsz = (plan.rtot + 3) // 4, 4 * ldv       # the kernel's layout: V[r // 4][c][r % 4]
+    V = np.zeros((ngroups + 1) * gsz)
     split = _section(it, "OFF_RS_SPLIT", it[H["RS_NSPLIT"]])
     written = np.zeros(V.size, dtype=np.int64)
     for t in range(P.RS_NT):
@@ -232,6 +233,10 @@ def run_resident(plan, given, params=None, sources=None):
                     written[d] = 99
                 acc = 0.0
     assert all(written[d] in (1, 2) for d in split)
+    Vrc = V.reshape(ngroups + 1, ldv, 4).transpose(0, 2, 1).reshape(-1, ldv).copy()   # row major
+    assert not Vrc[:, no + 1].any()
+    Vrc[:, no + 1] = 1.0                                       # the ones column (set once per launch)
+    assert ldv >= no + 2
     # ---- Hessian and gradient: packs of four 4x4 blocks (plan_tables.h RT_*)
     nb = (no + 3) // 4
     TW = P.RS_TRIP_WORDS
@@ -259,46 +264,46 @@ def run_resident(plan, given, params=None, sources=None):
     Pm, q = np.full((no, no), np.nan), np.full(no, np.nan)
     four = np.arange(4)
     assert wtrip[:, 1].sum() == len(trips)
+    gbytes = gsz * 8
     for first_trip, count in wtrip:
-        assert count % 2 == 0
-        acc, open_pack = None, None
+        acc, open_pack, S = None, None, np.zeros((4, 4, 4))
         for x in trips[first_trip:first_trip + count]:
-            word = int(x[2])
-            if word == 0 and open_pack is None:
-                continue                                  # padding to an even count
-            rows, half, nop = word & 31, (word >> P.RT_HALF) & 1, (word >> P.RT_NOP) & 1
+            word = int(x[P.RT_WORD])
+            rows, short = word & 31, (word >> P.RT_SHORT) & 1
+            half, nop = (word >> P.RT_HALF) & 1, (word >> P.RT_NOP) & 1
             live, qmask = (word >> P.RT_LIVE) & 15, (word >> P.RT_QMASK) & 15
-            pack = (int(x[4]), int(x[5]), live, qmask)
-            assert rows <= 16 and live and not qmask & ~live
+            pack = (int(x[P.RT_BI]), int(x[P.RT_BJ]), live, qmask)
+            assert rows in (0, 4, 16) and live and not qmask & ~live and short == (rows == 4)
             if (word >> P.RT_FIRST) & 1:
-                assert open_pack is None
+                assert open_pack is None and not S.any()
                 acc, open_pack = np.zeros((4, 4, 4)), pack
             assert open_pack == pack
-            w, aim = prm[x[3] // 8], prm[x[7] // 8]
-            xa, xb, xd = x[0] // 8, x[1] // 8, x[6] // 8
-            parts = [(rows, half, nop, w, aim, xa, xb, xd)]
-            tword = int(x[P.RT_TAIL + 2])
-            if tword:                                     # the tail k-step: rows of its own
-                assert 1 <= (tword & 31) <= 4 and rows > 0
-                parts.append((tword & 31, (tword >> P.RT_HALF) & 1, (tword >> P.RT_NOP) & 1,
-                              prm[x[P.RT_TAIL + 3] // 8], prm[x[P.RT_TAIL + 5] // 8],
-                              x[P.RT_TAIL] // 8, x[P.RT_TAIL + 1] // 8, x[P.RT_TAIL + 4] // 8))
-            else:
-                assert not x[P.RT_TAIL:].any()
-            for rows_, half_, nop_, w_, aim_, ya, yb, yd in parts:
-                s = 0.5 if half_ else 1.0
+            assert rows or ((word >> P.RT_FIRST) & 1 and (word >> P.RT_LAST) & 1)
+            w, aim = prm[x[P.RT_W] // 8], prm[x[P.RT_AIM] // 8]
+            assert x[P.RT_A] % gbytes == 0 and x[P.RT_B] % gbytes == 0
+            ra, rb = 4 * (x[P.RT_A] // gbytes), 4 * (x[P.RT_B] // gbytes)
+            if rows:
+                assert (x[P.RT_D] - no * 32) % gbytes == 0
+                rd = 4 * ((x[P.RT_D] - no * 32) // gbytes)
+            for g in range(4):
+                bi, bj = (pack[0] >> (8 * g)) & 255, (pack[1] >> (8 * g)) & 255
+                assert bi < nb and bj < nb
+                for k in range(rows):
+                    av = Vrc[ra + k, 4 * bi + four]
+                    if (qmask >> g) & 1:          # B operand of a block of q: d, ones (, junk, junk)
+                        bv = np.array([Vrc[rd + k, no], Vrc[rd + k, no + 1], 0.0, 0.0])
+                    else:
+                        bv = Vrc[rb + k, 4 * bj + four]
+                    S[g] += np.outer(av, bv)
+            if (word >> P.RT_TERM_END) & 1:       # the term's sum enters the pack with its weight
+                assert rows
+                ws = (0.5 * w) if half else w
                 for g in range(4):
-                    bi, bj = (pack[0] >> (8 * g)) & 255, (pack[1] >> (8 * g)) & 255
-                    assert bi < nb and bj < nb
-                    for k in range(rows_):
-                        av = w_ * V[ya + k * ldv + 4 * bi + four]
-                        if (qmask >> g) & 1:
-                            bv = np.full(4, s * (V[yd + k * ldv + no] - aim_))
-                        elif nop_:
-                            bv = np.zeros(4)
-                        else:
-                            bv = V[yb + k * ldv + 4 * bj + four]
-                        acc[g] += np.outer(av, bv)
+                    if (qmask >> g) & 1:
+                        acc[g][:, 0] += ws * (S[g][:, 0] - aim * S[g][:, 1])
+                    else:
+                        acc[g] += (0.0 if nop else w) * S[g]
+                S = np.zeros((4, 4, 4))
             if (word >> P.RT_LAST) & 1:
                 for g in range(4):
                     if not (live >> g) & 1:
@@ -321,6 +326,7 @@ def run_resident(plan, given, params=None, sources=None):
                                     assert np.isnan(Pm[col, row])
                                     Pm[col, row] = Pm[row, col]
                 open_pack = None
+                assert not S.any()                       # every term was closed
         assert open_pack is None
     assert not np.isnan(q).any()
     Pm[np.isnan(Pm)] = 0.0        # blocks no term reaches: zeroed once per workgroup, never written
@@ -332,17 +338,20 @@ def run_resident(plan, given, params=None, sources=None):
         assert it[H["RR_PACKED"]] and len(gd) >= nc * (no // 2)
         for e in range(nc * (no // 2)):
             R, cp = divmod(e, no // 2)
-            assert gd[e, 0] == (rr[R, 0] + 2 * cp) | ((rr[R, 1] + 2 * cp) << 16)
+            assert gd[e, 0] == (rr[R, 0] + 8 * cp) | ((rr[R, 1] + 8 * cp) << 16)
             assert gd[e, 1] == rr[R, 4] | (rr[R, 5] << 16)
     for R in range(nc):
         rec = rr[R]
         ac = ad = 0.0
         for ax in range(rec[12]):
             arrow = prm[rec[4 + ax]]
-            G[R] += arrow * V[rec[ax]:rec[ax] + no]
+            assert rec[ax] % gsz < 4                         # column 0 of a row
+            vrow = Vrc[4 * (rec[ax] // gsz) + rec[ax] % gsz]
+            G[R] += arrow * vrow[:no]
             ac += arrow * prm[rec[8 + ax]]
-            ad += arrow * V[rec[ax] + no]
+            ad += arrow * vrow[no]
         for ax in range(rec[12], P.RS_AXMAX):       # the kernel's fast path reads two axes
             assert prm[rec[4 + ax]] == 0.0
         h[R] = (prm[rec[13]] + ac) - ad
-    return {"P": Pm, "q": q, "G": G, "h": h, "V": V[:plan.rtot * ldv].reshape(plan.rtot, ldv)}
+    Vrc[:, no + 1] = 0.0                                   # (not part of the row-set program's V)
+    return {"P": Pm, "q": q, "G": G, "h": h, "V": Vrc[:plan.rtot]}

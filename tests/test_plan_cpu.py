@@ -269,7 +269,7 @@ def test_plan_tables_rejected_or_accepted_by_the_library(cpu_api):
 
 
 def test_persistent_kernel_tables_are_validated(cpu_api):
-    """The tables only the persistent kernel reads -- trips with their tails, packed row
+    """The tables only the persistent kernel reads -- full and short trips, packed row
     records, piece descriptors of G, per-column diagonal terms, the element program of the
     preview matrices -- are checked on the host like the rest: one corrupted word each."""
     import mpcasm.plan as P
@@ -291,16 +291,18 @@ def test_persistent_kernel_tables_are_validated(cpu_api):
     it = plan.itab
     assert it[_H["RS_OK"]] == 1 and it[_H["RS_NGDESC"]] > 0 and it[_H["PM_NFD"]] > 0
     trip0 = it[_H["OFF_RS_TRIP"]]
-    tails = [t for t in range(it[_H["RS_NTRIP"]]) if it[trip0 + t * P.RS_TRIP_WORDS + P.RT_TAIL + 2]]
-    assert tails                                        # the one-row terminal terms ride as tails
-    tail = trip0 + tails[0] * P.RS_TRIP_WORDS + P.RT_TAIL
+    shorts = [t for t in range(it[_H["RS_NTRIP"]])
+              if (it[trip0 + t * P.RS_TRIP_WORDS + P.RT_WORD] >> P.RT_SHORT) & 1]
+    assert shorts                                       # the one-row terminal terms: short trips
+    short = trip0 + shorts[0] * P.RS_TRIP_WORDS
     corruptions = {
-        "trip: 17 rows": (trip0 + 2, (it[trip0 + 2] & ~31) | 17),
-        "trip: A offset off the workspace": (trip0 + 0, 8 * it[_H["RTOT"]] * it[_H["LDV"]]),
-        "trip: weight slot": (trip0 + 3, 8 * int(it[_H["NPARAMS"]])),
-        "trip: block column": (trip0 + 5, 0x7F7F7F7F),
-        "tail: 5 rows": (tail + 2, 5),
-        "tail: misaligned offset": (tail + 0, it[tail + 0] + 4),
+        "trip: 17 rows": (trip0 + P.RT_WORD, (it[trip0 + P.RT_WORD] & ~31) | 17),
+        "trip: A offset off the workspace": (trip0 + P.RT_A, 8 * it[_H["RTOT"]] * it[_H["LDV"]]),
+        "trip: weight slot": (trip0 + P.RT_W, 8 * int(it[_H["NPARAMS"]])),
+        "trip: block column": (trip0 + P.RT_BJ, 0x7F7F7F7F),
+        "short trip: 5 rows": (short + P.RT_WORD, (it[short + P.RT_WORD] & ~31) | 5),
+        "short trip: misaligned offset": (short + P.RT_A, it[short + P.RT_A] + 4),
+        "trip: d offset not on column no": (trip0 + P.RT_D, it[trip0 + P.RT_D] + 8),
         "wave list": (it[_H["OFF_RS_WTRIP"]] + 1, it[it[_H["OFF_RS_WTRIP"]] + 1] + 2),
         "row record: packed words": (it[_H["OFF_RS_RR"]] + P.RS_RR_WORDS - 2, 0x12340000),
         "piece descriptor of G": (it[_H["OFF_RS_GDESC"]] + 2, it[it[_H["OFF_RS_GDESC"]] + 2] + 2),
