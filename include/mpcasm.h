@@ -55,7 +55,7 @@ const char* mpcasm_status_string(int status);
  * the persistent kernel (per-instance fused kernel if it fits), 2 = always the
  * staged K2 -> K3 -> K4 pipeline with the workspace in HBM.  The parity tests use
  * it to exercise every path; all paths give the same results. */
-enum { MPCASM_OPT_PATH = 1, MPCASM_OPT_PHASE_MASK = 2, MPCASM_OPT_RESIDENT_PER_CU = 3 };
+enum { MPCASM_OPT_PATH = 1, MPCASM_OPT_PHASE_MASK = 2, MPCASM_OPT_RESIDENT_PER_CU = 3, MPCASM_OPT_JIT = 4 };
 /* MPCASM_OPT_PHASE_MASK is a profiling aid (timing-only ablation of the fused
  * kernels: bit 0 compose, 1 Hessian, 2 gradient, 3 constraints, 4 input staging
  * after the first instance, 5 P/q stores, 7 register prefetch of the next instance's
@@ -64,8 +64,21 @@ enum { MPCASM_OPT_PATH = 1, MPCASM_OPT_PHASE_MASK = 2, MPCASM_OPT_RESIDENT_PER_C
  * default 0xBF).  Results are WRONG with any of bits 0-5 cleared -- never use it
  * outside a profile.
  * MPCASM_OPT_RESIDENT_PER_CU (tuning aid): workgroups of the persistent kernel per CU;
- * 0 (default) = chosen from the batch size, never more than are resident at once. */
+ * 0 (default) = chosen from the batch size, never more than are resident at once.
+ * MPCASM_OPT_JIT: the persistent kernel compiled for the very plan by hiprtc (its sizes and
+ * matrix-core trip lists become constants; same source, same results as the ahead-of-time
+ * kernel): 0 (default) = for batches of at least 1024 instances, when libhiprtc.so is there
+ * (compiled once per plan structure and device, on the first such launch: that launch blocks
+ * for the compilation, a second or two); 1 = for every batch; 2 = never.
+ * These options are process-wide test / tuning hooks, not part of a launch's state: set them
+ * before other threads start launching. */
 int mpcasm_set_option(int option, int value);
+/* Diagnostic, needs no device: validates the tables as mpcasm_plan_create does, generates the
+ * per-plan constants and compiles the persistent kernel for them with hiprtc (gfx950).
+ * MPCASM_OK, MPCASM_ERR_LIMIT (no persistent kernel for this plan, or no libhiprtc.so) or
+ * MPCASM_ERR_HIP (compilation failed); the compiler's log goes to `log` (may be NULL). */
+int mpcasm_jit_check(const int32_t* h_itab, size_t n_itab, const double* h_dtab, size_t n_dtab,
+                     char* log, size_t log_capacity);
 
 /* K1  horizon extension ---------------------------------------------------
  * Replaces tools.extend_matrices(N, A, B)      python/mpc_interface/tools.py:14-33

@@ -7,7 +7,10 @@
 
 #include <algorithm>
 #include <new>
+#include <string>
+#include <vector>
 
+#include "jit.h"
 #include "kernels.h"
 
 using namespace mpcasm;
@@ -24,6 +27,7 @@ struct mpcasm_plan {
   double* d_dtab;
   int device;
   int num_cus;
+  std::vector<int32_t> h_itab;  // host copy: what a specialised kernel is generated from (jit.hip)
 };
 
 namespace {
@@ -392,6 +396,65 @@ int make_src_table(const mpcasm_plan* plan, const double* const* h_src,
 
 }  // namespace
 
+namespace {
+// the int fields of the device-side view, from the (validated) header and tables on the host
+void plan_dev_from_tables(const int32_t* it, PlanDev* out) {
+  PlanDev& d = *out;
+  d.ng = it[H_NG]; d.no = it[H_NO]; d.nc = it[H_NC]; d.nparams = it[H_NPARAMS];
+  d.nsrc = it[H_NSRC]; d.nbase = it[H_NBASE]; d.nseg = it[H_NSEG]; d.rtot = it[H_RTOT];
+  d.nent = it[H_NENT]; d.ngterm = it[H_NGTERM]; d.nlimit = it[H_NLIMIT]; d.nlax = it[H_NLAX];
+  d.pmrows = it[H_PMROWS]; d.pm_nent = it[H_PM_NENT]; d.ldv = it[H_LDV];
+  d.off_seg = it[H_OFF_SEG]; d.off_colseg = it[H_OFF_COLSEG]; d.off_rowptr = it[H_OFF_ROWPTR];
+  d.off_entbase = it[H_OFF_ENTBASE]; d.off_entk = it[H_OFF_ENTK]; d.off_gterm = it[H_OFF_GTERM];
+  d.off_limit = it[H_OFF_LIMIT]; d.off_lax = it[H_OFF_LAX]; d.off_rowlimit = it[H_OFF_ROWLIMIT];
+  d.off_pm_rowptr = it[H_OFF_PM_ROWPTR]; d.off_pm_entbase = it[H_OFF_PM_ENTBASE];
+  d.off_pm_entk = it[H_OFF_PM_ENTK];
+  d.doff_entcoef = it[H_DOFF_ENTCOEF]; d.doff_pm_entcoef = it[H_DOFF_PM_ENTCOEF];
+  d.fused_ok = it[H_FUSED_OK]; d.arena_total = it[H_ARENA_TOTAL]; d.off_arena = it[H_OFF_ARENA];
+  d.nfd = it[H_NFD]; d.off_fd_idx = it[H_OFF_FD_IDX]; d.off_fd_ptr = it[H_OFF_FD_PTR];
+  d.nops = it[H_NOPS]; d.off_op = it[H_OFF_OP]; d.ncoef = it[H_NCOEF];
+  d.doff_coefpool = it[H_DOFF_COEFPOOL];
+  d.rs_ok = it[H_RS_OK]; d.rs_jc = it[H_RS_JC]; d.rs_sym = it[H_RS_SYM];
+  d.rs_ntrip = it[H_RS_NTRIP]; d.off_rs_src = it[H_OFF_RS_SRC]; d.off_rs_gidx = it[H_OFF_RS_GIDX];
+  d.off_rs_dst = it[H_OFF_RS_DST]; d.doff_rs_coef = it[H_DOFF_RS_COEF];
+  d.off_rs_trip = it[H_OFF_RS_TRIP]; d.off_rs_wtrip = it[H_OFF_RS_WTRIP];
+  d.rs_nsplit = it[H_RS_NSPLIT]; d.off_rs_split = it[H_OFF_RS_SPLIT];
+  d.off_rs_rr = it[H_OFF_RS_RR]; d.rs_unit = it[H_RS_UNIT]; d.rs_nchunk = it[H_RS_NCHUNK];
+  d.off_rs_inmeta = it[H_OFF_RS_INMETA]; d.rs_img = it[H_RS_IMG];
+  d.rs_img_given = it[H_RS_IMG_GIVEN]; d.rs_img_params = it[H_RS_IMG_PARAMS];
+  d.doff_rs_const = it[H_DOFF_RS_CONST];
+  d.rs_nlti = it[H_RS_NLTI]; d.off_rs_lti = it[H_OFF_RS_LTI]; d.rs_img_dma = it[H_RS_IMG_DMA];
+  d.rs_ab = it[H_RS_AB]; d.off_rs_abmeta = it[H_OFF_RS_ABMETA];
+  d.rr_packed = it[H_RR_PACKED];
+  d.off_rs_dpar = it[H_OFF_RS_DPAR]; d.doff_rs_dcoef = it[H_DOFF_RS_DCOEF];
+  d.rs_ngdesc = it[H_RS_NGDESC]; d.off_rs_gdesc = it[H_OFF_RS_GDESC];
+  d.pm_nfd = it[H_PM_NFD]; d.off_pm_map = it[H_OFF_PM_MAP]; d.off_pm_fdptr = it[H_OFF_PM_FDPTR];
+  d.off_pm_op = it[H_OFF_PM_OP]; d.doff_pm_pool = it[H_DOFF_PM_POOL];
+  d.rs_src16 = 0;
+  if (d.rs_ok && d.rs_unit == 16)
+    for (int64_t i = 0; i < (int64_t)d.rs_nchunk * 64; ++i) {
+      const int st = it[d.off_rs_inmeta + 2 * i];
+      if (st < d.nsrc) d.rs_src16 |= 1u << st;
+    }
+  d.doff_diagcoef = it[H_DOFF_DIAGCOEF];
+  d.ndiag = 0;
+  d.rs_sym_any = 1;
+  for (int g = 0; g < it[H_NGTERM]; ++g) {
+    const int32_t* r = it + it[H_OFF_GTERM] + g * GT_WORDS;
+    if (r[GT_FLAGS] & GT_FLAG_DIAG) ++d.ndiag;
+    if ((r[GT_FLAGS] & GT_FLAG_P) && r[GT_AOFF] != r[GT_BOFF]) d.rs_sym_any = 0;
+  }
+  d.max_axes = 0;
+  for (int l = 0; l < it[H_NLIMIT]; ++l) {
+    const int na = it[it[H_OFF_LIMIT] + l * LM_WORDS + LM_NAXES];
+    if (na > d.max_axes) d.max_axes = na;
+  }
+  // the op table is read as int2: keep its word offset even (the compiler pads it)
+  if (d.fused_ok && (d.off_op & 1)) d.fused_ok = 0;
+}
+
+}  // namespace
+
 extern "C" {
 
 int mpcasm_abi_version(void) { return 1000; }
@@ -412,6 +475,11 @@ int mpcasm_set_option(int option, int value) {
   }
   if (option == MPCASM_OPT_PHASE_MASK) {
     g_phase_mask = value;
+    return MPCASM_OK;
+  }
+  if (option == MPCASM_OPT_JIT) {
+    if (value < 0 || value > 2) return MPCASM_ERR_ARG;
+    g_jit = value;
     return MPCASM_OK;
   }
   if (option == MPCASM_OPT_RESIDENT_PER_CU) {
@@ -477,68 +545,38 @@ int mpcasm_plan_create(const int32_t* h_itab, size_t n_itab, const double* h_dta
     return hip_fail(e);
   }
   PlanDev& d = plan->dev;
-  const int32_t* it = h_itab;
+  plan_dev_from_tables(h_itab, &d);
   d.itab = plan->d_itab;
   d.dtab = plan->d_dtab;
-  d.ng = it[H_NG]; d.no = it[H_NO]; d.nc = it[H_NC]; d.nparams = it[H_NPARAMS];
-  d.nsrc = it[H_NSRC]; d.nbase = it[H_NBASE]; d.nseg = it[H_NSEG]; d.rtot = it[H_RTOT];
-  d.nent = it[H_NENT]; d.ngterm = it[H_NGTERM]; d.nlimit = it[H_NLIMIT]; d.nlax = it[H_NLAX];
-  d.pmrows = it[H_PMROWS]; d.pm_nent = it[H_PM_NENT]; d.ldv = it[H_LDV];
-  d.off_seg = it[H_OFF_SEG]; d.off_colseg = it[H_OFF_COLSEG]; d.off_rowptr = it[H_OFF_ROWPTR];
-  d.off_entbase = it[H_OFF_ENTBASE]; d.off_entk = it[H_OFF_ENTK]; d.off_gterm = it[H_OFF_GTERM];
-  d.off_limit = it[H_OFF_LIMIT]; d.off_lax = it[H_OFF_LAX]; d.off_rowlimit = it[H_OFF_ROWLIMIT];
-  d.off_pm_rowptr = it[H_OFF_PM_ROWPTR]; d.off_pm_entbase = it[H_OFF_PM_ENTBASE];
-  d.off_pm_entk = it[H_OFF_PM_ENTK];
-  d.doff_entcoef = it[H_DOFF_ENTCOEF]; d.doff_pm_entcoef = it[H_DOFF_PM_ENTCOEF];
-  d.fused_ok = it[H_FUSED_OK]; d.arena_total = it[H_ARENA_TOTAL]; d.off_arena = it[H_OFF_ARENA];
-  d.nfd = it[H_NFD]; d.off_fd_idx = it[H_OFF_FD_IDX]; d.off_fd_ptr = it[H_OFF_FD_PTR];
-  d.nops = it[H_NOPS]; d.off_op = it[H_OFF_OP]; d.ncoef = it[H_NCOEF];
-  d.doff_coefpool = it[H_DOFF_COEFPOOL];
-  d.rs_ok = it[H_RS_OK]; d.rs_jc = it[H_RS_JC]; d.rs_sym = it[H_RS_SYM];
-  d.rs_ntrip = it[H_RS_NTRIP]; d.off_rs_src = it[H_OFF_RS_SRC]; d.off_rs_gidx = it[H_OFF_RS_GIDX];
-  d.off_rs_dst = it[H_OFF_RS_DST]; d.doff_rs_coef = it[H_DOFF_RS_COEF];
-  d.off_rs_trip = it[H_OFF_RS_TRIP]; d.off_rs_wtrip = it[H_OFF_RS_WTRIP];
-  d.rs_nsplit = it[H_RS_NSPLIT]; d.off_rs_split = it[H_OFF_RS_SPLIT];
-  d.off_rs_rr = it[H_OFF_RS_RR]; d.rs_unit = it[H_RS_UNIT]; d.rs_nchunk = it[H_RS_NCHUNK];
-  d.off_rs_inmeta = it[H_OFF_RS_INMETA]; d.rs_img = it[H_RS_IMG];
-  d.rs_img_given = it[H_RS_IMG_GIVEN]; d.rs_img_params = it[H_RS_IMG_PARAMS];
-  d.doff_rs_const = it[H_DOFF_RS_CONST];
-  d.rs_nlti = it[H_RS_NLTI]; d.off_rs_lti = it[H_OFF_RS_LTI]; d.rs_img_dma = it[H_RS_IMG_DMA];
-  d.rs_ab = it[H_RS_AB]; d.off_rs_abmeta = it[H_OFF_RS_ABMETA];
-  d.rr_packed = it[H_RR_PACKED];
-  d.off_rs_dpar = it[H_OFF_RS_DPAR]; d.doff_rs_dcoef = it[H_DOFF_RS_DCOEF];
-  d.rs_ngdesc = it[H_RS_NGDESC]; d.off_rs_gdesc = it[H_OFF_RS_GDESC];
-  d.pm_nfd = it[H_PM_NFD]; d.off_pm_map = it[H_OFF_PM_MAP]; d.off_pm_fdptr = it[H_OFF_PM_FDPTR];
-  d.off_pm_op = it[H_OFF_PM_OP]; d.doff_pm_pool = it[H_DOFF_PM_POOL];
-  d.rs_src16 = 0;
-  if (d.rs_ok && d.rs_unit == 16)
-    for (int64_t i = 0; i < (int64_t)d.rs_nchunk * 64; ++i) {
-      const int st = it[d.off_rs_inmeta + 2 * i];
-      if (st < d.nsrc) d.rs_src16 |= 1u << st;
-    }
+  plan->h_itab.assign(h_itab, h_itab + n_itab);
   {
     hipDeviceProp_t prop;
     plan->num_cus = 256;
     if (hipGetDeviceProperties(&prop, plan->device) == hipSuccess && prop.multiProcessorCount > 0)
       plan->num_cus = prop.multiProcessorCount;
   }
-  d.doff_diagcoef = it[H_DOFF_DIAGCOEF];
-  d.ndiag = 0;
-  d.rs_sym_any = 1;
-  for (int g = 0; g < it[H_NGTERM]; ++g) {
-    const int32_t* r = it + it[H_OFF_GTERM] + g * GT_WORDS;
-    if (r[GT_FLAGS] & GT_FLAG_DIAG) ++d.ndiag;
-    if ((r[GT_FLAGS] & GT_FLAG_P) && r[GT_AOFF] != r[GT_BOFF]) d.rs_sym_any = 0;
-  }
-  d.max_axes = 0;
-  for (int l = 0; l < it[H_NLIMIT]; ++l) {
-    const int na = it[it[H_OFF_LIMIT] + l * LM_WORDS + LM_NAXES];
-    if (na > d.max_axes) d.max_axes = na;
-  }
-  // the op table is read as int2: keep its word offset even (the compiler pads it)
-  if (d.fused_ok && (d.off_op & 1)) d.fused_ok = 0;
   *out_plan = plan;
   return MPCASM_OK;
+}
+
+int mpcasm_jit_check(const int32_t* h_itab, size_t n_itab, const double* h_dtab, size_t n_dtab,
+                     char* log, size_t log_capacity) {
+  if (!h_itab || (n_dtab && !h_dtab)) return MPCASM_ERR_ARG;
+  if (log && log_capacity) log[0] = 0;
+  const int rc = validate_plan(h_itab, h_dtab, n_itab, n_dtab);
+  if (rc != MPCASM_OK) return rc;
+  PlanDev d;
+  memset(&d, 0, sizeof d);
+  plan_dev_from_tables(h_itab, &d);
+  if (!d.rs_ok) return MPCASM_ERR_LIMIT;
+  std::vector<char> code;
+  std::string text;
+  const int out = jit_compile(jit_spec_header(d, h_itab), &code, &text);
+  if (log && log_capacity) {
+    strncpy(log, text.c_str(), log_capacity - 1);
+    log[log_capacity - 1] = 0;
+  }
+  return out;
 }
 
 int mpcasm_plan_destroy(mpcasm_plan* plan) {
@@ -590,7 +628,8 @@ int mpcasm_assemble(const mpcasm_plan* plan, const double* const* h_src,
   if (rc != MPCASM_OK) return rc;
   hipError_t err;
   rc = launch_assemble(d, src, d_params, d_given, d_P, d_q, d_G, d_h, d_work, batch,
-                       plan->num_cus, static_cast<hipStream_t>(stream), &err);
+                       plan->num_cus, static_cast<hipStream_t>(stream), &err, plan->h_itab.data(),
+                       plan->device);
   if (rc == MPCASM_ERR_HIP) g_last_hip = (int)err;
   return rc;
 }
@@ -659,16 +698,23 @@ int g_resident_per_cu = 0;  // tuning aid (MPCASM_OPT_RESIDENT_PER_CU): 0 = auto
 // dispatch: fused single launch when the problem fits on chip, else staged
 int launch_assemble(const PlanDev& p, const SrcTable& src, const double* params,
                     const double* given, double* P, double* q, double* G, double* h, void* work,
-                    int batch, int num_cus, hipStream_t stream, hipError_t* err) {
+                    int batch, int num_cus, hipStream_t stream, hipError_t* err,
+                    const int32_t* h_itab, int device) {
   // the persistent kernel may take a whole CU's LDS (one workgroup of 8 wavefronts per
   // CU still beats the staged pipeline by far); the per-instance fused kernel is only
   // worth it while two workgroups fit
   constexpr size_t RESIDENT_LDS_LIMIT = 156 * 1024, FUSED_LDS_LIMIT = 80 * 1024;
   const size_t rs = resident_lds_bytes(p);
   if (rs != 0 && rs <= RESIDENT_LDS_LIMIT && (g_path == 0 || p.rs_nlti != 0) &&
-      resident_inputs_aligned(p, src, params, given))
+      resident_inputs_aligned(p, src, params, given)) {
+    // large batches: the same kernel compiled for this very plan (jit.hip), when available
+    if (h_itab != nullptr)
+      if (const void* k = jit_kernel_for(p, h_itab, device, batch, rs))
+        return jit_launch(k, p, src, params, given, P, q, G, h, batch, num_cus, g_resident_per_cu,
+                          stream, err);
     return launch_assemble_resident(p, src, params, given, P, q, G, h, work, batch, rs, num_cus,
                                     stream, err);
+  }
   // horizon matrices generated on chip exist in the persistent kernel only
   if (p.rs_nlti != 0) return MPCASM_ERR_LIMIT;
   const size_t lds = fused_lds_bytes(p, 4);

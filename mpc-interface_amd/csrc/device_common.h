@@ -3,51 +3,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "device_prims.h"
 #include "kernels.h"
 
 namespace mpcasm {
-
-typedef double f64x4 __attribute__((ext_vector_type(4)));
-
-// D = A(16x4) * B(4x16) + C on the fp64 matrix core.
-// Lane l supplies A[l & 15][l >> 4] and B[l >> 4][l & 15]; D register r of lane l
-// is element (row = (l >> 4) + 4 r, col = l & 15).
-__device__ __forceinline__ f64x4 mfma_f64_16x16x4(double a, double b, f64x4 c) {
-  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
-}
-// four independent 4x4x4 products: lane l feeds A[x][k] / B[k][x] and receives D[k][x] of
-// block g, where x = l & 3, g = (l >> 2) & 3, k = l >> 4 (tools/microbench/mfma4x4_layout.hip)
-__device__ __forceinline__ double mfma_f64_4x4x4(double a, double b, double c) {
-  return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
-}
-
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains
-// the vector-memory counter (s_waitcnt vmcnt(0)), i.e. it waits for every global
-// store in flight to be acknowledged by HBM -- a full memory round trip per
-// barrier in kernels that stream results out between LDS phases.  LDS operations
-// of a wavefront complete in order, so lgkmcnt(0) + s_barrier is sufficient for
-// data handed over through LDS; loads whose results feed LDS writes are waited
-// for by the compiler through the data dependency.
-__device__ __forceinline__ void lds_barrier() {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-}
-
-// the value of lane T of every quad, in all four lanes of the quad (DPP quad_perm)
-template <int T>
-__device__ __forceinline__ double quad_broadcast(double v) {
-  constexpr int ctl = T | (T << 2) | (T << 4) | (T << 6);
-  return __hiloint2double(__builtin_amdgcn_mov_dpp(__double2hiint(v), ctl, 0xF, 0xF, true),
-                          __builtin_amdgcn_mov_dpp(__double2loint(v), ctl, 0xF, 0xF, true));
-}
-
-// sum over the 64 lanes of a wavefront, result in every lane
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
 
 // Contribution of the diagonal gterms (GT_FLAG_DIAG, plan_tables.h) to P[c][c] and q[c]:
 // rows coef_k e_{c0+k} never enter the workspace; body.py:292-300 reduces to

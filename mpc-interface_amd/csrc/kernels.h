@@ -5,36 +5,10 @@
 #include <stdint.h>
 
 #include "../../include/mpcasm.h"
+#include "plan_dev.h"
 #include "plan_tables.h"
 
 namespace mpcasm {
-
-// device-side view of a plan (pointers into the device copies of the tables)
-struct PlanDev {
-  const int32_t* itab;
-  const double* dtab;
-  int ng, no, nc, nparams, nsrc, nbase, nseg, rtot, nent, ngterm, nlimit, nlax, pmrows, pm_nent, ldv;
-  int off_seg, off_colseg, off_rowptr, off_entbase, off_entk, off_gterm, off_limit, off_lax, off_rowlimit;
-  int off_pm_rowptr, off_pm_entbase, off_pm_entk;
-  int doff_entcoef, doff_pm_entcoef;
-  // fused program
-  int fused_ok, arena_total, off_arena, nfd, off_fd_idx, off_fd_ptr, nops, off_op, ncoef,
-      doff_coefpool, max_axes, rs_sym_any;  // rs_sym_any: every Hessian term has A == B
-  // resident program
-  int rs_ok, rs_jc, rs_sym, rs_ntrip, off_rs_src, off_rs_gidx, off_rs_dst, doff_rs_coef,
-      off_rs_trip, off_rs_wtrip, rs_nsplit, off_rs_split, off_rs_rr, rs_unit,
-      rs_nchunk, off_rs_inmeta, rs_img, rs_img_given, rs_img_params, doff_rs_const, rs_nlti,
-      off_rs_lti, rs_img_dma, rs_ab, off_rs_abmeta, rr_packed, off_rs_dpar, doff_rs_dcoef,
-      rs_ngdesc, off_rs_gdesc, pm_nfd, off_pm_map, off_pm_fdptr, off_pm_op, doff_pm_pool;
-  unsigned rs_src16;  // sources that the 16-byte image loads read (bit per source)
-  int doff_diagcoef, ndiag;  // diagonal gterms: coefficient list, number of such terms
-};
-
-// sources of one launch (device pointers + per-instance strides, by value)
-struct SrcTable {
-  const double* ptr[MAX_SOURCES];
-  long long stride[MAX_SOURCES];
-};
 
 // fill.hip
 int launch_fill_su(const double* A, const double* B, double* S, double* U, int batch, int N, int n,
@@ -59,9 +33,12 @@ int launch_assemble_resident(const PlanDev& p, const SrcTable& src, const double
                              const double* given, double* P, double* q, double* G, double* h,
                              void* work, int batch, size_t lds_bytes, int num_cus,
                              hipStream_t stream, hipError_t* err);
+// h_itab / device: the plan's tables on the host and its device, for the per-plan compiled
+// kernel (jit.hip); nullptr = ahead-of-time kernels only
 int launch_assemble(const PlanDev& p, const SrcTable& src, const double* params,
                     const double* given, double* P, double* q, double* G, double* h, void* work,
-                    int batch, int num_cus, hipStream_t stream, hipError_t* err);
+                    int batch, int num_cus, hipStream_t stream, hipError_t* err,
+                    const int32_t* h_itab = nullptr, int device = 0);
 int launch_preview_matrices(const PlanDev& p, const SrcTable& src, double* PM, int batch,
                             hipStream_t stream, hipError_t* err);
 int launch_box_transform(double* params, long long nparams, int batch, const int32_t* facets,

@@ -22,7 +22,9 @@
 //   gterm    one accumulation  P += w A^T B,  q += w A^T r  of body.py:292-300
 //   limit    one Constraint (restrictions.py:15) -> rows of G, h
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <stdint.h>
+#endif
 
 namespace mpcasm {
 

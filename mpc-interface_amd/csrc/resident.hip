@@ -37,16 +37,38 @@
 // Reference semantics: body.py:149-193 (preview rows), :236-264 + restrictions.py:
 // 175-199 (constraints), :266-302, :322-329 (costs); identical plan tables and
 // numerics contract as assemble.hip / fused.hip.
+//
+// ONE source, two builds.  Ahead of time (libmpcasm.so) the kernel reads the plan's sizes and
+// the trip lists at run time.  Compiled by hiprtc for ONE plan (MPCASM_SPEC, jit.hip) the very
+// same body sees them as constants from a generated "plan_spec.h": the plan's sizes fold into
+// immediates (no kernel-argument reloads, no scalar-register spills) and every wavefront's
+// trip list is unrolled into straight-line code -- no records, no flag tests, no loop.
+#ifdef __HIPCC_RTC__
+using __hip_internal::int32_t;
+using __hip_internal::int64_t;
+using __hip_internal::uint32_t;
+using __hip_internal::uint64_t;
+typedef unsigned long uintptr_t;
+#else
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#endif
 
-#include "device_common.h"
+#include "device_prims.h"
+#include "plan_dev.h"
+#ifdef MPCASM_SPEC
+#include "plan_spec.h"  // namespace mpcasm::spec: PlanConst, TRIPS, WTRIP (generated per plan)
+#endif
+#ifndef __HIPCC_RTC__
 #include "kernels.h"
+#endif
 
 namespace mpcasm {
 
+#ifndef __HIPCC_RTC__
 extern int g_phase_mask;  // diagnostic (timing-only ablation), fused.hip
 extern int g_resident_per_cu;  // tuning aid, capi.hip
+#endif
 
 namespace {
 
@@ -65,7 +87,8 @@ constexpr int GU = 6;  // 16-byte pieces of G a worker thread may own a descript
 // offsets and parameter indices fit 16 bits): mode 1.  Mode 2: a small problem (every
 // stream-wave thread owns at most GU pieces) keeps a ready-made descriptor per piece in
 // LDS -- 12 KB that buy back the row/column bookkeeping; 0: the general path.
-__host__ __device__ inline int resident_g_mode(const PlanDev& p) {
+template <class PlanT>
+__host__ __device__ inline int resident_g_mode(const PlanT& p) {
   if (!p.rr_packed) return 0;
   return p.rs_ngdesc != 0 ? 2 : 1;
 }
@@ -73,7 +96,8 @@ static_assert(GU == RS_GDESC_PIECES && WT == RS_GDESC_THREADS, "descriptor table
 
 // doubles of the workspace: row groups of four, column by column (plan_tables.h RT_*), one
 // spare group behind the last (the lanes of a block of q read two columns past the ones)
-__host__ __device__ inline int resident_v_doubles(const PlanDev& p) {
+template <class PlanT>
+__host__ __device__ inline int resident_v_doubles(const PlanT& p) {
   return ((p.rtot + 3) / 4 + 1) * 4 * p.ldv;
 }
 
@@ -84,7 +108,8 @@ struct ResidentLayout {
   int i_rr, i_meta, i_wtrip, i_split, i_lti, i_abmeta, i_gdesc;  // offsets in ints inside the int region
 };
 
-__host__ __device__ inline ResidentLayout resident_layout(const PlanDev& p) {
+template <class PlanT>
+__host__ __device__ inline ResidentLayout resident_layout(const PlanT& p) {
   ResidentLayout L;
   L.ldp = even_up_i(p.no);
   int o = 0;
@@ -137,11 +162,110 @@ __device__ __forceinline__ void dma4(const void* gsrc, unsigned lds_base) {
 }
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+#ifdef MPCASM_SPEC
+// ---- K3 of a specialised kernel: a wavefront's trips as straight-line code --------------
+struct TripState {
+  const char* Vlane;  // workspace + lk * group_bytes + lx * 32
+  const char* prc;    // this instance's parameters
+  double *Pl, *ql;
+  const double* dvec;
+  int lx, lg, lk;
+  const char *ap, *bp;  // of the current pack
+  int bi, bj;
+  bool isq, live;
+  double acc, sum;
+};
+
+template <int I>
+__device__ __forceinline__ void spec_trip(TripState& s) {
+  using PC = spec::PlanConst;
+  constexpr int A = spec::TRIPS[I][RT_A], B = spec::TRIPS[I][RT_B], D = spec::TRIPS[I][RT_D];
+  constexpr int W = spec::TRIPS[I][RT_W], AIM = spec::TRIPS[I][RT_AIM], WORD = spec::TRIPS[I][RT_WORD];
+  constexpr int BI = spec::TRIPS[I][RT_BI], BJ = spec::TRIPS[I][RT_BJ];
+  constexpr int group_bytes = 4 * PC::ldv * 8, ldp = (PC::no + 1) & ~1;
+  constexpr int qmask = (WORD >> RT_QMASK) & 15, livemask = (WORD >> RT_LIVE) & 15;
+  constexpr bool nop = (WORD >> RT_NOP) & 1, half = (WORD >> RT_HALF) & 1;
+  if constexpr ((WORD >> RT_FIRST) & 1) {  // a new pack: what this lane reads and owns
+    // (from an opaque copy of the lane's group: a handful of instructions per pack and
+    // instance -- hoisted out of the instance loop, every pack's constants would sit in
+    // registers for the whole launch, and the kernel has none to spare)
+    int lg_ = s.lg;
+    asm volatile("" : "+v"(lg_));
+    s.bi = (BI >> (8 * lg_)) & 255;
+    s.bj = (BJ >> (8 * lg_)) & 255;
+    s.isq = (qmask >> lg_) & 1;
+    s.live = (livemask >> lg_) & 1;
+    s.ap = s.Vlane + s.bi * 128;
+    s.bp = s.Vlane + (s.isq ? 0 : s.bj * 128);
+    s.acc = 0.0;
+  }
+  if constexpr ((WORD & 31) != 0) {
+    const char* bsrc = qmask == 0 ? s.bp + B : (qmask == livemask ? s.bp + D : s.bp + (s.isq ? D : B));
+    if constexpr (!((WORD >> RT_SHORT) & 1)) {
+      const double2* a2 = reinterpret_cast<const double2*>(s.ap + A);
+      const double2* b2 = reinterpret_cast<const double2*>(bsrc);
+      const double2 a01 = a2[0], a23 = a2[1], b01 = b2[0], b23 = b2[1];
+      s.sum = mfma_f64_4x4x4(a01.x, b01.x, s.sum);
+      s.sum = mfma_f64_4x4x4(a01.y, b01.y, s.sum);
+      s.sum = mfma_f64_4x4x4(a23.x, b23.x, s.sum);
+      s.sum = mfma_f64_4x4x4(a23.y, b23.y, s.sum);
+    } else {
+      const int short_shift = s.lk * 8 - s.lk * group_bytes;
+      const double a = *reinterpret_cast<const double*>(s.ap + (A + short_shift));
+      const double b = *reinterpret_cast<const double*>(bsrc + short_shift);
+      s.sum = mfma_f64_4x4x4(a, b, s.sum);
+    }
+    if constexpr ((WORD >> RT_TERM_END) & 1) {
+      const double w = *reinterpret_cast<const double*>(s.prc + W);
+      if constexpr (qmask != 0 || nop) {
+        const double aim = *reinterpret_cast<const double*>(s.prc + AIM);
+        const double ws = half ? 0.5 * w : w;
+        const double ones = quad_broadcast<1>(s.sum);
+        const double m = s.isq ? ws : (nop ? 0.0 : w);
+        s.acc = fma(m, fma(-(s.isq ? aim : 0.0), ones, s.sum), s.acc);
+      } else {
+        s.acc = fma(w, s.sum, s.acc);
+      }
+      s.sum = 0.0;
+    }
+  }
+  if constexpr ((WORD >> RT_LAST) & 1) {  // the pack is complete: into P and q in LDS
+    const int row = 4 * s.bi + s.lk, col = 4 * s.bj + s.lx;
+    if (s.live && row < PC::no) {
+      if (s.isq) {
+        if (s.lx == 0) s.ql[row] = s.acc + s.dvec[ldp + row];
+      } else if (col < PC::no) {
+        const double val = s.acc + (row == col ? s.dvec[col] : 0.0);
+        s.Pl[row * ldp + col] = val;
+        if (PC::rs_sym && s.bi != s.bj) s.Pl[col * ldp + row] = val;
+      }
+    }
+  }
+}
+
+template <int I, int N>
+__device__ __forceinline__ void spec_trips(TripState& s) {
+  if constexpr (I < N) {
+    spec_trip<I>(s);
+    // (one trip's operands at a time: hoisting the reads of later trips over this one's
+    // products costs more registers than the 128 a wavefront has at four per SIMD)
+    __builtin_amdgcn_sched_barrier(0);
+    spec_trips<I + 1, N>(s);
+  }
+}
+template <int WAVE>
+__device__ __forceinline__ void spec_wave_trips(TripState& s) {
+  spec_trips<spec::WTRIP[WAVE][0], spec::WTRIP[WAVE][0] + spec::WTRIP[WAVE][1]>(s);
+}
+#endif  // MPCASM_SPEC
+
 // GEN: the plan has source groups generated on chip (K1 fused); without them that code is
-// not even compiled in, it costs registers
-template <int JC, bool STAMPS, bool GEN>
-__global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
-    PlanDev p, SrcTable src, const double* __restrict__ params, const double* __restrict__ given,
+// not even compiled in, it costs registers.  PlanT: PlanDev (sizes at run time) or
+// spec::PlanConst (the same names as constants); plan_itab / plan_dtab: the plan's tables.
+template <int JC, bool STAMPS, bool GEN, class PlanT>
+__device__ __forceinline__ void resident_body(
+    const PlanT& p, const int32_t* __restrict__ plan_itab, const double* __restrict__ plan_dtab,
+    const SrcTable& src, const double* __restrict__ params, const double* __restrict__ given,
     double* __restrict__ P, double* __restrict__ q, double* __restrict__ G,
     double* __restrict__ h, int batch, int phases, unsigned long long* __restrict__ stamps) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -190,16 +314,16 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
   // ---- once per workgroup, first: what the input fetch needs (stream table, per-lane load
   // tables), so that the first instance's image is on its way while the rest is set up
   {
-    const int2* t2 = reinterpret_cast<const int2*>(p.itab + p.off_rs_abmeta);
+    const int2* t2 = reinterpret_cast<const int2*>(plan_itab + p.off_rs_abmeta);
     for (int i = tid; i < p.rs_ab * 2; i += NT) abmeta[i] = t2[i];
-    t2 = reinterpret_cast<const int2*>(p.itab + p.off_rs_inmeta);
+    t2 = reinterpret_cast<const int2*>(plan_itab + p.off_rs_inmeta);
     for (int i = tid; i < nchunk * 64; i += NT) meta[i] = t2[i];
-    for (int i = tid; i < p.rs_nlti * RS_LTI_WORDS; i += NT) lti[i] = (p.itab + p.off_rs_lti)[i];
+    for (int i = tid; i < p.rs_nlti * RS_LTI_WORDS; i += NT) lti[i] = (plan_itab + p.off_rs_lti)[i];
     // input streams: the sources, then given, params, the plan's constants
     if (tid < p.nsrc + 3) {
       const int s = tid - p.nsrc;
       const double* base = s < 0 ? src.ptr[tid]
-                                 : (s == 0 ? given : (s == 1 ? params : p.dtab + p.doff_rs_const));
+                                 : (s == 0 ? given : (s == 1 ? params : plan_dtab + p.doff_rs_const));
       const long long stride =
           s < 0 ? src.stride[tid] : (s == 0 ? (long long)p.ng : (s == 1 ? (long long)p.nparams : 0));
       reinterpret_cast<const double**>(strm)[2 * tid] = base;
@@ -390,10 +514,10 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
   int c_sg[JC], c_dst[JC];  // c_sg: image offset of the source | of the given value << 16
   double c_coef[JC];
   {
-    const int32_t* tsrc = p.itab + p.off_rs_src;
-    const int32_t* tg = p.itab + p.off_rs_gidx;
-    const int32_t* tdst = p.itab + p.off_rs_dst;
-    const double* tcoef = p.dtab + p.doff_rs_coef;
+    const int32_t* tsrc = plan_itab + p.off_rs_src;
+    const int32_t* tg = plan_itab + p.off_rs_gidx;
+    const int32_t* tdst = plan_itab + p.off_rs_dst;
+    const double* tcoef = plan_dtab + p.doff_rs_coef;
 #pragma unroll
     for (int j = 0; j < JC; ++j) {
       const bool have = j < p.rs_jc;
@@ -417,7 +541,7 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
     // All loads from the plan first (every one a trip to L2), then the LDS stores: table
     // by table the latencies would add up.
     constexpr int RRK = 3;  // row-record words per thread in the first batch
-    const int32_t* trr = p.itab + p.off_rs_rr;  // row records of G, precomputed by the plan compiler
+    const int32_t* trr = plan_itab + p.off_rs_rr;  // row records of G, precomputed by the plan compiler
     const int nrr = nc * RR_WORDS;
     int v_rr[RRK], v_wtrip = 0, v_split = 0;
     int2 v_gd[GU];
@@ -429,20 +553,20 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
     if (ct >= 0) {
 #pragma unroll
       for (int k = 0; k < RRK; ++k) v_rr[k] = ct + k * CT < nrr ? trr[ct + k * CT] : 0;
-      if (ct < RS_WAVES * 2) v_wtrip = (p.itab + p.off_rs_wtrip)[ct];
-      if (ct < p.rs_nsplit) v_split = (p.itab + p.off_rs_split)[ct];
+      if (ct < RS_WAVES * 2) v_wtrip = (plan_itab + p.off_rs_wtrip)[ct];
+      if (ct < p.rs_nsplit) v_split = (plan_itab + p.off_rs_split)[ct];
     }
     if (own_gd) {
       // the descriptors of this thread's pieces of G (made by the plan compiler): piece
       // e = wt + u WT, packed, read back as 8 bytes
-      const int2* gd = reinterpret_cast<const int2*>(p.itab + p.off_rs_gdesc);
+      const int2* gd = reinterpret_cast<const int2*>(plan_itab + p.off_rs_gdesc);
 #pragma unroll
       for (int u = 0; u < GU; ++u) v_gd[u] = gd[u * WT + wt_];
     }
     if (own_diag) {
       // the diagonal gterms on column ct; free slots read the 0.0 behind the parameters
-      v_dpar = reinterpret_cast<const int4*>(p.itab + p.off_rs_dpar)[ct];
-      v_dcoef = reinterpret_cast<const double2*>(p.dtab + p.doff_rs_dcoef)[ct];
+      v_dpar = reinterpret_cast<const int4*>(plan_itab + p.off_rs_dpar)[ct];
+      v_dcoef = reinterpret_cast<const double2*>(plan_dtab + p.doff_rs_dcoef)[ct];
     }
     if (ct >= 0) {
       // blocks of P no term reaches stay zero for the whole launch
@@ -457,7 +581,7 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
       for (int i = ct + RRK * CT; i < nrr; i += CT) rr[i] = trr[i];
       if (ct < RS_WAVES * 2) wtrip[ct] = v_wtrip;
       if (ct < p.rs_nsplit) split[ct] = v_split;
-      for (int i = ct + CT; i < p.rs_nsplit; i += CT) split[i] = (p.itab + p.off_rs_split)[i];
+      for (int i = ct + CT; i < p.rs_nsplit; i += CT) split[i] = (plan_itab + p.off_rs_split)[i];
     }
     if (own_gd) {
 #pragma unroll
@@ -720,6 +844,33 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
       MPCASM_STAMP(3)
       __builtin_amdgcn_s_setprio(2);  // (as the matrix waves: trips first)
     }
+#ifdef MPCASM_SPEC
+    if (P != nullptr && (phases & 2)) {
+      // ---- K3, specialised: the wavefront's trips unrolled (spec_trip)
+      static_assert(RS_WAVES == 8, "one case per wavefront");
+      TripState st;
+      st.Vlane = reinterpret_cast<const char*>(V) + lk * (4 * ldv * 8) + lx * 32;
+      st.prc = reinterpret_cast<const char*>(prm);
+      st.Pl = Pl;
+      st.ql = ql;
+      st.dvec = dvec;
+      st.lx = lx, st.lg = lg, st.lk = lk;
+      st.ap = st.bp = st.Vlane;
+      st.bi = st.bj = 0;
+      st.isq = st.live = false;
+      st.acc = st.sum = 0.0;
+      switch (wave) {
+        case 0: spec_wave_trips<0>(st); break;
+        case 1: spec_wave_trips<1>(st); break;
+        case 2: spec_wave_trips<2>(st); break;
+        case 3: spec_wave_trips<3>(st); break;
+        case 4: spec_wave_trips<4>(st); break;
+        case 5: spec_wave_trips<5>(st); break;
+        case 6: spec_wave_trips<6>(st); break;
+        default: spec_wave_trips<7>(st); break;
+      }
+    }
+#else
     if (P != nullptr && (phases & 2)) {
       // ---- K3: this wavefront's packs of Hessian and gradient blocks on the matrix core
       // -> P, q in LDS.  v_mfma_f64_4x4x4_4b_f64: lane l feeds element x = l & 3 of block
@@ -734,7 +885,7 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
       const int tn = __builtin_amdgcn_readfirstlane(wtrip[2 * wave + 1]);
       typedef int i32x8 __attribute__((ext_vector_type(8)));
       typedef const __attribute__((address_space(4))) i32x8* const_i32x8_ptr;  // -> s_load
-      const_i32x8_ptr tg = (const_i32x8_ptr)(uintptr_t)(p.itab + p.off_rs_trip) + t0;
+      const_i32x8_ptr tg = (const_i32x8_ptr)(uintptr_t)(plan_itab + p.off_rs_trip) + t0;
       if (tn > 0) {
         const char* prc = reinterpret_cast<const char*>(prm);
         const int group_bytes = 4 * ldv * (int)sizeof(double);
@@ -806,6 +957,7 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
         }
       }
     }
+#endif  // MPCASM_SPEC
     MPCASM_STAMP(2)
     __builtin_amdgcn_s_setprio(0);
     lds_barrier();  // C: P and q are in LDS, the workspace is dead
@@ -852,6 +1004,32 @@ __global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
 #undef SETUP_STAMP
 }
 
+#ifdef MPCASM_SPEC
+}  // namespace
+// the kernel of ONE plan (hiprtc): everything about the plan is a constant
+extern "C" __global__ __launch_bounds__(RS_NT, 4) void resident_spec_kernel(
+    const int32_t* __restrict__ plan_itab, const double* __restrict__ plan_dtab, SrcTable src,
+    const double* __restrict__ params, const double* __restrict__ given, double* __restrict__ P,
+    double* __restrict__ q, double* __restrict__ G, double* __restrict__ h, int batch, int phases,
+    unsigned long long* __restrict__ stamps) {
+  constexpr spec::PlanConst p{};
+  resident_body<spec::JC, false, spec::PlanConst::rs_nlti != 0>(p, plan_itab, plan_dtab, src, params,
+                                                               given, P, q, G, h, batch, phases, stamps);
+}
+namespace {
+#else
+template <int JC, bool STAMPS, bool GEN>
+__global__ __launch_bounds__(NT, 4) void resident_assemble_kernel(
+    PlanDev p, SrcTable src, const double* __restrict__ params, const double* __restrict__ given,
+    double* __restrict__ P, double* __restrict__ q, double* __restrict__ G,
+    double* __restrict__ h, int batch, int phases, unsigned long long* __restrict__ stamps) {
+  resident_body<JC, STAMPS, GEN>(p, p.itab, p.dtab, src, params, given, P, q, G, h, batch, phases,
+                                 stamps);
+}
+#endif
+
+#ifndef __HIPCC_RTC__
+
 template <int JC>
 int launch_jc(const PlanDev& p, const SrcTable& src, const double* params, const double* given,
               double* P, double* q, double* G, double* h, void* work, int batch, size_t lds_bytes,
@@ -891,9 +1069,11 @@ int launch_jc(const PlanDev& p, const SrcTable& src, const double* params, const
   *err = hipGetLastError();
   return *err == hipSuccess ? MPCASM_OK : MPCASM_ERR_HIP;
 }
+#endif  // !__HIPCC_RTC__
 
 }  // namespace
 
+#ifndef __HIPCC_RTC__
 // 0 when the resident kernel cannot take this plan, else its dynamic LDS bytes
 size_t resident_lds_bytes(const PlanDev& p) {
   if (!p.rs_ok || p.rs_jc > RS_JC_MAX || p.no > WT || p.no < 1 || p.max_axes > AXMAX) return 0;
@@ -925,5 +1105,6 @@ int launch_assemble_resident(const PlanDev& p, const SrcTable& src, const double
   return launch_jc<RS_JC_MAX>(MPCASM_RS_ARGS);
 #undef MPCASM_RS_ARGS
 }
+#endif  // !__HIPCC_RTC__
 
 }  // namespace mpcasm

@@ -14,6 +14,7 @@ OK = 0
 OPT_PATH = 1
 OPT_PHASE_MASK = 2
 OPT_RESIDENT_PER_CU = 3
+OPT_JIT = 4            # 0: specialise the persistent kernel for batches >= 1024, 1: always, 2: never
 PHASE_DEFAULT = 0xBF   # every phase on, cycle stamps (bit 6) off
 PHASE_STAMPS = 0x40
 STATUS = {
@@ -40,6 +41,8 @@ SIGNATURES = {
     "mpcasm_plan_create": (ctypes.c_int, [_void_p, ctypes.c_size_t, _void_p, ctypes.c_size_t,
                                           ctypes.POINTER(_void_p)]),
     "mpcasm_plan_destroy": (ctypes.c_int, [_void_p]),
+    "mpcasm_jit_check": (ctypes.c_int, [_void_p, ctypes.c_size_t, _void_p, ctypes.c_size_t,
+                                        ctypes.c_char_p, ctypes.c_size_t]),
     "mpcasm_plan_sizes": (ctypes.c_int, [_void_p, ctypes.POINTER(ctypes.c_int64)]),
     "mpcasm_workspace_bytes": (ctypes.c_int, [_void_p, ctypes.c_int,
                                               ctypes.POINTER(ctypes.c_size_t)]),

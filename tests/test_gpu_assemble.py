@@ -15,14 +15,18 @@ from oracle import qp_oracle as orc
 pytestmark = pytest.mark.gpu
 
 
-PATHS = {"resident": 0, "fused": 1, "staged": 2}
+# path name -> (MPCASM_OPT_PATH, MPCASM_OPT_JIT): the persistent kernel ahead of time and
+# compiled per plan by hiprtc (forced on for every batch size here), the per-instance fused
+# kernel, the staged pipeline
+PATHS = {"resident": (0, 2), "resident-jit": (0, 1), "fused": (1, 2), "staged": (2, 2)}
+RESIDENT = ("resident", "resident-jit")
 
 
 @pytest.fixture(autouse=True, params=list(PATHS))
 def kernel_path(request):
-    """Every test runs on each assembly path: the persistent fused kernel, the
-    per-instance fused kernel (both taken only when one instance fits on chip) and
-    the staged K2 -> K3 -> K4 pipeline."""
+    """Every test runs on each assembly path: the persistent fused kernel (ahead of time, and
+    specialised for the plan at run time), the per-instance fused kernel (all taken only when
+    one instance fits on chip) and the staged K2 -> K3 -> K4 pipeline."""
     import torch
 
     if not torch.cuda.is_available():
@@ -30,9 +34,11 @@ def kernel_path(request):
     from mpcasm import capi
 
     lib = capi.load()
-    assert lib.mpcasm_set_option(capi.OPT_PATH, PATHS[request.param]) == 0
+    assert lib.mpcasm_set_option(capi.OPT_PATH, PATHS[request.param][0]) == 0
+    assert lib.mpcasm_set_option(capi.OPT_JIT, PATHS[request.param][1]) == 0
     yield request.param
     lib.mpcasm_set_option(capi.OPT_PATH, 0)
+    lib.mpcasm_set_option(capi.OPT_JIT, 0)
 
 
 def check_drop_in(form, g, prefix, parts=True):
@@ -230,7 +236,7 @@ def test_biped_batch_horizon_matrices_generated_on_chip(gpu_api, kernel_path):
     fill_su + assemble; both QP widths; shared and per-instance systems."""
     from mpcasm import engine
 
-    if kernel_path != "resident":
+    if kernel_path not in RESIDENT:
         pytest.skip("generated sources exist in the persistent kernel only")
     get_A, get_B, _ = gpu_api.tools.get_system_matrices("J->CCC")
     for times, width in (([7, 15], 34), ([6, 14], 36)):
@@ -364,7 +370,7 @@ def test_generated_horizon_matrices_other_systems(gpu_api, kernel_path, nx, nu, 
     are no powers of two.  Per-instance (A, B) against fill_su + assemble and the oracle."""
     from mpcasm import engine
 
-    if kernel_path != "resident":
+    if kernel_path not in RESIDENT:
         pytest.skip("generated sources exist in the persistent kernel only")
     rng = np.random.default_rng(100 * nx + N)
     form = problems.random_lti(gpu_api, rng, nx=nx, nu=nu, N=N)
@@ -401,7 +407,7 @@ def test_batched_box_transforms(gpu_api, kernel_path):
     from mpcasm import engine
     from mpcasm.boxes import BoxBatch
 
-    if kernel_path != "resident":
+    if kernel_path not in RESIDENT:
         pytest.skip("the transforms act on the parameters, one assembly path is enough")
     form = problems.biped(gpu_api, problems.BipedConfig(step_samples=8))
     form.update(step_times=np.array([6, 14]), step_count=0)

@@ -316,3 +316,28 @@ def test_persistent_kernel_tables_are_validated(cpu_api):
         assert bad[word] != value, what
         bad[word] = value
         assert create(bad) == -2, what
+
+
+def test_the_persistent_kernel_compiles_for_a_plan_without_a_device(cpu_api):
+    """mpcasm_jit_check: plan tables -> generated constants -> hiprtc (gfx950).  No GPU is
+    needed to compile, so the run-time specialisation of the persistent kernel (csrc/jit.hip)
+    is build-checked here for the biped (K1 fused and not), the reference's test_body problem
+    and a crossed-cost plan."""
+    lib = capi.load()
+    forms = []
+    form = problems.biped(cpu_api, problems.BipedConfig(step_samples=8))
+    form.update(step_times=np.array([6, 14]), step_count=0)
+    forms += [(form, ("LIP",)), (form, ())]
+    forms.append((problems.body_case(cpu_api), ()))
+    log = ctypes.create_string_buffer(1 << 16)
+    for form, lti in forms:
+        plan = compile_plan(form, lti=lti)
+        assert plan.itab[_H["RS_OK"]] == 1
+        rc = lib.mpcasm_jit_check(plan.itab.ctypes.data, plan.itab.size, plan.dtab.ctypes.data,
+                                  plan.dtab.size, log, len(log))
+        assert rc == 0, log.value.decode()
+    # a plan the persistent kernel does not take is reported as such, not compiled
+    big = compile_plan(problems.random_lti(cpu_api, np.random.default_rng(3), N=16))
+    if big.itab[_H["RS_OK"]] == 0:
+        assert lib.mpcasm_jit_check(big.itab.ctypes.data, big.itab.size, big.dtab.ctypes.data,
+                                    big.dtab.size, None, 0) == -5

@@ -10,7 +10,7 @@ sys.path.insert(0, "tools")
 rows = {}
 for f in glob.glob("gpurun_out/pmc_ph/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "resident_assemble" in r["Kernel_Name"]:
+        if "resident_" in r["Kernel_Name"]:
             rows.setdefault(int(r["Dispatch_Id"]), {})[r["Counter_Name"]] = float(r["Counter_Value"])
 names = ["all", "none", "staging", "compose", "hessian", "constraints", "Pq-store"]
 ids = sorted(rows)
