@@ -670,6 +670,10 @@ __device__ __forceinline__ void resident_body(
       // ... and, two instances ahead, the (A, B) of the systems whose matrices are built here
       if (wave == 0 && (GEN && p.rs_nlti != 0) && nxt + gridDim.x < batch) fetch_ab(nxt + gridDim.x, buf);
       MPCASM_STAMP(7)
+      // the last matrix wave builds the next instance's horizon tables (its (A, B) landed and
+      // were waited for by wave 0 a whole instance ago) beside the stream waves' G; the plan
+      // compiler gives it that many trips fewer
+      if (wave == MW - 1 && (GEN && p.rs_nlti != 0) && nxt < batch) generate_sources(buf ^ 1, buf ^ 1);
       // the trips are what the barrier at the end of the phase waits for: they get the issue
       // slots before the other workgroup's G and compose (measured: 49.4 -> 48.4 us on C2)
       __builtin_amdgcn_s_setprio(2);
@@ -838,9 +842,6 @@ __device__ __forceinline__ void resident_body(
           hb[R] = (prm[rec[RR_EXTREME]] + ac) - ad;
         }
       }
-      // the last stream wave builds the next instance's horizon tables (its (A, B) landed
-      // and were waited for by wave 0 a whole instance ago)
-      if (wave == RS_WAVES - 1 && (GEN && p.rs_nlti != 0) && nxt < batch) generate_sources(buf ^ 1, buf ^ 1);
       MPCASM_STAMP(3)
       __builtin_amdgcn_s_setprio(2);  // (as the matrix waves: trips first)
     }

@@ -44,6 +44,10 @@ RS_JC_MAX = 12                            # compose ops a thread can keep in reg
 RS_TRIP_WORDS = 8
 # cost model of the wavefront assignment (rounded cycles of one wavefront), see _resident_program
 TRIP_COST, TRIP_STEP_COST, TERM_COST, TRIP_Q_COST, PACK_COST, G_PIECE_COST = 250, 40, 80, 80, 350, 420
+import os as _os
+if _os.environ.get("MPCASM_TRIP_COSTS"):          # tuning aid: "trip,step,term,q,pack,piece"
+    (TRIP_COST, TRIP_STEP_COST, TERM_COST, TRIP_Q_COST, PACK_COST,
+     G_PIECE_COST) = (int(x) for x in _os.environ["MPCASM_TRIP_COSTS"].split(","))
 # trip record (csrc/plan_tables.h RT_*): words A, B, D, W, AIM, WORD, BI, BJ;
 # WORD = rows (16 or 4) | short << 5 | half << 6 | nop << 7 | first << 8 | last << 9 | live << 10
 #        | qmask << 14 | last trip of its term in the pack << 18
@@ -829,12 +833,12 @@ def _resident_program(fused, gterms, no, ldv, image, ng, nparams, nc_rows):
     loads = []
     for w in range(RS_WAVES):
         if w < NW:
-            loads.append((350 * len(range(w, image["nchunk"], NW)), w))
+            gen = 3300 if image["groups"] and w == NW - 1 else 0   # builds the horizon tables
+            loads.append((350 * len(range(w, image["nchunk"], NW)) + gen, w))
         else:                                      # threads of this wave own pieces e = wt + u WT
             first = (w - NW) * 64
             own = len(range(first, pieces, stream_threads))
-            gen = 3300 if image["groups"] and w == RS_WAVES - 1 else 0   # builds the tables
-            loads.append((G_PIECE_COST * own + 500 + gen, w))
+            loads.append((G_PIECE_COST * own + 500, w))
     heapq.heapify(loads)
     wave_packs = [[] for _ in range(RS_WAVES)]
     for k in sorted(range(len(pack_trips)), key=lambda k: -cost[k]):

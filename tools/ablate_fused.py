@@ -24,9 +24,14 @@ def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     work = bench.build_workload(B, 1)
     engine, form = work["engine"], work["form"]
-    asm = engine.Assembler(form, batch=B)
+    lti = os.environ.get("MPCASM_LTI") == "1"   # horizon matrices generated on chip
+    asm = engine.Assembler(form, batch=B, lti=["LIP"] if lti else ())
+    if lti:
+        asm.bind_lti("LIP", torch.as_tensor(work["A"], device="cuda"), torch.as_tensor(work["B"], device="cuda"))
     given = torch.as_tensor(work["given"], device="cuda")
     lib = capi.load()
+    if os.environ.get("MPCASM_JIT"):
+        lib.mpcasm_set_option(capi.OPT_JIT, int(os.environ["MPCASM_JIT"]))
     lib.mpcasm_set_option(capi.OPT_PATH, int(os.environ.get("MPCASM_PATH", "0")))
     pf = 0x80 if os.environ.get("MPCASM_PREFETCH", "1") == "1" else 0   # register prefetch
     masks = [("all", 0x3F), ("none", 0), ("staging", 0x10), ("compose", 1), ("hessian", 2),
