@@ -77,7 +77,9 @@ class Formulation:
         self.goals = {}             # name -> Cost
 
         self.update_incorporations = use.do_not_update
-        self._asm = None            # full-problem assembler of the current structure
+        self._asm_cache = {}        # structure key -> [Assembler, tick its sources were bound at]
+        self._tick = 0              # make_preview_matrices calls so far
+        self._frozen = {}           # (dynamics, k) -> horizon matrix as of the last of them
         self._device = None
 
     # ---- incorporations (body.py:38-94) ------------------------------------
@@ -176,32 +178,53 @@ class Formulation:
         limits += [l for box in self.constraint_boxes.values() for l in box.constraints]
         return limits
 
-    def _assembler(self, costs=None, limits=None):
-        """Assembler (batch 1) carrying the current numbers.  The full-problem one
-        is kept until the next ``make_preview_matrices`` (the preview matrices are
-        frozen in between, as ``self.PM`` is in the reference); the Cost /
-        Constraint numbers are re-read on every call and a change of their
-        structure (schedule, L, shapes, membership) recompiles the plan."""
-        from mpcasm.engine import Assembler
-        from mpcasm.plan import structure_fingerprint
+    _ASM_CACHE_MAX = 24
 
-        if costs is None and limits is None:
-            asm = self._asm
-            if asm is not None and (
-                    asm.plan.fingerprint != structure_fingerprint(self.goals, self._all_limits())
-                    or not asm.refresh_params()):
-                asm = None
-            if asm is None:
-                asm = self._asm = Assembler(self, batch=1, device=self._device)
-            return asm
-        return Assembler(self, batch=1, device=self._device,
-                         costs={} if costs is None else costs,
-                         limits=[] if limits is None else limits)
+    def _assembler(self, costs=None, limits=None):
+        """Assembler (batch 1) for the whole problem, or for the given costs / limits, carrying
+        the numbers of the last ``make_preview_matrices`` (the preview matrices are frozen in
+        between, as ``self.PM`` is in the reference) and the current Cost / Constraint
+        numbers.  Compiled plans are cached by *structure* (domain, definition coefficients,
+        schedules, L contents, field shapes): a tick that keeps the structure -- every tick of
+        the walking loop within one phase -- re-uploads the horizon matrices and parameters of a
+        cached plan instead of compiling one (the reference re-interprets the description on
+        every tick, body.py:142-193; compiling per tick would cost more than that)."""
+        from mpcasm.engine import Assembler
+        from mpcasm.plan import formulation_key, structure_fingerprint
+
+        whole = costs is None and limits is None
+        use_costs = self.goals if whole else ({} if costs is None else costs)
+        use_limits = self._all_limits() if whole else ([] if limits is None else limits)
+        key = (whole, formulation_key(self), structure_fingerprint(use_costs, use_limits))
+        entry = self._asm_cache.get(key)
+        if entry is not None:
+            asm, bound_at = entry
+            if bound_at != self._tick and not asm.rebind_sources(self, self._frozen):
+                entry = None
+            elif not asm.refresh_params():
+                entry = None
+            else:
+                entry[1] = self._tick
+        if entry is None:
+            if len(self._asm_cache) >= self._ASM_CACHE_MAX:
+                self._asm_cache.pop(next(iter(self._asm_cache)))      # oldest first
+            asm = (Assembler(self, batch=1, device=self._device) if whole else
+                   Assembler(self, batch=1, device=self._device, costs=use_costs, limits=use_limits))
+            asm.rebind_sources(self, self._frozen)
+            self._asm_cache[key] = [asm, self._tick]
+        return asm
 
     def make_preview_matrices(self):
-        """``self.PM[var] = (Mg, Mo)`` for every definition (body.py:149-193),
-        produced by the K2 kernel when first read."""
-        self._asm = None
+        """``self.PM[var] = (Mg, Mo)`` for every definition (body.py:149-193), produced by the
+        K2 kernel when first read.  The horizon matrices are frozen here (host copies, a few
+        KB): what the kernels read until the next call, whatever the dynamics objects do
+        meanwhile -- the reference's ``self.PM`` behaves the same way."""
+        self._tick += 1
+        self._frozen = {
+            (name, k): np.array(M, dtype=np.float64, copy=True)
+            for name, dyn in self.dynamics.items()
+            for k, M in enumerate(getattr(dyn, "matrices", ()))
+        }
         self.PM = _PreviewMatrices(self)
 
     def get_matrices_from_dynamics(self, variable):
@@ -227,9 +250,9 @@ class Formulation:
     def preview(self, given, optim, variable, axes=None):
         """``Mg @ given + Mo @ optim`` (body.py:209-219), on the device."""
         asm = self._assembler()
-        if not hasattr(self, "_pm_dev") or self._pm_dev[0] is not asm:
-            self._pm_dev = (asm, asm.preview_matrices())
-        values = asm.preview(self._pm_dev[1], np.asarray(given, dtype=float).reshape(1, -1),
+        if getattr(self, "_pm_dev", (None, None))[:2] != (asm, self._tick):
+            self._pm_dev = (asm, self._tick, asm.preview_matrices())
+        values = asm.preview(self._pm_dev[2], np.asarray(given, dtype=float).reshape(1, -1),
                              np.asarray(optim, dtype=float).reshape(1, -1))[0].cpu().numpy()
 
         def rows_of(name):

@@ -184,6 +184,28 @@ class Assembler:
     def source_keys(self):
         return list(self._src_index.keys())
 
+    def rebind_sources(self, form, frozen=None):
+        """Re-read every horizon matrix / coefficient block from ``form`` (``frozen``: the
+        snapshot of the horizon matrices taken by ``make_preview_matrices``) into this
+        assembler's shared source slots -- what a tick changes when the structure stays.
+        Returns False when a block no longer is what the plan compiled it as (recompile)."""
+        fresh = []
+        for s in self.plan.sources:
+            block = s.getter(form, frozen) if s.getter is not None else s.array
+            if block is None:
+                return False
+            fresh.append(np.ascontiguousarray(block, dtype=np.float64))
+        generated = {i for g in self.plan.lti for i in g["ids"]}
+        for i, block in enumerate(fresh):
+            if i not in generated:
+                self._src[i], self._src_stride[i] = _as_device(self._torch, block, self.device), 0
+        for g in self.plan.lti:     # S[0][j][i] = A[i][j], U_j[0][0][i] = B[i][j]  (tools.py:14-33)
+            ids = g["ids"]
+            A = fresh[ids[-1]][0].T
+            Bm = np.stack([fresh[ids[j]][0, 0, :] for j in range(g["m"])], axis=1)
+            self.bind_lti(g["name"], A, Bm)
+        return True
+
     def bind_source(self, key, tensor):
         """Use ``tensor`` for the horizon matrix ``key = (dynamics name, k)``:
         shape ``(N, p, n)`` (shared) or ``(B, N, p, n)`` (one per instance)."""

@@ -11,6 +11,8 @@ centres, extremes, horizon matrices) stay outside, as device buffers.
 This module is host logic only (numpy / scipy.sparse); it never evaluates a
 preview matrix or a QP block -- that is the kernels' job.
 """
+import hashlib
+
 import numpy as np
 import scipy.sparse as sp
 
@@ -70,9 +72,13 @@ class Source:
     """One horizon matrix read by the definitions: ``ExtendedSystem.matrices[k]``
     (key ``(dynamics name, k)``) or an anonymous constant coefficient block."""
 
-    def __init__(self, key, array):
+    def __init__(self, key, array, getter=None):
         self.key = key
         self.array = np.ascontiguousarray(array, dtype=np.float64)
+        # getter(form, frozen) -> the block's current numbers (same shape), or None when it is
+        # no longer what the plan compiled it as; ``frozen``: {(dynamics, k): array} snapshot of
+        # the horizon matrices (Formulation.make_preview_matrices), may be None
+        self.getter = getter
 
 
 class Plan:
@@ -145,12 +151,12 @@ class _Builder:
         self.param_getters = []
 
     # ---- sources ---------------------------------------------------------
-    def source_id(self, key, array):
+    def source_id(self, key, array, getter=None):
         if key not in self._source_ids:
             if len(self.sources) >= MAX_SOURCES:
                 raise ValueError("more than %d horizon matrices in one formulation" % MAX_SOURCES)
             self._source_ids[key] = len(self.sources)
-            self.sources.append(Source(key, array))
+            self.sources.append(Source(key, array, getter))
         return self._source_ids[key]
 
     # ---- base variables (body.py:158-177) ----------------------------------
@@ -180,7 +186,13 @@ class _Builder:
                 if (src.ndim == 3 and sID < src.shape[2]
                         and matrix.shape == src.shape[:2]
                         and np.array_equal(matrix, src[..., sID])):
-                    sid = self.source_id((dyn_name, dID), src)
+                    def current(form, frozen, name=dyn_name, k=dID, shape=src.shape):
+                        M = (frozen or {}).get((name, k))
+                        if M is None:
+                            M = form.dynamics[name].matrices[k]
+                        return M if np.shape(M) == shape else None
+
+                    sid = self.source_id((dyn_name, dID), src, current)
                     n = src.shape[2]
                     seg = [sid, sID, src.shape[1] * n, n, dst0, length, SEG_GATHER, 0]
             if seg is None:
@@ -192,7 +204,12 @@ class _Builder:
                 if rows == length and np.array_equal(block, np.eye(rows)):
                     seg = [0, 0, 0, 0, dst0, length, SEG_IDENTITY, 0]
                 else:
-                    sid = self.source_id(("const", var, pos), np.array(block))
+                    def current(form, frozen, v=var, k=pos, shape=(rows, length)):
+                        M = np.asarray(list(form.definitions[v].values())[k], dtype=np.float64)
+                        M = np.broadcast_to(M, shape) if M.ndim < 2 else M
+                        return M if M.shape == shape else None
+
+                    sid = self.source_id(("const", var, pos), np.array(block), current)
                     seg = [sid, 0, length, 1, dst0, length, SEG_GATHER, 0]
             colseg[dst0:dst0 + length] = len(self.segments)
             self.segments.append(seg)
@@ -320,8 +337,16 @@ class _Builder:
         return start
 
 
+def _digest(a):
+    """Shape and a digest of the numbers of a coefficient block (cache keys)."""
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a.shape, hashlib.blake2b(a.tobytes(), digest_size=8).digest()
+
+
 def _ids(seq):
-    return tuple(id(x) for x in seq) if seq else ()
+    # L matrices are folded into the plan's coefficients: their CONTENT is structure (an
+    # in-place edit, or a new array at a recycled address, must not meet a stale plan)
+    return tuple(_digest(x) for x in seq) if seq else ()
 
 
 def _sched(schedule):
@@ -330,7 +355,7 @@ def _sched(schedule):
 
 def structure_fingerprint(costs, limits):
     """Cheap key of everything in the costs / limits that is *structure* for a
-    plan (objects, variables, schedules, L identities, field shapes)."""
+    plan (objects, variables, schedules, L contents, field shapes)."""
     key = []
     for name, c in costs.items():
         key.append(("c", name, id(c), c.variable, c.cross, tuple(c.axes), _sched(c.schedule),
@@ -338,6 +363,30 @@ def structure_fingerprint(costs, limits):
     for l in limits:
         key.append(("l", id(l), l.variable, tuple(l.axes), _sched(l.schedule), _ids(l.L),
                     np.shape(l.arrow), np.shape(l.center), np.shape(l.extreme)))
+    return tuple(key)
+
+
+def formulation_key(form):
+    """Everything about a Formulation, besides its costs and limits, that a compiled plan
+    depends on: the QP domain, the shapes of the horizon matrices, which coefficient blocks of
+    the dynamics' variables are identities, and the CONTENT of every derived definition's
+    coefficients (those are folded into the plan's tables; the blocks of the dynamics'
+    variables stay outside as rebindable sources).  Two formulations (or two ticks of one)
+    with equal keys can share a plan: only sources and parameters differ."""
+    key = [tuple(form.domain.items()), tuple(form.optim_variables)]
+    for name, dyn in form.dynamics.items():
+        key.append((name, type(dyn).__name__,
+                    tuple(np.shape(M) for M in getattr(dyn, "matrices", ()))))
+    for var, combo in form.definitions.items():
+        if var in form.of:
+            items = []
+            for dep, m in combo.items():
+                m = np.asarray(m, dtype=np.float64)
+                eye = m.ndim == 2 and m.shape[0] == m.shape[1] and np.array_equal(m, np.eye(m.shape[0]))
+                items.append((dep, m.shape, eye))
+            key.append((var, form.of[var], tuple(items)))
+        else:
+            key.append((var, tuple((dep, _digest(m)) for dep, m in combo.items())))
     return tuple(key)
 
 

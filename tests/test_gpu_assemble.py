@@ -666,3 +666,56 @@ def test_wide_hessian_with_a_crossed_term(gpu_api):
     assert np.abs(Qo - Qo.T).max() > 1e-6
     for mine, ref in ((A, Ao), (h, ho), (Q, Qo), (q, qo)):
         assert_close(mine, ref, RTOL_TIGHT)
+
+
+def test_ticks_reuse_compiled_plans(gpu_api, kernel_path, monkeypatch):
+    """The per-tick API compiles a plan once per *structure*: 18 ticks of the walking loop see
+    three structures (two steps in the preview / one / the step just taken), every other tick
+    re-uploads horizon matrices and parameters of a cached plan -- and the per-cost / per-limit
+    calls reuse theirs.  Results as in test_biped_ticks_drop_in (checked there tick by tick);
+    here: the number of compilations, and that an in-place edit of an L matrix or of a
+    definition's coefficients is seen (content, not identity, keys the cache)."""
+    if kernel_path not in RESIDENT[:1]:
+        pytest.skip("host-side caching: one path is enough")
+    import mpcasm.engine as engine
+
+    compiled = []
+    real = engine.compile_plan
+    monkeypatch.setattr(engine, "compile_plan", lambda *a, **k: compiled.append(1) or real(*a, **k))
+    conf = problems.BipedConfig(step_samples=8)
+    form = problems.biped(gpu_api, conf)
+    clock = problems.StepClock(conf.step_samples, conf.num_steps)
+    rng = np.random.default_rng(5)
+    for tick in range(18):
+        form.update(step_times=clock.step_times, step_count=clock.step_count)
+        given = form.arrange_given(problems.biped_given_collector(form, rng, 0.01))
+        A, h, Q, q = form.generate_all_qp_matrices(given)
+        Ao, ho, Qo, qo = orc.assemble(form, given)
+        assert_close(A, Ao, RTOL_TIGHT), assert_close(h, ho, RTOL_TIGHT)
+        assert_close(Q, Qo, RTOL_TIGHT), assert_close(q, qo, RTOL_TIGHT)
+        Q1, q1 = form.generate_qp_cost(form.goals["track vel_x"], given)
+        maps = orc.qp_index_maps(form.domain, form.optim_variables)
+        PMo = orc.preview_matrices(form, maps)
+        Qo1, qo1 = orc.qp_cost(PMo, form.goals["track vel_x"], given)
+        assert_close(Q1, Qo1, RTOL_TIGHT), assert_close(q1, qo1, RTOL_TIGHT)
+        clock.tick()
+    assert len(compiled) <= 8, len(compiled)      # 18 ticks x 2 assemblers without the cache
+
+    # content keys the cache: an in-place edit of a derived definition's coefficient
+    form2 = problems.body_case(gpu_api)
+    given = np.arange(form2.given_len, dtype=float).reshape(-1, 1)
+    before = form2.generate_all_qp_matrices(given)
+    form2.definitions["DCM_x"].matrices[1] = 0.5
+    form2.make_preview_matrices()
+    after = form2.generate_all_qp_matrices(given)
+    want = orc.assemble(form2, given)
+    for mine, ref in zip(after, want):
+        assert_close(mine, ref, RTOL_TIGHT)
+    assert not np.allclose(before[2], after[2])
+    # ... and of an L matrix, in place
+    lim = form2.constraints["steppingArea"][0]
+    lim.L[0][:] = 2.0 * np.eye(9)
+    mine = form2.generate_qp_constraint(lim, given)
+    ref = orc.qp_constraint(orc.preview_matrices(
+        form2, orc.qp_index_maps(form2.domain, form2.optim_variables)), lim, given)
+    assert_close(mine[0], ref[0], RTOL_TIGHT), assert_close(mine[1], ref[1], RTOL_TIGHT)
