@@ -210,6 +210,21 @@ int mpcasm_box_transform(double* d_params, int64_t n_params, int batch, const in
                          int nfacets, int op, const double* d_arg, int64_t arg_stride,
                          void* stream);
 
+/* f4, state space: replaces Box.recenter_in_SS / translate_in_SS            restrictions.py:390-404, 417-431
+ * (through Constraint.SS_to_TS, :240-250) for the boxes whose facets carry an L -- those of
+ * Box.state_space (:342-378: L = the facet's normal in the state space) and task-space boxes
+ * built with L.  Per instance a state-space point p [ss_dim][axes] (one column per task-space
+ * axis); facet f gets, per centre row r and axis a,
+ *   MPCASM_BOX_RECENTER   center[r][a]  = sum_v L[f][a][r][v] p[v][a]
+ *   MPCASM_BOX_TRANSLATE  center[r][a] += sum_v L[f][a][r][v] p[v][a]
+ * d_L [nfacets][axes][lrows][ss_dim]: the facets' L matrices (the same for every instance:
+ * they are part of the plan's structure); a facet's centre field must have lrows rows.
+ * d_arg [batch][arg_stride] with arg_stride = ss_dim * axes (0: one point for all). */
+int mpcasm_box_transform_ss(double* d_params, int64_t n_params, int batch,
+                            const int32_t* d_facets, int nfacets, int op, const double* d_L,
+                            int lrows, int ss_dim, const double* d_arg, int64_t arg_stride,
+                            void* stream);
+
 #ifdef __cplusplus
 }
 #endif

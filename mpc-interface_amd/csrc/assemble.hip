@@ -722,6 +722,42 @@ __global__ __launch_bounds__(BLOCK) void box_transform_kernel(double* __restrict
     }
 }
 
+// f4, state space (restrictions.py:390-404, 417-431 through SS_to_TS, :240-250): the centre of
+// facet f becomes (or moves by) L_f,a . p[:, a] per task-space axis a; one thread per
+// (instance, facet).
+__global__ __launch_bounds__(BLOCK) void box_transform_ss_kernel(
+    double* __restrict__ params, long long nparams, int batch, const int32_t* __restrict__ facets,
+    int nfacets, int op, const double* __restrict__ L, int lrows, int ss_dim,
+    const double* __restrict__ arg, long long arg_stride) {
+  const long t = (long)blockIdx.x * BLOCK + threadIdx.x;
+  if (t >= (long)batch * nfacets) return;
+  const long inst = t / nfacets;
+  const int fi = (int)(t - inst * nfacets);
+  const int32_t* f = facets + fi * 7;
+  double* center = params + inst * nparams + f[2];
+  const int axes = f[6];
+  const double* p = arg + inst * arg_stride;               // [ss_dim][axes]
+  const double* Lf = L + (size_t)fi * axes * lrows * ss_dim;  // [axes][lrows][ss_dim]
+  for (int r = 0; r < lrows; ++r)
+    for (int x = 0; x < axes; ++x) {
+      double v = 0.0;
+      for (int k = 0; k < ss_dim; ++k) v = fma(Lf[((size_t)x * lrows + r) * ss_dim + k], p[k * axes + x], v);
+      center[r * axes + x] = (op == MPCASM_BOX_TRANSLATE ? center[r * axes + x] : 0.0) + v;
+    }
+}
+
+int launch_box_transform_ss(double* params, long long nparams, int batch, const int32_t* facets,
+                            int nfacets, int op, const double* L, int lrows, int ss_dim,
+                            const double* arg, long long arg_stride, hipStream_t stream,
+                            hipError_t* err) {
+  const long total = (long)batch * nfacets;
+  hipLaunchKernelGGL(box_transform_ss_kernel, dim3((unsigned)((total + BLOCK - 1) / BLOCK)),
+                     dim3(BLOCK), 0, stream, params, nparams, batch, facets, nfacets, op, L, lrows,
+                     ss_dim, arg, arg_stride);
+  *err = hipGetLastError();
+  return *err == hipSuccess ? MPCASM_OK : MPCASM_ERR_HIP;
+}
+
 int launch_box_transform(double* params, long long nparams, int batch, const int32_t* facets,
                          int nfacets, int op, const double* arg, long long arg_stride,
                          hipStream_t stream, hipError_t* err) {

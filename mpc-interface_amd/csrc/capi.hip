@@ -676,6 +676,23 @@ int mpcasm_box_transform(double* d_params, int64_t n_params, int batch, const in
   return rc;
 }
 
+int mpcasm_box_transform_ss(double* d_params, int64_t n_params, int batch,
+                            const int32_t* d_facets, int nfacets, int op, const double* d_L,
+                            int lrows, int ss_dim, const double* d_arg, int64_t arg_stride,
+                            void* stream) {
+  if (batch < 0 || nfacets < 0 || n_params < 0 || arg_stride < 0 || lrows < 1 || ss_dim < 1 ||
+      (op != MPCASM_BOX_RECENTER && op != MPCASM_BOX_TRANSLATE))
+    return MPCASM_ERR_ARG;
+  if (batch == 0 || nfacets == 0) return MPCASM_OK;
+  if (!d_params || !d_facets || !d_L || !d_arg) return MPCASM_ERR_ARG;
+  hipError_t err;
+  const int rc = launch_box_transform_ss(d_params, n_params, batch, d_facets, nfacets, op, d_L,
+                                         lrows, ss_dim, d_arg, arg_stride,
+                                         static_cast<hipStream_t>(stream), &err);
+  if (rc == MPCASM_ERR_HIP) g_last_hip = (int)err;
+  return rc;
+}
+
 int mpcasm_gather(const double* d_src, int64_t src_stride, const int32_t* d_index, int nnz,
                   double* d_dst, int batch, void* stream) {
   if (nnz < 0 || batch < 0 || src_stride < 0) return MPCASM_ERR_ARG;

@@ -44,6 +44,10 @@ int launch_preview_matrices(const PlanDev& p, const SrcTable& src, double* PM, i
 int launch_box_transform(double* params, long long nparams, int batch, const int32_t* facets,
                          int nfacets, int op, const double* arg, long long arg_stride,
                          hipStream_t stream, hipError_t* err);
+int launch_box_transform_ss(double* params, long long nparams, int batch, const int32_t* facets,
+                            int nfacets, int op, const double* L, int lrows, int ss_dim,
+                            const double* arg, long long arg_stride, hipStream_t stream,
+                            hipError_t* err);
 int launch_gather(const double* src, long long src_stride, const int32_t* index, int nnz,
                   double* dst, int batch, hipStream_t stream, hipError_t* err);
 int launch_preview(const double* PM, const double* given, const double* optim, double* out,

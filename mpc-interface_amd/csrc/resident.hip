@@ -1043,9 +1043,11 @@ int launch_jc(const PlanDev& p, const SrcTable& src, const double* params, const
   // residency of this instantiation at this LDS size: queried once, then cached (the
   // launch path itself makes no other runtime call, so it can be graph-captured)
   static thread_local size_t cached_lds[3] = {0, 0, 0};
-  static thread_local int cached_per_cu[3] = {0, 0, 0};
+  static thread_local int cached_per_cu[3] = {0, 0, 0}, cached_device[3] = {-1, -1, -1};
   const int slot = (g_phase_mask & 64) ? 2 : (p.rs_nlti != 0 ? 1 : 0);
-  if (cached_lds[slot] != lds_bytes) {
+  int device = 0;
+  (void)hipGetDevice(&device);  // (the attribute and the occupancy belong to one device)
+  if (cached_lds[slot] != lds_bytes || cached_device[slot] != device) {
     if (lds_bytes > 64 * 1024) {
       *err = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -1056,6 +1058,7 @@ int launch_jc(const PlanDev& p, const SrcTable& src, const double* params, const
     if (*err != hipSuccess) return MPCASM_ERR_HIP;
     cached_per_cu[slot] = n;
     cached_lds[slot] = lds_bytes;
+    cached_device[slot] = device;
   }
   // persistent grid: exactly the workgroups that are resident at once, never more
   // than there are instances

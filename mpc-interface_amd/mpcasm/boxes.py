@@ -46,6 +46,16 @@ class BoxBatch:
         self.axes = records[0][6]
         if self.axes > 4:
             raise ValueError("boxes of more than 4 axes are not supported")
+        self._records = records
+        # state-space boxes (Box.state_space, or a task-space box built with L): the facets' L,
+        # [nfacets][axes][lrows][ss_dim] -- part of the structure, the same for every instance
+        self._L = None
+        Ls = [facet.L for facet in box.constraints]
+        if all(Ls):
+            stack = np.asarray([[np.atleast_2d(np.asarray(l, dtype=np.float64)) for l in L] for L in Ls])
+            if stack.ndim == 4 and stack.shape[1] == self.axes:
+                self._L = torch.as_tensor(np.ascontiguousarray(stack), device=asm.device)
+                self.lrows, self.ss_dim = int(stack.shape[2]), int(stack.shape[3])
         self._facets = torch.as_tensor(np.asarray(records, dtype=np.int32), device=asm.device)
         self.nfacets = len(records)
         self.scale_factor = torch.ones(asm.batch, dtype=torch.float64, device=asm.device)
@@ -76,8 +86,52 @@ class BoxBatch:
         applied to every row: ``arrow_row <- arrow_row @ R.T``."""
         self._run(capi.BOX_ROTATE, rotations, self.axes * self.axes)
 
+    def _run_ss(self, op, point):
+        asm, torch = self.asm, self.asm._torch
+        if self._L is None:
+            raise ValueError("this box has no L matrices: it lives in the task space only")
+        if any(rec[3] != self.lrows for rec in self._records):
+            raise ValueError("the facets' centre fields were compiled with %s rows, a state-space "
+                             "point gives %d" % (sorted({rec[3] for rec in self._records}), self.lrows))
+        width = self.ss_dim * self.axes
+        point = torch.as_tensor(point, dtype=torch.float64, device=asm.device)
+        if point.shape[-2:] != (self.ss_dim, self.axes) and not (
+                self.axes == 1 and point.shape[-1] == self.ss_dim):
+            # the reference's message (restrictions.py:393-400)
+            raise ValueError("The 'new_center' must have {} rows and {} columns, but its shape "
+                             "is {}".format(self.ss_dim, self.axes, tuple(point.shape)))
+        point = point.reshape(-1, width)
+        if point.shape[0] not in (1, asm.batch):
+            raise ValueError("expected 1 or %d instances, got %d" % (asm.batch, point.shape[0]))
+        point = point.contiguous()
+        with torch.cuda.device(asm.device):
+            rc = capi.load().mpcasm_box_transform_ss(
+                asm.params.data_ptr(), asm.params.shape[1], asm.batch, self._facets.data_ptr(),
+                self.nfacets, op, self._L.data_ptr(), self.lrows, self.ss_dim, point.data_ptr(),
+                width if point.shape[0] == asm.batch else 0,
+                ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        capi.check(rc, "mpcasm_box_transform_ss")
+
+    def recenter_in_SS(self, new_center):
+        """restrictions.py:390-404: every facet's centre becomes ``SS_to_TS(new_center)``,
+        ``new_center`` ``(B, ss_dimention, ts_dimention)`` -- one column per task-space axis."""
+        self._run_ss(capi.BOX_RECENTER, new_center)
+
+    def translate_in_SS(self, translation):
+        """restrictions.py:417-431: centres move by ``SS_to_TS(translation)``."""
+        self._run_ss(capi.BOX_TRANSLATE, translation)
+
+    def _per_row_arrows(self, what):
+        # Constraint.normalize gives every extreme row its own arrow row before it flips signs
+        # (restrictions.py:181-194); a facet compiled with ONE arrow for several extremes has
+        # no room for that in the parameters
+        if any(rec[1] == 1 and rec[5] > 1 for rec in self._records):
+            raise ValueError("%s may flip single rows of a facet: build the box with one arrow "
+                             "per row (arrow of shape (rows, axes))" % what)
+
     def scale_box(self, scale_factor):
         """restrictions.py:474-478: extremes times ``scale_factor / previous factor``."""
+        self._per_row_arrows("scale_box")
         torch = self.asm._torch
         new = torch.as_tensor(scale_factor, dtype=torch.float64, device=self.asm.device).reshape(-1)
         new = new.expand(self.asm.batch).contiguous()
@@ -87,4 +141,5 @@ class BoxBatch:
     def set_safety_margin(self, margin):
         """restrictions.py:480-486: extremes shrink by ``margin * norm(arrow)`` (the
         Frobenius norm of a facet's whole arrow field, as ``np.linalg.norm`` gives it)."""
+        self._per_row_arrows("set_safety_margin")
         self._run(capi.BOX_MARGIN, margin, 1)

@@ -59,6 +59,9 @@ SIGNATURES = {
     "mpcasm_box_transform": (ctypes.c_int, [_void_p, ctypes.c_int64, ctypes.c_int, _void_p,
                                             ctypes.c_int, ctypes.c_int, _void_p, ctypes.c_int64,
                                             _void_p]),
+    "mpcasm_box_transform_ss": (ctypes.c_int, [_void_p, ctypes.c_int64, ctypes.c_int, _void_p,
+                                               ctypes.c_int, ctypes.c_int, _void_p, ctypes.c_int,
+                                               ctypes.c_int, _void_p, ctypes.c_int64, _void_p]),
 }
 BOX_RECENTER, BOX_TRANSLATE, BOX_ROTATE, BOX_SCALE, BOX_MARGIN = range(5)
 

@@ -719,3 +719,52 @@ def test_ticks_reuse_compiled_plans(gpu_api, kernel_path, monkeypatch):
     ref = orc.qp_constraint(orc.preview_matrices(
         form2, orc.qp_index_maps(form2.domain, form2.optim_variables)), lim, given)
     assert_close(mine[0], ref[0], RTOL_TIGHT), assert_close(mine[1], ref[1], RTOL_TIGHT)
+
+
+def test_batched_state_space_box_transforms(gpu_api, kernel_path):
+    """f4, second half (restrictions.py:342-378, 390-404, 417-431): a box made by
+    Box.state_space (facet normals as L), re-centred and translated IN THE STATE SPACE for every
+    instance at once (mpcasm_box_transform_ss), then scaled and shrunk by the task-space
+    operations -- against the same calls on the host Box, instance by instance, assembled by the
+    oracle."""
+    import copy
+
+    from mpcasm import engine
+    from mpcasm.boxes import BoxBatch
+
+    if kernel_path not in RESIDENT:
+        pytest.skip("the transforms act on the parameters, one assembly path is enough")
+    form = problems.body_case(gpu_api)
+    verts = np.array([[0.3, 0.1], [-0.2, 0.25], [-0.3, -0.15], [0.2, -0.3]])
+    form.incorporate_box("dcm window", gpu_api.Box.state_space("DCM_x", verts, schedule=range(7, 9)))
+    form.make_preview_matrices()
+    batch = 7
+    rng = np.random.default_rng(33)
+    given = rng.normal(0, 0.3, [batch, form.given_len])
+    asm = engine.Assembler(form, batch=batch)
+    window = BoxBatch(asm, form, "dcm window")
+    assert window.ss_dim == 2 and window.lrows == 1 and window.axes == 1
+    centers = rng.normal(0, 0.2, [batch, 2, 1])
+    shifts = rng.normal(0, 0.05, [batch, 2, 1])
+    window.recenter_in_SS(centers)
+    window.translate_in_SS(shifts)
+    window.translate_in_SS(np.array([[0.01], [-0.02]]))      # one point for all
+    window.scale_box(rng.uniform(0.7, 1.2, batch) * 0 + 1.1)
+    window.set_safety_margin(0.01)
+    G, h = (t.cpu().numpy() for t in asm.assemble(given)[2:])
+    for b in (0, 3, batch - 1):
+        ref = copy.deepcopy(form)
+        box = ref.constraint_boxes["dcm window"]
+        box.recenter_in_SS(centers[b])
+        box.translate_in_SS(shifts[b])
+        box.translate_in_SS(np.array([[0.01], [-0.02]]))
+        box.scale_box(1.1)
+        box.set_safety_margin(0.01)
+        Ao, ho, _, _ = orc.assemble(ref, given[b].reshape(-1, 1))
+        assert_close(G[b], Ao, RTOL_TIGHT, "G of instance %d" % b)
+        assert_close(h[b], ho.ravel(), RTOL_TIGHT, "h of instance %d" % b)
+    # misuse: the reference's shape error, and a task-space box has no state space
+    with pytest.raises(ValueError, match="must have 2 rows and 1 columns"):
+        window.recenter_in_SS(np.zeros((batch, 3, 1)))
+    with pytest.raises(ValueError, match="task space only"):
+        BoxBatch(asm, form, "kine").recenter_in_SS(np.zeros((2, 2)))
