@@ -153,6 +153,7 @@ int validate_plan(const int32_t* it, const double* h_dtab, size_t n_itab, size_t
     r = r && in_range(it[H_OFF_RS_TRIP], ((int64_t)it[H_RS_NTRIP] + 2) * RS_TRIP_WORDS, n, H_WORDS);
     r = r && in_range(it[H_OFF_RS_WTRIP], RS_WAVES * 2, n, H_WORDS);
     r = r && in_range(it[H_OFF_RS_SPLIT], it[H_RS_NSPLIT], n, H_WORDS);
+    r = r && it[H_RS_NZBLK] >= 0 && in_range(it[H_OFF_RS_ZBLK], it[H_RS_NZBLK], n, H_WORDS);
     r = r && (it[H_OFF_RS_TRIP] % 8 == 0);
     r = r && in_range(it[H_OFF_RS_RR], nc * RS_RR_WORDS, n, H_WORDS) && it[H_OFF_RS_RR] % 4 == 0;
     r = r && in_range(it[H_OFF_RS_INMETA], nchunk * 64 * 2, n, H_WORDS) &&
@@ -181,6 +182,10 @@ int validate_plan(const int32_t* it, const double* h_dtab, size_t n_itab, size_t
       if (sp[i] < 0 || sp[i] >= vsize) return MPCASM_ERR_PLAN;
     const int nb = ((int)no + 3) / 4;  // 4-column blocks of the unknowns
     if (nb > RS_BLOCKS_MAX) return MPCASM_ERR_PLAN;
+    for (int i = 0; i < it[H_RS_NZBLK]; ++i) {
+      const int z = (it + it[H_OFF_RS_ZBLK])[i];
+      if (z < 0 || (z >> 8) >= nb || (z & 255) >= nb) return MPCASM_ERR_PLAN;
+    }
     const int32_t* tr = it + it[H_OFF_RS_TRIP];
     for (int i = 0; i < 2 * RS_TRIP_WORDS; ++i)
       if (tr[it[H_RS_NTRIP] * RS_TRIP_WORDS + i] != 0) return MPCASM_ERR_PLAN;
@@ -428,6 +433,7 @@ void plan_dev_from_tables(const int32_t* it, PlanDev* out) {
   d.rr_packed = it[H_RR_PACKED];
   d.off_rs_dpar = it[H_OFF_RS_DPAR]; d.doff_rs_dcoef = it[H_DOFF_RS_DCOEF];
   d.rs_ngdesc = it[H_RS_NGDESC]; d.off_rs_gdesc = it[H_OFF_RS_GDESC];
+  d.rs_nzblk = it[H_RS_NZBLK]; d.off_rs_zblk = it[H_OFF_RS_ZBLK];
   d.pm_nfd = it[H_PM_NFD]; d.off_pm_map = it[H_OFF_PM_MAP]; d.off_pm_fdptr = it[H_OFF_PM_FDPTR];
   d.off_pm_op = it[H_OFF_PM_OP]; d.doff_pm_pool = it[H_DOFF_PM_POOL];
   d.rs_src16 = 0;
@@ -720,7 +726,7 @@ int launch_assemble(const PlanDev& p, const SrcTable& src, const double* params,
   // the persistent kernel may take a whole CU's LDS (one workgroup of 8 wavefronts per
   // CU still beats the staged pipeline by far); the per-instance fused kernel is only
   // worth it while two workgroups fit
-  constexpr size_t RESIDENT_LDS_LIMIT = 156 * 1024, FUSED_LDS_LIMIT = 80 * 1024;
+  constexpr size_t FUSED_LDS_LIMIT = 80 * 1024;
   const size_t rs = resident_lds_bytes(p);
   if (rs != 0 && rs <= RESIDENT_LDS_LIMIT && (g_path == 0 || p.rs_nlti != 0) &&
       resident_inputs_aligned(p, src, params, given)) {

@@ -23,7 +23,8 @@ namespace mpcasm {
   X(off_rs_rr) X(rs_unit) X(rs_nchunk) X(off_rs_inmeta) X(rs_img) X(rs_img_given)                   \
   X(rs_img_params) X(doff_rs_const) X(rs_nlti) X(off_rs_lti) X(rs_img_dma) X(rs_ab)                 \
   X(off_rs_abmeta) X(rr_packed) X(off_rs_dpar) X(doff_rs_dcoef) X(rs_ngdesc) X(off_rs_gdesc)        \
-  X(pm_nfd) X(off_pm_map) X(off_pm_fdptr) X(off_pm_op) X(doff_pm_pool) X(doff_diagcoef) X(ndiag)
+  X(pm_nfd) X(off_pm_map) X(off_pm_fdptr) X(off_pm_op) X(doff_pm_pool) X(doff_diagcoef) X(ndiag)      \
+  X(rs_nzblk) X(off_rs_zblk)
 
 // device-side view of a plan (pointers into the device copies of the tables).
 //   rs_sym_any: every Hessian term has A == B;  rs_src16: sources that the 16-byte image loads
@@ -36,6 +37,9 @@ struct PlanDev {
 #undef MPCASM_X
   unsigned rs_src16;
 };
+
+// LDS the persistent kernel may ask for (a whole CU's 160 KiB less what the runtime keeps)
+constexpr int RESIDENT_LDS_LIMIT = 156 * 1024;
 
 // sources of one launch (device pointers + per-instance strides, by value)
 struct SrcTable {

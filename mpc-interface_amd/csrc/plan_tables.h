@@ -133,6 +133,8 @@ enum HeaderWord : int {
   H_PM_NOPS,
   H_DOFF_PM_POOL,   // [PM_NPOOL] distinct coefficients
   H_PM_NPOOL,
+  H_RS_NZBLK,       // 4x4 blocks of P no term reaches (both triangles): exact zeros
+  H_OFF_RS_ZBLK,    // [RS_NZBLK] block row << 8 | block column
   H_WORDS = 96
 };
 

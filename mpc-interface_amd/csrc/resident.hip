@@ -77,6 +77,10 @@ constexpr int MW = RS_NW;         // wavefronts that run the matrix core
 constexpr int WT = NT - MW * 64;  // threads of the worker wavefronts
 constexpr int AXMAX = RS_AXMAX;
 constexpr int RR_WORDS = RS_RR_WORDS;
+// ... of which a row of at most two axes whose fields fit 16 bits (H_RR_PACKED) needs four in LDS:
+// voff0 | voff1 << 16, arrow0 | arrow1 << 16, center0 | center1 << 16, extreme (a missing second
+// axis points at workspace row 0 with the always-zero parameter: it adds exact zeros)
+constexpr int RR_COMPACT = 4;
 static_assert(RS_DIAG_MAX == 2, "the per-column diagonal table holds two terms");
 
 __host__ __device__ inline int even_up_i(int x) { return (x + 1) & ~1; }
@@ -94,17 +98,19 @@ __host__ __device__ inline int resident_g_mode(const PlanT& p) {
 }
 static_assert(GU == RS_GDESC_PIECES && WT == RS_GDESC_THREADS, "descriptor table of G");
 
-// doubles of the workspace: row groups of four, column by column (plan_tables.h RT_*), one
-// spare group behind the last (the lanes of a block of q read two columns past the ones)
+// doubles of the workspace: row groups of four, column by column (plan_tables.h RT_*), and a
+// few spare doubles behind the last group (the lanes of a block of q read two columns past
+// the ones)
 template <class PlanT>
 __host__ __device__ inline int resident_v_doubles(const PlanT& p) {
-  return ((p.rtot + 3) / 4 + 1) * 4 * p.ldv;
+  return (p.rtot + 3) / 4 * 4 * p.ldv + 16;
 }
 
 struct ResidentLayout {
   // offsets in doubles
   int v, pl, ql, dvec, dcoef, dpar, img, ab, streams, ints, total_doubles;
   int ldp;                                            // leading dimension of P in LDS
+  int p_direct;  // 1: P does not fit beside the workspace -- its blocks go straight to HBM
   int i_rr, i_meta, i_wtrip, i_split, i_lti, i_abmeta, i_gdesc;  // offsets in ints inside the int region
 };
 
@@ -114,7 +120,7 @@ __host__ __device__ inline ResidentLayout resident_layout(const PlanT& p) {
   L.ldp = even_up_i(p.no);
   int o = 0;
   L.v = o;      o += resident_v_doubles(p);
-  L.pl = o;     o += p.no * L.ldp;
+  L.pl = o;     // (placed last, see below: it is what a wide problem drops)
   L.ql = o;     o += L.ldp;
   // diagonal gterms: addends of P[c][c] and q[c] of this instance, then per column the
   // (weight, aim) parameter slots and coefficients of the (at most RS_DIAG_MAX) terms on it
@@ -126,7 +132,7 @@ __host__ __device__ inline ResidentLayout resident_layout(const PlanT& p) {
   L.streams = o; o += 2 * (MAX_SOURCES + 3);  // (base pointer, bytes per instance) per stream
   L.ints = o;
   int i = 0;  // the first two start 16-byte aligned
-  L.i_rr = i;    i += p.nc * RR_WORDS;
+  L.i_rr = i;    i += p.nc * (p.rr_packed ? RR_COMPACT : RR_WORDS);
   L.i_meta = i;  i += p.rs_nchunk * 64 * 2;
   L.i_abmeta = i; i += p.rs_ab * 2 * 2;
   L.i_gdesc = i;  i += resident_g_mode(p) == 2 ? GU * WT * 2 : 0;  // per-thread piece descriptors of G
@@ -134,6 +140,11 @@ __host__ __device__ inline ResidentLayout resident_layout(const PlanT& p) {
   L.i_split = i; i += p.rs_nsplit;
   L.i_lti = i;   i += p.rs_nlti * RS_LTI_WORDS;
   o += even_up_i(i) / 2;
+  // P in LDS (dense, read out with 16-byte stores) when it fits beside everything else; else
+  // the blocks of P leave the matrix core for HBM directly (8-byte stores, 32-byte runs)
+  L.p_direct = (long)(o + p.no * L.ldp) * 8 > RESIDENT_LDS_LIMIT ? 1 : 0;
+  L.pl = o;
+  if (!L.p_direct) o += p.no * L.ldp;
   L.total_doubles = o;
   return L;
 }
@@ -167,7 +178,9 @@ __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" :
 struct TripState {
   const char* Vlane;  // workspace + lk * group_bytes + lx * 32
   const char* prc;    // this instance's parameters
-  double *Pl, *ql;
+  double *Pl, *ql;  // Pl: P in LDS (leading dimension ldp), or this instance's P in HBM (no)
+  int ldpl;
+  bool mirror;
   const double* dvec;
   int lx, lg, lk;
   const char *ap, *bp;  // of the current pack
@@ -236,8 +249,8 @@ __device__ __forceinline__ void spec_trip(TripState& s) {
         if (s.lx == 0) s.ql[row] = s.acc + s.dvec[ldp + row];
       } else if (col < PC::no) {
         const double val = s.acc + (row == col ? s.dvec[col] : 0.0);
-        s.Pl[row * ldp + col] = val;
-        if (PC::rs_sym && s.bi != s.bj) s.Pl[col * ldp + row] = val;
+        s.Pl[row * s.ldpl + col] = val;
+        if (PC::rs_sym && s.bi != s.bj) s.Pl[col * s.ldpl + row] = val;
       }
     }
   }
@@ -542,7 +555,7 @@ __device__ __forceinline__ void resident_body(
     // by table the latencies would add up.
     constexpr int RRK = 3;  // row-record words per thread in the first batch
     const int32_t* trr = plan_itab + p.off_rs_rr;  // row records of G, precomputed by the plan compiler
-    const int nrr = nc * RR_WORDS;
+    const int nrr = p.rr_packed ? 0 : nc * RR_WORDS;  // (packed plans keep compact records, below)
     int v_rr[RRK], v_wtrip = 0, v_split = 0;
     int2 v_gd[GU];
     int4 v_dpar = int4{0, 0, 0, 0};
@@ -570,7 +583,8 @@ __device__ __forceinline__ void resident_body(
     }
     if (ct >= 0) {
       // blocks of P no term reaches stay zero for the whole launch
-      for (int i = ct; i < no * ldp; i += CT) Pl[i] = 0.0;
+      if (!L.p_direct)
+        for (int i = ct; i < no * ldp; i += CT) Pl[i] = 0.0;
       double2* V2 = reinterpret_cast<double2*>(V);
       const int n2 = resident_v_doubles(p) / 2;
       for (int i = ct; i < n2; i += CT) V2[i] = double2{0.0, 0.0};
@@ -579,6 +593,12 @@ __device__ __forceinline__ void resident_body(
       for (int k = 0; k < RRK; ++k)
         if (ct + k * CT < nrr) rr[ct + k * CT] = v_rr[k];
       for (int i = ct + RRK * CT; i < nrr; i += CT) rr[i] = trr[i];
+      if (p.rr_packed)
+        for (int R = ct; R < nc; R += CT) {
+          const int32_t* g = trr + R * RR_WORDS;
+          reinterpret_cast<int4*>(rr)[R] =
+              int4{g[RR_PACKED], g[RR_PACKED + 1], g[RR_CENTER] | (g[RR_CENTER + 1] << 16), g[RR_EXTREME]};
+        }
       if (ct < RS_WAVES * 2) wtrip[ct] = v_wtrip;
       if (ct < p.rs_nsplit) split[ct] = v_split;
       for (int i = ct + CT; i < p.rs_nsplit; i += CT) split[i] = (plan_itab + p.off_rs_split)[i];
@@ -694,9 +714,9 @@ __device__ __forceinline__ void resident_body(
           // reads (record -> parameters, d -> arithmetic) costs a wave as much as a whole
           // batch when it runs on its own after G
           const bool h_mine = wt_ < nc;
-          const int* hrec = rr + (h_mine ? wt_ : 0) * RR_WORDS;
-          const int4 hr = *reinterpret_cast<const int4*>(hrec + RR_NAXES);  // naxes, extreme, packed
-          const int2 hc = *reinterpret_cast<const int2*>(hrec + RR_CENTER);
+          const int4 hc4 = reinterpret_cast<const int4*>(rr)[h_mine ? wt_ : 0];  // compact record
+          const int4 hr = int4{0, hc4.w, hc4.x, hc4.y};  // -, extreme, packed rows, packed arrows
+          const int2 hc = int2{hc4.z & 0xFFFF, (int)((unsigned)hc4.z >> 16)};
           double ha0 = 0.0, ha1 = 0.0, hc0 = 0.0, hc1 = 0.0, hd0 = 0.0, hd1 = 0.0, hext = 0.0;
 #pragma unroll
           for (int u0 = 0; u0 < GU; u0 += 3) {
@@ -751,7 +771,7 @@ __device__ __forceinline__ void resident_body(
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
               const int Rr = e0 + u * WT < gtotal ? R : 0;
-              ds[u] = *reinterpret_cast<const int2*>(rr + Rr * RR_WORDS + RR_PACKED);
+              ds[u] = *reinterpret_cast<const int2*>(rr + Rr * RR_COMPACT);
               c2[u] = 8 * cp;
               cp += g_dcp;
               R += g_dR;
@@ -831,6 +851,15 @@ __device__ __forceinline__ void resident_body(
         int Rh = g_mode == 2 ? wt + WT : wt;  // (the descriptor path has done row wt already)
         asm volatile("" : "+v"(Rh));
         for (int R = Rh; R < nc; R += WT) {
+          if (p.rr_packed) {
+            const int4 c = reinterpret_cast<const int4*>(rr)[R];
+            const double a0 = prm[c.y & 0xFFFF], a1 = prm[(unsigned)c.y >> 16];
+            double ac = a0 * prm[c.z & 0xFFFF], ad = a0 * V[(c.x & 0xFFFF) + 4 * no];
+            ac += a1 * prm[(unsigned)c.z >> 16];
+            ad = fma(a1, V[((unsigned)c.x >> 16) + 4 * no], ad);
+            hb[R] = (prm[c.w] + ac) - ad;
+            continue;
+          }
           const int* rec = rr + R * RR_WORDS;
           const int naxes = rec[RR_NAXES];
           double ac = 0.0, ad = 0.0;
@@ -852,7 +881,8 @@ __device__ __forceinline__ void resident_body(
       TripState st;
       st.Vlane = reinterpret_cast<const char*>(V) + lk * (4 * ldv * 8) + lx * 32;
       st.prc = reinterpret_cast<const char*>(prm);
-      st.Pl = Pl;
+      st.Pl = L.p_direct ? P + (size_t)inst * no * no : Pl;
+      st.ldpl = L.p_direct ? no : ldp;
       st.ql = ql;
       st.dvec = dvec;
       st.lx = lx, st.lg = lg, st.lk = lk;
@@ -950,8 +980,10 @@ __device__ __forceinline__ void resident_body(
               } else if (col < no) {
                 // the diagonal gterms' addend where row == col
                 const double val = acc + (row == col ? dvec[col] : 0.0);
-                Pl[row * ldp + col] = val;
-                if (p.rs_sym && bi != bj) Pl[col * ldp + row] = val;
+                double* Pout = L.p_direct ? P + (size_t)inst * no * no : Pl;
+                const int ldo = L.p_direct ? no : ldp;
+                Pout[row * ldo + col] = val;
+                if (p.rs_sym && bi != bj) Pout[col * ldo + row] = val;
               }
             }
           }
@@ -980,7 +1012,22 @@ __device__ __forceinline__ void resident_body(
       // image: thread t of this phase is thread (t + MW * 64) % NT of the workgroup
       int t_ = tid >= MW * 64 ? tid - MW * 64 : tid + WT;
       asm volatile("" : "+v"(t_));
-      if ((no & 1) == 0) {
+      if (L.p_direct) {
+        // P went out block by block; what no term reaches is written here: zeros, 16 bytes
+        // per thread and piece (block, row, half of the row)
+        const int32_t* zb = plan_itab + p.off_rs_zblk;
+        for (int e = t_; e < p.rs_nzblk * 8; e += NT) {
+          const int z = zb[e >> 3], row = 4 * (z >> 8) + ((e >> 1) & 3), col = 4 * (z & 255) + 2 * (e & 1);
+          if (row < no && col < no) {
+            if (col + 1 < no && ((no & 1) == 0))
+              *reinterpret_cast<double2*>(Pb + (size_t)row * no + col) = double2{0.0, 0.0};
+            else {
+              Pb[(size_t)row * no + col] = 0.0;
+              if (col + 1 < no) Pb[(size_t)row * no + col + 1] = 0.0;
+            }
+          }
+        }
+      } else if ((no & 1) == 0) {
         // ldp == no here, so P in LDS is dense: a flat 16-byte copy
         const int total = no * npair;
         double2* P2 = reinterpret_cast<double2*>(Pb);

@@ -34,7 +34,7 @@ _H = {name: i for i, name in enumerate([
     "RS_IMG_PARAMS", "DOFF_RS_CONST", "DOFF_DIAGCOEF", "NDIAGCOEF", "RS_NLTI", "OFF_RS_LTI",
     "RS_IMG_DMA", "RS_AB", "OFF_RS_ABMETA", "RR_PACKED", "OFF_RS_DPAR", "DOFF_RS_DCOEF",
     "RS_NGDESC", "OFF_RS_GDESC", "PM_NFD", "OFF_PM_MAP", "OFF_PM_FDPTR", "OFF_PM_OP", "PM_NOPS",
-    "DOFF_PM_POOL", "PM_NPOOL",
+    "DOFF_PM_POOL", "PM_NPOOL", "RS_NZBLK", "OFF_RS_ZBLK",
 ])}
 H_WORDS = 96
 assert len(_H) <= H_WORDS
@@ -696,7 +696,7 @@ def _resident_program(fused, gterms, no, ldv, image, ng, nparams, nc_rows):
 
     NT, NW = RS_NT, RS_NW
     z = np.zeros(0, dtype=np.int32)
-    out = dict(ok=0, jc=0, sym=0, src=z, gidx=z, dst=z, coef=np.zeros(0), trips=z, ntrip=0, split=z,
+    out = dict(ok=0, jc=0, sym=0, src=z, gidx=z, dst=z, coef=np.zeros(0), trips=z, ntrip=0, split=z, zblk=z,
                wtrip=np.zeros(RS_WAVES * 2, dtype=np.int32))
     if not fused["ok"] or image["img"] > 65535 or nparams > 65535:
         return out
@@ -902,6 +902,17 @@ def _resident_program(fused, gterms, no, ldv, image, ng, nparams, nc_rows):
         wtrip[2 * w + 1] = len(trips) - wtrip[2 * w]
     ntrip = len(trips)
     trips += [[0] * RS_TRIP_WORDS] * 2             # the kernel reads two records ahead
+    # blocks of P no term reaches (both triangles): exact zeros; the kernel that keeps P in LDS
+    # zeroes them once per workgroup, the one that writes P straight to HBM (wide problems)
+    # writes them per instance
+    reached = set()
+    for (bi, bj) in p_blocks:
+        reached.add((bi, bj))
+        if sym:
+            reached.add((bj, bi))
+    zblk = np.asarray([(bi << 8) | bj for bi in range(nb) for bj in range(nb)
+                       if (bi, bj) not in reached], dtype=np.int32)
+    out.update(zblk=zblk)
     out.update(ok=1, jc=jc, sym=sym, src=src.reshape(-1), gidx=gidx.reshape(-1),
                dst=dst.reshape(-1), coef=coef.reshape(-1),
                trips=np.asarray(trips, dtype=np.int32).reshape(-1), ntrip=ntrip, wtrip=wtrip,
@@ -1141,6 +1152,7 @@ def compile_plan(form, costs=None, limits=None, lti=()):
         ("OFF_RS_TRIP", resident["trips"]),
         ("OFF_RS_WTRIP", resident["wtrip"]),
         ("OFF_RS_SPLIT", resident["split"]),
+        ("OFF_RS_ZBLK", resident["zblk"]),
         ("OFF_RS_RR", rs_rr),
         ("OFF_RS_INMETA", image["meta"]),
         ("OFF_RS_ABMETA", image["ab_meta"]),
@@ -1234,6 +1246,7 @@ def compile_plan(form, costs=None, limits=None, lti=()):
     header[_H["RS_OK"]], header[_H["RS_JC"]] = resident["ok"], resident["jc"]
     header[_H["RS_SYM"]] = resident["sym"]
     header[_H["RS_NTRIP"]] = resident["ntrip"]
+    header[_H["RS_NZBLK"]] = resident["zblk"].size
     header[_H["RS_NSPLIT"]] = resident["split"].size
     header[_H["RS_UNIT"]], header[_H["RS_NCHUNK"]] = image["unit"], image["nchunk"]
     header[_H["RS_IMG"]] = image["img"]

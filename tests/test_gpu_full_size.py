@@ -210,3 +210,36 @@ def test_on_chip_horizon_tables_of_an_unstable_badly_conditioned_system(gpu_api,
     finally:
         lip.matrices = saved
         lip.update_definitions()
+
+
+@pytest.mark.parametrize("jit", [2, 1])
+def test_c3_on_the_persistent_kernel(gpu_api, torch_gpu, jit):
+    """C3 with its horizon matrices built on chip: one instance no longer fits in LDS with P
+    beside the workspace, so the persistent kernel sends the blocks of P straight to HBM (and
+    writes the blocks no term reaches as zeros, per instance).  Against the staged pipeline on
+    the same inputs (bit for bit where the arithmetic is the same: G, h) and the oracle."""
+    torch = torch_gpu
+    from mpcasm import capi
+    from mpcasm.engine import Assembler
+
+    form = problems.lipm3d(gpu_api, N=32)
+    B = 1500
+    rng = np.random.default_rng(9)
+    given = torch.as_tensor(rng.normal(0, 0.1, [B, form.given_len]), device="cuda")
+    lib = capi.load()
+    lib.mpcasm_set_option(capi.OPT_JIT, jit)
+    try:
+        one = Assembler(form, batch=B, lti=["LIP"])
+        # garbage in the result buffers first: every element must be written, zeros included
+        out = tuple(torch.full_like(t, float("nan")) for t in one.assemble(given))
+        P, q, G, h = (t.clone() for t in one.assemble(given, out=out))
+    finally:
+        lib.mpcasm_set_option(capi.OPT_JIT, 0)
+    assert not any(torch.isnan(t).any().item() for t in (P, q, G, h))
+    ref = Assembler(form, batch=B)
+    Ps, qs, Gs, hs = ref.assemble(given)
+    assert _rel(P, Ps) <= 1e-13 and _rel(q, qs) <= 1e-13 and _rel(G, Gs) <= 1e-13 and _rel(h, hs) <= 1e-13
+    for b in (0, B - 1):
+        Ao, ho, Qo, qo = orc.assemble(form, given[b].cpu().numpy().reshape(-1, 1))
+        assert_close(P[b].cpu().numpy(), Qo, RTOL_TIGHT), assert_close(q[b].cpu().numpy(), qo.ravel(), RTOL_TIGHT)
+        assert_close(G[b].cpu().numpy(), Ao, RTOL_TIGHT), assert_close(h[b].cpu().numpy(), ho.ravel(), RTOL_TIGHT)
