@@ -434,8 +434,9 @@ def run_rank(args):
             traffic = pmc["traffic_bytes_per_launch"]
     except (OSError, ValueError, KeyError):
         pass
-    kernel_name = "mpcasm_assemble -> resident_assemble_kernel (%sK2 compose + K3 hessian_mfma + " \
-                  "K4 constraint_stack fused in one persistent launch)" \
+    kernel_name = "mpcasm_assemble -> resident_spec_kernel: the persistent kernel (%sK2 compose + K3 " \
+                  "hessian_mfma + K4 constraint_stack in one launch) compiled for this plan by hiprtc; " \
+                  "resident_assemble_kernel (ahead of time) when libhiprtc.so is missing" \
                   % ("K1 horizon tables + " if fused else "")
     record = {
         "metric": METRIC,

@@ -52,7 +52,13 @@ def main():
     A = np.stack([get_A(tau=t) for t in taus])
     B = np.stack([get_B(tau=t) for t in taus])
     run("biped N=24, K1 fused", form, 16384, lti=("LIP", A, B))
-    run("C3 lipm3d N=32", problems.lipm3d(api, N=32), 16384)
+    form3 = problems.lipm3d(api, N=32)
+    run("C3 lipm3d N=32 (staged)", form3, 16384)
+    lip3 = form3.dynamics["LIP"]
+    # S[0][j][i] = A[i][j], U_0[0][0][i] = B[i][0]  (tools.py:14-33): the system's own (A, B)
+    run("C3 lipm3d N=32, K1 fused", form3, 16384,
+        lti=("LIP", np.broadcast_to(lip3.matrices[1][0].T, (16384, 3, 3)).copy(),
+             np.broadcast_to(lip3.matrices[0][0, 0, :, None], (16384, 3, 1)).copy()))
     run("C4 random LTI N=64", problems.random_lti(api, np.random.default_rng(20262), N=64), 256, 3)
 
 

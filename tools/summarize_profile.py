@@ -24,7 +24,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def short(name):
-    for key in ("resident_assemble_kernel", "fused_assemble_kernel", "fill_lti_tiny_kernel",
+    for key in ("resident_spec_kernel", "resident_assemble_kernel", "fused_assemble_kernel",
+                "fill_lti_quad_kernel", "fill_ltv_row_kernel", "fill_lti_tiny_kernel",
                 "fill_lti_kernel", "fill_ltv_wave_kernel", "fill_ltv_kernel", "compose_rowsets_kernel", "hessian_kernel",
                 "constraints_kernel", "compose_preview_kernel", "preview_kernel"):
         if key in name:
@@ -83,13 +84,14 @@ def main():
             "assemble_avg_launch_ms_hipEvent": bench["stats"]["roofline"]["avg_launch_ms"],
             "step": bench["stats"]["config"].get("step"),
         }
-        if "fill" in bench["stats"]:
+        if "fill_in_step" in bench["stats"]:
             summary["bench_in_profiled_run"]["fill_avg_launch_ms_hipEvent"] = \
-                bench["stats"]["fill"]["avg_launch_ms"]
+                bench["stats"]["fill_in_step"]["avg_launch_ms"]
     json.dump(summary, open(os.path.join(prof, tag + "_pmc.json"), "w"), indent=1)
-    dominant = "resident_assemble_kernel"
+    dominant = "resident_spec_kernel" if "resident_spec_kernel" in summary["kernels"] \
+        else "resident_assemble_kernel"
     if dominant in summary["kernels"]:
-        fused = "fill" not in bench.get("stats", bench.get("fetch", {}))
+        fused = "fill_in_step" not in bench.get("stats", bench.get("fetch", {}))
         json.dump({"kernel": dominant, "batch_per_gpu": batch, "source": tag + "_pmc.json",
                    "k1_fused": fused,
                    "traffic_bytes_per_launch": summary["kernels"][dominant]["hbm_bytes_per_launch"]},
