@@ -55,7 +55,8 @@ const char* mpcasm_status_string(int status);
  * the persistent kernel (per-instance fused kernel if it fits), 2 = always the
  * staged K2 -> K3 -> K4 pipeline with the workspace in HBM.  The parity tests use
  * it to exercise every path; all paths give the same results. */
-enum { MPCASM_OPT_PATH = 1, MPCASM_OPT_PHASE_MASK = 2, MPCASM_OPT_RESIDENT_PER_CU = 3, MPCASM_OPT_JIT = 4 };
+enum { MPCASM_OPT_PATH = 1, MPCASM_OPT_PHASE_MASK = 2, MPCASM_OPT_RESIDENT_PER_CU = 3, MPCASM_OPT_JIT = 4,
+       MPCASM_OPT_P_DIRECT = 5 };
 /* MPCASM_OPT_PHASE_MASK is a profiling aid (timing-only ablation of the fused
  * kernels: bit 0 compose, 1 Hessian, 2 gradient, 3 constraints, 4 input staging
  * after the first instance, 5 P/q stores, 7 register prefetch of the next instance's
@@ -70,6 +71,9 @@ enum { MPCASM_OPT_PATH = 1, MPCASM_OPT_PHASE_MASK = 2, MPCASM_OPT_RESIDENT_PER_C
  * kernel): 0 (default) = for batches of at least 1024 instances, when libhiprtc.so is there
  * (compiled once per plan structure and device, on the first such launch: that launch blocks
  * for the compilation, a second or two); 1 = for every batch; 2 = never.
+ * MPCASM_OPT_P_DIRECT (read by mpcasm_plan_create): how the persistent kernel writes P -- 0
+ * (default) and 1: its 4x4 blocks go from the matrix core straight to HBM; 2: collected in LDS and
+ * copied out with 16-byte stores whenever P fits there beside the workspace.
  * These options are process-wide test / tuning hooks, not part of a launch's state: set them
  * before other threads start launching. */
 int mpcasm_set_option(int option, int value);

@@ -16,6 +16,7 @@
 using namespace mpcasm;
 
 namespace mpcasm {
+int g_p_direct = 0;  // MPCASM_OPT_P_DIRECT (read when a plan is created)
 extern int g_path;
 extern int g_phase_mask;
 extern int g_resident_per_cu;
@@ -457,6 +458,7 @@ void plan_dev_from_tables(const int32_t* it, PlanDev* out) {
   }
   // the op table is read as int2: keep its word offset even (the compiler pads it)
   if (d.fused_ok && (d.off_op & 1)) d.fused_ok = 0;
+  d.rs_p_direct = d.rs_ok ? resident_choose_p_direct(d, g_p_direct) : 0;
 }
 
 }  // namespace
@@ -481,6 +483,11 @@ int mpcasm_set_option(int option, int value) {
   }
   if (option == MPCASM_OPT_PHASE_MASK) {
     g_phase_mask = value;
+    return MPCASM_OK;
+  }
+  if (option == MPCASM_OPT_P_DIRECT) {
+    if (value < 0 || value > 2) return MPCASM_ERR_ARG;
+    g_p_direct = value;
     return MPCASM_OK;
   }
   if (option == MPCASM_OPT_JIT) {

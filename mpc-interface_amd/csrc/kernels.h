@@ -26,6 +26,7 @@ int launch_assemble_fused(const PlanDev& p, const SrcTable& src, const double* p
                           int batch, size_t lds_bytes, hipStream_t stream, hipError_t* err);
 // resident.hip
 size_t resident_lds_bytes(const PlanDev& p);
+int resident_choose_p_direct(const PlanDev& p, int option);
 // whether this launch's buffers meet the alignment the plan's input loads assume
 bool resident_inputs_aligned(const PlanDev& p, const SrcTable& src, const double* params,
                              const double* given);

@@ -18,15 +18,17 @@ pytestmark = pytest.mark.gpu
 # path name -> (MPCASM_OPT_PATH, MPCASM_OPT_JIT): the persistent kernel ahead of time and
 # compiled per plan by hiprtc (forced on for every batch size here), the per-instance fused
 # kernel, the staged pipeline
-PATHS = {"resident": (0, 2), "resident-jit": (0, 1), "fused": (1, 2), "staged": (2, 2)}
-RESIDENT = ("resident", "resident-jit")
+PATHS = {"resident": (0, 2, 0), "resident-jit": (0, 1, 0), "resident-lds": (0, 2, 2),
+         "fused": (1, 2, 0), "staged": (2, 2, 0)}     # (..., MPCASM_OPT_P_DIRECT)
+RESIDENT = ("resident", "resident-jit", "resident-lds")
 
 
 @pytest.fixture(autouse=True, params=list(PATHS))
 def kernel_path(request):
-    """Every test runs on each assembly path: the persistent fused kernel (ahead of time, and
-    specialised for the plan at run time), the per-instance fused kernel (all taken only when
-    one instance fits on chip) and the staged K2 -> K3 -> K4 pipeline."""
+    """Every test runs on each assembly path: the persistent fused kernel (ahead of time,
+    specialised for the plan at run time, and with P collected in LDS instead of stored block by
+    block), the per-instance fused kernel (all taken only when one instance fits on chip) and
+    the staged K2 -> K3 -> K4 pipeline."""
     import torch
 
     if not torch.cuda.is_available():
@@ -36,9 +38,11 @@ def kernel_path(request):
     lib = capi.load()
     assert lib.mpcasm_set_option(capi.OPT_PATH, PATHS[request.param][0]) == 0
     assert lib.mpcasm_set_option(capi.OPT_JIT, PATHS[request.param][1]) == 0
+    assert lib.mpcasm_set_option(capi.OPT_P_DIRECT, PATHS[request.param][2]) == 0
     yield request.param
     lib.mpcasm_set_option(capi.OPT_PATH, 0)
     lib.mpcasm_set_option(capi.OPT_JIT, 0)
+    lib.mpcasm_set_option(capi.OPT_P_DIRECT, 0)
 
 
 def check_drop_in(form, g, prefix, parts=True):

@@ -22,7 +22,9 @@ def main():
         work = bench.build_workload(min(B, 4096), 1)
         times = (B + 4095) // 4096
         tile = lambda x: np.concatenate([x] * times)[:B]
+        lib.mpcasm_set_option(capi.OPT_P_DIRECT, int(os.environ.get("MPCASM_P_DIRECT", "0")))
         asm = work["engine"].Assembler(work["form"], batch=B, lti=["LIP"])
+        lib.mpcasm_set_option(capi.OPT_P_DIRECT, 0)
         asm.bind_lti("LIP", torch.as_tensor(tile(work["A"]), device="cuda"),
                      torch.as_tensor(tile(work["B"]), device="cuda"))
         given = torch.as_tensor(tile(work["given"]), device="cuda")
