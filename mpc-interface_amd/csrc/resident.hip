@@ -14,21 +14,21 @@
 // The wavefronts SPECIALISE.  Waves 0-3 ("matrix waves") are the only ones that read
 // HBM: they fetch the next instance's input image with LDS-DMA loads
 // (global_load_lds_dwordx4: no registers, no staging pass) into the other half of a
-// double buffer, and run the Hessian tiles on the fp64 matrix core
-// (v_mfma_f64_16x16x4_f64).  The gradient rides along: column `no` of a workspace row
-// holds d, so the tile column that contains it yields q = sum_k w a[k][.] s (d[k] - aim)
-// from the same products.  Waves 4-7 ("stream waves") only write HBM: the rows of G
-// and h while the matrix waves work on P.  A wave's memory counter (vmcnt) therefore
-// never mixes a load it must wait for with a store it need not wait for.
+// double buffer.  Waves 4-7 ("stream waves") write the rows of G and h.  All eight run the
+// Hessian and gradient on the fp64 matrix core in 4x4 blocks (v_mfma_f64_4x4x4_4b_f64, four
+// independent blocks per instruction; plan_tables.h RT_*): the workspace keeps the four rows a
+// lane feeds to four k-steps side by side (two ds_read_b128 per operand), a term's weight is
+// applied once to its block sum, the gradient rides along through a column of ones, and the
+// blocks of P go from the accumulators straight to HBM (or, optionally, through LDS).
 //
 // Per instance, three barriers:
-//   A | all: diagonal terms, K2 compose the workspace V[rtot][no+1] = [Mo | d = Mg.given]
-//       from the image (Mg is never stored; the preview matrices never touch HBM)
-//   B | matrix waves: start the next image's loads, Hessian + gradient tiles -> P, q in LDS
-//       (structurally-zero tiles skipped, only ti <= tj when every term is symmetric,
-//       mirrored on the way); stream waves: G, h -> HBM
+//   A | all: diagonal terms, K2 compose the workspace V = [Mo | d = Mg.given | 1] from the
+//       image (Mg is never stored; the preview matrices never touch HBM)
+//   B | matrix waves: start the next image's loads; everyone: its packs of blocks -> P (HBM),
+//       q (LDS); stream waves: G, h -> HBM; the last matrix wave: the next instance's
+//       horizon tables when they are generated on chip
 //   C | matrix waves: wait for the image, clear the workspace elements that two threads
-//       add into; all: P, q -> HBM with 16-byte stores
+//       add into; all: q and the zero blocks of P -> HBM
 // Barriers order LDS only (lds_barrier), so result stores stay in flight across phases.
 // Within a phase all operand loads are issued before the first use (explicit load
 // batches), because the compiler will not hoist LDS reads over LDS writes of the same
