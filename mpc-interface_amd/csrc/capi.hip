@@ -741,7 +741,7 @@ int launch_assemble(const PlanDev& p, const SrcTable& src, const double* params,
     if (h_itab != nullptr)
       if (const void* k = jit_kernel_for(p, h_itab, device, batch, rs))
         return jit_launch(k, p, src, params, given, P, q, G, h, batch, num_cus, g_resident_per_cu,
-                          stream, err);
+                          work, stream, err);
     return launch_assemble_resident(p, src, params, given, P, q, G, h, work, batch, rs, num_cus,
                                     stream, err);
   }

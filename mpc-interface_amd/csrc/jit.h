@@ -16,12 +16,13 @@ extern int g_phase_mask;  // fused.hip
 // "plan_spec.h" of a plan: its sizes and trip lists as constants
 std::string jit_spec_header(const PlanDev& d, const int32_t* h_itab);
 // resident.hip + that header -> gfx950 code object (needs libhiprtc.so, no device)
-int jit_compile(const std::string& header, std::vector<char>* code, std::string* log);
+int jit_compile(const std::string& header, std::vector<char>* code, std::string* log,
+                bool stamps = false);
 // the compiled kernel of (plan structure, device), or nullptr: use the ahead-of-time kernel
 const void* jit_kernel_for(const PlanDev& d, const int32_t* h_itab, int device, int batch,
                            size_t lds_bytes);
 int jit_launch(const void* kernel, const PlanDev& p, const SrcTable& src, const double* params,
                const double* given, double* P, double* q, double* G, double* h, int batch,
-               int num_cus, int per_cu_limit, hipStream_t stream, hipError_t* err);
+               int num_cus, int per_cu_limit, void* work, hipStream_t stream, hipError_t* err);
 
 }  // namespace mpcasm

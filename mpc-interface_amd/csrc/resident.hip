@@ -1055,13 +1055,21 @@ __device__ __forceinline__ void resident_body(
 #ifdef MPCASM_SPEC
 }  // namespace
 // the kernel of ONE plan (hiprtc): everything about the plan is a constant
-extern "C" __global__ __launch_bounds__(RS_NT, 4) void resident_spec_kernel(
+#ifndef MPCASM_SPEC_WAVES_PER_EU
+#define MPCASM_SPEC_WAVES_PER_EU 4
+#endif
+extern "C" __global__ __launch_bounds__(RS_NT, MPCASM_SPEC_WAVES_PER_EU) void resident_spec_kernel(
     const int32_t* __restrict__ plan_itab, const double* __restrict__ plan_dtab, SrcTable src,
     const double* __restrict__ params, const double* __restrict__ given, double* __restrict__ P,
     double* __restrict__ q, double* __restrict__ G, double* __restrict__ h, int batch, int phases,
     unsigned long long* __restrict__ stamps) {
   constexpr spec::PlanConst p{};
-  resident_body<spec::JC, false, spec::PlanConst::rs_nlti != 0>(p, plan_itab, plan_dtab, src, params,
+#ifdef MPCASM_SPEC_STAMPS  // diagnostic build (MPCASM_OPT_PHASE_MASK bit 6): per-wave cycle sums
+  constexpr bool stamped = true;
+#else
+  constexpr bool stamped = false;
+#endif
+  resident_body<spec::JC, stamped, spec::PlanConst::rs_nlti != 0>(p, plan_itab, plan_dtab, src, params,
                                                                given, P, q, G, h, batch, phases, stamps);
 }
 namespace {

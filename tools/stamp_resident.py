@@ -28,6 +28,8 @@ def main():
         asm.bind_lti("LIP", torch.as_tensor(work["A"], device="cuda"), torch.as_tensor(work["B"], device="cuda"))
     given = torch.as_tensor(work["given"], device="cuda")
     lib = capi.load()
+    if os.environ.get("MPCASM_JIT"):
+        lib.mpcasm_set_option(capi.OPT_JIT, int(os.environ["MPCASM_JIT"]))
     for _ in range(3):
         asm.assemble(given)
     lib.mpcasm_set_option(capi.OPT_PHASE_MASK, capi.PHASE_DEFAULT | capi.PHASE_STAMPS)
