@@ -40,7 +40,31 @@ __host__ __device__ inline size_t lti_lds_doubles(int N, int n, int m) {
   return even_up((size_t)m * N * n) + 2 * even_up((size_t)n * (m + n)) + even_up((size_t)n * n);
 }
 
-template <int TPI, bool GENERIC>
+// `count2` sixteen-byte words from LDS (8-byte aligned: ds_read2_b64) to HBM, lane q handles
+// words q, q + 64, ...; UNR reads go out before the first store waits for them.  `src` and `dst`
+// already carry the lane's own offset (2 lane doubles / lane words).
+template <int UNR>
+__device__ __forceinline__ void stream_words(const double* __restrict__ src,
+                                             double2* __restrict__ dst, int count2, int lane) {
+  const int last = count2 - 1 - lane;   // (clamped reads stay inside the run; stores are masked)
+  for (int base = 0; base < count2; base += 64 * UNR) {
+    double2 v[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int q = min(base + 64 * u, last);
+      v[u].x = src[2 * q];
+      v[u].y = src[2 * q + 1];
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u)
+      if (base + 64 * u <= last) dst[base + 64 * u] = v[u];
+  }
+}
+
+// PAD (one system per workgroup, N n even): every input's table is followed by N n zeros, so
+// that a row of U is one window of it (see fill_lti_quad_kernel) and the wavefronts stream whole
+// rows with a constant-address loop instead of walking (row, position) counters with selects.
+template <int TPI, bool GENERIC, bool PAD = false>
 __global__ __launch_bounds__(BLOCK) void fill_lti_kernel(const double* __restrict__ A,
                                                          const double* __restrict__ B,
                                                          double* __restrict__ S,
@@ -56,8 +80,9 @@ __global__ __launch_bounds__(BLOCK) void fill_lti_kernel(const double* __restric
   const int rl = N * n;        // doubles in one output row U[j][k][:][:]
   const int xw = m + n;        // columns of X = [A^d B | A^{d+1}]
   const int xsz = n * xw;
-  double* R = lds + (size_t)slot * lti_lds_doubles(N, n, m);  // [m][rl] block-reversed A^d B
-  double* X = R + even_up((size_t)m * rl);                    // [2][xw][n] column-major
+  const int rs = PAD ? 2 * rl : rl;  // doubles from one input's table to the next
+  double* R = lds + (size_t)slot * lti_lds_doubles(N, n, m);  // [m][rs] block-reversed A^d B (| zeros)
+  double* X = R + even_up((size_t)m * rs);                    // [2][xw][n] column-major
   double* Am = X + 2 * even_up((size_t)xsz);                  // [n][n] row-major
   const size_t xstep = even_up((size_t)xsz);
 
@@ -91,13 +116,16 @@ __global__ __launch_bounds__(BLOCK) void fill_lti_kernel(const double* __restric
     }
   };
 
+  if (PAD) {  // the upper halves of the tables: zeros for the whole launch of this workgroup
+    for (int e = tid; e < m * rl; e += TPI) R[(size_t)(e / rl) * rs + rl + (e % rl)] = 0.0;
+  }
   if (live) {
     for (int e = tid; e < n * n; e += TPI) Am[e] = Ab[e];
     for_each_element([&](int e, int c, int i) {
       if (c < m) {
         const double v = Bb[i * m + c];
         X[e] = v;
-        R[(size_t)c * rl + (size_t)(N - 1) * n + i] = v;  // d = 0
+        R[(size_t)c * rs + (size_t)(N - 1) * n + i] = v;  // d = 0
       } else {
         const double v = Ab[i * n + (c - m)];
         X[e] = v;
@@ -117,7 +145,7 @@ __global__ __launch_bounds__(BLOCK) void fill_lti_kernel(const double* __restric
         for (int t = 0; t < n; ++t) v = fma(Am[i * n + t], Xp[c * n + t], v);
         Xc[e] = v;
         if (c < m)
-          R[(size_t)c * rl + (size_t)(N - 1 - d) * n + i] = v;
+          R[(size_t)c * rs + (size_t)(N - 1 - d) * n + i] = v;
         else
           Sb[(size_t)d * n * n + (e - n * m)] = v;
       });
@@ -127,6 +155,16 @@ __global__ __launch_bounds__(BLOCK) void fill_lti_kernel(const double* __restric
 
   if (!live) return;
 
+  if (PAD) {
+    // rows (j, k) dealt to the wavefronts: row = window of [R_j | zeros] at (N-1-k) n
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, rl2 = rl >> 1;
+    for (int row = wave; row < m * N; row += TPI / 64) {
+      const int j = row / N, k = row - j * N;
+      stream_words<6>(R + (size_t)j * rs + (size_t)(N - 1 - k) * n + 2 * lane,
+                      reinterpret_cast<double2*>(Ub + (size_t)row * rl) + lane, rl2, lane);
+    }
+    return;
+  }
   // write phase: row (j, k) = window of R_j shifted by (N-1-k) n, zeros after (k+1) n
   if ((rl & 1) == 0) {
     const int rl2 = rl >> 1;
@@ -674,27 +712,6 @@ __host__ __device__ inline size_t quad_lds_doubles(int N, int n, int m, int spw)
   return (size_t)spw * ((size_t)N * n * n + (size_t)m * 2 * N * n) + 64;   // + idle lanes' scratch
 }
 
-// `count2` sixteen-byte words from LDS (8-byte aligned: ds_read2_b64) to HBM, lane q handles
-// words q, q + 64, ...; UNR reads go out before the first store waits for them.  `src` and `dst`
-// already carry the lane's own offset (2 lane doubles / lane words).
-template <int UNR>
-__device__ __forceinline__ void stream_words(const double* __restrict__ src,
-                                             double2* __restrict__ dst, int count2, int lane) {
-  const int last = count2 - 1 - lane;   // (clamped reads stay inside the run; stores are masked)
-  for (int base = 0; base < count2; base += 64 * UNR) {
-    double2 v[UNR];
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      const int q = min(base + 64 * u, last);
-      v[u].x = src[2 * q];
-      v[u].y = src[2 * q + 1];
-    }
-#pragma unroll
-    for (int u = 0; u < UNR; ++u)
-      if (base + 64 * u <= last) dst[base + 64 * u] = v[u];
-  }
-}
-
 template <int NS>
 __global__ __launch_bounds__(64) void fill_lti_quad_kernel(const double* __restrict__ A,
                                                            const double* __restrict__ B,
@@ -1072,6 +1089,15 @@ int launch_fill_su(const double* A, const double* B, double* S, double* U, int b
     } else if (per > LDS_MAX) {
       return MPCASM_ERR_LIMIT;  // the A^d B table of one system must fit in LDS
     } else if (xsz <= BLOCK * EPT) {
+      const size_t padded = per + (size_t)m * N * n * sizeof(double);
+      if (pairs && padded <= 78 * 1024) {  // (two workgroups still share a CU)
+        if ((*err = allow_lds(fill_lti_kernel<BLOCK, false, true>, padded)) != hipSuccess)
+          return MPCASM_ERR_HIP;
+        hipLaunchKernelGGL((fill_lti_kernel<BLOCK, false, true>), dim3(batch), dim3(BLOCK), padded,
+                           stream, A, B, S, U, batch, N, n, m);
+        *err = hipGetLastError();
+        return *err == hipSuccess ? MPCASM_OK : MPCASM_ERR_HIP;
+      }
       if ((*err = allow_lds(fill_lti_kernel<BLOCK, false>, per)) != hipSuccess)
         return MPCASM_ERR_HIP;
       hipLaunchKernelGGL((fill_lti_kernel<BLOCK, false>), dim3(batch), dim3(BLOCK), per, stream, A,
