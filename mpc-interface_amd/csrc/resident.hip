@@ -704,6 +704,8 @@ __device__ __forceinline__ void resident_body(
       if (G != nullptr && (phases & 8)) {
         // ---- K4: constraint rows straight to HBM ---------------------------------------
         double* Gb = G + (size_t)inst * nc * no;
+        int four = 4;  // (the distance, in doubles, between two columns of a workspace row)
+        asm volatile("" : "+v"(four));
         if (g_mode == 2) {
           // per piece: its packed descriptor -> arrows and workspace rows -> arithmetic ->
           // one 16-byte store; the reads of three pieces are in flight together
@@ -739,8 +741,10 @@ __device__ __forceinline__ void resident_body(
               a0[u] = prm[ds[u].y & 0xFFFF];
               a1[u] = prm[(unsigned)ds[u].y >> 16];
               // (columns 2cp, 2cp+1 of a row lie four doubles apart: one ds_read2_b64)
-              v0[u] = double2{V[ds[u].x & 0xFFFF], V[(ds[u].x & 0xFFFF) + 4]};
-              v1[u] = double2{V[(unsigned)ds[u].x >> 16], V[((unsigned)ds[u].x >> 16) + 4]};
+              // ... as TWO ds_read_b64 (2 LDS cycles each, 64 banks) -- the compiler would fuse
+              // them into one ds_read2_b64 (8 cycles, 32 banks); `four` is opaque to it
+              v0[u] = double2{V[ds[u].x & 0xFFFF], V[(ds[u].x & 0xFFFF) + four]};
+              v1[u] = double2{V[(unsigned)ds[u].x >> 16], V[((unsigned)ds[u].x >> 16) + four]};
             }
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
@@ -786,8 +790,8 @@ __device__ __forceinline__ void resident_body(
             for (int u = 0; u < 3; ++u) {
               a0[u] = prm[ds[u].y & 0xFFFF];
               a1[u] = prm[(unsigned)ds[u].y >> 16];
-              v0[u] = double2{V[(ds[u].x & 0xFFFF) + c2[u]], V[(ds[u].x & 0xFFFF) + c2[u] + 4]};
-              v1[u] = double2{V[((unsigned)ds[u].x >> 16) + c2[u]], V[((unsigned)ds[u].x >> 16) + c2[u] + 4]};
+              v0[u] = double2{V[(ds[u].x & 0xFFFF) + c2[u]], V[(ds[u].x & 0xFFFF) + c2[u] + four]};
+              v1[u] = double2{V[((unsigned)ds[u].x >> 16) + c2[u]], V[((unsigned)ds[u].x >> 16) + c2[u] + four]};
             }
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
