@@ -268,6 +268,8 @@ int validate_plan(const int32_t* it, const double* h_dtab, size_t n_itab, size_t
       const int64_t ngd = it[H_RS_NGDESC];
       if (ngd != 0) {
         const int64_t pieces = nc * (no / 2);
+        if (it[H_RS_GSINGLE] < 0 || (it[H_RS_GSINGLE] >> (RS_GDESC_PIECES * (RS_GDESC_THREADS / 64))) != 0)
+          return MPCASM_ERR_PLAN;
         if (!it[H_RR_PACKED] || ngd != (int64_t)RS_GDESC_PIECES * RS_GDESC_THREADS || pieces > ngd ||
             !in_range(it[H_OFF_RS_GDESC], ngd * 2, n, H_WORDS) || it[H_OFF_RS_GDESC] % 2)
           return MPCASM_ERR_PLAN;
@@ -275,9 +277,11 @@ int validate_plan(const int32_t* it, const double* h_dtab, size_t n_itab, size_t
         for (int64_t e = 0; e < ngd; ++e) {  // the same numbers as the row record of the piece
           const int64_t R = e < pieces ? e / (no / 2) : 0, cp = e < pieces ? e % (no / 2) : 0;
           const int32_t* x = rrw + R * RS_RR_WORDS;
-          if ((uint32_t)gd[2 * e] != (((uint32_t)x[RR_VOFF] + 8 * cp) | (((uint32_t)x[RR_VOFF + 1] + 8 * cp) << 16)) ||
-              (uint32_t)gd[2 * e + 1] != (uint32_t)x[RR_PACKED + 1])
-            return MPCASM_ERR_PLAN;
+          const uint32_t v0 = (uint32_t)x[RR_VOFF] + 8 * cp, v1 = (uint32_t)x[RR_VOFF + 1] + 8 * cp;
+          const uint32_t a0 = (uint32_t)x[RR_ARROW], a1 = (uint32_t)x[RR_ARROW + 1];
+          const bool as_is = (uint32_t)gd[2 * e] == (v0 | (v1 << 16)) && (uint32_t)gd[2 * e + 1] == (a0 | (a1 << 16));
+          const bool swapped = (uint32_t)gd[2 * e] == (v1 | (v0 << 16)) && (uint32_t)gd[2 * e + 1] == (a1 | (a0 << 16));
+          if (!as_is && !swapped) return MPCASM_ERR_PLAN;
         }
       }
     }
@@ -435,6 +439,7 @@ void plan_dev_from_tables(const int32_t* it, PlanDev* out) {
   d.off_rs_dpar = it[H_OFF_RS_DPAR]; d.doff_rs_dcoef = it[H_DOFF_RS_DCOEF];
   d.rs_ngdesc = it[H_RS_NGDESC]; d.off_rs_gdesc = it[H_OFF_RS_GDESC];
   d.rs_nzblk = it[H_RS_NZBLK]; d.off_rs_zblk = it[H_OFF_RS_ZBLK];
+  d.rs_gsingle = it[H_RS_GSINGLE];
   d.pm_nfd = it[H_PM_NFD]; d.off_pm_map = it[H_OFF_PM_MAP]; d.off_pm_fdptr = it[H_OFF_PM_FDPTR];
   d.off_pm_op = it[H_OFF_PM_OP]; d.doff_pm_pool = it[H_DOFF_PM_POOL];
   d.rs_src16 = 0;

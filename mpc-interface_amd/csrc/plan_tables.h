@@ -120,7 +120,8 @@ enum HeaderWord : int {
   H_RS_NGDESC,      // RS_GDESC_PIECES * RS_GDESC_THREADS when the table below exists, else 0
   H_OFF_RS_GDESC,   // [RS_NGDESC][2] small problems: a ready-made descriptor of every 16-byte piece of
                     //    G; piece e = columns 2cp, 2cp+1 of row R = e / (no/2):
-                    //    (voff0 + 8cp) | (voff1 + 8cp) << 16, arrow0 | arrow1 << 16
+                    //    (voff0 + 8cp) | (voff1 + 8cp) << 16, arrow0 | arrow1 << 16 -- the two axes
+                    //    in either order (the one that can be non-zero first, see H_RS_GSINGLE)
   // the preview matrices [Mg | Mo] element by element (0 elements: the tables are absent and
   // K2 alone walks the row program): H_OFF_PM_MAP [PMROWS * (NG + NO)] index of the element's
   // op list or -1 (structural zero); element i = sum over ops H_OFF_PM_FDPTR[i] .. [i+1] of
@@ -135,6 +136,9 @@ enum HeaderWord : int {
   H_PM_NPOOL,
   H_RS_NZBLK,       // 4x4 blocks of P no term reaches (both triangles): exact zeros
   H_OFF_RS_ZBLK,    // [RS_NZBLK] block row << 8 | block column
+  H_RS_GSINGLE,     // bit u * 4 + w: every piece of G of round u of stream wave w (descriptor table)
+                    //    has at most ONE axis that can be non-zero in its columns -- the first of
+                    //    its descriptor: the second workspace row and arrow are not read
   H_WORDS = 96
 };
 

@@ -715,6 +715,8 @@ __device__ __forceinline__ void resident_body(
           // h of row wt_ rides with the first batch of pieces: its chain of dependent LDS
           // reads (record -> parameters, d -> arithmetic) costs a wave as much as a whole
           // batch when it runs on its own after G
+          // (compiled for the plan this is a constant: the branches below fold away)
+          const bool all_single = p.rs_gsingle == (1 << (GU * (WT / 64))) - 1;
           const bool h_mine = wt_ < nc;
           const int4 hc4 = reinterpret_cast<const int4*>(rr)[h_mine ? wt_ : 0];  // compact record
           const int4 hr = int4{0, hc4.w, hc4.x, hc4.y};  // -, extreme, packed rows, packed arrows
@@ -734,24 +736,35 @@ __device__ __forceinline__ void resident_body(
               hd1 = V[((unsigned)hr.z >> 16) + 4 * no];
               hext = prm[hr.y];
             }
+            // rounds whose pieces all have one axis that can be non-zero (p.rs_gsingle: known to
+            // the plan compiler, wave-uniform) read one workspace row and one arrow
             double a0[3], a1[3];
             double2 v0[3], v1[3];
+            bool one[3];
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
+              one[u] = all_single || ((p.rs_gsingle >> ((u0 + u) * (WT / 64) + (wave - MW))) & 1);
               a0[u] = prm[ds[u].y & 0xFFFF];
-              a1[u] = prm[(unsigned)ds[u].y >> 16];
-              // (columns 2cp, 2cp+1 of a row lie four doubles apart: one ds_read2_b64)
-              // ... as TWO ds_read_b64 (2 LDS cycles each, 64 banks) -- the compiler would fuse
-              // them into one ds_read2_b64 (8 cycles, 32 banks); `four` is opaque to it
+              // (columns 2cp, 2cp+1 of a row lie four doubles apart) ... as TWO ds_read_b64 (2 LDS
+              // cycles each, 64 banks) -- the compiler would fuse them into one ds_read2_b64 (8
+              // cycles, 32 banks); `four` is opaque to it
               v0[u] = double2{V[ds[u].x & 0xFFFF], V[(ds[u].x & 0xFFFF) + four]};
-              v1[u] = double2{V[(unsigned)ds[u].x >> 16], V[((unsigned)ds[u].x >> 16) + four]};
+              if (!one[u]) {
+                a1[u] = prm[(unsigned)ds[u].y >> 16];
+                v1[u] = double2{V[(unsigned)ds[u].x >> 16], V[((unsigned)ds[u].x >> 16) + four]};
+              }
             }
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
               const int e = wt_ + (u0 + u) * WT;
               double2 r;
-              r.x = fma(a1[u], v1[u].x, a0[u] * v0[u].x);
-              r.y = fma(a1[u], v1[u].y, a0[u] * v0[u].y);
+              if (one[u]) {
+                r.x = a0[u] * v0[u].x;
+                r.y = a0[u] * v0[u].y;
+              } else {
+                r.x = fma(a1[u], v1[u].x, a0[u] * v0[u].x);
+                r.y = fma(a1[u], v1[u].y, a0[u] * v0[u].y);
+              }
               if (e < gtotal) G2[e] = r;
             }
             if (u0 == 0 && h_mine) {  // h = (extreme + arrow . center) - arrow . d   (body.py:264)

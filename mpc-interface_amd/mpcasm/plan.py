@@ -34,7 +34,7 @@ _H = {name: i for i, name in enumerate([
     "RS_IMG_PARAMS", "DOFF_RS_CONST", "DOFF_DIAGCOEF", "NDIAGCOEF", "RS_NLTI", "OFF_RS_LTI",
     "RS_IMG_DMA", "RS_AB", "OFF_RS_ABMETA", "RR_PACKED", "OFF_RS_DPAR", "DOFF_RS_DCOEF",
     "RS_NGDESC", "OFF_RS_GDESC", "PM_NFD", "OFF_PM_MAP", "OFF_PM_FDPTR", "OFF_PM_OP", "PM_NOPS",
-    "DOFF_PM_POOL", "PM_NPOOL", "RS_NZBLK", "OFF_RS_ZBLK",
+    "DOFF_PM_POOL", "PM_NPOOL", "RS_NZBLK", "OFF_RS_ZBLK", "RS_GSINGLE",
 ])}
 H_WORDS = 96
 assert len(_H) <= H_WORDS
@@ -1178,6 +1178,7 @@ def compile_plan(form, costs=None, limits=None, lti=()):
     # thread owns: piece e = t + u RS_GDESC_THREADS, columns 2cp, 2cp+1 of row R = e // (no/2):
     # rs_index(row0, 2cp) | rs_index(row1, 2cp) << 16, arrow0 | arrow1 << 16
     rs_gdesc = np.zeros(0, dtype=np.int32)
+    rs_gsingle = 0
     rr_ok = rs_rr.size == nc * RS_RR_WORDS
     packed_ok = (rr_ok and no % 2 == 0 and nc > 0 and (b.rtot + 8) * ldv < 65536
                  and len(b.params) < 65535
@@ -1188,9 +1189,33 @@ def compile_plan(form, costs=None, limits=None, lti=()):
         live = e < nc * (no // 2)
         R = np.where(live, e // (no // 2), 0)
         cp = np.where(live, e % (no // 2), 0)
-        word0 = (recs[R, 0] + 8 * cp) | ((recs[R, 1] + 8 * cp) << 16)    # rs_index(row, 2 cp)
-        word1 = recs[R, 4] | (recs[R, 5] << 16)
+        # Which of a piece's (at most two) axes can be non-zero in its two columns at all: an
+        # element of the workspace nothing is composed into is an exact zero.  The axis that can
+        # goes first; where all 64 pieces of one wavefront's round have at most one such axis
+        # (the usual case: a variable per axis, columns partitioned by axis) the kernel reads one
+        # workspace row and one arrow instead of two (bit u * 4 + wave of RS_GSINGLE).
+        nz = np.zeros(max(rtot, 1) * ldv, dtype=bool)
+        nz[fused["fd_idx"]] = True
+        nz = nz.reshape(-1, ldv)
+
+        def can(voff, col):                              # voff = rs_index(row, 0)
+            row = (voff // (4 * ldv)) * 4 + voff % (4 * ldv)
+            return nz[row, col] | nz[row, col + 1]
+
+        v0, v1, a0, a1 = recs[R, 0], recs[R, 1], recs[R, 4], recs[R, 5]
+        two = recs[R, 12] >= 2
+        c0, c1 = can(v0, 2 * cp), two & can(v1, 2 * cp)
+        swap = c1 & ~c0                                  # only the second axis can: it goes first
+        v0, v1 = np.where(swap, v1, v0), np.where(swap, v0, v1)
+        a0, a1 = np.where(swap, a1, a0), np.where(swap, a0, a1)
+        single = ~(c0 & c1) | ~live
+        word0 = (v0 + 8 * cp) | ((v1 + 8 * cp) << 16)    # rs_index(row, 2 cp)
+        word1 = a0 | (a1 << 16)
         rs_gdesc = np.stack([word0, word1], axis=1).astype(np.uint32).view(np.int32).reshape(-1)
+        rounds = single.reshape(RS_GDESC_PIECES, RS_GDESC_THREADS // 64, 64).all(axis=2)
+        rs_gsingle = int(sum(1 << (u * (RS_GDESC_THREADS // 64) + w)
+                             for u in range(RS_GDESC_PIECES) for w in range(RS_GDESC_THREADS // 64)
+                             if rounds[u, w]))
     pmprog = _preview_program(b, pm_rowptr, pm_entbase, pm_entk, pm_entcoef, pmrows)
     sections += [("OFF_RS_DPAR", rs_dpar.reshape(-1)), ("OFF_RS_GDESC", rs_gdesc),
                  ("OFF_PM_MAP", pmprog["map"]), ("OFF_PM_FDPTR", pmprog["fd_ptr"]),
@@ -1246,6 +1271,7 @@ def compile_plan(form, costs=None, limits=None, lti=()):
     header[_H["RS_OK"]], header[_H["RS_JC"]] = resident["ok"], resident["jc"]
     header[_H["RS_SYM"]] = resident["sym"]
     header[_H["RS_NTRIP"]] = resident["ntrip"]
+    header[_H["RS_GSINGLE"]] = rs_gsingle
     header[_H["RS_NZBLK"]] = resident["zblk"].size
     header[_H["RS_NSPLIT"]] = resident["split"].size
     header[_H["RS_UNIT"]], header[_H["RS_NCHUNK"]] = image["unit"], image["nchunk"]

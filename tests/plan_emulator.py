@@ -338,8 +338,16 @@ def run_resident(plan, given, params=None, sources=None):
         assert it[H["RR_PACKED"]] and len(gd) >= nc * (no // 2)
         for e in range(nc * (no // 2)):
             R, cp = divmod(e, no // 2)
-            assert gd[e, 0] == (rr[R, 0] + 8 * cp) | ((rr[R, 1] + 8 * cp) << 16)
-            assert gd[e, 1] == rr[R, 4] | (rr[R, 5] << 16)
+            v0, v1, a0, a1 = rr[R, 0] + 8 * cp, rr[R, 1] + 8 * cp, rr[R, 4], rr[R, 5]
+            as_is = gd[e, 0] == v0 | (v1 << 16) and gd[e, 1] == a0 | (a1 << 16)
+            swapped = gd[e, 0] == v1 | (v0 << 16) and gd[e, 1] == a1 | (a0 << 16)
+            assert as_is or swapped
+            # a round marked "one axis": the second of the descriptor is structurally zero here
+            u, w = divmod(e // 64, P.RS_GDESC_THREADS // 64)
+            if (int(it[H["RS_GSINGLE"]]) >> (u * (P.RS_GDESC_THREADS // 64) + w)) & 1:
+                second, arrow = int(gd[e, 0] >> 16), int(gd[e, 1] >> 16)
+                # ... or absent (the always-zero parameter slot)
+                assert (V[second] == 0.0 and V[second + 4] == 0.0) or arrow == nparams
     for R in range(nc):
         rec = rr[R]
         ac = ad = 0.0
