@@ -71,9 +71,10 @@ enum { MPCASM_OPT_PATH = 1, MPCASM_OPT_PHASE_MASK = 2, MPCASM_OPT_RESIDENT_PER_C
  * kernel): 0 (default) = for batches of at least 1024 instances, when libhiprtc.so is there
  * (compiled once per plan structure and device, on the first such launch: that launch blocks
  * for the compilation, a second or two); 1 = for every batch; 2 = never.
- * MPCASM_OPT_P_DIRECT (read by mpcasm_plan_create): how the persistent kernel writes P -- 0
- * (default) and 1: its 4x4 blocks go from the matrix core straight to HBM; 2: collected in LDS and
- * copied out with 16-byte stores whenever P fits there beside the workspace.
+ * MPCASM_OPT_P_DIRECT (read by mpcasm_plan_create): how the persistent kernel writes P -- 1: its
+ * 4x4 blocks go from the matrix core straight to HBM; 2: collected in LDS and copied out with
+ * 16-byte stores whenever P fits there beside the workspace; 0 (default): as 2 for launches whose
+ * outputs stream to HBM (200 MB and more), as 1 for smaller ones.
  * These options are process-wide test / tuning hooks, not part of a launch's state: set them
  * before other threads start launching. */
 int mpcasm_set_option(int option, int value);

@@ -87,8 +87,7 @@ int validate_plan(const int32_t* it, const double* h_dtab, size_t n_itab, size_t
       if (ar[2 * s] < 1 || ar[2 * s + 1] < 0 ||
           (int64_t)ar[2 * s] + ar[2 * s + 1] > it[H_ARENA_TOTAL])
         return MPCASM_ERR_PLAN;
-    // (indices of the persistent kernel's workspace layout: whole groups of four rows)
-    const int64_t vsize = (int64_t)((it[H_RTOT] + 3) / 4) * 4 * it[H_LDV];
+    const int64_t vsize = (int64_t)it[H_RTOT] * it[H_LDV];
     const int32_t* fi = it + it[H_OFF_FD_IDX];
     const int32_t* fp = it + it[H_OFF_FD_PTR];
     if (fp[0] != 0 || fp[it[H_NFD]] != it[H_NOPS]) return MPCASM_ERR_PLAN;
@@ -169,8 +168,7 @@ int validate_plan(const int32_t* it, const double* h_dtab, size_t n_itab, size_t
       const double* c = h_dtab + it[H_DOFF_RS_CONST];
       if (c[0] != 1.0 || c[1] != 1.0 || c[2] != 0.0 || c[3] != 0.0) return MPCASM_ERR_PLAN;
     }
-    // (indices of the persistent kernel's workspace layout: whole groups of four rows)
-    const int64_t vsize = (int64_t)((it[H_RTOT] + 3) / 4) * 4 * it[H_LDV];
+    const int64_t vsize = (int64_t)it[H_RTOT] * it[H_LDV];
     const int32_t* ts = it + it[H_OFF_RS_SRC];
     const int32_t* tg = it + it[H_OFF_RS_GIDX];
     const int32_t* td = it + it[H_OFF_RS_DST];
@@ -190,7 +188,7 @@ int validate_plan(const int32_t* it, const double* h_dtab, size_t n_itab, size_t
     const int32_t* tr = it + it[H_OFF_RS_TRIP];
     for (int i = 0; i < 2 * RS_TRIP_WORDS; ++i)
       if (tr[it[H_RS_NTRIP] * RS_TRIP_WORDS + i] != 0) return MPCASM_ERR_PLAN;
-    const int64_t group_bytes = 4 * (int64_t)it[H_LDV] * 8, ngroups = (it[H_RTOT] + 3) / 4;
+    const int64_t row_bytes = (int64_t)it[H_LDV] * 8;
     if (it[H_LDV] < no + 2) return MPCASM_ERR_PLAN;  // columns: unknowns, d, ones
     for (int i = 0; i < it[H_RS_NTRIP]; ++i) {
       const int32_t* x = tr + i * RS_TRIP_WORDS;
@@ -206,11 +204,11 @@ int validate_plan(const int32_t* it, const double* h_dtab, size_t n_itab, size_t
       for (int g = 0; g < 4; ++g)  // (all four groups load, live or not)
         if (((x[RT_BI] >> (8 * g)) & 255) >= nb || ((x[RT_BJ] >> (8 * g)) & 255) >= nb)
           return MPCASM_ERR_PLAN;
-      // offsets: whole row groups (the d offset: column `no` of its group); a full trip reads
-      // four groups, a short one a single group
-      const int64_t offs[3] = {x[RT_A], x[RT_B], (int64_t)x[RT_D] - (rows > 0 ? no * 32 : 0)};
+      // offsets: whole rows on group boundaries (the d offset: column `no` of its row); a trip
+      // reads `rows` rows from each
+      const int64_t offs[3] = {x[RT_A], x[RT_B], (int64_t)x[RT_D] - (rows > 0 ? no * 8 : 0)};
       for (int k = 0; k < 3; ++k)
-        if (offs[k] < 0 || offs[k] % group_bytes || offs[k] / group_bytes + rows / 4 > ngroups)
+        if (offs[k] < 0 || offs[k] % (4 * row_bytes) || offs[k] / row_bytes + rows > it[H_RTOT])
           return MPCASM_ERR_PLAN;
     }
     {  // every wavefront's trips: consecutive, whole packs (first ... last)
@@ -244,8 +242,8 @@ int validate_plan(const int32_t* it, const double* h_dtab, size_t n_itab, size_t
           x[RR_EXTREME] >= it[H_NPARAMS])
         return MPCASM_ERR_PLAN;
       for (int a = 0; a < RS_AXMAX; ++a)
-        if (x[RR_VOFF + a] < 0 || x[RR_VOFF + a] % (4 * it[H_LDV]) >= 4 ||
-            x[RR_VOFF + a] / (4 * it[H_LDV]) >= (it[H_RTOT] + 3) / 4 || x[RR_ARROW + a] < 0 ||
+        if (x[RR_VOFF + a] < 0 || x[RR_VOFF + a] % it[H_LDV] != 0 ||
+            x[RR_VOFF + a] / it[H_LDV] >= std::max<int64_t>(it[H_RTOT], 1) || x[RR_ARROW + a] < 0 ||
             x[RR_ARROW + a] > it[H_NPARAMS] || x[RR_CENTER + a] < 0 ||
             x[RR_CENTER + a] > it[H_NPARAMS])
           return MPCASM_ERR_PLAN;
@@ -277,7 +275,7 @@ int validate_plan(const int32_t* it, const double* h_dtab, size_t n_itab, size_t
         for (int64_t e = 0; e < ngd; ++e) {  // the same numbers as the row record of the piece
           const int64_t R = e < pieces ? e / (no / 2) : 0, cp = e < pieces ? e % (no / 2) : 0;
           const int32_t* x = rrw + R * RS_RR_WORDS;
-          const uint32_t v0 = (uint32_t)x[RR_VOFF] + 8 * cp, v1 = (uint32_t)x[RR_VOFF + 1] + 8 * cp;
+          const uint32_t v0 = (uint32_t)x[RR_VOFF] + 2 * cp, v1 = (uint32_t)x[RR_VOFF + 1] + 2 * cp;
           const uint32_t a0 = (uint32_t)x[RR_ARROW], a1 = (uint32_t)x[RR_ARROW + 1];
           const bool as_is = (uint32_t)gd[2 * e] == (v0 | (v1 << 16)) && (uint32_t)gd[2 * e + 1] == (a0 | (a1 << 16));
           const bool swapped = (uint32_t)gd[2 * e] == (v1 | (v0 << 16)) && (uint32_t)gd[2 * e + 1] == (a1 | (a0 << 16));
@@ -589,7 +587,15 @@ int mpcasm_jit_check(const int32_t* h_itab, size_t n_itab, const double* h_dtab,
   if (!d.rs_ok) return MPCASM_ERR_LIMIT;
   std::vector<char> code;
   std::string text;
-  const int out = jit_compile(jit_spec_header(d, h_itab), &code, &text);
+  // (both forms of the P hand-over when the size of a launch picks one)
+  const int small = resident_p_direct_for(d, 1), large = resident_p_direct_for(d, 1 << 30);
+  int out = MPCASM_OK;
+  for (int form : {small, large}) {
+    if (form == large && small != large && out != MPCASM_OK) break;
+    d.rs_p_direct = form;
+    out = jit_compile(jit_spec_header(d, h_itab), &code, &text);
+    if (small == large) break;
+  }
   if (log && log_capacity) {
     strncpy(log, text.c_str(), log_capacity - 1);
     log[log_capacity - 1] = 0;
@@ -731,10 +737,12 @@ int g_path = 0;  // test hook (MPCASM_OPT_PATH): 0 best, 1 no resident kernel, 2
 int g_resident_per_cu = 0;  // tuning aid (MPCASM_OPT_RESIDENT_PER_CU): 0 = automatic
 
 // dispatch: fused single launch when the problem fits on chip, else staged
-int launch_assemble(const PlanDev& p, const SrcTable& src, const double* params,
+int launch_assemble(const PlanDev& plan, const SrcTable& src, const double* params,
                     const double* given, double* P, double* q, double* G, double* h, void* work,
                     int batch, int num_cus, hipStream_t stream, hipError_t* err,
                     const int32_t* h_itab, int device) {
+  PlanDev p = plan;
+  p.rs_p_direct = p.rs_ok ? resident_p_direct_for(plan, batch) : 0;  // (the launch's size decides)
   // the persistent kernel may take a whole CU's LDS (one workgroup of 8 wavefronts per
   // CU still beats the staged pipeline by far); the per-instance fused kernel is only
   // worth it while two workgroups fit

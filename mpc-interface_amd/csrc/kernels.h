@@ -27,6 +27,7 @@ int launch_assemble_fused(const PlanDev& p, const SrcTable& src, const double* p
 // resident.hip
 size_t resident_lds_bytes(const PlanDev& p);
 int resident_choose_p_direct(const PlanDev& p, int option);
+int resident_p_direct_for(const PlanDev& p, int batch);
 // whether this launch's buffers meet the alignment the plan's input loads assume
 bool resident_inputs_aligned(const PlanDev& p, const SrcTable& src, const double* params,
                              const double* given);

@@ -120,7 +120,7 @@ enum HeaderWord : int {
   H_RS_NGDESC,      // RS_GDESC_PIECES * RS_GDESC_THREADS when the table below exists, else 0
   H_OFF_RS_GDESC,   // [RS_NGDESC][2] small problems: a ready-made descriptor of every 16-byte piece of
                     //    G; piece e = columns 2cp, 2cp+1 of row R = e / (no/2):
-                    //    (voff0 + 8cp) | (voff1 + 8cp) << 16, arrow0 | arrow1 << 16 -- the two axes
+                    //    (voff0 + 2cp) | (voff1 + 2cp) << 16, arrow0 | arrow1 << 16 -- the two axes
                     //    in either order (the one that can be non-zero first, see H_RS_GSINGLE)
   // the preview matrices [Mg | Mo] element by element (0 elements: the tables are absent and
   // K2 alone walks the row program): H_OFF_PM_MAP [PMROWS * (NG + NO)] index of the element's
@@ -188,24 +188,23 @@ constexpr int32_t RS_DST_ACC = 1 << 30;
 // reaches structurally exist (plus the diagonal of P and all of q, which the diagonal gterms
 // add into); four of them form a *pack*, one accumulator register: lane group j of the
 // instruction works on the pack's block j.
-// The persistent kernel keeps the workspace in LDS in groups of four rows, a group column by
-// column: element (r, c) at (r / 4) (4 LDV) + 4 c + r % 4 (columns: the unknowns, d = Mg.given in
-// column `no`, ones in column no + 1), row-sets start on group boundaries and are followed by
-// zero rows up to the next one.  Trip record (8 words = one s_load_dwordx8): 16 rows (four
-// groups, four k-steps: the lanes of k-step row l >> 4 own group l >> 4, its four rows are their
-// A / B operands of the four k-steps -- 32 contiguous bytes) or, *short*, 4 rows (one group,
-// one k-step, k-step row l >> 4 owns row l >> 4) of one gterm into one pack.  RT_A / RT_B: BYTE
-// offset of the first group of the A / B rows; RT_D: BYTE offset of column `no` in the first
-// group of the d rows -- what the lanes of a block of q read as their B operand: element 0 of
-// the block row is d, element 1 the ones, so that D[.][0] = sum a d and D[.][1] = sum a;
-// RT_W / RT_AIM: BYTE offset of the weight / aim among the parameters; RT_WORD: rows (16, 4;
-// 0: a pack nothing adds into -- it is still written) | short << 5 | half << 6 (the term is
-// halved) | nop << 7 (no Hessian part: blocks of P get nothing) | first trip of its pack << 8
-// | last << 9 | live lane groups << 10 | lane groups that hold a block of q << 14 | last
-// trip of its term in the pack << 18: there the term's sum S enters the pack as w S (blocks of
-// P) or (w s) (S[.][0] - aim S[.][1]) (blocks of q).  RT_BI / RT_BJ: block row / block column
-// of the four lane groups, a byte each (groups that are not live repeat a live one's; the
-// column of a block of q is not used).  A wavefront's trips of one pack are consecutive.
+// The persistent kernel keeps the workspace in LDS row major, V[r][c] with leading dimension LDV
+// (columns: the unknowns, d = Mg.given in column `no`, ones in column no + 1); rows come in groups
+// of four: row-sets start on a group boundary and are followed by zero rows up to the next one.
+// Trip record (8 words = one s_load_dwordx8): 16 rows (four k-steps; lane row l >> 4 = lk feeds
+// k-step u the row base + (0, 8, 4, 12)[lk] + u: the two lane rows a 32-lane LDS read serves lie 8
+// rows apart, half the banks with LDV = 2 mod 4) or, *short*, 4 rows (one k-step, lane row lk
+// feeds row base + lk) of one gterm into one pack.  RT_A / RT_B: BYTE offset of the first A / B
+// row; RT_D: BYTE offset of column `no` of the first d row -- what the lanes of a block of q read
+// as their B operand: element 0 of the block row is d, element 1 the ones, so that D[.][0] = sum a d
+// and D[.][1] = sum a; RT_W / RT_AIM: BYTE offset of the weight / aim among the parameters;
+// RT_WORD: rows (16, 4; 0: a pack nothing adds into -- it is still written) | short << 5 |
+// half << 6 (the term is halved) | nop << 7 (no Hessian part: blocks of P get nothing) | first
+// trip of its pack << 8 | last << 9 | live lane groups << 10 | lane groups that hold a block of
+// q << 14 | last trip of its term in the pack << 18: there the term's sum S enters the pack as
+// w S (blocks of P) or (w s) (S[.][0] - aim S[.][1]) (blocks of q).  RT_BI / RT_BJ: block row /
+// block column of the four lane groups, a byte each (groups that are not live repeat a live
+// one's; the column of a block of q is not used).  A wavefront's trips of one pack are consecutive.
 enum { RT_A = 0, RT_B, RT_D, RT_W, RT_AIM, RT_WORD, RT_BI, RT_BJ };
 enum { RT_SHORT = 5, RT_HALF = 6, RT_NOP = 7, RT_FIRST = 8, RT_LAST = 9, RT_LIVE = 10, RT_QMASK = 14,
        RT_TERM_END = 18 };

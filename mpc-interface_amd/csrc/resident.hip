@@ -98,12 +98,11 @@ __host__ __device__ inline int resident_g_mode(const PlanT& p) {
 }
 static_assert(GU == RS_GDESC_PIECES && WT == RS_GDESC_THREADS, "descriptor table of G");
 
-// doubles of the workspace: row groups of four, column by column (plan_tables.h RT_*), and a
-// few spare doubles behind the last group (the lanes of a block of q read two columns past
-// the ones)
+// doubles of the workspace: row major (plan_tables.h RT_*), and a few spare doubles behind the
+// last row (the lanes of a block of q read two columns past the ones)
 template <class PlanT>
 __host__ __device__ inline int resident_v_doubles(const PlanT& p) {
-  return (p.rtot + 3) / 4 * 4 * p.ldv + 16;
+  return p.rtot * p.ldv + 16;
 }
 
 struct ResidentLayout {
@@ -173,10 +172,15 @@ __device__ __forceinline__ void dma4(const void* gsrc, unsigned lds_base) {
 }
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+// Row of a 16-row trip that lane row lk feeds to k-step 0 (k-step u: that row + u).  The two
+// lane rows one 32-lane LDS read serves (lk = 0, 1 and 2, 3) lie 8 rows apart: with
+// ldv = 2 (mod 4) that is 32 banks, so the read touches every bank once.
+__device__ __forceinline__ int resident_trip_row(int lk) { return ((lk & 1) << 3) | ((lk & 2) << 1); }
+
 #ifdef MPCASM_SPEC
 // ---- K3 of a specialised kernel: a wavefront's trips as straight-line code --------------
 struct TripState {
-  const char* Vlane;  // workspace + lk * group_bytes + lx * 32
+  const char* Vlane;  // workspace + (0, 8, 4, 12)[lk] rows + lx * 8
   const char* prc;    // this instance's parameters
   double *Pl, *ql;  // Pl: P in LDS (leading dimension ldp), or this instance's P in HBM (no)
   int ldpl;
@@ -195,7 +199,7 @@ __device__ __forceinline__ void spec_trip(TripState& s) {
   constexpr int A = spec::TRIPS[I][RT_A], B = spec::TRIPS[I][RT_B], D = spec::TRIPS[I][RT_D];
   constexpr int W = spec::TRIPS[I][RT_W], AIM = spec::TRIPS[I][RT_AIM], WORD = spec::TRIPS[I][RT_WORD];
   constexpr int BI = spec::TRIPS[I][RT_BI], BJ = spec::TRIPS[I][RT_BJ];
-  constexpr int group_bytes = 4 * PC::ldv * 8, ldp = (PC::no + 1) & ~1;
+  constexpr int row_bytes = PC::ldv * 8, ldp = (PC::no + 1) & ~1;
   constexpr int qmask = (WORD >> RT_QMASK) & 15, livemask = (WORD >> RT_LIVE) & 15;
   constexpr bool nop = (WORD >> RT_NOP) & 1, half = (WORD >> RT_HALF) & 1;
   if constexpr ((WORD >> RT_FIRST) & 1) {  // a new pack: what this lane reads and owns
@@ -208,22 +212,30 @@ __device__ __forceinline__ void spec_trip(TripState& s) {
     s.bj = (BJ >> (8 * lg_)) & 255;
     s.isq = (qmask >> lg_) & 1;
     s.live = (livemask >> lg_) & 1;
-    s.ap = s.Vlane + s.bi * 128;
-    s.bp = s.Vlane + (s.isq ? 0 : s.bj * 128);
+    s.ap = s.Vlane + s.bi * 32;
+    s.bp = s.Vlane + (s.isq ? 0 : s.bj * 32);
     s.acc = 0.0;
   }
   if constexpr ((WORD & 31) != 0) {
     const char* bsrc = qmask == 0 ? s.bp + B : (qmask == livemask ? s.bp + D : s.bp + (s.isq ? D : B));
     if constexpr (!((WORD >> RT_SHORT) & 1)) {
-      const double2* a2 = reinterpret_cast<const double2*>(s.ap + A);
-      const double2* b2 = reinterpret_cast<const double2*>(bsrc);
-      const double2 a01 = a2[0], a23 = a2[1], b01 = b2[0], b23 = b2[1];
-      s.sum = mfma_f64_4x4x4(a01.x, b01.x, s.sum);
-      s.sum = mfma_f64_4x4x4(a01.y, b01.y, s.sum);
-      s.sum = mfma_f64_4x4x4(a23.x, b23.x, s.sum);
-      s.sum = mfma_f64_4x4x4(a23.y, b23.y, s.sum);
+      // eight 8-byte reads at immediate offsets (k-step u is row u of the lane's four) and the
+      // four products: mfma_trip16.  An offset that does not fit the instruction's 16 bits goes
+      // into the address.
+      constexpr int span = 3 * row_bytes;
+      constexpr int AH = A + span < 65536 ? 0 : A, DH = D + span < 65536 ? 0 : D, BH = B + span < 65536 ? 0 : B;
+      const unsigned pa = (unsigned)(uintptr_t)s.ap + AH;
+      if constexpr (qmask == 0) {
+        s.sum = mfma_trip16<A - AH, B - BH, row_bytes>(pa, (unsigned)(uintptr_t)s.bp + BH, s.sum);
+      } else if constexpr (qmask == livemask) {
+        s.sum = mfma_trip16<A - AH, D - DH, row_bytes>(pa, (unsigned)(uintptr_t)s.bp + DH, s.sum);
+      } else {
+        // (mixed pack: the lanes of a block of q read d, the others B -- one offset for both, the
+        // difference goes into the address)
+        s.sum = mfma_trip16<A - AH, B - BH, row_bytes>(pa, (unsigned)(uintptr_t)s.bp + BH + (s.isq ? D - B : 0), s.sum);
+      }
     } else {
-      const int short_shift = s.lk * 8 - s.lk * group_bytes;
+      const int short_shift = (s.lk - resident_trip_row(s.lk)) * row_bytes;
       const double a = *reinterpret_cast<const double*>(s.ap + (A + short_shift));
       const double b = *reinterpret_cast<const double*>(bsrc + short_shift);
       s.sum = mfma_f64_4x4x4(a, b, s.sum);
@@ -516,11 +528,21 @@ __device__ __forceinline__ void resident_body(
       }
     }
   };
+  // The n-th instance of this workgroup.  Large batches go round the workgroups in runs of four
+  // consecutive instances: an instance's q and h are not whole 128-byte lines, and a line that
+  // two workgroups (two XCDs, two L2s) each write a part of goes to HBM twice, as partial
+  // writes -- four instances' q and h end on a line boundary for every even problem size, and
+  // what one workgroup writes within a few microseconds merges in its L2
+  // (tools/microbench/store_rate3.hip: +9 % on the C2 output pattern alone).
+  const int run_shift = (long)batch >= 16L * gridDim.x && !(phases & 256) ? 2 : 0;  // (bit 8: A/B aid)
+  auto instance_at = [&](int n) -> long {
+    return ((((long)(n >> run_shift) * gridDim.x + blockIdx.x)) << run_shift) + (n & ((1 << run_shift) - 1));
+  };
   if (wave < MW) {  // the first instance's inputs start their trip now
-    fetch_image(blockIdx.x, 0, false);
+    fetch_image(instance_at(0), 0, false);
     if (wave == 0 && (GEN && p.rs_nlti != 0)) {
-      fetch_ab(blockIdx.x, 0);
-      if ((long)blockIdx.x + gridDim.x < batch) fetch_ab((long)blockIdx.x + gridDim.x, 1);
+      fetch_ab(instance_at(0), 0);
+      if (instance_at(1) < batch) fetch_ab(instance_at(1), 1);
     }
   }
   // ---- once per workgroup: the compose program into registers ------------------
@@ -616,7 +638,7 @@ __device__ __forceinline__ void resident_body(
   lds_barrier();
   SETUP_STAMP(5)
   // column no + 1 of the workspace: ones, for the whole launch (nothing composes into it)
-  for (int r = tid; r < ((p.rtot + 3) & ~3); r += NT) V[(r >> 2) * 4 * ldv + 4 * (no + 1) + (r & 3)] = 1.0;
+  for (int r = tid; r < p.rtot; r += NT) V[r * ldv + no + 1] = 1.0;
 
   const bool lookahead = (phases & 128) != 0;  // diagnostic: off = fetch only when needed
   if (wave < MW) {
@@ -631,6 +653,28 @@ __device__ __forceinline__ void resident_body(
   const int npair = no >> 1;
   const int gtotal = nc * npair;
   const int g_mode = resident_g_mode(p);
+  // P handed over block by block (L.p_direct): the blocks no term reaches are written as zeros
+  // after barrier C, 16 bytes per thread and piece (block, row, half of the row).  A thread's
+  // first ZK pieces are the same for every instance: where they go is worked out once, here
+  // (element offset in P | 1 << 30 one 16-byte store | 1 << 29 two elements; -1 nothing) --
+  // read from the table per instance, the load's trip to L2 and back sat on the stream waves'
+  // way to barrier A.
+  constexpr int ZK = 2;
+  int zoff[ZK];
+  {
+    const int t0 = tid >= MW * 64 ? tid - MW * 64 : tid + WT;  // (the order of the P / q phase)
+    const int32_t* zb = plan_itab + p.off_rs_zblk;
+#pragma unroll
+    for (int k = 0; k < ZK; ++k) {
+      const int e = t0 + k * NT;
+      zoff[k] = -1;
+      if (L.p_direct && e < p.rs_nzblk * 8) {
+        const int z = zb[e >> 3], row = 4 * (z >> 8) + ((e >> 1) & 3), col = 4 * (z & 255) + 2 * (e & 1);
+        if (row < no && col < no)
+          zoff[k] = (row * no + col) | (col + 1 < no ? ((no & 1) == 0 ? 1 << 30 : 1 << 29) : 0);
+      }
+    }
+  }
   // (row, column pair) of this thread's first piece, and the step from piece to piece
   const int g_first = wt >= 0 && npair > 0 ? ((wt / npair) << 16) | (wt % npair) : 0;
   const int g_dR = npair > 0 ? WT / npair : 0, g_dcp = npair > 0 ? WT % npair : 0;
@@ -638,7 +682,7 @@ __device__ __forceinline__ void resident_body(
 
   if (STAMPS && stamping) t_prev = __builtin_amdgcn_s_memtime();
   int buf = 0, iter = 0;  // iter: instances this workgroup has started
-  for (long inst = blockIdx.x; inst < batch; inst += gridDim.x, buf ^= 1, ++iter) {
+  for (long inst = instance_at(0); inst < batch; inst = instance_at(iter + 1), buf ^= 1, ++iter) {
     const double* img = lds + L.img + buf * p.rs_img;
     const double* prm = img + p.rs_img_params;
     lds_barrier();  // A: this instance's image landed, P and q of the previous one read out
@@ -680,7 +724,7 @@ __device__ __forceinline__ void resident_body(
         }
       }
     };
-    const long nxt = inst + gridDim.x;
+    const long nxt = instance_at(iter + 1), nxt2 = instance_at(iter + 2);
     if (wave < MW) {
       compose();
       lds_barrier();  // B: workspace complete
@@ -688,7 +732,7 @@ __device__ __forceinline__ void resident_body(
       // the next instance's image starts its trip from HBM now
       if (lookahead && nxt < batch && (phases & 16)) fetch_image(nxt, buf ^ 1, iter >= 1);
       // ... and, two instances ahead, the (A, B) of the systems whose matrices are built here
-      if (wave == 0 && (GEN && p.rs_nlti != 0) && nxt + gridDim.x < batch) fetch_ab(nxt + gridDim.x, buf);
+      if (wave == 0 && (GEN && p.rs_nlti != 0) && nxt2 < batch) fetch_ab(nxt2, buf);
       MPCASM_STAMP(7)
       // the last matrix wave builds the next instance's horizon tables (its (A, B) landed and
       // were waited for by wave 0 a whole instance ago) beside the stream waves' G; the plan
@@ -704,8 +748,6 @@ __device__ __forceinline__ void resident_body(
       if (G != nullptr && (phases & 8)) {
         // ---- K4: constraint rows straight to HBM ---------------------------------------
         double* Gb = G + (size_t)inst * nc * no;
-        int four = 4;  // (the distance, in doubles, between two columns of a workspace row)
-        asm volatile("" : "+v"(four));
         if (g_mode == 2) {
           // per piece: its packed descriptor -> arrows and workspace rows -> arithmetic ->
           // one 16-byte store; the reads of three pieces are in flight together
@@ -717,45 +759,53 @@ __device__ __forceinline__ void resident_body(
           // batch when it runs on its own after G
           // (compiled for the plan this is a constant: the branches below fold away)
           const bool all_single = p.rs_gsingle == (1 << (GU * (WT / 64))) - 1;
+          // pieces whose reads are in flight together: three, or -- compiled for a plan whose
+          // pieces all have one axis (half the operands) -- all six: two LDS round trips (the
+          // descriptors, then arrows and workspace rows) per instance instead of four
+#ifdef MPCASM_SPEC
+          constexpr int GB = spec::PlanConst::rs_gsingle == (1 << (GU * (WT / 64))) - 1 ? GU : 3;
+#else
+          constexpr int GB = 3;
+#endif
+          static_assert(GU % GB == 0, "batches of pieces");
           const bool h_mine = wt_ < nc;
           const int4 hc4 = reinterpret_cast<const int4*>(rr)[h_mine ? wt_ : 0];  // compact record
           const int4 hr = int4{0, hc4.w, hc4.x, hc4.y};  // -, extreme, packed rows, packed arrows
           const int2 hc = int2{hc4.z & 0xFFFF, (int)((unsigned)hc4.z >> 16)};
           double ha0 = 0.0, ha1 = 0.0, hc0 = 0.0, hc1 = 0.0, hd0 = 0.0, hd1 = 0.0, hext = 0.0;
 #pragma unroll
-          for (int u0 = 0; u0 < GU; u0 += 3) {
-            int2 ds[3];
+          for (int u0 = 0; u0 < GU; u0 += GB) {
+            int2 ds[GB];
 #pragma unroll
-            for (int u = 0; u < 3; ++u) ds[u] = gdesc[(u0 + u) * WT + wt_];
+            for (int u = 0; u < GB; ++u) ds[u] = gdesc[(u0 + u) * WT + wt_];
             if (u0 == 0) {
               ha0 = prm[hr.w & 0xFFFF];
               ha1 = prm[(unsigned)hr.w >> 16];
               hc0 = prm[hc.x];
               hc1 = prm[hc.y];
-              hd0 = V[(hr.z & 0xFFFF) + 4 * no];
-              hd1 = V[((unsigned)hr.z >> 16) + 4 * no];
+              hd0 = V[(hr.z & 0xFFFF) + no];
+              hd1 = V[((unsigned)hr.z >> 16) + no];
               hext = prm[hr.y];
             }
             // rounds whose pieces all have one axis that can be non-zero (p.rs_gsingle: known to
             // the plan compiler, wave-uniform) read one workspace row and one arrow
-            double a0[3], a1[3];
-            double2 v0[3], v1[3];
-            bool one[3];
+            double a0[GB], a1[GB];
+            double2 v0[GB], v1[GB];
+            bool one[GB];
 #pragma unroll
-            for (int u = 0; u < 3; ++u) {
+            for (int u = 0; u < GB; ++u) {
               one[u] = all_single || ((p.rs_gsingle >> ((u0 + u) * (WT / 64) + (wave - MW))) & 1);
               a0[u] = prm[ds[u].y & 0xFFFF];
-              // (columns 2cp, 2cp+1 of a row lie four doubles apart) ... as TWO ds_read_b64 (2 LDS
-              // cycles each, 64 banks) -- the compiler would fuse them into one ds_read2_b64 (8
-              // cycles, 32 banks); `four` is opaque to it
-              v0[u] = double2{V[ds[u].x & 0xFFFF], V[(ds[u].x & 0xFFFF) + four]};
+              // (columns 2cp, 2cp+1 of a row: one 16-byte read; a wavefront's pieces run along
+              // the rows, 16 lanes = 256 contiguous bytes where a row is that long)
+              v0[u] = *reinterpret_cast<const double2*>(V + (ds[u].x & 0xFFFF));
               if (!one[u]) {
                 a1[u] = prm[(unsigned)ds[u].y >> 16];
-                v1[u] = double2{V[(unsigned)ds[u].x >> 16], V[((unsigned)ds[u].x >> 16) + four]};
+                v1[u] = *reinterpret_cast<const double2*>(V + ((unsigned)ds[u].x >> 16));
               }
             }
 #pragma unroll
-            for (int u = 0; u < 3; ++u) {
+            for (int u = 0; u < GB; ++u) {
               const int e = wt_ + (u0 + u) * WT;
               double2 r;
               if (one[u]) {
@@ -789,7 +839,7 @@ __device__ __forceinline__ void resident_body(
             for (int u = 0; u < 3; ++u) {
               const int Rr = e0 + u * WT < gtotal ? R : 0;
               ds[u] = *reinterpret_cast<const int2*>(rr + Rr * RR_COMPACT);
-              c2[u] = 8 * cp;
+              c2[u] = 2 * cp;
               cp += g_dcp;
               R += g_dR;
               if (cp >= npair) {
@@ -803,8 +853,8 @@ __device__ __forceinline__ void resident_body(
             for (int u = 0; u < 3; ++u) {
               a0[u] = prm[ds[u].y & 0xFFFF];
               a1[u] = prm[(unsigned)ds[u].y >> 16];
-              v0[u] = double2{V[(ds[u].x & 0xFFFF) + c2[u]], V[(ds[u].x & 0xFFFF) + c2[u] + four]};
-              v1[u] = double2{V[((unsigned)ds[u].x >> 16) + c2[u]], V[((unsigned)ds[u].x >> 16) + c2[u] + four]};
+              v0[u] = *reinterpret_cast<const double2*>(V + (ds[u].x & 0xFFFF) + c2[u]);
+              v1[u] = *reinterpret_cast<const double2*>(V + ((unsigned)ds[u].x >> 16) + c2[u]);
             }
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
@@ -829,7 +879,7 @@ __device__ __forceinline__ void resident_body(
             double2 accv{0.0, 0.0};
             for (int ax = 0; ax < naxes; ++ax) {
               const double a = prm[rec[RR_ARROW + ax]];
-              const double2 v = double2{V[rec[RR_VOFF + ax] + 8 * cp], V[rec[RR_VOFF + ax] + 8 * cp + 4]};
+              const double2 v = *reinterpret_cast<const double2*>(V + rec[RR_VOFF + ax] + 2 * cp);
               accv.x = fma(a, v.x, accv.x);
               accv.y = fma(a, v.y, accv.y);
             }
@@ -853,7 +903,7 @@ __device__ __forceinline__ void resident_body(
             const int naxes = rec[RR_NAXES];
             double accv = 0.0;
             for (int ax = 0; ax < naxes; ++ax)
-              accv = fma(prm[rec[RR_ARROW + ax]], V[rec[RR_VOFF + ax] + 4 * c], accv);
+              accv = fma(prm[rec[RR_ARROW + ax]], V[rec[RR_VOFF + ax] + c], accv);
             Gb[e] = accv;
             e += WT;
             c += dc;
@@ -871,9 +921,9 @@ __device__ __forceinline__ void resident_body(
           if (p.rr_packed) {
             const int4 c = reinterpret_cast<const int4*>(rr)[R];
             const double a0 = prm[c.y & 0xFFFF], a1 = prm[(unsigned)c.y >> 16];
-            double ac = a0 * prm[c.z & 0xFFFF], ad = a0 * V[(c.x & 0xFFFF) + 4 * no];
+            double ac = a0 * prm[c.z & 0xFFFF], ad = a0 * V[(c.x & 0xFFFF) + no];
             ac += a1 * prm[(unsigned)c.z >> 16];
-            ad = fma(a1, V[((unsigned)c.x >> 16) + 4 * no], ad);
+            ad = fma(a1, V[((unsigned)c.x >> 16) + no], ad);
             hb[R] = (prm[c.w] + ac) - ad;
             continue;
           }
@@ -883,7 +933,7 @@ __device__ __forceinline__ void resident_body(
           for (int ax = 0; ax < naxes; ++ax) {
             const double a = prm[rec[RR_ARROW + ax]];
             ac += a * prm[rec[RR_CENTER + ax]];
-            ad = fma(a, V[rec[RR_VOFF + ax] + 4 * no], ad);
+            ad = fma(a, V[rec[RR_VOFF + ax] + no], ad);
           }
           hb[R] = (prm[rec[RR_EXTREME]] + ac) - ad;
         }
@@ -896,7 +946,7 @@ __device__ __forceinline__ void resident_body(
       // ---- K3, specialised: the wavefront's trips unrolled (spec_trip)
       static_assert(RS_WAVES == 8, "one case per wavefront");
       TripState st;
-      st.Vlane = reinterpret_cast<const char*>(V) + lk * (4 * ldv * 8) + lx * 32;
+      st.Vlane = reinterpret_cast<const char*>(V) + resident_trip_row(lk) * (ldv * 8) + lx * 8;
       st.prc = reinterpret_cast<const char*>(prm);
       st.Pl = L.p_direct ? P + (size_t)inst * no * no : Pl;
       st.ldpl = L.p_direct ? no : ldp;
@@ -936,11 +986,11 @@ __device__ __forceinline__ void resident_body(
       const_i32x8_ptr tg = (const_i32x8_ptr)(uintptr_t)(plan_itab + p.off_rs_trip) + t0;
       if (tn > 0) {
         const char* prc = reinterpret_cast<const char*>(prm);
-        const int group_bytes = 4 * ldv * (int)sizeof(double);
-        // full trip: k-step row lk owns row group lk of the trip; short trip: row lk of the
-        // one group -- `short_shift` moves a lane's address from the one to the other
-        const int short_shift = lk * (int)sizeof(double) - lk * group_bytes;
-        const char* Vlane = reinterpret_cast<const char*>(V) + lk * group_bytes + lx * 32;
+        const int row_bytes = ldv * (int)sizeof(double);
+        // full trip: lane row lk owns rows resident_trip_row(lk) + u of the trip; short trip:
+        // row lk -- `short_shift` moves a lane's address from the one to the other
+        const int short_shift = (lk - resident_trip_row(lk)) * row_bytes;
+        const char* Vlane = reinterpret_cast<const char*>(V) + resident_trip_row(lk) * row_bytes + lx * 8;
         const char *ap = Vlane, *bp = Vlane;  // of the current pack
         int bi = 0, bj = 0;
         bool isq = false, live = false;
@@ -955,20 +1005,22 @@ __device__ __forceinline__ void resident_body(
             bj = (r[RT_BJ] >> (8 * lg)) & 255;
             isq = (word >> (RT_QMASK + lg)) & 1;
             live = (word >> (RT_LIVE + lg)) & 1;
-            ap = Vlane + bi * 128;
-            bp = Vlane + (isq ? 0 : bj * 128);  // (the d offset of a record points at column `no`)
+            ap = Vlane + bi * 32;
+            bp = Vlane + (isq ? 0 : bj * 32);  // (the d offset of a record points at column `no`)
             acc = 0.0;
           }
           if (word & 31) {
             const int boff = isq ? r[RT_D] : r[RT_B];
             if (!((word >> RT_SHORT) & 1)) {
-              const double2* a2 = reinterpret_cast<const double2*>(ap + r[RT_A]);
-              const double2* b2 = reinterpret_cast<const double2*>(bp + boff);
-              const double2 a01 = a2[0], a23 = a2[1], b01 = b2[0], b23 = b2[1];
-              sum = mfma_f64_4x4x4(a01.x, b01.x, sum);
-              sum = mfma_f64_4x4x4(a01.y, b01.y, sum);
-              sum = mfma_f64_4x4x4(a23.x, b23.x, sum);
-              sum = mfma_f64_4x4x4(a23.y, b23.y, sum);
+              const char *ar = ap + r[RT_A], *br = bp + boff;
+              double a[4], b[4];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                a[u] = *reinterpret_cast<const double*>(ar + u * row_bytes);
+                b[u] = *reinterpret_cast<const double*>(br + u * row_bytes);
+              }
+#pragma unroll
+              for (int u = 0; u < 4; ++u) sum = mfma_f64_4x4x4(a[u], b[u], sum);
             } else {
               const double a = *reinterpret_cast<const double*>(ap + (r[RT_A] + short_shift));
               const double b = *reinterpret_cast<const double*>(bp + (boff + short_shift));
@@ -1030,10 +1082,21 @@ __device__ __forceinline__ void resident_body(
       int t_ = tid >= MW * 64 ? tid - MW * 64 : tid + WT;
       asm volatile("" : "+v"(t_));
       if (L.p_direct) {
-        // P went out block by block; what no term reaches is written here: zeros, 16 bytes
-        // per thread and piece (block, row, half of the row)
+        // P went out block by block; what no term reaches is written here: zeros (zoff above;
+        // beyond ZK pieces per thread, from the table)
+#pragma unroll
+        for (int k = 0; k < ZK; ++k)
+          if (zoff[k] >= 0) {
+            double* z = Pb + (zoff[k] & 0xFFFFFF);
+            if (zoff[k] & (1 << 30))
+              *reinterpret_cast<double2*>(z) = double2{0.0, 0.0};
+            else {
+              z[0] = 0.0;
+              if (zoff[k] & (1 << 29)) z[1] = 0.0;
+            }
+          }
         const int32_t* zb = plan_itab + p.off_rs_zblk;
-        for (int e = t_; e < p.rs_nzblk * 8; e += NT) {
+        for (int e = t_ + ZK * NT; e < p.rs_nzblk * 8; e += NT) {
           const int z = zb[e >> 3], row = 4 * (z >> 8) + ((e >> 1) & 3), col = 4 * (z & 255) + 2 * (e & 1);
           if (row < no && col < no) {
             if (col + 1 < no && ((no & 1) == 0))
@@ -1150,16 +1213,26 @@ int launch_jc(const PlanDev& p, const SrcTable& src, const double* params, const
 }  // namespace
 
 #ifndef __HIPCC_RTC__
-// Whether the blocks of P leave the matrix core for HBM directly instead of being collected in
-// LDS and copied out: always when P does not fit beside the workspace; otherwise unless the
-// option (MPCASM_OPT_P_DIRECT = 2) asks for the LDS copy -- measured on C2 the direct stores
-// are 5-7 % faster (no read-out phase, 10 KB less LDS traffic per instance; the 32-byte runs
-// merge in L2: HBM write traffic stays at the algorithmic bytes).
+// Whether the blocks of P leave the matrix core for HBM directly (8-byte stores, 32-byte runs)
+// instead of being collected in LDS and copied out in 16-byte pieces: 1 always -- P does not fit
+// beside the workspace, or MPCASM_OPT_P_DIRECT = 1; 0 never (option 2); 2 by the size of the
+// launch (resident_p_direct_for).
 int resident_choose_p_direct(const PlanDev& p, int option) {
   PlanDev q = p;
   q.rs_p_direct = 0;
   const bool fits = (size_t)resident_layout(q).total_doubles * sizeof(double) <= (size_t)RESIDENT_LDS_LIMIT;
-  return (!fits || option != 2) ? 1 : 0;
+  return (!fits || option == 1) ? 1 : (option == 2 ? 0 : 2);
+}
+
+// ... for one launch: while the outputs of a launch stay in the 256 MiB Infinity Cache the direct
+// stores are 4 % faster (no read-out phase, 10 KB less LDS traffic per instance on C2: 35.1
+// against 36.6 us at B = 4096); once they stream to HBM the short runs cost a fifth of the
+// write rate (588 against 465 us at B = 65536; tools/microbench/store_rate3.hip shows the same
+// on the bare store pattern).
+int resident_p_direct_for(const PlanDev& p, int batch) {
+  if (p.rs_p_direct != 2) return p.rs_p_direct;
+  const double out_bytes = 8.0 * ((double)p.no * p.no + p.no + (double)p.nc * p.no + p.nc) * batch;
+  return out_bytes < 200e6 ? 1 : 0;
 }
 
 // 0 when the resident kernel cannot take this plan, else its dynamic LDS bytes

@@ -45,7 +45,7 @@ RS_LTI_WORDS, RS_LTI_MAX = 8, 4           # record of a source group generated o
 RS_JC_MAX = 12                            # compose ops a thread can keep in registers
 RS_TRIP_WORDS = 8
 # cost model of the wavefront assignment (rounded cycles of one wavefront), see _resident_program
-TRIP_COST, TRIP_STEP_COST, TERM_COST, TRIP_Q_COST, PACK_COST, G_PIECE_COST = 250, 40, 80, 80, 350, 420
+TRIP_COST, TRIP_STEP_COST, TERM_COST, TRIP_Q_COST, PACK_COST, G_PIECE_COST = 200, 30, 60, 60, 250, 500
 import os as _os
 if _os.environ.get("MPCASM_TRIP_COSTS"):          # tuning aid: "trip,step,term,q,pack,piece"
     (TRIP_COST, TRIP_STEP_COST, TERM_COST, TRIP_Q_COST, PACK_COST,
@@ -528,11 +528,13 @@ def _fused_program(b, rowptr, entbase, entk, entcoef, rtot, ldv):
 
 
 def rs_index(r, c, ldv):
-    """Where the persistent kernel keeps element (r, c) of the workspace in LDS: rows in
-    groups of four, a group column by column -- V[r // 4][c][r % 4] -- so that the four rows a
-    lane feeds to four k-steps of the matrix core are 32 contiguous bytes (two ds_read_b128)
-    and the two columns of a 16-byte piece of G lie 32 bytes apart (one ds_read2_b64)."""
-    return (r // 4) * (4 * ldv) + 4 * c + (r % 4)
+    """Where the persistent kernel keeps element (r, c) of the workspace in LDS: row major,
+    ``V[r][c]`` with leading dimension ``ldv`` (columns: the unknowns, d = Mg.given, ones).  Rows
+    come in groups of four (row-sets start on a group, zero rows pad them): a 16-row trip feeds
+    lane row lk of the matrix core the rows ``base + (0, 8, 4, 12)[lk] + u``, u = k-step -- the two
+    lane rows an 8-byte LDS read serves together lie 8 rows apart, which with ldv = 2 (mod 4) is
+    half the banks -- and the two columns of a 16-byte piece of G are adjacent."""
+    return r * ldv + c
 
 
 def _resident_rows(limit_recs, lax_recs, nparams, ldv):
@@ -837,7 +839,7 @@ def _resident_program(fused, gterms, no, ldv, image, ng, nparams, nc_rows):
         bi_bytes = sum(k[0] << (8 * j) for j, k in enumerate(grp))
         bj_bytes = sum(k[1] << (8 * j) for j, k in enumerate(grp))
         lst = []
-        group_bytes = 4 * ldv * 8
+        row_bytes = ldv * 8
         for gi in sorted(tids):
             aoff, boff, nrows, wparam, doff, aimparam, flags = terms[gi][:7]
             half = 1 if flags & GT_FLAG_HALF else 0
@@ -850,8 +852,8 @@ def _resident_program(fused, gterms, no, ldv, image, ng, nparams, nc_rows):
                 # full trips of 16 rows (four groups, four k-steps); what is left goes group by
                 # group: *short* trips, one k-step each
                 rows = 16 if n4 - k0 >= 16 else 4
-                mine.append([(aoff + k0) // 4 * group_bytes, (brow + k0) // 4 * group_bytes,
-                             (doff + k0) // 4 * group_bytes + no * 32, wparam * 8, aimparam * 8,
+                mine.append([(aoff + k0) * row_bytes, (brow + k0) * row_bytes,
+                             (doff + k0) * row_bytes + no * 8, wparam * 8, aimparam * 8,
                              rows | ((rows == 4) << RT_SHORT) | (half << RT_HALF) | (nop << RT_NOP),
                              bi_bytes, bj_bytes])
                 k0 += rows
@@ -1199,8 +1201,7 @@ def compile_plan(form, costs=None, limits=None, lti=()):
         nz = nz.reshape(-1, ldv)
 
         def can(voff, col):                              # voff = rs_index(row, 0)
-            row = (voff // (4 * ldv)) * 4 + voff % (4 * ldv)
-            return nz[row, col] | nz[row, col + 1]
+            return nz[voff // ldv, col] | nz[voff // ldv, col + 1]
 
         v0, v1, a0, a1 = recs[R, 0], recs[R, 1], recs[R, 4], recs[R, 5]
         two = recs[R, 12] >= 2
@@ -1209,7 +1210,7 @@ def compile_plan(form, costs=None, limits=None, lti=()):
         v0, v1 = np.where(swap, v1, v0), np.where(swap, v0, v1)
         a0, a1 = np.where(swap, a1, a0), np.where(swap, a0, a1)
         single = ~(c0 & c1) | ~live
-        word0 = (v0 + 8 * cp) | ((v1 + 8 * cp) << 16)    # rs_index(row, 2 cp)
+        word0 = (v0 + 2 * cp) | ((v1 + 2 * cp) << 16)    # rs_index(row, 2 cp)
         word1 = a0 | (a1 << 16)
         rs_gdesc = np.stack([word0, word1], axis=1).astype(np.uint32).view(np.int32).reshape(-1)
         rounds = single.reshape(RS_GDESC_PIECES, RS_GDESC_THREADS // 64, 64).all(axis=2)

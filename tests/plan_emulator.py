@@ -212,8 +212,8 @@ def run_resident(plan, given, params=None, sources=None):
     gix = _section(it, "OFF_RS_GIDX", jc * P.RS_NT).reshape(jc, P.RS_NT)
     dst = _section(it, "OFF_RS_DST", jc * P.RS_NT).reshape(jc, P.RS_NT)
     cf = dt[it[H["DOFF_RS_COEF"]]:it[H["DOFF_RS_COEF"]] + jc * P.RS_NT].reshape(jc, P.RS_NT)
-    ngroups, gsz = (plan.rtot + 3) // 4, 4 * ldv       # the kernel's layout: V[r // 4][c][r % 4]
-    V = np.zeros((ngroups + 1) * gsz)
+    assert plan.rtot % 4 == 0                           # row-sets are padded to groups of four
+    V = np.zeros(plan.rtot * ldv + 16)                  # the kernel's layout: row major
     split = _section(it, "OFF_RS_SPLIT", it[H["RS_NSPLIT"]])
     written = np.zeros(V.size, dtype=np.int64)
     for t in range(P.RS_NT):
@@ -233,7 +233,7 @@ def run_resident(plan, given, params=None, sources=None):
                     written[d] = 99
                 acc = 0.0
     assert all(written[d] in (1, 2) for d in split)
-    Vrc = V.reshape(ngroups + 1, ldv, 4).transpose(0, 2, 1).reshape(-1, ldv).copy()   # row major
+    Vrc = V[:plan.rtot * ldv].reshape(plan.rtot, ldv).copy()
     assert not Vrc[:, no + 1].any()
     Vrc[:, no + 1] = 1.0                                       # the ones column (set once per launch)
     assert ldv >= no + 2
@@ -264,7 +264,7 @@ def run_resident(plan, given, params=None, sources=None):
     Pm, q = np.full((no, no), np.nan), np.full(no, np.nan)
     four = np.arange(4)
     assert wtrip[:, 1].sum() == len(trips)
-    gbytes = gsz * 8
+    rbytes = ldv * 8
     for first_trip, count in wtrip:
         acc, open_pack, S = None, None, np.zeros((4, 4, 4))
         for x in trips[first_trip:first_trip + count]:
@@ -280,11 +280,11 @@ def run_resident(plan, given, params=None, sources=None):
             assert open_pack == pack
             assert rows or ((word >> P.RT_FIRST) & 1 and (word >> P.RT_LAST) & 1)
             w, aim = prm[x[P.RT_W] // 8], prm[x[P.RT_AIM] // 8]
-            assert x[P.RT_A] % gbytes == 0 and x[P.RT_B] % gbytes == 0
-            ra, rb = 4 * (x[P.RT_A] // gbytes), 4 * (x[P.RT_B] // gbytes)
+            assert x[P.RT_A] % (4 * rbytes) == 0 and x[P.RT_B] % (4 * rbytes) == 0
+            ra, rb = x[P.RT_A] // rbytes, x[P.RT_B] // rbytes
             if rows:
-                assert (x[P.RT_D] - no * 32) % gbytes == 0
-                rd = 4 * ((x[P.RT_D] - no * 32) // gbytes)
+                assert (x[P.RT_D] - no * 8) % (4 * rbytes) == 0
+                rd = (x[P.RT_D] - no * 8) // rbytes
             for g in range(4):
                 bi, bj = (pack[0] >> (8 * g)) & 255, (pack[1] >> (8 * g)) & 255
                 assert bi < nb and bj < nb
@@ -338,7 +338,7 @@ def run_resident(plan, given, params=None, sources=None):
         assert it[H["RR_PACKED"]] and len(gd) >= nc * (no // 2)
         for e in range(nc * (no // 2)):
             R, cp = divmod(e, no // 2)
-            v0, v1, a0, a1 = rr[R, 0] + 8 * cp, rr[R, 1] + 8 * cp, rr[R, 4], rr[R, 5]
+            v0, v1, a0, a1 = rr[R, 0] + 2 * cp, rr[R, 1] + 2 * cp, rr[R, 4], rr[R, 5]
             as_is = gd[e, 0] == v0 | (v1 << 16) and gd[e, 1] == a0 | (a1 << 16)
             swapped = gd[e, 0] == v1 | (v0 << 16) and gd[e, 1] == a1 | (a0 << 16)
             assert as_is or swapped
@@ -347,14 +347,14 @@ def run_resident(plan, given, params=None, sources=None):
             if (int(it[H["RS_GSINGLE"]]) >> (u * (P.RS_GDESC_THREADS // 64) + w)) & 1:
                 second, arrow = int(gd[e, 0] >> 16), int(gd[e, 1] >> 16)
                 # ... or absent (the always-zero parameter slot)
-                assert (V[second] == 0.0 and V[second + 4] == 0.0) or arrow == nparams
+                assert (V[second] == 0.0 and V[second + 1] == 0.0) or arrow == nparams
     for R in range(nc):
         rec = rr[R]
         ac = ad = 0.0
         for ax in range(rec[12]):
             arrow = prm[rec[4 + ax]]
-            assert rec[ax] % gsz < 4                         # column 0 of a row
-            vrow = Vrc[4 * (rec[ax] // gsz) + rec[ax] % gsz]
+            assert rec[ax] % ldv == 0                        # column 0 of a row
+            vrow = Vrc[rec[ax] // ldv]
             G[R] += arrow * vrow[:no]
             ac += arrow * prm[rec[8 + ax]]
             ad += arrow * vrow[no]

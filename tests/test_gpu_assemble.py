@@ -18,9 +18,9 @@ pytestmark = pytest.mark.gpu
 # path name -> (MPCASM_OPT_PATH, MPCASM_OPT_JIT): the persistent kernel ahead of time and
 # compiled per plan by hiprtc (forced on for every batch size here), the per-instance fused
 # kernel, the staged pipeline
-PATHS = {"resident": (0, 2, 0), "resident-jit": (0, 1, 0), "resident-lds": (0, 2, 2),
-         "fused": (1, 2, 0), "staged": (2, 2, 0)}     # (..., MPCASM_OPT_P_DIRECT)
-RESIDENT = ("resident", "resident-jit", "resident-lds")
+PATHS = {"resident": (0, 2, 1), "resident-jit": (0, 1, 1), "resident-lds": (0, 2, 2),
+         "resident-jit-lds": (0, 1, 2), "fused": (1, 2, 0), "staged": (2, 2, 0)}  # (..., MPCASM_OPT_P_DIRECT)
+RESIDENT = ("resident", "resident-jit", "resident-lds", "resident-jit-lds")
 
 
 @pytest.fixture(autouse=True, params=list(PATHS))

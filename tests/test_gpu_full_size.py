@@ -243,3 +243,47 @@ def test_c3_on_the_persistent_kernel(gpu_api, torch_gpu, jit):
         Ao, ho, Qo, qo = orc.assemble(form, given[b].cpu().numpy().reshape(-1, 1))
         assert_close(P[b].cpu().numpy(), Qo, RTOL_TIGHT), assert_close(q[b].cpu().numpy(), qo.ravel(), RTOL_TIGHT)
         assert_close(G[b].cpu().numpy(), Ao, RTOL_TIGHT), assert_close(h[b].cpu().numpy(), ho.ravel(), RTOL_TIGHT)
+
+
+@pytest.mark.parametrize("jit", [2, 1])
+def test_a_large_batch_goes_round_the_workgroups_in_runs_of_four(gpu_api, torch_gpu, jit):
+    """From 16 instances per workgroup on, the persistent kernel hands out runs of four consecutive
+    instances (whole cache lines of q and h per workgroup) and, once a launch's outputs stream to
+    HBM, collects P in LDS: B = 8197 (not a multiple of four, 270 MB of outputs) with a different
+    system in every instance, every element pre-set to NaN, against the staged pipeline fed the
+    K1 fill's S, U of the same systems."""
+    torch = torch_gpu
+    from mpcasm import capi, engine
+
+    conf = problems.BipedConfig(step_samples=8)             # N = 16: the C2 shape, no = 36, nc = 76
+    form = problems.biped(gpu_api, conf)
+    form.update(step_times=np.array([6, 14]), step_count=0)
+    N, B = conf.horizon_lenght, 8197
+    rng = np.random.default_rng(77)
+    get_A, get_B, _ = gpu_api.tools.get_system_matrices("J->CCC")
+    taus = rng.uniform(0.09, 0.11, B)
+    A = torch.as_tensor(np.stack([get_A(tau=t) for t in taus]), device="cuda")
+    Bm = torch.as_tensor(np.stack([get_B(tau=t) for t in taus]), device="cuda")
+    given = torch.as_tensor(rng.normal(0, 0.1, [B, form.given_len]), device="cuda")
+    lib = capi.load()
+    lib.mpcasm_set_option(capi.OPT_JIT, jit)
+    try:
+        one = engine.Assembler(form, batch=B, lti=["LIP"])
+        one.bind_lti("LIP", A, Bm)
+        out = tuple(torch.full_like(t, float("nan")) for t in one.assemble(given))
+        P, q, G, h = (t.clone() for t in one.assemble(given, out=out))
+    finally:
+        lib.mpcasm_set_option(capi.OPT_JIT, 0)
+    assert not any(torch.isnan(t).any().item() for t in (P, q, G, h))
+    lib.mpcasm_set_option(capi.OPT_PATH, 2)
+    try:
+        ref = engine.Assembler(form, batch=B)
+        S, U = engine.fill_su(A, Bm, N)
+        ref.bind_source(("LIP", 0), U[:, 0])
+        ref.bind_source(("LIP", 1), S)
+        Ps, qs, Gs, hs = ref.assemble(given)
+    finally:
+        lib.mpcasm_set_option(capi.OPT_PATH, 0)
+    for t, r in ((P, Ps), (q, qs), (G, Gs), (h, hs)):
+        per_instance = (t - r).flatten(1).abs().amax(1) / r.flatten(1).abs().amax(1).clamp_min(1e-300)
+        assert per_instance.max().item() <= 1e-11, int(per_instance.argmax())

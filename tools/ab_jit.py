@@ -16,8 +16,25 @@ import bench  # noqa: E402
 from mpcasm import capi  # noqa: E402
 
 
+def box_store_rate():
+    """TB/s of a plain 512 MB fill on this box: boxes differ by several per cent, so times from
+    different calls are compared relative to this."""
+    x = torch.empty(1 << 26, dtype=torch.float64, device="cuda")
+    for _ in range(3):
+        x.fill_(1.0)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        x.fill_(1.0)
+    e1.record()
+    torch.cuda.synchronize()
+    return x.numel() * 8 / (e0.elapsed_time(e1) / 20 * 1e-3) / 1e12
+
+
 def main():
     lib = capi.load()
+    print("box: 512 MB fill at %.2f TB/s" % box_store_rate())
     for B in [int(a) for a in sys.argv[1:]] or [4096, 65536]:
         work = bench.build_workload(min(B, 4096), 1)
         times = (B + 4095) // 4096
@@ -28,6 +45,8 @@ def main():
         asm.bind_lti("LIP", torch.as_tensor(tile(work["A"]), device="cuda"),
                      torch.as_tensor(tile(work["B"]), device="cuda"))
         given = torch.as_tensor(tile(work["given"]), device="cuda")
+        if "MPCASM_PHASES" in os.environ:       # e.g. 0x1BF: instances one by one round the workgroups
+            lib.mpcasm_set_option(capi.OPT_PHASE_MASK, int(os.environ["MPCASM_PHASES"], 0))
         res = {2: [], 1: []}
         for rnd in range(5):
             for mode in (2, 1):
