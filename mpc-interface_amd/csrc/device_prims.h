@@ -62,6 +62,24 @@ __device__ __forceinline__ double mfma_trip16(unsigned pa, unsigned pb, double s
   return sum;
 }
 
+// Results that a wavefront writes as whole cache lines (16 bytes per lane, consecutive lanes)
+// leave for HBM with nontemporal stores: written once, not read again by this launch, they need
+// not stay in L2 -- measured on the persistent assembly kernel at B = 65536 (2.2 GB of outputs):
+// 491 -> 419 us on the same box, nothing lost at B = 4096.  NOT for short runs that only make a
+// whole line together with a neighbour's store (the 32-byte runs of a 4x4 block of P, q, h): those
+// must meet in L2 (same kernel, B = 4096, blocks of P nontemporal: 34 -> 51 us).
+#ifndef MPCASM_PLAIN_STORES
+__device__ __forceinline__ void store_result(double2* dst, double2 v) {
+  typedef double v2d __attribute__((ext_vector_type(2)));
+  const v2d w = {v.x, v.y};
+  __builtin_nontemporal_store(w, reinterpret_cast<v2d*>(dst));
+}
+__device__ __forceinline__ void store_result(double* dst, double v) { __builtin_nontemporal_store(v, dst); }
+#else
+__device__ __forceinline__ void store_result(double2* dst, double2 v) { *dst = v; }
+__device__ __forceinline__ void store_result(double* dst, double v) { *dst = v; }
+#endif
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains
 // the vector-memory counter (s_waitcnt vmcnt(0)), i.e. it waits for every global
 // store in flight to be acknowledged by HBM -- a full memory round trip per

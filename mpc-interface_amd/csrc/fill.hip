@@ -717,9 +717,18 @@ __global__ __launch_bounds__(64) void fill_lti_quad_kernel(const double* __restr
                                                            const double* __restrict__ B,
                                                            double* __restrict__ S,
                                                            double* __restrict__ U, int batch, int N,
-                                                           int m, int spw, int lshift) {
+                                                           int m, int spw, int lshift, int whole_lines) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   constexpr int n = NS, nn = NS * NS;
+  // rows of U that are whole cache lines (N n a multiple of 16) leave with nontemporal stores:
+  // 0.68 -> 0.77 of HBM at 524 288 C2 systems, no difference below 65 536; rows that end
+  // inside a line (N n = 300) lose a fifth with them -- the halves of a line must meet in L2
+  auto put = [whole_lines](double2* dst, double2 v) {
+    if (whole_lines)
+      store_result(dst, v);
+    else
+      *dst = v;
+  };
   const int lane = threadIdx.x;
   const int rl = N * n, rl2 = rl >> 1;
   const long sys0 = (long)blockIdx.x * spw;
@@ -804,19 +813,19 @@ __global__ __launch_bounds__(64) void fill_lti_quad_kernel(const double* __restr
             v[u].y = win[-(g + u) * lds_step + 1];
           }
 #pragma unroll
-          for (int u = 0; u < 4; ++u) dst[(size_t)(g + u) * out_step] = v[u];
+          for (int u = 0; u < 4; ++u) put(&dst[(size_t)(g + u) * out_step], v[u]);
         }
         for (; g < full; ++g) {
           double2 v;
           v.x = win[-g * lds_step];
           v.y = win[-g * lds_step + 1];
-          dst[(size_t)g * out_step] = v;
+          put(&dst[(size_t)g * out_step], v);
         }
         if (tail) {
           double2 v;
           v.x = win[-full * lds_step];
           v.y = win[-full * lds_step + 1];
-          dst[(size_t)full * out_step] = v;
+          put(&dst[(size_t)full * out_step], v);
         }
       }
     }
@@ -1046,7 +1055,7 @@ int launch_fill_su(const double* A, const double* B, double* S, double* U, int b
       int lshift = 0;
       while (lshift < 6 && (1 << lshift) < (N * n) / 2) ++lshift;
       hipLaunchKernelGGL(kernel, dim3((batch + spw - 1) / spw), dim3(64), bytes, stream, A, B, S, U,
-                         batch, N, m, spw, lshift);
+                         batch, N, m, spw, lshift, (N * n) % 16 == 0 ? 1 : 0);
       *err = hipGetLastError();
       return *err == hipSuccess ? MPCASM_OK : MPCASM_ERR_HIP;
     }

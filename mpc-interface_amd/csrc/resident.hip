@@ -261,6 +261,8 @@ __device__ __forceinline__ void spec_trip(TripState& s) {
         if (s.lx == 0) s.ql[row] = s.acc + s.dvec[ldp + row];
       } else if (col < PC::no) {
         const double val = s.acc + (row == col ? s.dvec[col] : 0.0);
+        // (to LDS or, block by block, to HBM: ordinary stores -- the 32-byte runs of a block
+        // must meet in L2 to leave it as whole lines)
         s.Pl[row * s.ldpl + col] = val;
         if (PC::rs_sym && s.bi != s.bj) s.Pl[col * s.ldpl + row] = val;
       }
@@ -815,7 +817,7 @@ __device__ __forceinline__ void resident_body(
                 r.x = fma(a1[u], v1[u].x, a0[u] * v0[u].x);
                 r.y = fma(a1[u], v1[u].y, a0[u] * v0[u].y);
               }
-              if (e < gtotal) G2[e] = r;
+              if (e < gtotal) store_result(&G2[e], r);
             }
             if (u0 == 0 && h_mine) {  // h = (extreme + arrow . center) - arrow . d   (body.py:264)
               double ac = ha0 * hc0, ad = ha0 * hd0;
@@ -862,7 +864,7 @@ __device__ __forceinline__ void resident_body(
               double2 r;
               r.x = fma(a1[u], v1[u].x, a0[u] * v0[u].x);
               r.y = fma(a1[u], v1[u].y, a0[u] * v0[u].y);
-              if (e < gtotal) G2[e] = r;
+              if (e < gtotal) store_result(&G2[e], r);
             }
           }
         } else if ((no & 1) == 0) {
@@ -883,7 +885,7 @@ __device__ __forceinline__ void resident_body(
               accv.x = fma(a, v.x, accv.x);
               accv.y = fma(a, v.y, accv.y);
             }
-            G2[e] = accv;
+            store_result(&G2[e], accv);
             e += WT;
             cp += dcp;
             R += dR;
@@ -904,7 +906,7 @@ __device__ __forceinline__ void resident_body(
             double accv = 0.0;
             for (int ax = 0; ax < naxes; ++ax)
               accv = fma(prm[rec[RR_ARROW + ax]], V[rec[RR_VOFF + ax] + c], accv);
-            Gb[e] = accv;
+            store_result(&Gb[e], accv);
             e += WT;
             c += dc;
             R += dR;
@@ -1112,15 +1114,15 @@ __device__ __forceinline__ void resident_body(
         const int total = no * npair;
         double2* P2 = reinterpret_cast<double2*>(Pb);
         const double2* Pl2 = reinterpret_cast<const double2*>(Pl);
-        for (int e = t_; e < total; e += NT) P2[e] = Pl2[e];
+        for (int e = t_; e < total; e += NT) store_result(&P2[e], Pl2[e]);
       } else {
         for (int e = t_; e < no * no; e += NT) {
           const int row = e / no;
-          Pb[e] = Pl[row * ldp + (e - row * no)];
+          store_result(&Pb[e], Pl[row * ldp + (e - row * no)]);
         }
       }
       double* qb = q + (size_t)inst * no;
-      for (int c = t_; c < no; c += NT) qb[c] = ql[c];
+      for (int c = t_; c < no; c += NT) qb[c] = ql[c];  // (q, h: part lines, they meet their neighbours in L2)
     }
     MPCASM_STAMP(6)
   }

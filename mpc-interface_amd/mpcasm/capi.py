@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmpcasm.so")
+# (MPCASM_LIB: another build of the library, for A/B measurements)
+LIB_PATH = os.environ.get("MPCASM_LIB") or os.path.join(_HERE, "libmpcasm.so")
 
 OK = 0
 OPT_PATH = 1
