@@ -122,6 +122,17 @@ int mpcasm_plan_destroy(mpcasm_plan* plan);
  * out[7]=preview rows (sum over definitions). */
 int mpcasm_plan_sizes(const mpcasm_plan* plan, int64_t out[8]);
 
+/* f3  sparse hand-off, first form: a plan compiled with csc=... (mpcasm/plan.py) makes
+ * mpcasm_assemble write the `data` arrays of
+ *   Q = scipy.sparse.csc_matrix(Q); A = scipy.sparse.csc_matrix(A)
+ *   python/use_examples/simple_functional_example/biped_mpc_loop.py:57-58
+ * directly -- d_P is then [batch][out[0]], d_G [batch][out[1]] (both 0 for a dense plan);
+ * indptr / indices are the plan compiler's, one pattern for the whole batch (entries that
+ * happen to be 0.0 are stored).  Such a plan exists on the persistent kernel only:
+ * mpcasm_plan_create answers MPCASM_ERR_LIMIT when the problem does not fit on chip (assemble
+ * dense and convert with mpcasm_gather then). */
+int mpcasm_plan_csc_sizes(const mpcasm_plan* plan, int64_t out[2]);
+
 /* Bytes of scratch the assembly of `batch` instances needs (device memory,
  * caller-allocated, 16-byte aligned). */
 int mpcasm_workspace_bytes(const mpcasm_plan* plan, int batch, size_t* out_bytes);

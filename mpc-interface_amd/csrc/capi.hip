@@ -283,6 +283,35 @@ int validate_plan(const int32_t* it, const double* h_dtab, size_t n_itab, size_t
         }
       }
     }
+    if (it[H_CSC_PNNZ] != 0 || it[H_CSC_GNNZ] != 0) {  // the CSC hand-off tables
+      const int64_t pn = it[H_CSC_PNNZ], gn = it[H_CSC_GNNZ], ldp = no + (no & 1);
+      if (gn * nc > (1ll << 27)) return MPCASM_ERR_PLAN;  // (far beyond what fits on chip)
+      if (pn < 0 || gn < 0 || pn > no * no || gn > nc * no || (it[H_CSC_GSINGLE] & ~1) ||
+          !in_range(it[H_OFF_CSC_P], pn, n, H_WORDS) || !in_range(it[H_OFF_CSC_G], gn * 2, n, H_WORDS) ||
+          it[H_OFF_CSC_G] % 2)
+        return MPCASM_ERR_PLAN;
+      const int32_t* cp = it + it[H_OFF_CSC_P];
+      for (int64_t k = 0; k < pn; ++k)
+        if (cp[k] < 0 || cp[k] / ldp >= no || cp[k] % ldp >= no) return MPCASM_ERR_PLAN;
+      // an entry of G: the numbers of some row's record, its axes in either order, one column
+      const int32_t* cg = it + it[H_OFF_CSC_G];
+      for (int64_t k = 0; k < gn; ++k) {
+        const uint32_t w0 = (uint32_t)cg[2 * k], w1 = (uint32_t)cg[2 * k + 1];
+        bool found = false;
+        for (int64_t R = 0; R < nc && !found; ++R) {
+          const int32_t* x = rrw + R * RS_RR_WORDS;
+          if (x[RR_NAXES] > 2) return MPCASM_ERR_PLAN;
+          for (int sw = 0; sw < 2 && !found; ++sw) {
+            const uint32_t v0 = (uint32_t)x[RR_VOFF + sw], v1 = (uint32_t)x[RR_VOFF + 1 - sw];
+            const uint32_t a0 = (uint32_t)x[RR_ARROW + sw], a1 = (uint32_t)x[RR_ARROW + 1 - sw];
+            if (w1 != (a0 | (a1 << 16))) continue;
+            const uint32_t c = (w0 & 0xFFFF) - v0;
+            found = (w0 & 0xFFFF) >= v0 && c < (uint32_t)no && (w0 >> 16) == v1 + c && v1 + c < 65536;
+          }
+        }
+        if (!found) return MPCASM_ERR_PLAN;
+      }
+    }
     for (int64_t g = 0; g < nlti; ++g) {  // generated groups: loaded A, B and the tables
       const int32_t* x = it + it[H_OFF_RS_LTI] + g * RS_LTI_WORDS;
       const int64_t gn = x[LT_N], gm = x[LT_M], gN = x[LT_HORIZON];
@@ -438,6 +467,9 @@ void plan_dev_from_tables(const int32_t* it, PlanDev* out) {
   d.rs_ngdesc = it[H_RS_NGDESC]; d.off_rs_gdesc = it[H_OFF_RS_GDESC];
   d.rs_nzblk = it[H_RS_NZBLK]; d.off_rs_zblk = it[H_OFF_RS_ZBLK];
   d.rs_gsingle = it[H_RS_GSINGLE];
+  d.csc_pnnz = it[H_CSC_PNNZ]; d.off_csc_p = it[H_OFF_CSC_P];
+  d.csc_gnnz = it[H_CSC_GNNZ]; d.off_csc_g = it[H_OFF_CSC_G];
+  d.csc_gsingle = it[H_CSC_GSINGLE];
   d.pm_nfd = it[H_PM_NFD]; d.off_pm_map = it[H_OFF_PM_MAP]; d.off_pm_fdptr = it[H_OFF_PM_FDPTR];
   d.off_pm_op = it[H_OFF_PM_OP]; d.doff_pm_pool = it[H_DOFF_PM_POOL];
   d.rs_src16 = 0;
@@ -462,6 +494,8 @@ void plan_dev_from_tables(const int32_t* it, PlanDev* out) {
   // the op table is read as int2: keep its word offset even (the compiler pads it)
   if (d.fused_ok && (d.off_op & 1)) d.fused_ok = 0;
   d.rs_p_direct = d.rs_ok ? resident_choose_p_direct(d, g_p_direct) : 0;
+  // the CSC form of P is read out of its LDS copy: such a plan has no other way
+  if (d.csc_pnnz != 0 && d.rs_ok) d.rs_p_direct = resident_choose_p_direct(d, 2);
 }
 
 }  // namespace
@@ -537,6 +571,15 @@ int mpcasm_plan_create(const int32_t* h_itab, size_t n_itab, const double* h_dta
   *out_plan = nullptr;
   const int rc = validate_plan(h_itab, h_dtab, n_itab, n_dtab);
   if (rc != MPCASM_OK) return rc;
+  {  // a CSC plan runs on the persistent kernel with P in LDS, or not at all
+    PlanDev probe;
+    memset(&probe, 0, sizeof probe);
+    plan_dev_from_tables(h_itab, &probe);
+    if ((probe.csc_pnnz != 0 || probe.csc_gnnz != 0) &&
+        (probe.rs_p_direct != 0 || resident_lds_bytes(probe) == 0 ||
+         resident_lds_bytes(probe) > RESIDENT_LDS_LIMIT))
+      return MPCASM_ERR_LIMIT;
+  }
   if (mpcasm_device_count() == 0) return MPCASM_ERR_NODEVICE;
 
   mpcasm_plan* plan = new (std::nothrow) mpcasm_plan();
@@ -618,6 +661,13 @@ int mpcasm_plan_sizes(const mpcasm_plan* plan, int64_t out[8]) {
   const PlanDev& d = plan->dev;
   out[0] = d.ng; out[1] = d.no; out[2] = d.nc; out[3] = d.nparams;
   out[4] = d.nsrc; out[5] = d.rtot; out[6] = d.ldv; out[7] = d.pmrows;
+  return MPCASM_OK;
+}
+
+int mpcasm_plan_csc_sizes(const mpcasm_plan* plan, int64_t out[2]) {
+  if (!plan || !out) return MPCASM_ERR_ARG;
+  out[0] = plan->dev.csc_pnnz;
+  out[1] = plan->dev.csc_gnnz;
   return MPCASM_OK;
 }
 
@@ -748,7 +798,7 @@ int launch_assemble(const PlanDev& plan, const SrcTable& src, const double* para
   // worth it while two workgroups fit
   constexpr size_t FUSED_LDS_LIMIT = 80 * 1024;
   const size_t rs = resident_lds_bytes(p);
-  if (rs != 0 && rs <= RESIDENT_LDS_LIMIT && (g_path == 0 || p.rs_nlti != 0) &&
+  if (rs != 0 && rs <= RESIDENT_LDS_LIMIT && (g_path == 0 || p.rs_nlti != 0 || p.csc_pnnz != 0 || p.csc_gnnz != 0) &&
       resident_inputs_aligned(p, src, params, given)) {
     // large batches: the same kernel compiled for this very plan (jit.hip), when available
     if (h_itab != nullptr)
@@ -758,8 +808,9 @@ int launch_assemble(const PlanDev& plan, const SrcTable& src, const double* para
     return launch_assemble_resident(p, src, params, given, P, q, G, h, work, batch, rs, num_cus,
                                     stream, err);
   }
-  // horizon matrices generated on chip exist in the persistent kernel only
-  if (p.rs_nlti != 0) return MPCASM_ERR_LIMIT;
+  // horizon matrices generated on chip and the CSC form of the results exist in the persistent
+  // kernel only
+  if (p.rs_nlti != 0 || p.csc_pnnz != 0 || p.csc_gnnz != 0) return MPCASM_ERR_LIMIT;
   const size_t lds = fused_lds_bytes(p, 4);
   if (lds != 0 && lds <= FUSED_LDS_LIMIT && g_path <= 1)
     return launch_assemble_fused(p, src, params, given, P, q, G, h, batch, lds, stream, err);

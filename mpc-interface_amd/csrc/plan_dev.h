@@ -24,7 +24,8 @@ namespace mpcasm {
   X(rs_img_params) X(doff_rs_const) X(rs_nlti) X(off_rs_lti) X(rs_img_dma) X(rs_ab)                 \
   X(off_rs_abmeta) X(rr_packed) X(off_rs_dpar) X(doff_rs_dcoef) X(rs_ngdesc) X(off_rs_gdesc)        \
   X(pm_nfd) X(off_pm_map) X(off_pm_fdptr) X(off_pm_op) X(doff_pm_pool) X(doff_diagcoef) X(ndiag)      \
-  X(rs_nzblk) X(off_rs_zblk) X(rs_p_direct) X(rs_gsingle)
+  X(rs_nzblk) X(off_rs_zblk) X(rs_p_direct) X(rs_gsingle)                                           \
+  X(csc_pnnz) X(off_csc_p) X(csc_gnnz) X(off_csc_g) X(csc_gsingle)
 
 // device-side view of a plan (pointers into the device copies of the tables).
 //   rs_p_direct: the persistent kernel sends the blocks of P straight to HBM (set by

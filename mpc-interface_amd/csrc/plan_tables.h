@@ -139,8 +139,20 @@ enum HeaderWord : int {
   H_RS_GSINGLE,     // bit u * 4 + w: every piece of G of round u of stream wave w (descriptor table)
                     //    has at most ONE axis that can be non-zero in its columns -- the first of
                     //    its descriptor: the second workspace row and arrow are not read
+  // CSC hand-off (biped_mpc_loop.py:57-58 for a batch): a plan with CSC_PNNZ != 0 makes
+  // mpcasm_assemble write, instead of dense P and G, the data arrays of their CSC forms on a
+  // fixed pattern -- P [batch][CSC_PNNZ], G [batch][CSC_GNNZ]; q and h as ever.  Only the
+  // persistent kernel runs such a plan (P collected in LDS).
+  H_CSC_PNNZ,
+  H_OFF_CSC_P,      // [CSC_PNNZ] where the k-th stored entry sits in the LDS copy of P:
+                    //    row * (NO rounded up to even) + column
+  H_CSC_GNNZ,
+  H_OFF_CSC_G,      // [CSC_GNNZ][2] per stored entry (R, c) of G, from R's row record:
+                    //    (voff0 + c) | (voff1 + c) << 16, arrow0 | arrow1 << 16 (either order)
+  H_CSC_GSINGLE,    // 1: at most one axis of every stored entry can be non-zero, the first
   H_WORDS = 96
 };
+static_assert(H_CSC_GSINGLE < H_WORDS, "plan header");
 
 // segment record
 enum { SEG_SRC = 0, SEG_OFF0, SEG_ROWSTRIDE, SEG_ELEMSTRIDE, SEG_DST0, SEG_LEN, SEG_KIND, SEG_PAD, SEG_WORDS = 8 };

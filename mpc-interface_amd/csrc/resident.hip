@@ -93,6 +93,7 @@ constexpr int GU = 6;  // 16-byte pieces of G a worker thread may own a descript
 // LDS -- 12 KB that buy back the row/column bookkeeping; 0: the general path.
 template <class PlanT>
 __host__ __device__ inline int resident_g_mode(const PlanT& p) {
+  if (p.csc_gnnz != 0 || p.csc_pnnz != 0) return 3;  // CSC hand-off: entry by entry (plan_tables.h H_CSC_*)
   if (!p.rr_packed) return 0;
   return p.rs_ngdesc != 0 ? 2 : 1;
 }
@@ -110,7 +111,7 @@ struct ResidentLayout {
   int v, pl, ql, dvec, dcoef, dpar, img, ab, streams, ints, total_doubles;
   int ldp;                                            // leading dimension of P in LDS
   int p_direct;  // 1: P does not fit beside the workspace -- its blocks go straight to HBM
-  int i_rr, i_meta, i_wtrip, i_split, i_lti, i_abmeta, i_gdesc;  // offsets in ints inside the int region
+  int i_rr, i_meta, i_wtrip, i_split, i_lti, i_abmeta, i_gdesc, i_cscp;  // offsets in ints inside the int region
 };
 
 template <class PlanT>
@@ -134,7 +135,10 @@ __host__ __device__ inline ResidentLayout resident_layout(const PlanT& p) {
   L.i_rr = i;    i += p.nc * (p.rr_packed ? RR_COMPACT : RR_WORDS);
   L.i_meta = i;  i += p.rs_nchunk * 64 * 2;
   L.i_abmeta = i; i += p.rs_ab * 2 * 2;
-  L.i_gdesc = i;  i += resident_g_mode(p) == 2 ? GU * WT * 2 : 0;  // per-thread piece descriptors of G
+  // per-thread piece descriptors of G; CSC hand-off: per-entry descriptors of G, then where the
+  // stored entries of P sit in its LDS copy
+  L.i_gdesc = i;  i += resident_g_mode(p) == 2 ? GU * WT * 2 : (resident_g_mode(p) == 3 ? 2 * p.csc_gnnz : 0);
+  L.i_cscp = i;   i += resident_g_mode(p) == 3 ? p.csc_pnnz : 0;
   L.i_wtrip = i; i += RS_WAVES * 2;
   L.i_split = i; i += p.rs_nsplit;
   L.i_lti = i;   i += p.rs_nlti * RS_LTI_WORDS;
@@ -623,6 +627,11 @@ __device__ __forceinline__ void resident_body(
           reinterpret_cast<int4*>(rr)[R] =
               int4{g[RR_PACKED], g[RR_PACKED + 1], g[RR_CENTER] | (g[RR_CENTER + 1] << 16), g[RR_EXTREME]};
         }
+      if (resident_g_mode(p) == 3) {  // CSC hand-off tables
+        const int2* cg = reinterpret_cast<const int2*>(plan_itab + p.off_csc_g);
+        for (int i = ct; i < p.csc_gnnz; i += CT) gdesc[i] = cg[i];
+        for (int i = ct; i < p.csc_pnnz; i += CT) (itb + L.i_cscp)[i] = (plan_itab + p.off_csc_p)[i];
+      }
       if (ct < RS_WAVES * 2) wtrip[ct] = v_wtrip;
       if (ct < p.rs_nsplit) split[ct] = v_split;
       for (int i = ct + CT; i < p.rs_nsplit; i += CT) split[i] = (plan_itab + p.off_rs_split)[i];
@@ -731,6 +740,11 @@ __device__ __forceinline__ void resident_body(
       compose();
       lds_barrier();  // B: workspace complete
       MPCASM_STAMP(1)
+      // the trips are what the barrier at the end of the phase waits for: they get the issue
+      // slots before the other workgroup's G and compose (measured: 49.4 -> 48.4 us on C2) -- and
+      // so does the request for the next image, which otherwise queues behind the stream waves'
+      // first stores of G for some 600 cycles
+      __builtin_amdgcn_s_setprio(2);
       // the next instance's image starts its trip from HBM now
       if (lookahead && nxt < batch && (phases & 16)) fetch_image(nxt, buf ^ 1, iter >= 1);
       // ... and, two instances ahead, the (A, B) of the systems whose matrices are built here
@@ -740,9 +754,6 @@ __device__ __forceinline__ void resident_body(
       // were waited for by wave 0 a whole instance ago) beside the stream waves' G; the plan
       // compiler gives it that many trips fewer
       if (wave == MW - 1 && (GEN && p.rs_nlti != 0) && nxt < batch) generate_sources(buf ^ 1, buf ^ 1);
-      // the trips are what the barrier at the end of the phase waits for: they get the issue
-      // slots before the other workgroup's G and compose (measured: 49.4 -> 48.4 us on C2)
-      __builtin_amdgcn_s_setprio(2);
     } else {
       compose();
       lds_barrier();  // B: workspace complete
@@ -750,7 +761,33 @@ __device__ __forceinline__ void resident_body(
       if (G != nullptr && (phases & 8)) {
         // ---- K4: constraint rows straight to HBM ---------------------------------------
         double* Gb = G + (size_t)inst * nc * no;
-        if (g_mode == 2) {
+        if (g_mode == 3) {
+          // CSC hand-off: entry k of this instance's G data = arrow . workspace at (R, c) of the
+          // k-th stored entry; consecutive lanes write consecutive entries (8 bytes each), the
+          // reads of three entries are in flight together
+          double* Gd = G + (size_t)inst * p.csc_gnnz;
+          int w_ = wt;
+          asm volatile("" : "+v"(w_));
+          for (int e0 = w_; e0 < p.csc_gnnz; e0 += 3 * WT) {
+            int2 ds[3];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) ds[u] = gdesc[min(e0 + u * WT, p.csc_gnnz - 1)];
+            double a0[3], a1[3], v0[3], v1[3];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+              a0[u] = prm[ds[u].y & 0xFFFF];
+              v0[u] = V[ds[u].x & 0xFFFF];
+              if (!p.csc_gsingle) {
+                a1[u] = prm[(unsigned)ds[u].y >> 16];
+                v1[u] = V[(unsigned)ds[u].x >> 16];
+              }
+            }
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+              if (e0 + u * WT < p.csc_gnnz)
+                Gd[e0 + u * WT] = p.csc_gsingle ? a0[u] * v0[u] : fma(a1[u], v1[u], a0[u] * v0[u]);
+          }
+        } else if (g_mode == 2) {
           // per piece: its packed descriptor -> arrows and workspace rows -> arithmetic ->
           // one 16-byte store; the reads of three pieces are in flight together
           double2* G2 = reinterpret_cast<double2*>(Gb);
@@ -1109,6 +1146,11 @@ __device__ __forceinline__ void resident_body(
             }
           }
         }
+      } else if (g_mode == 3) {
+        // CSC hand-off: the stored entries of P, in the pattern's order, out of its LDS copy
+        double* Pd = P + (size_t)inst * p.csc_pnnz;
+        const int* cp = itb + L.i_cscp;
+        for (int e = t_; e < p.csc_pnnz; e += NT) Pd[e] = Pl[cp[e]];
       } else if ((no & 1) == 0) {
         // ldp == no here, so P in LDS is dense: a flat 16-byte copy
         const int total = no * npair;

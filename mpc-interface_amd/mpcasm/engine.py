@@ -118,13 +118,19 @@ class Assembler:
         :meth:`bind_lti`.
     """
 
-    def __init__(self, form, batch=1, device=None, costs=None, limits=None, lti=()):
+    def __init__(self, form, batch=1, device=None, costs=None, limits=None, lti=(), csc=None):
         torch = require_device()
         self._torch = torch
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None \
             else torch.device(device)
         self.batch = int(batch)
-        self.plan = compile_plan(form, costs=costs, limits=limits, lti=tuple(lti))
+        # csc = "upper" / "full": :meth:`assemble` returns the CSC ``data`` arrays of P (its upper
+        # triangle / all of it) and G instead of the dense matrices -- ``(B, nnz)`` each, on the
+        # pattern of :meth:`csc_pattern` -- written by the assembly kernel itself
+        # (biped_mpc_loop.py:57-58 without a second pass).  ValueError / RuntimeError when the
+        # problem does not run on the persistent kernel: assemble dense and use export_csc.
+        self.plan = compile_plan(form, costs=costs, limits=limits, lti=tuple(lti), csc=csc)
+        self.csc = self.plan.csc
         p = self.plan
         self.ng, self.no, self.nc = p.ng, p.no, p.nc
 
@@ -288,8 +294,10 @@ class Assembler:
         if out is None:
             if self._out is None:
                 f = dict(dtype=torch.float64, device=self.device)
-                self._out = (torch.empty((B, no, no), **f), torch.empty((B, no), **f),
-                             torch.empty((B, nc, no), **f), torch.empty((B, nc), **f))
+                pshape = (B, self.csc["pnnz"]) if self.csc else (B, no, no)
+                gshape = (B, self.csc["gnnz"]) if self.csc else (B, nc, no)
+                self._out = (torch.empty(pshape, **f), torch.empty((B, no), **f),
+                             torch.empty(gshape, **f), torch.empty((B, nc), **f))
             out = self._out
         P, q, G, h = out
         if not want_cost:
@@ -313,6 +321,8 @@ class Assembler:
         large for the structural analysis."""
         from .plan import csc_pattern
 
+        if self.csc:      # the pattern the assembly itself writes
+            return self.csc[which]
         key = (which, bool(upper))
         if key not in self._csc:
             mask = {"P": self.plan.P_pattern, "G": self.plan.G_pattern}[which]
@@ -328,6 +338,8 @@ class Assembler:
         every instance's ``M = P`` or ``G`` on the pattern of :meth:`csc_pattern`
         (biped_mpc_loop.py:57-58, batched).  ``dense`` defaults to the last :meth:`assemble`."""
         torch = self._torch
+        if self.csc:
+            raise ValueError("this assembler writes the CSC form itself: assemble() returns it")
         self.csc_pattern(which, upper)
         index = self._csc[(which, bool(upper))][2]
         if dense is None:

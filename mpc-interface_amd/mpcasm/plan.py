@@ -35,6 +35,7 @@ _H = {name: i for i, name in enumerate([
     "RS_IMG_DMA", "RS_AB", "OFF_RS_ABMETA", "RR_PACKED", "OFF_RS_DPAR", "DOFF_RS_DCOEF",
     "RS_NGDESC", "OFF_RS_GDESC", "PM_NFD", "OFF_PM_MAP", "OFF_PM_FDPTR", "OFF_PM_OP", "PM_NOPS",
     "DOFF_PM_POOL", "PM_NPOOL", "RS_NZBLK", "OFF_RS_ZBLK", "RS_GSINGLE",
+    "CSC_PNNZ", "OFF_CSC_P", "CSC_GNNZ", "OFF_CSC_G", "CSC_GSINGLE",
 ])}
 H_WORDS = 96
 assert len(_H) <= H_WORDS
@@ -981,7 +982,7 @@ def csc_pattern(mask, upper=False):
     return indptr, rows_sorted.astype(np.int32), flat
 
 
-def compile_plan(form, costs=None, limits=None, lti=()):
+def compile_plan(form, costs=None, limits=None, lti=(), csc=None):
     """Compile ``form`` (an up-to-date Formulation: sizes and IDs current).
 
     ``costs``: dict name -> Cost to include (default ``form.goals``);
@@ -989,7 +990,13 @@ def compile_plan(form, costs=None, limits=None, lti=()):
     ``form.constraints`` then of ``form.constraint_boxes``, body.py:306-315);
     ``lti``: names of ExtendedSystem dynamics whose horizon matrices the assembly kernel
     generates on chip from per-instance ``(A, B)`` instead of reading ``S, U`` (K1 fused into
-    the assembly; only the persistent kernel can run such a plan).
+    the assembly; only the persistent kernel can run such a plan);
+    ``csc``: ``"upper"`` or ``"full"`` -- the plan's assembly writes, instead of dense P and G,
+    the ``data`` arrays of their CSC forms on the structural pattern (P: its upper triangle /
+    all of it), what ``scipy.sparse.csc_matrix(Q)``, ``csc_matrix(A)`` hand the solver in
+    biped_mpc_loop.py:57-58: ``P`` becomes ``(B, plan.csc["pnnz"])``, ``G``
+    ``(B, plan.csc["gnnz"])``; ``plan.csc["P"]``, ``plan.csc["G"]`` hold ``(indptr, indices)``.
+    Only the persistent kernel writes this form: ValueError when the plan cannot run there.
     """
     b = _Builder(form)
     b.flatten_definitions()
@@ -1217,7 +1224,46 @@ def compile_plan(form, costs=None, limits=None, lti=()):
         rs_gsingle = int(sum(1 << (u * (RS_GDESC_THREADS // 64) + w)
                              for u in range(RS_GDESC_PIECES) for w in range(RS_GDESC_THREADS // 64)
                              if rounds[u, w]))
+    # ---- CSC hand-off: where the stored entries sit (P: in the LDS copy of P, leading
+    # dimension no rounded up to even) and, per stored entry (R, c) of G, what a 16-byte piece
+    # has for two columns: rs_index(row0, c) | rs_index(row1, c) << 16, arrow0 | arrow1 << 16
+    P_pattern, G_pattern = _structural_patterns(
+        form, b, fused, gterms, limit_recs, lax_recs, rtot, ldv, no, nc)
+    csc_p = csc_g = np.zeros(0, dtype=np.int32)
+    csc_info, csc_gsingle = None, 0
+    if csc is not None:
+        if csc not in ("upper", "full"):
+            raise ValueError("csc: 'upper', 'full' or None")
+        two_axes = (rr_ok and (b.rtot + 8) * ldv < 65536 and len(b.params) < 65535
+                    and bool((rs_rr.reshape(nc, RS_RR_WORDS)[:, 12] <= 2).all()))
+        if not (resident["ok"] and two_axes):
+            raise ValueError("this plan does not run on the persistent kernel: assemble dense "
+                             "and convert with export_csc")
+        pm = np.ones((no, no), dtype=bool) if P_pattern is None else P_pattern
+        gm = np.ones((nc, no), dtype=bool) if G_pattern is None else G_pattern
+        p_indptr, p_indices, p_flat = csc_pattern(pm, csc == "upper")
+        g_indptr, g_indices, g_flat = csc_pattern(gm)
+        ldp = no + (no & 1)
+        csc_p = ((p_flat // no) * ldp + p_flat % no).astype(np.int32)
+        recs = rs_rr.reshape(nc, RS_RR_WORDS).astype(np.int64)
+        R, c = g_flat.astype(np.int64) // no, g_flat.astype(np.int64) % no
+        nz = np.zeros(max(rtot, 1) * ldv, dtype=bool)
+        nz[fused["fd_idx"]] = True
+        if fused["fd_idx"].size == 0:
+            nz[:] = True
+        v0, v1, a0, a1 = recs[R, 0], recs[R, 1], recs[R, 4], recs[R, 5]
+        c0, c1 = nz[v0 + c], (recs[R, 12] >= 2) & nz[v1 + c]
+        swap = c1 & ~c0                                  # only the second axis can be non-zero
+        v0, v1 = np.where(swap, v1, v0), np.where(swap, v0, v1)
+        a0, a1 = np.where(swap, a1, a0), np.where(swap, a0, a1)
+        csc_g = np.stack([(v0 + c) | ((v1 + c) << 16), a0 | (a1 << 16)], axis=1) \
+            .astype(np.uint32).view(np.int32).reshape(-1)
+        csc_gsingle = int(bool((~(c0 & c1)).all()))
+        csc_info = dict(kind=csc, pnnz=int(p_flat.size), gnnz=int(g_flat.size),
+                        P=(p_indptr, p_indices), G=(g_indptr, g_indices),
+                        p_flat=p_flat, g_flat=g_flat)
     pmprog = _preview_program(b, pm_rowptr, pm_entbase, pm_entk, pm_entcoef, pmrows)
+    sections += [("OFF_CSC_P", csc_p), ("OFF_CSC_G", csc_g)]
     sections += [("OFF_RS_DPAR", rs_dpar.reshape(-1)), ("OFF_RS_GDESC", rs_gdesc),
                  ("OFF_PM_MAP", pmprog["map"]), ("OFF_PM_FDPTR", pmprog["fd_ptr"]),
                  ("OFF_PM_OP", pmprog["ops"])]
@@ -1231,7 +1277,7 @@ def compile_plan(form, costs=None, limits=None, lti=()):
             parts.append(np.zeros(1, dtype=np.int32))
             off += 1
         if name in ("OFF_RS_RR", "OFF_RS_INMETA", "OFF_RS_ABMETA", "OFF_RS_DPAR",
-                    "OFF_RS_GDESC") and off & 3:   # ... 16-byte quads
+                    "OFF_RS_GDESC", "OFF_CSC_G") and off & 3:   # ... 16-byte quads
             pad = 4 - (off & 3)
             parts.append(np.zeros(pad, dtype=np.int32))
             off += pad
@@ -1273,6 +1319,8 @@ def compile_plan(form, costs=None, limits=None, lti=()):
     header[_H["RS_SYM"]] = resident["sym"]
     header[_H["RS_NTRIP"]] = resident["ntrip"]
     header[_H["RS_GSINGLE"]] = rs_gsingle
+    header[_H["CSC_PNNZ"]], header[_H["CSC_GNNZ"]] = csc_p.size, csc_g.size // 2
+    header[_H["CSC_GSINGLE"]] = csc_gsingle
     header[_H["RS_NZBLK"]] = resident["zblk"].size
     header[_H["RS_NSPLIT"]] = resident["split"].size
     header[_H["RS_UNIT"]], header[_H["RS_NCHUNK"]] = image["unit"], image["nchunk"]
@@ -1307,7 +1355,7 @@ def compile_plan(form, costs=None, limits=None, lti=()):
     plan.given_ID = {v: form.given_ID[v] for v in form.given_variables}
     plan.n_gterms = len(gterms)
     plan.resident = resident
-    plan.P_pattern, plan.G_pattern = _structural_patterns(
-        form, b, fused, gterms, limit_recs, lax_recs, rtot, ldv, no, nc)
+    plan.P_pattern, plan.G_pattern = P_pattern, G_pattern
+    plan.csc = csc_info
     plan.lti = [dict(name=g["name"], n=g["n"], m=g["m"], N=g["N"], ids=list(g["ids"])) for g in groups]
     return plan

@@ -361,5 +361,22 @@ def run_resident(plan, given, params=None, sources=None):
         for ax in range(rec[12], P.RS_AXMAX):       # the kernel's fast path reads two axes
             assert prm[rec[4 + ax]] == 0.0
         h[R] = (prm[rec[13]] + ac) - ad
+    out = {"P": Pm, "q": q, "G": G, "h": h}
+    if it[H["CSC_PNNZ"]] or it[H["CSC_GNNZ"]]:      # the CSC hand-off: data arrays as the kernel writes them
+        ldp = no + (no & 1)
+        Pl = np.zeros((no, ldp))
+        Pl[:, :no] = Pm
+        cp = _section(it, "OFF_CSC_P", it[H["CSC_PNNZ"]])
+        assert ((cp // ldp < no) & (cp % ldp < no)).all()
+        out["P_data"] = Pl.ravel()[cp]
+        cg = _section(it, "OFF_CSC_G", it[H["CSC_GNNZ"]] * 2).view(np.uint32).reshape(-1, 2)
+        v0, v1 = (cg[:, 0] & 0xFFFF).astype(int), (cg[:, 0] >> 16).astype(int)
+        a0, a1 = (cg[:, 1] & 0xFFFF).astype(int), (cg[:, 1] >> 16).astype(int)
+        if it[H["CSC_GSINGLE"]]:                   # the second axis is never read: it must not matter
+            assert ((V[v1] == 0.0) | (a1 == nparams)).all()
+            out["G_data"] = prm[a0] * V[v0]
+        else:
+            out["G_data"] = prm[a1] * V[v1] + prm[a0] * V[v0]
     Vrc[:, no + 1] = 0.0                                   # (not part of the row-set program's V)
-    return {"P": Pm, "q": q, "G": G, "h": h, "V": Vrc[:plan.rtot]}
+    out["V"] = Vrc[:plan.rtot]
+    return out

@@ -772,3 +772,51 @@ def test_batched_state_space_box_transforms(gpu_api, kernel_path):
         window.recenter_in_SS(np.zeros((batch, 3, 1)))
     with pytest.raises(ValueError, match="task space only"):
         BoxBatch(asm, form, "kine").recenter_in_SS(np.zeros((2, 2)))
+
+
+def test_csc_data_written_by_the_assembly(gpu_api, kernel_path):
+    """f3 without a second pass: an Assembler built with csc=... gets the ``data`` arrays of
+    ``scipy.sparse.csc_matrix(Q)`` (upper triangle, what OSQP takes) and ``csc_matrix(A)``
+    (biped_mpc_loop.py:57-58) from the assembly kernel itself.  Against scipy on the oracle's
+    dense matrices, instance by instance, and against the dense assembly of the same inputs
+    entry for entry (bit for bit: the arithmetic is the same); every stored entry is written
+    (buffers pre-set to NaN).  The biped with its horizon matrices built on chip, and the
+    reference's test_body problem (crossed cost: P stored in full)."""
+    import scipy.sparse as sp
+    import torch
+    from mpcasm import engine
+
+    if kernel_path not in RESIDENT:
+        pytest.skip("only the persistent kernel writes the CSC form")
+    biped = problems.biped(gpu_api, problems.BipedConfig(step_samples=8))
+    biped.update(step_times=np.array([6, 14]), step_count=0)
+    for form, lti, kind, batch in ((biped, ["LIP"], "upper", 301), (problems.body_case(gpu_api), [], "full", 9)):
+        rng = np.random.default_rng(41)
+        given = rng.normal(0, 0.2, [batch, form.given_len])
+        sparse = engine.Assembler(form, batch=batch, lti=lti, csc=kind)
+        dense = engine.Assembler(form, batch=batch, lti=lti)
+        c = sparse.csc
+        assert sparse.csc_pattern("P") == c["P"] and sparse.csc_pattern("G") == c["G"]
+        out = (torch.full((batch, c["pnnz"]), float("nan"), dtype=torch.float64, device="cuda"),
+               torch.full((batch, form.optim_len), float("nan"), dtype=torch.float64, device="cuda"),
+               torch.full((batch, c["gnnz"]), float("nan"), dtype=torch.float64, device="cuda"),
+               torch.full((batch, dense.nc), float("nan"), dtype=torch.float64, device="cuda"))
+        Pd, q, Gd, h = (t.cpu().numpy() for t in sparse.assemble(given, out=out))
+        P, q2, G, h2 = (t.cpu().numpy() for t in dense.assemble(given))
+        assert not any(np.isnan(t).any() for t in (Pd, q, Gd, h))
+        assert np.array_equal(Pd, P.reshape(batch, -1)[:, c["p_flat"]])
+        assert np.array_equal(Gd, G.reshape(batch, -1)[:, c["g_flat"]])
+        assert np.array_equal(q, q2) and np.array_equal(h, h2)
+        for b in (0, batch // 2, batch - 1):
+            Ao, ho, Qo, qo = orc.assemble(form, given[b].reshape(-1, 1))
+            Qs = sp.csc_matrix(np.triu(Qo) if kind == "upper" else Qo)
+            As = sp.csc_matrix(Ao)
+            mine_P = sp.csc_matrix((Pd[b], c["P"][1], c["P"][0]), shape=Qo.shape)
+            mine_G = sp.csc_matrix((Gd[b], c["G"][1], c["G"][0]), shape=Ao.shape)
+            assert_close(mine_P.toarray(), Qs.toarray(), RTOL_TIGHT, "P of instance %d" % b)
+            assert_close(mine_G.toarray(), As.toarray(), RTOL_TIGHT, "G of instance %d" % b)
+            # scipy stores no entry the pattern lacks
+            assert not (Qs.toarray() != 0)[~sparse.plan.P_pattern].any()
+            assert not (As.toarray() != 0)[~sparse.plan.G_pattern].any()
+        with pytest.raises(ValueError, match="writes the CSC form itself"):
+            sparse.export_csc("P")

@@ -41,6 +41,54 @@ def check_plan(form, given, tol=1e-12):
     return plan
 
 
+def test_csc_plans_write_what_scipy_would_store(cpu_api):
+    """f3, written by the assembly itself: a plan compiled with csc='upper' / 'full' carries, per
+    stored entry, where the persistent kernel finds it (P) or how it computes it (G).  The
+    emulated kernel's data arrays, put on the plan's (indptr, indices), are the oracle's P (its
+    upper triangle) and G -- biped_mpc_loop.py:57-58 -- for the biped, K1 fused and not, and the
+    reference's test_body problem (crossed cost: a P that is not symmetric, stored in full)."""
+    import scipy.sparse as sp
+
+    biped = problems.biped(cpu_api, problems.BipedConfig(step_samples=8))
+    biped.update(step_times=np.array([6, 14]), step_count=0)
+    lib = capi.load()
+    for form, lti, kind in ((biped, (), "upper"), (biped, ("LIP",), "upper"),
+                            (problems.body_case(cpu_api), (), "full")):
+        rng = np.random.default_rng(5)
+        given = rng.standard_normal([form.given_len, 1])
+        plan = compile_plan(form, lti=lti, csc=kind)
+        A, h, Q, q = orc.assemble(form, given)
+        srcs = [s.array for s in plan.sources]
+        for g in plan.lti:                      # (A, B) travel in the group's first two sources
+            mats = form.dynamics[g["name"]].matrices
+            srcs[g["ids"][0]] = mats[-1][0].T.copy()
+            srcs[g["ids"][1]] = np.stack([mats[j][0, 0, :] for j in range(g["m"])], axis=1)
+        res = plan_emulator.run_resident(plan, given, sources=srcs)
+        c = plan.csc
+        assert res["P_data"].shape == (c["pnnz"],) and res["G_data"].shape == (c["gnnz"],)
+        Pm = sp.csc_matrix((res["P_data"], c["P"][1], c["P"][0]), shape=Q.shape).toarray()
+        Gm = sp.csc_matrix((res["G_data"], c["G"][1], c["G"][0]), shape=A.shape).toarray()
+        assert_close(Pm, np.triu(Q) if kind == "upper" else Q, 1e-12, "P")
+        assert_close(Gm, A, 1e-12, "G")
+        assert_close(res["q"], q.ravel(), 1e-12, "q"), assert_close(res["h"], h.ravel(), 1e-12, "h")
+        # ... and the library takes the tables (the device step is all that is missing here)
+        handle = ctypes.c_void_p()
+        rc = lib.mpcasm_plan_create(plan.itab.ctypes.data, plan.itab.size, plan.dtab.ctypes.data,
+                                    plan.dtab.size, ctypes.byref(handle))
+        assert rc in (0, -4), rc
+        if rc == 0:
+            lib.mpcasm_plan_destroy(handle)
+        # a corrupted entry is refused: a column outside the row, an arrow of another row
+        for word, value in ((_H["OFF_CSC_P"], None), (_H["OFF_CSC_G"], None)):
+            bad = plan.itab.copy()
+            bad[bad[word]] = 1 << 30
+            assert lib.mpcasm_plan_create(bad.ctypes.data, bad.size, plan.dtab.ctypes.data,
+                                          plan.dtab.size, ctypes.byref(handle)) == -2
+    # a problem that does not fit on chip has no such plan
+    with pytest.raises(ValueError):
+        compile_plan(problems.random_lti(cpu_api, np.random.default_rng(3), N=16), csc="upper")
+
+
 def test_structural_csc_patterns(cpu_api):
     """f3: the batch-wide sparsity patterns contain every numeric non-zero of the oracle's
     P and G; with generic numbers the P pattern IS scipy's; CSC ordering as scipy's."""

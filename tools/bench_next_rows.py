@@ -63,6 +63,29 @@ def main():
         print("f3 csc %s          nnz %5d of %6d  %8.3f ms  %7.0f GB/s written"
               % (which, indptr[-1], dense[0].numel(), t * 1e3, B * int(indptr[-1]) * 8 / t / 1e9))
 
+    # f3, written by the assembly itself: horizon matrices built on chip, P (upper triangle) and G
+    # leave as CSC data; against the dense assembly + the two gather passes on the same inputs
+    A = torch.as_tensor(work["A"], device="cuda")
+    Bm = torch.as_tensor(work["B"], device="cuda")
+    dense = engine.Assembler(form, batch=B, lti=["LIP"])
+    dense.bind_lti("LIP", A, Bm)
+    sparse = engine.Assembler(form, batch=B, lti=["LIP"], csc="upper")
+    sparse.bind_lti("LIP", A, Bm)
+    c = sparse.csc
+
+    def two_pass():
+        dense.assemble(given)
+        dense.export_csc("P", upper=True)
+        dense.export_csc("G")
+
+    t2 = timed(two_pass, 30)
+    t1 = timed(lambda: sparse.assemble(given), 30)
+    out_bytes = 8 * (c["pnnz"] + asm.no + c["gnnz"] + asm.nc)
+    print("f3 csc in one pass  nnz P %d (upper) G %d: %d B per instance instead of %d"
+          % (c["pnnz"], c["gnnz"], out_bytes, 8 * (asm.no * asm.no + asm.no + asm.nc * asm.no + asm.nc)))
+    print("   dense assembly + 2 gathers %8.3f ms  %10.0f QPs/s;  CSC from the kernel %8.3f ms  %10.0f QPs/s  (%.0f GB/s written)"
+          % (t2 * 1e3, B / t2, t1 * 1e3, B / t1, B * out_bytes / t1 / 1e9))
+
     # f4: box transforms on the per-instance parameters
     box = BoxBatch(asm, form, "support_polygon")
     rot = torch.eye(2, dtype=torch.float64, device="cuda").repeat(B, 1, 1)
