@@ -57,8 +57,12 @@ METRIC = "QP assemblies/sec (P,q,G,h), biped N=16 batched"
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--settle-ms", type=float, default=40.0,
+                    help="untimed steps before the warm-up until this much time has passed: the "
+                         "device's clocks take 15-25 ms of load to settle (tools/launch_series.py: "
+                         "the first launches after idle run up to 15 %% slower)")
     ap.add_argument("--batch", type=int, default=4096, help="instances per GPU")
     ap.add_argument("--rotate", type=int, default=3, help="output buffer sets the steps cycle over")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -213,11 +217,17 @@ def cpu_baseline_all_cores(budget_s=10.0):
 # --------------------------------------------------------------------------
 # sub-records (timed after the main region; never part of `value`)
 # --------------------------------------------------------------------------
-def _event_ms(torch, fn, reps, warm=3):
-    """Average duration of ``fn`` over ``reps`` back-to-back calls, hipEvents on the launch stream."""
-    for _ in range(warm):
-        fn()
+def _event_ms(torch, fn, reps, warm=3, settle_ms=30.0):
+    """Average duration of ``fn`` over ``reps`` back-to-back calls, hipEvents on the launch stream,
+    after ``warm`` calls and at least ``settle_ms`` of load (the clocks settle, tools/launch_series.py)."""
+    fn()                          # (a first call may compile a kernel)
     torch.cuda.synchronize()
+    t0, n = time.perf_counter(), 0
+    while n < warm or (time.perf_counter() - t0) * 1e3 < settle_ms:
+        for _ in range(4):
+            fn()
+        n += 4
+        torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
@@ -381,6 +391,15 @@ def run_rank(args):
             dist.barrier()
         torch.cuda.synchronize()
 
+    # clocks first (tools/launch_series.py), then the W warm-up steps of the contract
+    step(0)                       # (the first call compiles the kernel for the plan)
+    torch.cuda.synchronize()
+    settle_steps, t_settle = 0, time.perf_counter()
+    while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
+        for _ in range(16):
+            step(settle_steps)
+            settle_steps += 1
+        torch.cuda.synchronize()
     for k in range(args.warmup):
         step(k)
     sync_all()
@@ -445,6 +464,7 @@ def run_rank(args):
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
+        "settle": {"ms": args.settle_ms, "untimed_steps_before_warmup": settle_steps},
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
         "scaling": "weak",
