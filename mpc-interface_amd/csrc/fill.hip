@@ -23,6 +23,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <stdlib.h>
+
 #include "device_common.h"
 #include "kernels.h"
 
@@ -1044,7 +1046,10 @@ int launch_fill_su(const double* A, const double* B, double* S, double* U, int b
     // few states: registers + DPP recurrence, constant-address write loop
     int spw = 16 / (m + n);
     while (spw > 1 && quad_lds_doubles(N, n, m, spw) * sizeof(double) > 40 * 1024) --spw;
-    while (spw > 1 && (batch + spw - 1) / spw < 2048) --spw;
+    // (fewer systems per wavefront while the launch has fewer wavefronts than this: 8192 systems
+    // as 8192 wavefronts of one reach 0.66 of HBM, as 2048 of four 0.59; tuning aid: the variable)
+    static const int SPW_MIN_WAVES = getenv("MPCASM_FILL_MIN_WAVES") ? atoi(getenv("MPCASM_FILL_MIN_WAVES")) : 8192;
+    while (spw > 1 && (batch + spw - 1) / spw < SPW_MIN_WAVES) --spw;
     const size_t bytes = quad_lds_doubles(N, n, m, spw) * sizeof(double);
     if (bytes <= LDS_MAX) {
       auto kernel = n == 1   ? fill_lti_quad_kernel<1>

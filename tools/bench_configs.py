@@ -13,6 +13,7 @@ sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 
+import bench  # noqa: E402
 from mpcasm import engine, problems  # noqa: E402
 
 
@@ -22,16 +23,7 @@ def run(name, form, batch, reps=10, lti=None):
     if lti:     # horizon matrices built on chip from per-instance (A, B)
         asm.bind_lti(lti[0], torch.as_tensor(lti[1], device="cuda"), torch.as_tensor(lti[2], device="cuda"))
     given = torch.as_tensor(rng.normal(0, 0.1, [batch, form.given_len]), device="cuda")
-    for _ in range(2):
-        asm.assemble(given)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        asm.assemble(given)
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / reps
+    ms = bench._event_ms(torch, lambda: asm.assemble(given), reps)   # (after the clocks have settled)
     no, nc, ng = asm.no, asm.nc, asm.ng
     out_bytes = 8 * (no * no + no + nc * no + nc)
     print("%-28s B=%6d no=%4d nc=%5d rtot=%5d  %9.3f ms  %10.0f asm/s  %7.1f GB/s out"

@@ -10,9 +10,11 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "mpc-interface_amd"))
+sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 
+import bench  # noqa: E402
 from mpcasm import engine  # noqa: E402
 
 CASES = [  # name, n, m, N, ltv, batch
@@ -42,17 +44,7 @@ def main():
         B = torch.as_tensor(rng.standard_normal(shapeB), device="cuda")
         S = torch.empty((batch, N, n, n), dtype=torch.float64, device="cuda")
         U = torch.empty((batch, m, N, N, n), dtype=torch.float64, device="cuda")
-        for _ in range(3):
-            engine.fill_su(A, B, N, ltv=ltv, out=(S, U))
-        torch.cuda.synchronize()
-        reps = 20
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            engine.fill_su(A, B, N, ltv=ltv, out=(S, U))
-        e1.record()
-        torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) / reps * 1e3
+        us = bench._event_ms(torch, lambda: engine.fill_su(A, B, N, ltv=ltv, out=(S, U)), 20) * 1e3
         nbytes = 8 * (N * n * n + m * N * N * n) + 8 * (n * n + n * m) * (N if ltv else 1)
         gbs = nbytes * batch / (us * 1e-6) / 1e9
         print("%-22s %8d %10.1f %10.1f %9.0f %7.3f" % (name, batch, nbytes * batch / 1e6, us, gbs,

@@ -19,9 +19,13 @@ from mpcasm.boxes import BoxBatch  # noqa: E402
 from mpcasm.walkers import WalkerFleet  # noqa: E402
 
 
-def timed(fn, reps, warm=3):
-    for _ in range(warm):
+def timed(fn, reps, warm=3, settle_ms=30.0):
+    fn()
+    torch.cuda.synchronize()
+    t0, n = time.perf_counter(), 0
+    while n < warm or (time.perf_counter() - t0) * 1e3 < settle_ms:   # (the clocks settle under load)
         fn()
+        n += 1
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(reps):

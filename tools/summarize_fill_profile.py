@@ -11,6 +11,8 @@ import os
 import re
 import sys
 
+import proftrace
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -42,6 +44,12 @@ def main():
                     if r["Counter_Name"] == counter]
             if vals:
                 rec[counter + "_KiB_median"] = sorted(vals)[len(vals) // 2]
+        # the last 30 launches of the stats run: after the 40 ms the run spends warming the device
+        steady = proftrace.steady_ns(os.path.join(src, "stats%d" % i), "fill_l", 30)
+        if steady:
+            rec["average_all_launches_ns"] = rec.get("average_ns")
+            rec["average_ns"] = steady
+            rec["average_of"] = "the last 30 launches of the run (rocprofv3 --kernel-trace), device warm"
         if "average_ns" in rec:
             rec["achieved_GBps"] = nbytes / rec["average_ns"]
             rec["frac_of_8TBps"] = rec["achieved_GBps"] / 8000.0

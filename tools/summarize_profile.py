@@ -20,6 +20,8 @@ import json
 import os
 import sys
 
+import proftrace
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -78,6 +80,12 @@ def main():
         }
     stats_avg = {r[0]: float(r[3]) for r in rows}
     summary["kernel_average_ns"] = {k: v for k, v in stats_avg.items() if short(k)}
+    # (the average above covers every launch of the run, the first, slower ones included; the
+    # timed region of bench.py is its last `steps` launches)
+    for k in ("resident_spec_kernel", "resident_assemble_kernel"):
+        steady = proftrace.steady_ns(os.path.join(src, "stats"), k, 2000)
+        if steady:
+            summary.setdefault("kernel_average_last_2000_launches_ns", {})[k] = steady
     if "stats" in bench:
         summary["bench_in_profiled_run"] = {
             "value": bench["stats"]["value"],
