@@ -3,7 +3,8 @@
 // Same job as fused.hip, restructured so that a QP instance costs no table traffic,
 // no serial chains of dependent on-chip loads and no exposed HBM latency.  The
 // workgroups (512 threads = 8 wavefronts) are persistent: a few per CU, each loops
-// over instances b = blockIdx.x, += gridDim.x.  Everything that is *structure* is
+// over instances (b = blockIdx.x, += gridDim.x; large batches in runs of four consecutive
+// instances per workgroup, see instance_at).  Everything that is *structure* is
 // loaded once per workgroup and then stays on chip for the whole launch:
 //   * the compose program (K2): each thread owns a fixed handful of ops
 //     `coef * image[src] * image[given]` and keeps them in REGISTERS (JC slots);
@@ -16,10 +17,13 @@
 // (global_load_lds_dwordx4: no registers, no staging pass) into the other half of a
 // double buffer.  Waves 4-7 ("stream waves") write the rows of G and h.  All eight run the
 // Hessian and gradient on the fp64 matrix core in 4x4 blocks (v_mfma_f64_4x4x4_4b_f64, four
-// independent blocks per instruction; plan_tables.h RT_*): the workspace keeps the four rows a
-// lane feeds to four k-steps side by side (two ds_read_b128 per operand), a term's weight is
-// applied once to its block sum, the gradient rides along through a column of ones, and the
-// blocks of P go from the accumulators straight to HBM (or, optionally, through LDS).
+// independent blocks per instruction; plan_tables.h RT_*): the workspace is row major and a lane
+// row's four k-steps read rows 8 apart from the next lane row's (eight conflict-free 8-byte LDS
+// reads per trip, device_prims.h mfma_trip16), a term's weight is applied once to its block
+// sum, the gradient rides along through a column of ones, and the blocks of P go from the
+// accumulators straight to HBM (small launches, or when P does not fit) or are collected in
+// LDS and written with 16-byte nontemporal stores (launches that stream to HBM); a plan may
+// ask for the CSC data arrays of P and G instead of the dense matrices (g_mode 3).
 //
 // Per instance, three barriers:
 //   A | all: diagonal terms, K2 compose the workspace V = [Mo | d = Mg.given | 1] from the
