@@ -16,8 +16,9 @@ extern int g_phase_mask;  // fused.hip
 // "plan_spec.h" of a plan: its sizes and trip lists as constants
 std::string jit_spec_header(const PlanDev& d, const int32_t* h_itab);
 // resident.hip + that header -> gfx950 code object (needs libhiprtc.so, no device)
+// (phases >= 0: the phase mask as a constant of the build; -1: the kernel argument)
 int jit_compile(const std::string& header, std::vector<char>* code, std::string* log,
-                bool stamps = false);
+                bool stamps = false, int phases = 0xBF);
 // the compiled kernel of (plan structure, device), or nullptr: use the ahead-of-time kernel
 const void* jit_kernel_for(const PlanDev& d, const int32_t* h_itab, int device, int batch,
                            size_t lds_bytes);

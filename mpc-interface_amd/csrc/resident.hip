@@ -1197,8 +1197,15 @@ extern "C" __global__ __launch_bounds__(RS_NT, MPCASM_SPEC_WAVES_PER_EU) void re
 #else
   constexpr bool stamped = false;
 #endif
+  // (MPCASM_SPEC_PHASES: the kernel as it ships runs every phase -- with the mask a constant its
+  // tests and the code of the profiling variants fold away; a build per mask value otherwise)
+#ifdef MPCASM_SPEC_PHASES
+  const int mask = MPCASM_SPEC_PHASES;
+#else
+  const int mask = phases;
+#endif
   resident_body<spec::JC, stamped, spec::PlanConst::rs_nlti != 0>(p, plan_itab, plan_dtab, src, params,
-                                                               given, P, q, G, h, batch, phases, stamps);
+                                                               given, P, q, G, h, batch, mask, stamps);
 }
 namespace {
 #else
