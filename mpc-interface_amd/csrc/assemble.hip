@@ -505,6 +505,7 @@ __global__ __launch_bounds__(BLOCK) void constraints_kernel(PlanDev p,
     // all loads of four pieces of the row are issued before the first is used.
     double2* G2 = reinterpret_cast<double2*>(Grow);
     const int npair = no >> 1;
+    const bool whole_lines = (no & 15) == 0;
     const double a0 = s_arrow[row][0], a1 = naxes > 1 ? s_arrow[row][1] : 0.0;
     const double* v0p = Vb + s_voff[row][0];
     const double* v1p = Vb + s_voff[row][naxes > 1 ? 1 : 0];
@@ -522,7 +523,14 @@ __global__ __launch_bounds__(BLOCK) void constraints_kernel(PlanDev p,
         double2 acc;
         acc.x = fma(a1, v1[u].x, a0 * v0[u].x);
         acc.y = fma(a1, v1[u].y, a0 * v0[u].y);
-        if (cp < npair) G2[cp] = acc;
+        // (rows that are whole cache lines leave nontemporal: written once, not read by this
+        // launch -- device_prims.h store_result)
+        if (cp < npair) {
+          if (whole_lines)
+            store_result(&G2[cp], acc);
+          else
+            G2[cp] = acc;
+        }
       }
     }
   } else if ((no & 1) == 0) {
