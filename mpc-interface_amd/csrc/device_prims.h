@@ -62,6 +62,38 @@ __device__ __forceinline__ double mfma_trip16(unsigned pa, unsigned pb, double s
   return sum;
 }
 
+// ... with the rows' distance known only at run time (the ahead-of-time kernel): the same
+// statement on eight addresses.
+__device__ __forceinline__ double mfma_trip16_at(unsigned pa, unsigned pb, unsigned row_bytes, double sum) {
+  double a0, a1, a2, a3, b0, b1, b2, b3;
+  const unsigned pa1 = pa + row_bytes, pa2 = pa1 + row_bytes, pa3 = pa2 + row_bytes;
+  const unsigned pb1 = pb + row_bytes, pb2 = pb1 + row_bytes, pb3 = pb2 + row_bytes;
+  asm volatile(
+      "ds_read_b64 %1, %9\n\t"
+      "ds_read_b64 %5, %13\n\t"
+      "ds_read_b64 %2, %10\n\t"
+      "ds_read_b64 %6, %14\n\t"
+      "ds_read_b64 %3, %11\n\t"
+      "ds_read_b64 %7, %15\n\t"
+      "ds_read_b64 %4, %12\n\t"
+      "ds_read_b64 %8, %16\n\t"
+      "s_waitcnt lgkmcnt(6)\n\t"
+      "v_mfma_f64_4x4x4_4b_f64 %0, %1, %5, %0\n\t"
+      "s_waitcnt lgkmcnt(4)\n\t"
+      "s_nop 2\n\t"
+      "v_mfma_f64_4x4x4_4b_f64 %0, %2, %6, %0\n\t"
+      "s_waitcnt lgkmcnt(2)\n\t"
+      "s_nop 2\n\t"
+      "v_mfma_f64_4x4x4_4b_f64 %0, %3, %7, %0\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "s_nop 2\n\t"
+      "v_mfma_f64_4x4x4_4b_f64 %0, %4, %8, %0\n\t"
+      "s_nop 5"
+      : "+v"(sum), "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3)
+      : "v"(pa), "v"(pa1), "v"(pa2), "v"(pa3), "v"(pb), "v"(pb1), "v"(pb2), "v"(pb3));
+  return sum;
+}
+
 // Results that a wavefront writes as whole cache lines (16 bytes per lane, consecutive lanes)
 // leave for HBM with nontemporal stores: written once, not read again by this launch, they need
 // not stay in L2 -- measured on the persistent assembly kernel at B = 65536 (2.2 GB of outputs):

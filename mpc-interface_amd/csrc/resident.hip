@@ -1017,10 +1017,10 @@ __device__ __forceinline__ void resident_body(
       // -> P, q in LDS.  v_mfma_f64_4x4x4_4b_f64: lane l feeds element x = l & 3 of block
       // g = (l >> 2) & 3 in k-step row l >> 4 and receives D[l >> 4][l & 3] of block g.
       // A trip is one 32-byte record (wave-uniform, the same for every instance: read from
-      // the plan through the scalar cache, the next one on its way), two address adds, four
-      // 16-byte operand reads (the workspace keeps the four rows a lane feeds to the four
-      // k-steps side by side) and four MFMAs into the TERM's sum; nothing is scaled on the
-      // way.  The weight comes in once per term and pack: acc += w S, the lanes of a block of
+      // the plan through the scalar cache, the next one on its way), eight 8-byte operand reads
+      // (mfma_trip16_at: a lane's four rows are LDV apart, the two lane rows one read serves 8
+      // rows apart -- every bank once) and four MFMAs into the TERM's sum; nothing is scaled on
+      // the way.  The weight comes in once per term and pack: acc += w S, the lanes of a block of
       // q (B operand: d in element 0, ones in element 1) acc += (w s) (S[.][0] - aim S[.][1]).
       const int t0 = __builtin_amdgcn_readfirstlane(wtrip[2 * wave]);
       const int tn = __builtin_amdgcn_readfirstlane(wtrip[2 * wave + 1]);
@@ -1055,15 +1055,8 @@ __device__ __forceinline__ void resident_body(
           if (word & 31) {
             const int boff = isq ? r[RT_D] : r[RT_B];
             if (!((word >> RT_SHORT) & 1)) {
-              const char *ar = ap + r[RT_A], *br = bp + boff;
-              double a[4], b[4];
-#pragma unroll
-              for (int u = 0; u < 4; ++u) {
-                a[u] = *reinterpret_cast<const double*>(ar + u * row_bytes);
-                b[u] = *reinterpret_cast<const double*>(br + u * row_bytes);
-              }
-#pragma unroll
-              for (int u = 0; u < 4; ++u) sum = mfma_f64_4x4x4(a[u], b[u], sum);
+              sum = mfma_trip16_at((unsigned)(uintptr_t)(ap + r[RT_A]), (unsigned)(uintptr_t)(bp + boff),
+                                   (unsigned)row_bytes, sum);
             } else {
               const double a = *reinterpret_cast<const double*>(ap + (r[RT_A] + short_shift));
               const double b = *reinterpret_cast<const double*>(bp + (boff + short_shift));
