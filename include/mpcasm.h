@@ -68,7 +68,7 @@ enum { MPCASM_OPT_PATH = 1, MPCASM_OPT_PHASE_MASK = 2, MPCASM_OPT_RESIDENT_PER_C
  * 0 (default) = chosen from the batch size, never more than are resident at once.
  * MPCASM_OPT_JIT: the persistent kernel compiled for the very plan by hiprtc (its sizes and
  * matrix-core trip lists become constants; same source, same results as the ahead-of-time
- * kernel): 0 (default) = for batches of at least 1536 instances, when libhiprtc.so is there
+ * kernel): 0 (default) = for batches of at least 512 instances, when libhiprtc.so is there
  * (compiled once per plan structure and device, on the first such launch: that launch blocks
  * for the compilation, a second or two); 1 = for every batch; 2 = never.
  * MPCASM_OPT_P_DIRECT (read by mpcasm_plan_create): how the persistent kernel writes P -- 1: its

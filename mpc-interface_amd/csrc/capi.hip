@@ -648,6 +648,7 @@ int mpcasm_jit_check(const int32_t* h_itab, size_t n_itab, const double* h_dtab,
 
 int mpcasm_plan_destroy(mpcasm_plan* plan) {
   if (!plan) return MPCASM_OK;
+  jit_forget(plan->d_itab);
   hipError_t e1 = hipFree(plan->d_itab);
   hipError_t e2 = hipFree(plan->d_dtab);
   delete plan;

@@ -22,6 +22,8 @@ int jit_compile(const std::string& header, std::vector<char>* code, std::string*
 // the compiled kernel of (plan structure, device), or nullptr: use the ahead-of-time kernel
 const void* jit_kernel_for(const PlanDev& d, const int32_t* h_itab, int device, int batch,
                            size_t lds_bytes);
+// (called when a plan is destroyed: compiled kernels are remembered by the plan's device tables)
+void jit_forget(const void* itab);
 int jit_launch(const void* kernel, const PlanDev& p, const SrcTable& src, const double* params,
                const double* given, double* P, double* q, double* G, double* h, int batch,
                int num_cus, int per_cu_limit, void* work, hipStream_t stream, hipError_t* err);
