@@ -287,3 +287,42 @@ def test_a_large_batch_goes_round_the_workgroups_in_runs_of_four(gpu_api, torch_
     for t, r in ((P, Ps), (q, qs), (G, Gs), (h, hs)):
         per_instance = (t - r).flatten(1).abs().amax(1) / r.flatten(1).abs().amax(1).clamp_min(1e-300)
         assert per_instance.max().item() <= 1e-11, int(per_instance.argmax())
+
+
+@pytest.mark.parametrize("jit", [2, 1])
+def test_csc_data_at_a_batch_that_streams_to_hbm(gpu_api, torch_gpu, jit):
+    """The CSC form of the results (plans compiled with csc=) at B = 8197: runs of four instances
+    per workgroup, a last run that is not full, a different system in every instance.  Entry for
+    entry the dense assembly of the same inputs (bit for bit), every stored entry written."""
+    torch = torch_gpu
+    from mpcasm import capi, engine
+
+    conf = problems.BipedConfig(step_samples=8)
+    form = problems.biped(gpu_api, conf)
+    form.update(step_times=np.array([6, 14]), step_count=0)
+    B = 8197
+    rng = np.random.default_rng(78)
+    get_A, get_B, _ = gpu_api.tools.get_system_matrices("J->CCC")
+    taus = rng.uniform(0.09, 0.11, B)
+    A = torch.as_tensor(np.stack([get_A(tau=t) for t in taus]), device="cuda")
+    Bm = torch.as_tensor(np.stack([get_B(tau=t) for t in taus]), device="cuda")
+    given = torch.as_tensor(rng.normal(0, 0.1, [B, form.given_len]), device="cuda")
+    lib = capi.load()
+    lib.mpcasm_set_option(capi.OPT_JIT, jit)
+    try:
+        sparse = engine.Assembler(form, batch=B, lti=["LIP"], csc="upper")
+        sparse.bind_lti("LIP", A, Bm)
+        dense = engine.Assembler(form, batch=B, lti=["LIP"])
+        dense.bind_lti("LIP", A, Bm)
+        out = tuple(torch.full_like(t, float("nan")) for t in sparse.assemble(given))
+        Pd, q, Gd, h = sparse.assemble(given, out=out)
+        P, q2, G, h2 = dense.assemble(given)
+    finally:
+        lib.mpcasm_set_option(capi.OPT_JIT, 0)
+    c = sparse.csc
+    assert Pd.shape == (B, c["pnnz"]) and Gd.shape == (B, c["gnnz"])
+    assert not any(torch.isnan(t).any().item() for t in (Pd, q, Gd, h))
+    p_flat = torch.as_tensor(c["p_flat"].astype(np.int64), device="cuda")
+    g_flat = torch.as_tensor(c["g_flat"].astype(np.int64), device="cuda")
+    assert torch.equal(Pd, P.reshape(B, -1)[:, p_flat]) and torch.equal(Gd, G.reshape(B, -1)[:, g_flat])
+    assert torch.equal(q, q2) and torch.equal(h, h2)
