@@ -18,27 +18,15 @@ from mpcasm import capi  # noqa: E402
 
 def main():
     lib = capi.load()
-    for B in (1024, 3072, 4096, 6144, 16384, 65536):
+    for B in (4096, 16384):
         work = bench.build_workload(B, 1)
         asm = work["engine"].Assembler(work["form"], batch=B, lti=["LIP"])
         asm.bind_lti("LIP", torch.as_tensor(work["A"], device="cuda"), torch.as_tensor(work["B"], device="cuda"))
         given = torch.as_tensor(work["given"], device="cuda")
         line = "B=%6d " % B
-        for k in (1, 2, 3):
+        for k in (1, 2):
             lib.mpcasm_set_option(capi.OPT_RESIDENT_PER_CU, k)
-            ts = []
-            for rnd in range(3):
-                for _ in range(3):
-                    asm.assemble(given)
-                torch.cuda.synchronize()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                n = 30 if B <= 8192 else 6
-                e0.record()
-                for _ in range(n):
-                    asm.assemble(given)
-                e1.record()
-                torch.cuda.synchronize()
-                ts.append(e0.elapsed_time(e1) / n * 1e3)
+            ts = [bench._event_ms(torch, lambda: asm.assemble(given), 60) * 1e3]   # (device warm)
             line += "  k=%d %8.1f us" % (k, np.median(ts))
         lib.mpcasm_set_option(capi.OPT_RESIDENT_PER_CU, 0)
         print(line, flush=True)
