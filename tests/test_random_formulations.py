@@ -118,6 +118,19 @@ def test_plan_tables_random(cpu_api, seed):
         assert_close(res["q"], q.ravel(), 1e-12)
         assert_close(res["G"], A, 1e-12)
         assert_close(res["h"], h.ravel(), 1e-12)
+        # the CSC form of the same results, where the row records allow it (at most two axes):
+        # crossed costs make P unsymmetric, so all of it is stored
+        try:
+            sparse = compile_plan(form, csc="full")
+        except ValueError:
+            return
+        got = plan_emulator.run_resident(sparse, given)
+        c = sparse.csc
+        assert ((Q != 0) <= sparse.P_pattern).all() and ((A != 0) <= sparse.G_pattern).all()
+        assert_close(got["P_data"], Q.ravel()[c["p_flat"]], 1e-12)
+        assert_close(got["G_data"], A.ravel()[c["g_flat"]], 1e-12)
+        assert (np.diff(c["P"][0]) >= 0).all() and c["P"][0][-1] == c["pnnz"] == c["p_flat"].size
+        assert (np.diff(c["G"][0]) >= 0).all() and c["G"][0][-1] == c["gnnz"] == c["g_flat"].size
 
 
 @pytest.mark.gpu
@@ -177,3 +190,29 @@ def test_persistent_kernel_instance_loop(gpu_api):
                 assert_close(a, b, 1e-12, "%s seed %d" % (name, seed))
     finally:
         lib.mpcasm_set_option(capi.OPT_PATH, 0)
+
+
+@pytest.mark.gpu
+def test_csc_form_random(gpu_api):
+    """Random formulations whose problems fit on chip: the CSC data the persistent kernel writes
+    (plans compiled with csc='full') are, entry for entry, the dense results of the same inputs."""
+    from mpcasm.engine import Assembler
+
+    batch, done = 700, 0
+    for seed in SEEDS:
+        form, rng = random_formulation(gpu_api, seed)
+        given = rng.standard_normal([batch, form.given_len])
+        try:
+            sparse = Assembler(form, batch=batch, csc="full")
+        except (ValueError, RuntimeError):
+            continue                         # no persistent kernel for this problem
+        dense = Assembler(form, batch=batch)
+        Pd, q, Gd, h = (t.cpu().numpy() for t in sparse.assemble(given))
+        P, q2, G, h2 = (t.cpu().numpy() for t in dense.assemble(given))
+        c = sparse.csc
+        assert_close(Pd, P.reshape(batch, -1)[:, c["p_flat"]], 1e-13, "P seed %d" % seed)
+        assert_close(Gd, G.reshape(batch, -1)[:, c["g_flat"]], 1e-13, "G seed %d" % seed)
+        assert_close(q, q2, 1e-13, "q seed %d" % seed)
+        assert_close(h, h2, 1e-13, "h seed %d" % seed)
+        done += 1
+    assert done >= 6, done
