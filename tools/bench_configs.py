@@ -3,7 +3,6 @@
 whatever path the library selects for them."""
 import os
 import sys
-import time
 
 import numpy as np
 

@@ -3,9 +3,7 @@
 the same launches issued one by one: what the launch gaps are worth.  python tools/graph_replay.py [batch]"""
 import os
 import sys
-import time
 
-import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "mpc-interface_amd"))

@@ -4,7 +4,6 @@ import os, sys, numpy as np
 ROOT = "/root/repo" if os.path.isdir("/root/repo/tools") else os.environ["GRAFT_REPO_ROOT"]
 sys.path.insert(0, os.path.join(ROOT, "mpc-interface_amd")); sys.path.insert(0, ROOT)
 import torch, bench
-from mpcasm import capi
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 NL = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 GRP = int(sys.argv[3]) if len(sys.argv) > 3 else 1

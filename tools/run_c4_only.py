@@ -4,7 +4,6 @@ as `chunks` launches of `batch` instances on the staged pipeline -- the program
 tools/profile_c4.sh wraps in rocprofv3.   python tools/run_c4_only.py [batch] [chunks] [reps]"""
 import os
 import sys
-import time
 
 import numpy as np
 
