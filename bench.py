@@ -64,7 +64,12 @@ def parse_args(argv=None):
                          "device's clocks take 15-25 ms of load to settle (tools/launch_series.py: "
                          "the first launches after idle run up to 15 %% slower)")
     ap.add_argument("--batch", type=int, default=4096, help="instances per GPU")
-    ap.add_argument("--rotate", type=int, default=3, help="output buffer sets the steps cycle over")
+    ap.add_argument("--rotate", type=int, default=4, help="output buffer sets the steps cycle over")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="launch streams the (independent) steps are dealt to in turn: a launch starts on "
+                         "the CUs the one before has already left instead of waiting for its last "
+                         "workgroup and a launch gap (tools/two_streams.py: 30.4 -> 26.6 us per step); 1 = "
+                         "one stream.  The roofline record is always taken on ONE stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the fill / B=65536 / gather sub-records (main line only)")
@@ -378,12 +383,16 @@ def run_rank(args):
                 for _ in range(max(1, count))]
 
     asm, SU = make_assembler(B, A, Bm, work["aims"])
-    outs = output_sets(asm, B, args.rotate)
+    # (--two-kernels: the steps share the S, U buffer between fill and assembly -- one stream)
+    nstreams = max(1, args.streams) if fused else 1
+    # two launches in flight never write the same output set: at least twice as many sets as streams
+    outs = output_sets(asm, B, max(args.rotate, 2 * nstreams if nstreams > 1 else 1))
+    streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(nstreams - 1)]
 
-    def step(k):
+    def step(k, stream=None):
         if not fused:
-            engine.fill_su(A, Bm, N, out=SU)
-        return asm.assemble(given, out=outs[k % len(outs)])
+            engine.fill_su(A, Bm, N, out=SU, stream=stream)
+        return asm.assemble(given, out=outs[k % len(outs)], stream=stream)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -397,22 +406,42 @@ def run_rank(args):
     settle_steps, t_settle = 0, time.perf_counter()
     while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
         for _ in range(16):
-            step(settle_steps)
+            step(settle_steps, streams[settle_steps % nstreams])
             settle_steps += 1
         torch.cuda.synchronize()
     for k in range(args.warmup):
-        step(k)
+        step(k, streams[k % nstreams])
     sync_all()
 
-    # timed region: exactly K steps.  One pair of hipEvents on the launch stream brackets the
-    # K launches (K1-fused: a step IS one kernel, so event time / K = average launch duration,
-    # launch gaps included -- the conservative reading); --two-kernels adds a pair around the
-    # fill of every 8th step.
+    # timed region: exactly K steps, dealt to the launch streams in turn.  One pair of hipEvents
+    # brackets it: the first on stream 0 (the others wait for it), the second on stream 0 after
+    # it has waited for the others.
     e_begin, e_end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    fill_ev = []
     t0 = time.perf_counter()
-    e_begin.record()
+    e_begin.record(streams[0])
+    for s in streams[1:]:
+        s.wait_event(e_begin)
     for k in range(args.steps):
+        step(k, streams[k % nstreams])
+    for s in streams[1:]:
+        streams[0].wait_stream(s)
+    e_end.record(streams[0])
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        elapsed = mdist.max_over_ranks(elapsed, device=dev)
+    region_ms = e_begin.elapsed_time(e_end) / args.steps
+
+    # the dominant kernel by itself, for the roofline record: the same steps once more on ONE
+    # stream (K1-fused: a step IS one kernel, so event time / steps = average launch duration,
+    # launch gaps included -- the conservative reading; rocprofv3's kernel time of the same
+    # command with --streams 1 is what it is compared with); --two-kernels adds a pair of events
+    # around the fill of every 8th step.
+    k_steps = min(args.steps, 1000)
+    k_begin, k_end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    fill_ev = []
+    k_begin.record()
+    for k in range(k_steps):
         if not fused:
             if k % 8 == 0:
                 pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -423,13 +452,9 @@ def run_rank(args):
             else:
                 engine.fill_su(A, Bm, N, out=SU)
         asm.assemble(given, out=outs[k % len(outs)])
-    e_end.record()
+    k_end.record()
     sync_all()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        elapsed = mdist.max_over_ranks(elapsed, device=dev)
-
-    step_ms = e_begin.elapsed_time(e_end) / args.steps
+    step_ms = k_begin.elapsed_time(k_end) / k_steps
     fill_ms = float(np.mean([a.elapsed_time(b) for a, b in fill_ev])) if fill_ev else 0.0
     asm_ms = step_ms - fill_ms
 
@@ -478,6 +503,7 @@ def run_rank(args):
             "global_batch": B * world,
             "horizon": N,
             "output_buffer_sets": len(outs),
+            "launch_streams": nstreams,
             "step": "mpcasm_assemble, horizon matrices built on chip from per-instance (A,B) "
                     "(K1 fused)" if fused else "mpcasm_fill_su + mpcasm_assemble",
         },
@@ -492,8 +518,12 @@ def run_rank(args):
             "algorithmic_bytes_per_launch": bytes_asm * B,
             "algorithmic_bytes_per_assembly": bytes_asm,
             "avg_launch_ms": asm_ms,
-            "clock": "hipEvents on the launch stream around the %d timed launches" % args.steps,
+            "clock": "hipEvents on ONE launch stream around %d launches of the same steps, right after the "
+                     "timed region (launch gaps included); the timed region itself deals its launches to "
+                     "%d stream(s), where consecutive launches overlap" % (k_steps, nstreams),
         },
+        "timed_region": {"launch_streams": nstreams, "ms_per_step_hipEvents": region_ms,
+                         "one_stream_ms_per_step": step_ms},
         "hbm_GBps_end_to_end": (bytes_asm + (0 if fused else bytes_fill)) * value / 1e9,
     }
     if not fused:
