@@ -372,7 +372,11 @@ __device__ __forceinline__ void resident_body(
   // robin).  With registers to spare (FK > 0) a lane keeps the address of its piece of the
   // first FK chunks of its wave -- pointer into instance 0 and bytes per instance -- so that
   // a load costs one multiply-add; further chunks look their stream up in LDS.
+#ifdef MPCASM_SPEC
   constexpr int FK = JC <= 5 ? 3 : 0;
+#else
+  constexpr int FK = 0;  // (the ahead-of-time kernel has no registers to spare: it looks the streams up)
+#endif
   const char* f_base[FK > 0 ? FK : 1];
   int f_stride[FK > 0 ? FK : 1];
   // A chunk whose every lane reads a stream shared by the whole batch (stride 0: one model
@@ -674,8 +678,12 @@ __device__ __forceinline__ void resident_body(
   // (element offset in P | 1 << 30 one 16-byte store | 1 << 29 two elements; -1 nothing) --
   // read from the table per instance, the load's trip to L2 and back sat on the stream waves'
   // way to barrier A.
+#ifdef MPCASM_SPEC
   constexpr int ZK = 2;
-  int zoff[ZK];
+#else
+  constexpr int ZK = 0;  // (ahead of time: from the table, no registers held)
+#endif
+  int zoff[ZK > 0 ? ZK : 1];
   {
     const int t0 = tid >= MW * 64 ? tid - MW * 64 : tid + WT;  // (the order of the P / q phase)
     const int32_t* zb = plan_itab + p.off_rs_zblk;
