@@ -70,7 +70,7 @@ class WalkerFleet:
     ``{"p": steps in preview, "index": walker ids, "P", "q", "G", "h": device tensors}``.
     """
 
-    def __init__(self, batch, phases=None, conf=None, api=None, device=None):
+    def __init__(self, batch, phases=None, conf=None, api=None, device=None, graphs=False):
         from .engine import Assembler, require_device
 
         self._torch = require_device()
@@ -83,6 +83,11 @@ class WalkerFleet:
         self.clock = FleetClock(n, self.conf.num_steps, phases)
         self.device = device
         self._ticks, self._cache = 0, {}
+        # graphs=True: a tick's launches (parameter update, gather of `given`, one assembly per
+        # structure bucket) are captured in a hipGraph the first time its place in the step cycle
+        # comes round and replayed from then on -- the tick is a copy of `given` into a fixed
+        # buffer and one graph launch instead of a dozen host-side calls
+        self._use_graphs, self._graphs, self._given = bool(graphs), {}, None
 
         # one template formulation + assembler per structure bucket (steps in preview)
         self.buckets = {}
@@ -147,10 +152,9 @@ class WalkerFleet:
             self._cache[key] = entry
         return self._cache[key]
 
-    def tick(self, given):
-        """Assemble this tick's QPs (``given``: ``(batch, ng)`` tensor or array), then
-        advance every walker's clock."""
-        torch = self._torch
+    def _launch(self, given):
+        """This tick's launches for ``given`` (a device tensor): per structure bucket the
+        parameter update, the gather of its walkers' rows and the assembly."""
         out = []
         for item in self._bucket_inputs():
             p, idx = item["p"], item["idx"]
@@ -158,12 +162,37 @@ class WalkerFleet:
             asm = bucket["asm"]
             asm.bind_source(("steps", 0), item["E"])
             asm.params[:idx.size].index_copy_(1, bucket["center_cols"], item["centers"])
-            g = given if isinstance(given, torch.Tensor) else torch.as_tensor(
-                np.asarray(given, dtype=np.float64), device=asm.device)
-            g = g.to(asm.device).index_select(0, item["index"])
+            g = given.index_select(0, item["index"])
             P, q, G, h = asm.assemble(g, count=idx.size)
             out.append({"p": p, "index": idx, "P": P[:idx.size], "q": q[:idx.size],
                         "G": G[:idx.size], "h": h[:idx.size]})
+        return out
+
+    def tick(self, given):
+        """Assemble this tick's QPs (``given``: ``(batch, ng)`` tensor or array), then
+        advance every walker's clock.  The results live in the assemblers' own buffers: they
+        are valid until the next tick."""
+        torch = self._torch
+        dev = next(iter(self.buckets.values()))["asm"].device
+        g = given if isinstance(given, torch.Tensor) else torch.as_tensor(
+            np.asarray(given, dtype=np.float64), device=dev)
+        g = g.to(dev)
+        if not self._use_graphs:
+            out = self._launch(g)
+        else:
+            if self._given is None:
+                self._given = torch.empty((self.batch, self.given_len), dtype=torch.float64, device=dev)
+            self._given.copy_(g, non_blocking=True)
+            key = self._ticks % (2 * self.conf.step_samples)
+            if key not in self._graphs:
+                self._launch(self._given)            # once as it is: kernels compiled, buffers there
+                torch.cuda.synchronize(dev)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    out = self._launch(self._given)
+                self._graphs[key] = (graph, out)
+            graph, out = self._graphs[key]
+            graph.replay()
         self.clock.tick()
         self._ticks += 1
         return out

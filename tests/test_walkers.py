@@ -88,3 +88,26 @@ def test_fleet_against_the_oracle(gpu_api):
         for c in clocks:
             c.tick()
     assert widths == {34, 36}
+
+
+@pytest.mark.gpu
+def test_fleet_ticks_replayed_from_graphs(gpu_api):
+    """WalkerFleet(graphs=True): a tick is a copy of `given` and one hipGraph launch; over two
+    step cycles (capture in the first, replay in the second) every walker's QP is the one the
+    fleet computes launch by launch."""
+    import torch
+
+    conf = problems.BipedConfig(step_samples=8)
+    batch = 600
+    phases = np.arange(batch) % 8
+    plain = WalkerFleet(batch, phases=phases, conf=conf, api=gpu_api)
+    replayed = WalkerFleet(batch, phases=phases, conf=conf, api=gpu_api, graphs=True)
+    rng = np.random.default_rng(4)
+    for tick in range(2 * 2 * conf.step_samples + 3):
+        given = torch.as_tensor(rng.normal(0, 0.1, [batch, plain.given_len]), device="cuda")
+        a, b = plain.tick(given), replayed.tick(given)
+        assert [r["p"] for r in a] == [r["p"] for r in b]
+        for ra, rb in zip(a, b):
+            assert np.array_equal(ra["index"], rb["index"])
+            for k in ("P", "q", "G", "h"):
+                assert torch.equal(ra[k], rb[k]), (tick, k)

@@ -49,6 +49,10 @@ def main():
     # all of them up, the rate is that of the steady state)
     t = timed(lambda: fleet.tick(g_fleet), 64, warm=2 * fleet.conf.step_samples + 4)
     print("f1 walker fleet   %6d walkers  %8.3f ms per tick  %10.0f walker-ticks/s" % (B, t * 1e3, B / t))
+    # ... the same ticks replayed from hipGraphs (one per place in the step cycle)
+    fleet = WalkerFleet(B, conf=problems.BipedConfig(step_samples=8), graphs=True)
+    t = timed(lambda: fleet.tick(g_fleet), 64, warm=4 * fleet.conf.step_samples + 4)
+    print("   from hipGraphs %6d walkers  %8.3f ms per tick  %10.0f walker-ticks/s" % (B, t * 1e3, B / t))
 
     # f2: Mg.given + Mo.optim for every definition (body.py:209-219)
     PM = asm.preview_matrices()
