@@ -78,6 +78,10 @@ enum { MPCASM_OPT_PATH = 1, MPCASM_OPT_PHASE_MASK = 2, MPCASM_OPT_RESIDENT_PER_C
  * These options are process-wide test / tuning hooks, not part of a launch's state: set them
  * before other threads start launching. */
 int mpcasm_set_option(int option, int value);
+/* The same choice for ONE plan (MPCASM_OPT_PATH, MPCASM_OPT_JIT, MPCASM_OPT_RESIDENT_PER_CU; value
+ * -1: back to the process-wide value): part of the plan's state, read by every mpcasm_assemble on
+ * it -- what a caller with several plans on several threads uses instead of the hooks above. */
+int mpcasm_plan_set_option(mpcasm_plan* plan, int option, int value);
 /* Diagnostic, needs no device: validates the tables as mpcasm_plan_create does, generates the
  * per-plan constants and compiles the persistent kernel for them with hiprtc (gfx950).
  * MPCASM_OK, MPCASM_ERR_LIMIT (no persistent kernel for this plan, or no libhiprtc.so) or

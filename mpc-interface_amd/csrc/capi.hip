@@ -29,6 +29,9 @@ struct mpcasm_plan {
   int device;
   int num_cus;
   std::vector<int32_t> h_itab;  // host copy: what a specialised kernel is generated from (jit.hip)
+  // mpcasm_plan_set_option: this plan's own choice of path / per-plan compilation / workgroups
+  // per CU (-1: the process-wide value of mpcasm_set_option)
+  int opt_path = -1, opt_jit = -1, opt_per_cu = -1;
 };
 
 namespace {
@@ -540,6 +543,15 @@ int mpcasm_set_option(int option, int value) {
   return MPCASM_ERR_ARG;
 }
 
+int mpcasm_plan_set_option(mpcasm_plan* plan, int option, int value) {
+  if (!plan) return MPCASM_ERR_ARG;
+  if (option == MPCASM_OPT_PATH && value >= -1 && value <= 2) plan->opt_path = value;
+  else if (option == MPCASM_OPT_JIT && value >= -1 && value <= 2) plan->opt_jit = value;
+  else if (option == MPCASM_OPT_RESIDENT_PER_CU && value >= -1 && value <= 16) plan->opt_per_cu = value;
+  else return MPCASM_ERR_ARG;
+  return MPCASM_OK;
+}
+
 const char* mpcasm_status_string(int status) {
   switch (status) {
     case MPCASM_OK: return "ok";
@@ -702,6 +714,10 @@ int mpcasm_assemble(const mpcasm_plan* plan, const double* const* h_src,
   int rc = make_src_table(plan, h_src, h_src_stride, &src);
   if (rc != MPCASM_OK) return rc;
   hipError_t err;
+  // what this launch runs on: the plan's own options where it has them, else the process-wide ones
+  t_path = plan->opt_path >= 0 ? plan->opt_path : g_path;
+  t_jit = plan->opt_jit >= 0 ? plan->opt_jit : g_jit;
+  t_per_cu = plan->opt_per_cu >= 0 ? plan->opt_per_cu : g_resident_per_cu;
   rc = launch_assemble(d, src, d_params, d_given, d_P, d_q, d_G, d_h, d_work, batch,
                        plan->num_cus, static_cast<hipStream_t>(stream), &err, plan->h_itab.data(),
                        plan->device);
@@ -786,6 +802,8 @@ namespace mpcasm {
 
 int g_path = 0;  // test hook (MPCASM_OPT_PATH): 0 best, 1 no resident kernel, 2 staged only
 int g_resident_per_cu = 0;  // tuning aid (MPCASM_OPT_RESIDENT_PER_CU): 0 = automatic
+// the values in force for the launch this thread is making (mpcasm_assemble sets them)
+thread_local int t_path = 0, t_jit = 0, t_per_cu = 0;
 
 // dispatch: fused single launch when the problem fits on chip, else staged
 int launch_assemble(const PlanDev& plan, const SrcTable& src, const double* params,
@@ -799,12 +817,12 @@ int launch_assemble(const PlanDev& plan, const SrcTable& src, const double* para
   // worth it while two workgroups fit
   constexpr size_t FUSED_LDS_LIMIT = 80 * 1024;
   const size_t rs = resident_lds_bytes(p);
-  if (rs != 0 && rs <= RESIDENT_LDS_LIMIT && (g_path == 0 || p.rs_nlti != 0 || p.csc_pnnz != 0 || p.csc_gnnz != 0) &&
+  if (rs != 0 && rs <= RESIDENT_LDS_LIMIT && (t_path == 0 || p.rs_nlti != 0 || p.csc_pnnz != 0 || p.csc_gnnz != 0) &&
       resident_inputs_aligned(p, src, params, given)) {
     // large batches: the same kernel compiled for this very plan (jit.hip), when available
     if (h_itab != nullptr)
       if (const void* k = jit_kernel_for(p, h_itab, device, batch, rs))
-        return jit_launch(k, p, src, params, given, P, q, G, h, batch, num_cus, g_resident_per_cu,
+        return jit_launch(k, p, src, params, given, P, q, G, h, batch, num_cus, t_per_cu,
                           work, stream, err);
     return launch_assemble_resident(p, src, params, given, P, q, G, h, work, batch, rs, num_cus,
                                     stream, err);
@@ -813,7 +831,7 @@ int launch_assemble(const PlanDev& plan, const SrcTable& src, const double* para
   // kernel only
   if (p.rs_nlti != 0 || p.csc_pnnz != 0 || p.csc_gnnz != 0) return MPCASM_ERR_LIMIT;
   const size_t lds = fused_lds_bytes(p, 4);
-  if (lds != 0 && lds <= FUSED_LDS_LIMIT && g_path <= 1)
+  if (lds != 0 && lds <= FUSED_LDS_LIMIT && t_path <= 1)
     return launch_assemble_fused(p, src, params, given, P, q, G, h, batch, lds, stream, err);
   return launch_assemble_staged(p, src, params, given, P, q, G, h, work, batch, stream, err);
 }

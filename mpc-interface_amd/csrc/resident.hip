@@ -1255,7 +1255,7 @@ int launch_jc(const PlanDev& p, const SrcTable& src, const double* params, const
   // than there are instances
   int per_cu = cached_per_cu[slot];
   if (per_cu < 1) return MPCASM_ERR_LIMIT;
-  if (g_resident_per_cu > 0 && g_resident_per_cu < per_cu) per_cu = g_resident_per_cu;
+  if (t_per_cu > 0 && t_per_cu < per_cu) per_cu = t_per_cu;
   long grid = (long)num_cus * per_cu;
   if (grid > batch) grid = batch;
   hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(NT), lds_bytes, stream, p, src, params,

@@ -47,6 +47,7 @@ SIGNATURES = {
                                         ctypes.c_char_p, ctypes.c_size_t]),
     "mpcasm_plan_sizes": (ctypes.c_int, [_void_p, ctypes.POINTER(ctypes.c_int64)]),
     "mpcasm_plan_csc_sizes": (ctypes.c_int, [_void_p, ctypes.POINTER(ctypes.c_int64)]),
+    "mpcasm_plan_set_option": (ctypes.c_int, [_void_p, ctypes.c_int, ctypes.c_int]),
     "mpcasm_workspace_bytes": (ctypes.c_int, [_void_p, ctypes.c_int,
                                               ctypes.POINTER(ctypes.c_size_t)]),
     "mpcasm_assemble": (ctypes.c_int, [_void_p, ctypes.POINTER(_void_p),

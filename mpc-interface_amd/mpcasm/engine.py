@@ -175,6 +175,13 @@ class Assembler:
                 pass
             self._handle = None
 
+    def set_option(self, option, value):
+        """This assembler's own kernel path (``capi.OPT_PATH``), per-plan compilation
+        (``capi.OPT_JIT``) or workgroups per CU (``capi.OPT_RESIDENT_PER_CU``); ``-1``: the
+        process-wide value again.  Plan state, unlike ``mpcasm_set_option``."""
+        capi.check(capi.load().mpcasm_plan_set_option(self._handle, int(option), int(value)),
+                   "mpcasm_plan_set_option")
+
     # ---- per-instance numbers -------------------------------------------------
     def refresh_params(self):
         """Re-read weights / aims / arrows / centres / extremes from the Cost and

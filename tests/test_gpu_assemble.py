@@ -820,3 +820,31 @@ def test_csc_data_written_by_the_assembly(gpu_api, kernel_path):
             assert not (As.toarray() != 0)[~sparse.plan.G_pattern].any()
         with pytest.raises(ValueError, match="writes the CSC form itself"):
             sparse.export_csc("P")
+
+
+def test_options_of_one_plan(gpu_api, kernel_path):
+    """mpcasm_plan_set_option: a plan's own kernel path / per-plan compilation, independent of the
+    process-wide hooks the fixture sets -- two assemblers of the same problem, one pinned to the
+    staged pipeline and one to the per-plan persistent kernel, give the same QPs whatever the
+    process-wide choice is."""
+    from mpcasm import capi, engine
+
+    if kernel_path not in ("resident", "staged"):
+        pytest.skip("two process-wide settings are enough")
+    form = problems.body_case(gpu_api)
+    batch = 40
+    given = np.random.default_rng(8).normal(0, 0.3, [batch, form.given_len])
+    staged = engine.Assembler(form, batch=batch)
+    staged.set_option(capi.OPT_PATH, 2)
+    per_plan = engine.Assembler(form, batch=batch)
+    per_plan.set_option(capi.OPT_PATH, 0)
+    per_plan.set_option(capi.OPT_JIT, 1)
+    a = [t.cpu().numpy() for t in staged.assemble(given)]
+    b = [t.cpu().numpy() for t in per_plan.assemble(given)]
+    for x, y, name in zip(a, b, "PqGh"):
+        assert_close(x, y, 1e-13, name)
+    Ao, ho, Qo, qo = orc.assemble(form, given[7].reshape(-1, 1))
+    assert_close(b[0][7], Qo, RTOL_TIGHT, "P"), assert_close(b[2][7], Ao, RTOL_TIGHT, "G")
+    with pytest.raises(capi.MpcasmError):
+        staged.set_option(capi.OPT_P_DIRECT, 1)          # read at plan creation: not a plan option
+    staged.set_option(capi.OPT_PATH, -1)                 # back to the process-wide value
