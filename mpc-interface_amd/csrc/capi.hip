@@ -48,6 +48,181 @@ bool in_range(int64_t off, int64_t len, int64_t n, int64_t lo) {
   return off >= lo && len >= 0 && off + len <= n;
 }
 
+// the column tables (H_T_CI_OK) and the tiled program (H_T_OK): every stream, offset and row a
+// kernel of tiled.hip derives from them stays inside its table
+int validate_tiled(const int32_t* it, const double* h_dtab, int64_t n, int64_t nd) {
+  const int64_t ng = it[H_NG], no = it[H_NO], nc = it[H_NC], nbase = it[H_NBASE];
+  if ((it[H_T_CI_OK] & ~1) || (it[H_T_OK] & ~1)) return MPCASM_ERR_PLAN;
+  if (!it[H_T_CI_OK]) return it[H_T_OK] ? MPCASM_ERR_PLAN : MPCASM_OK;
+  const int64_t nop = it[H_T_NOP], ndelta = it[H_T_NDELTA], ddelta = it[H_T_DOFF_DELTA];
+  if (nop < no || nop < T_BLOCK || nop % T_BLOCK || ndelta < 2 ||
+      !in_range(ddelta, ndelta, nd, 0) || h_dtab[ddelta] != 0.0 ||
+      !in_range(it[H_OFF_T_CIG], nbase * ng * 2, n, H_WORDS) ||
+      !in_range(it[H_OFF_T_CIO], nbase * nop * 2, n, H_WORDS) || it[H_OFF_T_CIO] % 4 ||
+      !in_range(it[H_OFF_ARENA], (int64_t)it[H_NSRC] * 2, n, H_WORDS) ||
+      !in_range(it[H_OFF_ENTBASE], it[H_NENT], n, H_WORDS) ||
+      !in_range(it[H_OFF_ENTK], it[H_NENT], n, H_WORDS) ||
+      !in_range(it[H_OFF_PM_ENTBASE], it[H_PM_NENT], n, H_WORDS) ||
+      !in_range(it[H_OFF_PM_ENTK], it[H_PM_NENT], n, H_WORDS))
+    return MPCASM_ERR_PLAN;
+  // generated groups: their sources are tables in the scratch
+  const int64_t nlti = it[H_T_NLTI], twork = it[H_T_WORK];
+  if (nlti < 0 || nlti > RS_LTI_MAX || twork < it[H_RTOT] ||
+      !in_range(it[H_OFF_T_LTI], nlti * T_LTI_WORDS, n, H_WORDS))
+    return MPCASM_ERR_PLAN;
+  std::vector<int64_t> size(T_SID_CONST + 1, 0);
+  for (int sx = 0; sx < it[H_NSRC]; ++sx) size[sx] = (it + it[H_OFF_ARENA])[2 * sx + 1];
+  size[T_SID_CONST] = nd;
+  for (int64_t g = 0; g < nlti; ++g) {
+    const int32_t* x = it + it[H_OFF_T_LTI] + g * T_LTI_WORDS;
+    const int64_t gn = x[TL_N], gm = x[TL_M], gN = x[TL_HORIZON];
+    if (gn < 1 || gm < 1 || gN < 1 || gn > 64 || gm > 64 || gN > 4096 ||
+        !in_range(it[H_OFF_T_LTI_IDS] + (int64_t)x[TL_IDS], gm + 1, n, H_WORDS) || x[TL_IDS] < 0 ||
+        !in_range(x[TL_TA], gN * gn * gn, twork, it[H_RTOT]) ||
+        !in_range(x[TL_TB], gn * gm * 2 * gN, twork, it[H_RTOT]))
+      return MPCASM_ERR_PLAN;
+    const int32_t* ids = it + it[H_OFF_T_LTI_IDS] + x[TL_IDS];
+    for (int64_t j = 0; j <= gm; ++j) {
+      if (ids[j] < 0 || ids[j] >= it[H_NSRC]) return MPCASM_ERR_PLAN;
+      size[ids[j]] = j < gm ? gn * gm * 2 * gN : gN * gn * gn;
+    }
+  }
+  // rows of every base variable some program reads
+  std::vector<int64_t> kmax(std::max<int64_t>(nbase, 1), 0);
+  auto scan = [&](int off_b, int off_k, int64_t cnt) {
+    for (int64_t e = 0; e < cnt; ++e) {
+      const int64_t b = (it + off_b)[e], k = (it + off_k)[e];
+      if (b < 0 || b >= nbase || k < 0) return false;
+      kmax[b] = std::max(kmax[b], k);
+    }
+    return true;
+  };
+  if (!scan(it[H_OFF_ENTBASE], it[H_OFF_ENTK], it[H_NENT]) ||
+      !scan(it[H_OFF_PM_ENTBASE], it[H_OFF_PM_ENTK], it[H_PM_NENT]))
+    return MPCASM_ERR_PLAN;
+  auto table_ok = [&](const int32_t* ci, int64_t cols) {
+    for (int64_t b = 0; b < nbase; ++b)
+      for (int64_t c = 0; c < cols; ++c) {
+        const int64_t off = (uint32_t)ci[(b * cols + c) * 2];
+        const int32_t meta = ci[(b * cols + c) * 2 + 1];
+        const int64_t sid = (uint32_t)meta >> 24, rs = (meta << 8) >> 8;
+        if (sid > T_SID_CONST || (sid < T_SID_CONST && sid >= it[H_NSRC])) return false;
+        const int64_t lo = sid == T_SID_CONST ? ddelta : 0;
+        const int64_t hi = sid == T_SID_CONST ? ddelta + ndelta : size[sid];
+        const int64_t last = off + kmax[b] * rs;
+        if (off < lo || off >= hi || last < lo || last >= hi) return false;
+      }
+    return true;
+  };
+  if (!table_ok(it + it[H_OFF_T_CIG], ng) || !table_ok(it + it[H_OFF_T_CIO], nop))
+    return MPCASM_ERR_PLAN;
+  if (!it[H_T_OK]) return MPCASM_OK;
+  // the tiled program
+  const int64_t nstage = it[H_T_NSTAGE], rtot = it[H_RTOT];
+  if (no < T_BLOCK || (no & 1) || nstage < 0 ||
+      !in_range(it[H_OFF_T_STAGE], nstage * T_STAGE_WORDS, n, H_WORDS) || it[H_OFF_T_STAGE] % 4 ||
+      !in_range(it[H_OFF_T_GROW], nc * RS_AXMAX, n, H_WORDS) ||
+      !in_range(it[H_OFF_RS_RR], nc * RS_RR_WORDS, n, H_WORDS) ||
+      !in_range(it[H_OFF_ROWPTR], rtot + 1, n, H_WORDS))
+    return MPCASM_ERR_PLAN;
+  const int64_t ngrest = it[H_T_NGREST];
+  if (!in_range(it[H_OFF_T_SROW], nstage * 2 * 16, n, H_WORDS) ||
+      !in_range(it[H_T_DOFF_SCOEF], nstage * 2 * 16, nd, 0) ||
+      !in_range(it[H_OFF_T_PIG], nstage * 16 * T_PIG_MAX * 2, n, H_WORDS) || it[H_OFF_T_PIG] % 4 ||
+      ngrest < 0 || ngrest > nc || !in_range(it[H_OFF_T_GREST], ngrest, n, H_WORDS))
+    return MPCASM_ERR_PLAN;
+  const int32_t* rowptr = it + it[H_OFF_ROWPTR];
+  const int32_t* entbase = it + it[H_OFF_ENTBASE];
+  const int32_t* entk = it + it[H_OFF_ENTK];
+  const int32_t* srow = it + it[H_OFF_T_SROW];
+  const int32_t* pig = it + it[H_OFF_T_PIG];
+  const int32_t* grow = it + it[H_OFF_T_GROW];
+  const int32_t* rrw = it + it[H_OFF_RS_RR];
+  std::vector<char> g_written(std::max<int64_t>(nc, 1), 0);
+  int last_cls = 0;
+  for (int64_t sx = 0; sx < nstage; ++sx) {
+    const int32_t* x = it + it[H_OFF_T_STAGE] + sx * T_STAGE_WORDS;
+    const int rows = x[TS_INFO] & 255, fl = (x[TS_INFO] >> 8) & 255, cls = x[TS_INFO] >> 16;
+    // sorted by class; class 0 exactly for the stages without a Hessian part
+    if (x[TS_INFO] < 0 || cls < last_cls || cls > 4 || (cls > 0) != ((fl & TS_FLAG_P) != 0))
+      return MPCASM_ERR_PLAN;
+    last_cls = cls;
+    // the class covers the masks: in every 64-column quarter only tiles 0 .. cls - 1
+    if (fl & TS_FLAG_P)
+      for (int side = 0; side < 2; ++side) {
+        uint64_t m = ((uint64_t)(uint32_t)x[side ? TS_MASKB_HI : TS_MASKA_HI] << 32) |
+                     (uint32_t)x[side ? TS_MASKB_LO : TS_MASKA_LO];
+        if ((m >> 63) && cls < 4) return MPCASM_ERR_PLAN;  // (folded tiles: anything)
+        for (; m; m >>= 4)
+          if ((m & 15u) >> cls) return MPCASM_ERR_PLAN;
+      }
+    for (int side = 0; side < 2; ++side) {  // base rows of simple stages: the rows' own entries
+      if (!(fl & (side ? TS_FLAG_SIMPLE_B : TS_FLAG_SIMPLE_A))) continue;
+      const int row0 = side ? x[TS_BROW] : x[TS_AROW];
+      if (row0 < 0 || row0 + rows > rtot) return MPCASM_ERR_PLAN;
+      for (int i = 0; i < 16; ++i) {
+        const int k = srow[(sx * 2 + side) * 16 + i];
+        if (i < rows ? (rowptr[row0 + i] < 0 || rowptr[row0 + i] >= it[H_NENT] ||
+                        k != entk[rowptr[row0 + i]])
+                     : k != 0)
+          return MPCASM_ERR_PLAN;
+      }
+    }
+    for (int i = 0; i < 16; ++i)  // riding rows of G: one axis, this very workspace row, once
+      for (int t = 0; t < T_PIG_MAX; ++t) {
+        const int R = pig[((sx * 16 + i) * T_PIG_MAX + t) * 2], slot = pig[((sx * 16 + i) * T_PIG_MAX + t) * 2 + 1];
+        if (R == -1) continue;
+        if (R < 0 || R >= nc || i >= rows || !(fl & TS_FLAG_G) || g_written[R] ||
+            rrw[R * RS_RR_WORDS + RR_NAXES] != 1 || grow[R * RS_AXMAX] != x[TS_AROW] + i ||
+            slot != rrw[R * RS_RR_WORDS + RR_ARROW])
+          return MPCASM_ERR_PLAN;
+        g_written[R] = 1;
+      }
+    if (rows < 1 || rows > 16 || (fl & ~63) || x[TS_AROW] < 0 ||
+        x[TS_AROW] + rows > rtot || x[TS_BROW] < 0 || x[TS_BROW] + rows > rtot || x[TS_DROW] < 0 ||
+        x[TS_DROW] + rows > rtot || x[TS_WPARAM] < 0 || x[TS_WPARAM] >= it[H_NPARAMS] ||
+        x[TS_AIMPARAM] < 0 || x[TS_AIMPARAM] >= it[H_NPARAMS] ||
+        ((fl & TS_FLAG_SAME) != 0) != (x[TS_AROW] == x[TS_BROW]))
+      return MPCASM_ERR_PLAN;
+    // a stage flagged simple: one entry per row, all of the stated base
+    for (int side = 0; side < 2; ++side) {
+      if (!(fl & (side ? TS_FLAG_SIMPLE_B : TS_FLAG_SIMPLE_A))) continue;
+      const int row0 = side ? x[TS_BROW] : x[TS_AROW];
+      const int base = side ? (int)((uint32_t)x[TS_BASE] >> 16) : (x[TS_BASE] & 0xFFFF);
+      if (base >= nbase) return MPCASM_ERR_PLAN;
+      for (int r = row0; r < row0 + rows; ++r)
+        if (rowptr[r + 1] - rowptr[r] != 1 || rowptr[r] < 0 || rowptr[r] >= it[H_NENT] ||
+            entbase[rowptr[r]] != base)
+          return MPCASM_ERR_PLAN;
+    }
+  }
+  {  // every row of G is written exactly once: riding on a stage or listed in the rest
+    const int32_t* grest = it + it[H_OFF_T_GREST];
+    for (int64_t i = 0; i < ngrest; ++i) {
+      if (grest[i] < 0 || grest[i] >= nc || g_written[grest[i]]) return MPCASM_ERR_PLAN;
+      g_written[grest[i]] = 1;
+    }
+    for (int64_t R = 0; R < nc; ++R)
+      if (!g_written[R]) return MPCASM_ERR_PLAN;
+  }
+  for (int64_t R = 0; R < nc; ++R) {
+    const int32_t* x = rrw + R * RS_RR_WORDS;
+    if (x[RR_NAXES] < 0 || x[RR_NAXES] > RS_AXMAX || x[RR_EXTREME] < 0 ||
+        x[RR_EXTREME] >= it[H_NPARAMS])
+      return MPCASM_ERR_PLAN;
+    for (int a = 0; a < RS_AXMAX; ++a) {
+      const int row = grow[R * RS_AXMAX + a];
+      if (a < x[RR_NAXES] ? (row < 0 || row >= rtot) : row != -1) return MPCASM_ERR_PLAN;
+      if (x[RR_ARROW + a] < 0 || x[RR_ARROW + a] > it[H_NPARAMS] || x[RR_CENTER + a] < 0 ||
+          x[RR_CENTER + a] > it[H_NPARAMS])
+        return MPCASM_ERR_PLAN;
+      if (a < x[RR_NAXES] && (x[RR_ARROW + a] >= it[H_NPARAMS] || x[RR_CENTER + a] >= it[H_NPARAMS]))
+        return MPCASM_ERR_PLAN;
+    }
+  }
+  return MPCASM_OK;
+}
+
 int validate_plan(const int32_t* it, const double* h_dtab, size_t n_itab, size_t n_dtab) {
   if (n_itab < (size_t)H_WORDS) return MPCASM_ERR_PLAN;
   if (it[H_MAGIC] != PLAN_MAGIC || it[H_VERSION] != PLAN_VERSION) return MPCASM_ERR_PLAN;
@@ -353,6 +528,10 @@ int validate_plan(const int32_t* it, const double* h_dtab, size_t n_itab, size_t
     }
   }
 
+  {
+    const int vrc = validate_tiled(it, h_dtab, n, nd);
+    if (vrc != MPCASM_OK) return vrc;
+  }
   // content checks: every index a kernel dereferences stays inside its table
   const int32_t* seg = it + it[H_OFF_SEG];
   for (int s = 0; s < it[H_NSEG]; ++s) {
@@ -473,6 +652,13 @@ void plan_dev_from_tables(const int32_t* it, PlanDev* out) {
   d.csc_pnnz = it[H_CSC_PNNZ]; d.off_csc_p = it[H_OFF_CSC_P];
   d.csc_gnnz = it[H_CSC_GNNZ]; d.off_csc_g = it[H_OFF_CSC_G];
   d.csc_gsingle = it[H_CSC_GSINGLE];
+  d.t_ci_ok = it[H_T_CI_OK]; d.t_nop = it[H_T_NOP]; d.off_t_cig = it[H_OFF_T_CIG];
+  d.off_t_cio = it[H_OFF_T_CIO]; d.t_doff_delta = it[H_T_DOFF_DELTA]; d.t_ok = it[H_T_OK];
+  d.t_nstage = it[H_T_NSTAGE]; d.off_t_stage = it[H_OFF_T_STAGE]; d.t_nlti = it[H_T_NLTI];
+  d.off_t_lti = it[H_OFF_T_LTI]; d.off_t_lti_ids = it[H_OFF_T_LTI_IDS]; d.t_work = it[H_T_WORK];
+  d.off_t_grow = it[H_OFF_T_GROW];
+  d.off_t_srow = it[H_OFF_T_SROW]; d.t_doff_scoef = it[H_T_DOFF_SCOEF]; d.off_t_pig = it[H_OFF_T_PIG];
+  d.t_ngrest = it[H_T_NGREST]; d.off_t_grest = it[H_OFF_T_GREST];
   d.pm_nfd = it[H_PM_NFD]; d.off_pm_map = it[H_OFF_PM_MAP]; d.off_pm_fdptr = it[H_OFF_PM_FDPTR];
   d.off_pm_op = it[H_OFF_PM_OP]; d.doff_pm_pool = it[H_DOFF_PM_POOL];
   d.rs_src16 = 0;
@@ -690,7 +876,15 @@ int mpcasm_workspace_bytes(const mpcasm_plan* plan, int batch, size_t* out_bytes
   // persistent kernel take (8 wavefronts x 8 counters per resident workgroup for the phases
   // of the instance loop, as many again for the set-up)
   const size_t groups = (size_t)std::min<long>(batch, (long)plan->num_cus * 8);
-  *out_bytes = std::max(assemble_workspace_bytes(plan->dev, batch), 2 * groups * 8 * 8 * sizeof(uint64_t));
+  const size_t stamps = 2 * groups * 8 * 8 * sizeof(uint64_t);
+  // a wide problem on the tiled kernel needs d and the generated horizon tables only -- unless the
+  // options in force send it down the staged pipeline (a test hook): ask again after changing them
+  const int path = plan->opt_path >= 0 ? plan->opt_path : g_path;
+  if (tiled_eligible(plan->dev) && path != 2) {
+    *out_bytes = std::max(tiled_workspace_bytes(plan->dev, batch), stamps);
+    return MPCASM_OK;
+  }
+  *out_bytes = std::max(assemble_workspace_bytes(plan->dev, batch), stamps);
   return MPCASM_OK;
 }
 
@@ -827,8 +1021,11 @@ int launch_assemble(const PlanDev& plan, const SrcTable& src, const double* para
     return launch_assemble_resident(p, src, params, given, P, q, G, h, work, batch, rs, num_cus,
                                     stream, err);
   }
-  // horizon matrices generated on chip and the CSC form of the results exist in the persistent
-  // kernel only
+  // wide problems: one workgroup per block of P, rows composed straight into the LDS tiles
+  if (tiled_eligible(p) && t_path != 2 && p.csc_pnnz == 0 && p.csc_gnnz == 0)
+    return launch_assemble_tiled(p, src, params, given, P, q, G, h, work, batch, stream, err, h_itab);
+  // elsewhere, horizon matrices generated from (A, B) and the CSC form of the results exist in the
+  // persistent kernel only
   if (p.rs_nlti != 0 || p.csc_pnnz != 0 || p.csc_gnnz != 0) return MPCASM_ERR_LIMIT;
   const size_t lds = fused_lds_bytes(p, 4);
   if (lds != 0 && lds <= FUSED_LDS_LIMIT && t_path <= 1)

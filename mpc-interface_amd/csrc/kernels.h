@@ -19,6 +19,13 @@ size_t assemble_workspace_bytes(const PlanDev& p, int batch);
 int launch_assemble_staged(const PlanDev& p, const SrcTable& src, const double* params,
                            const double* given, double* P, double* q, double* G, double* h,
                            void* work, int batch, hipStream_t stream, hipError_t* err);
+// tiled.hip
+bool tiled_eligible(const PlanDev& p);
+size_t tiled_workspace_bytes(const PlanDev& p, int batch);
+int launch_assemble_tiled(const PlanDev& p, const SrcTable& src, const double* params,
+                          const double* given, double* P, double* q, double* G, double* h,
+                          void* work, int batch, hipStream_t stream, hipError_t* err,
+                          const int32_t* h_itab);
 // fused.hip
 size_t fused_lds_bytes(const PlanDev& p, int nw);
 int launch_assemble_fused(const PlanDev& p, const SrcTable& src, const double* params,

@@ -25,7 +25,10 @@ namespace mpcasm {
   X(off_rs_abmeta) X(rr_packed) X(off_rs_dpar) X(doff_rs_dcoef) X(rs_ngdesc) X(off_rs_gdesc)        \
   X(pm_nfd) X(off_pm_map) X(off_pm_fdptr) X(off_pm_op) X(doff_pm_pool) X(doff_diagcoef) X(ndiag)      \
   X(rs_nzblk) X(off_rs_zblk) X(rs_p_direct) X(rs_gsingle)                                           \
-  X(csc_pnnz) X(off_csc_p) X(csc_gnnz) X(off_csc_g) X(csc_gsingle)
+  X(csc_pnnz) X(off_csc_p) X(csc_gnnz) X(off_csc_g) X(csc_gsingle)                                  \
+  X(t_ci_ok) X(t_nop) X(off_t_cig) X(off_t_cio) X(t_doff_delta) X(t_ok) X(t_nstage)                 \
+  X(off_t_stage) X(t_nlti) X(off_t_lti) X(off_t_lti_ids) X(t_work) X(off_t_grow)                    \
+  X(off_t_srow) X(t_doff_scoef) X(off_t_pig) X(t_ngrest) X(off_t_grest)
 
 // device-side view of a plan (pointers into the device copies of the tables).
 //   rs_p_direct: the persistent kernel sends the blocks of P straight to HBM (set by

@@ -29,7 +29,7 @@
 namespace mpcasm {
 
 constexpr int32_t PLAN_MAGIC = 0x4D504341;  // 'MPCA'
-constexpr int32_t PLAN_VERSION = 20;
+constexpr int32_t PLAN_VERSION = 21;
 
 enum HeaderWord : int {
   H_MAGIC = 0,
@@ -150,9 +150,60 @@ enum HeaderWord : int {
   H_OFF_CSC_G,      // [CSC_GNNZ][2] per stored entry (R, c) of G, from R's row record:
                     //    (voff0 + c) | (voff1 + c) << 16, arrow0 | arrow1 << 16 (either order)
   H_CSC_GSINGLE,    // 1: at most one axis of every stored entry can be non-zero, the first
-  H_WORDS = 96
+  // ---- column tables (every plan): what one column of one base variable reads.  Entry
+  // (base b, column c) is two words: element offset inside its stream for base row 0, and
+  // rs | stream << 24 (rs: signed 24 bits, elements per base row): the value of base row k in
+  // that column is stream[offset + k * rs].  Streams 0 .. NSRC-1 are the launch's sources, stream
+  // T_SID_CONST is the plan's dtab: a column no segment covers reads the 0.0 at
+  // dtab[T_DOFF_DELTA] with rs = 0; an identity block reads the table of zeros with a single 1.0
+  // behind it (rs = -1).  CIG: the given columns [NBASE][NG]; CIO: the unknowns
+  // [NBASE][T_NOP], T_NOP = NO rounded up to whole blocks of T_BLOCK columns (the pad reads 0.0).
+  H_T_CI_OK,
+  H_T_NOP,
+  H_OFF_T_CIG,
+  H_OFF_T_CIO,      // (16-byte aligned: the tiled kernel reads two columns at once)
+  H_T_DOFF_DELTA,   // [T_NDELTA] dtab: 0.0, then 2L+1 doubles all zero but the middle one
+  H_T_NDELTA,
+  // ---- tiled program (wide problems, no >= T_BLOCK: one workgroup per T_BLOCK x T_BLOCK block of
+  // P, the workspace rows composed 16 at a time straight into the matrix core's LDS tiles) ----
+  H_T_OK,
+  H_T_NSTAGE,
+  H_OFF_T_STAGE,    // [T_NSTAGE][T_STAGE_WORDS] see TS_* below
+  H_T_NLTI,         // source groups whose horizon tables a pre-pass generates from (A, B)
+  H_OFF_T_LTI,      // [T_NLTI][T_LTI_WORDS] see TL_* below
+  H_OFF_T_LTI_IDS,  // the groups' source ids: U_0 .. U_{m-1}, S each
+  H_T_WORK,         // doubles of scratch per instance: d [RTOT rounded up to even], then the tables
+  H_OFF_T_GROW,     // [NC][RS_AXMAX] workspace row of every axis of every row of G (-1: no such axis)
+  H_OFF_T_SROW,     // [T_NSTAGE][2][16] base row k of every A row / B row of a simple stage (else 0)
+  H_T_DOFF_SCOEF,   // [T_NSTAGE][2][16] dtab: its coefficient (0.0 behind the stage's last row)
+  H_OFF_T_PIG,      // [T_NSTAGE][16][T_PIG_MAX][2] rows of G that are arrow * (this A row): row of G,
+                    //    arrow's parameter slot (-1: none); every such row of G is listed once
+  H_T_NGREST,       // rows of G that ride on no stage (several axes, rows no cost reads ...)
+  H_OFF_T_GREST,    // [T_NGREST] their indices, ascending
+  H_WORDS = 112
 };
-static_assert(H_CSC_GSINGLE < H_WORDS, "plan header");
+static_assert(H_OFF_T_GREST < H_WORDS, "plan header");
+
+constexpr int T_BLOCK = 128;       // columns of a block of P (tiled kernel)
+constexpr int T_SID_CONST = 32;    // the stream that is the plan's own dtab
+// stage record of the tiled kernel: up to 16 consecutive rows of one gterm.  TS_MASKA / TS_MASKB:
+// bit t set when 16-column tile t of the unknowns can be non-zero in the A / B rows (64 bits; tiles
+// beyond 62 fold onto bit 63).  TS_INFO = rows | flags << 8 | class << 16.  The stages are sorted
+// by class: 0 = no Hessian part (gradient, rows of G only); n = 1..4: inside every 64-column
+// quarter of the unknowns only the first n 16-column tiles of the A and of the B rows can be
+// non-zero, so a wavefront multiplies the first n x n tiles of its 64 x 64 quadrant.  TS_BASE =
+// base of the A rows | base of the B rows << 16 when every row of the stage is ONE entry of one
+// base (TS_FLAG_SIMPLE_*).  TS_FLAG_G: some A row carries rows of G (H_OFF_T_PIG).
+enum { TS_AROW = 0, TS_BROW, TS_DROW, TS_INFO, TS_WPARAM, TS_AIMPARAM, TS_MASKA_LO, TS_MASKA_HI,
+       TS_MASKB_LO, TS_MASKB_HI, TS_BASE, TS_PAD, T_STAGE_WORDS = 12 };
+enum { TS_FLAG_P = 1, TS_FLAG_HALF = 2, TS_FLAG_SIMPLE_A = 4, TS_FLAG_SIMPLE_B = 8, TS_FLAG_SAME = 16,
+       TS_FLAG_G = 32 };
+constexpr int T_PIG_MAX = 2;
+// generated group: sizes, where its source ids start in T_LTI_IDS, scratch offsets (doubles, per
+// instance) of TA = S itself [N][n][n] and of TB [n][m][2N]: row (i, j) holds N zeros, then
+// (A^d B)[i][j], d < N, so that U_j[k][l][i] = TB[i][j][N + k - l] for every k, l (zeros above the
+// diagonal included)
+enum { TL_N = 0, TL_M, TL_HORIZON, TL_IDS, TL_TA, TL_TB, TL_PAD0, TL_PAD1, T_LTI_WORDS = 8 };
 
 // segment record
 enum { SEG_SRC = 0, SEG_OFF0, SEG_ROWSTRIDE, SEG_ELEMSTRIDE, SEG_DST0, SEG_LEN, SEG_KIND, SEG_PAD, SEG_WORDS = 8 };

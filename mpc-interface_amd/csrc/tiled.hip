@@ -1,0 +1,603 @@
+// tiled.hip -- K2 + K3 + K4 for wide problems (no >= T_BLOCK: BASELINE config C4, nx=12 nu=6
+// N=64, no=384, nc=1536) on gfx950, WITHOUT a workspace in HBM.
+//
+// Reference semantics (python/mpc_interface/body.py):
+//   K2  make_preview_matrices / get_matrices_from_dynamics / _from_definition  :149-193
+//   K3  generate_qp_cost :266-302, generate_all_qp_costs :322-329
+//   K4  generate_qp_constraint :236-264, generate_all_qp_constraints :304-320
+//   K1  tools.extend_matrices, tools.py:14-33 (plans compiled with lti=[...]: the horizon
+//       tables come from a pre-pass on the system's own (A, B))
+//
+// The staged pipeline (assemble.hip) composes every row of the preview matrices into an HBM
+// workspace V (2.4 MB per C4 instance), and three more kernels read it back: 3.7 x the
+// algorithmic traffic, half of the time outside the matrix core.  Here a workgroup owns one
+// T_BLOCK x T_BLOCK block of one instance's P and composes the 16 rows of a *stage* straight
+// into the LDS tiles its MFMAs read -- through the plan's column tables (plan_tables.h
+// H_T_CI_OK): the value of base row k in column c is stream[offset(c) + k * rs(c)], no segment
+// lookup, no branch (columns nothing feeds and identity blocks read small constant tables).
+// Workgroups on the diagonal (bi == bj) also turn the same composed rows into the gradient
+// (VALU, while the matrix core runs) and compose + stream the rows of G of their column block;
+// the one of block (0, 0) writes h.  d = Mg . given (one value per workspace row) comes from a
+// small pre-pass.  Per stage the plan states which 16-column tiles can be non-zero at all
+// (TS_MASK*): products of structurally zero tiles are skipped -- for the block-lower-triangular
+// horizon matrices of an LTI system that is 34 of 64.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "device_common.h"
+#include "kernels.h"
+
+namespace mpcasm {
+
+namespace {
+
+constexpr int BLOCK = 256;
+constexpr int WAVES = BLOCK / 64;
+constexpr int TK = 16;              // rows of a stage
+constexpr int TLD = T_BLOCK + 16;   // row stride of an LDS tile (doubles): k-rows on disjoint bank halves
+constexpr int NSTREAM = T_SID_CONST + 1;
+
+__device__ __forceinline__ int sext24(int x) { return (x << 8) >> 8; }
+
+// the streams of one instance: sources at this instance's slice, then the plan's dtab
+__device__ __forceinline__ void stream_bases(const PlanDev& p, const SrcTable& src, long inst,
+                                             const double** s_base, int tid) {
+  if (tid < NSTREAM) {
+    const double* b = p.dtab;
+    if (tid < T_SID_CONST) b = tid < p.nsrc ? src.ptr[tid] + inst * src.stride[tid] : p.dtab;
+    s_base[tid] = b;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// pre-pass 1 (plans with generated groups): TA = S and TB of every group from (A, B), by the
+// reference's own recurrence X_d = A X_{d-1}, X_0 = [B | A] (tools.py:24-29).  One workgroup
+// per (instance, group); X lives in LDS, one barrier per step.
+// ---------------------------------------------------------------------------
+constexpr int LTI_XMAX = 2048;  // n (m + n) doubles of one X
+
+__global__ __launch_bounds__(BLOCK) void lti_tables_kernel(PlanDev p, SrcTable src,
+                                                           double* __restrict__ work,
+                                                           long long work_stride) {
+  __shared__ double sA[LTI_XMAX];
+  __shared__ double sX[2][LTI_XMAX];
+  const int tid = threadIdx.x;
+  const long inst = blockIdx.x / p.t_nlti;
+  const int g = blockIdx.x - inst * p.t_nlti;
+  const int32_t* rec = p.itab + p.off_t_lti + g * T_LTI_WORDS;
+  const int n = rec[TL_N], m = rec[TL_M], N = rec[TL_HORIZON];
+  const int32_t* ids = p.itab + p.off_t_lti_ids + rec[TL_IDS];
+  const double* A = src.ptr[ids[0]] + inst * src.stride[ids[0]];
+  const double* B = src.ptr[ids[1]] + inst * src.stride[ids[1]];
+  double* TA = work + inst * work_stride + rec[TL_TA];
+  double* TB = work + inst * work_stride + rec[TL_TB];
+  const int w = m + n, elems = n * w;
+  for (int e = tid; e < n * n; e += BLOCK) sA[e] = A[e];
+  for (int e = tid; e < elems; e += BLOCK) {
+    const int i = e / w, c = e - i * w;
+    sX[0][e] = c < m ? B[i * m + c] : A[i * n + (c - m)];
+  }
+  __syncthreads();
+  for (int d = 0; d < N; ++d) {
+    const double* X = sX[d & 1];
+    double* Xn = sX[(d + 1) & 1];
+    for (int e = tid; e < elems; e += BLOCK) {
+      const int i = e / w, c = e - i * w;
+      const double v = X[e];
+      if (c < m) {
+        double* row = TB + (size_t)(i * m + c) * 2 * N;
+        row[N + d] = v;
+        row[N - 1 - d] = 0.0;
+      } else {
+        TA[(size_t)d * n * n + (size_t)(c - m) * n + i] = v;  // S[k][j][i] = (A^{k+1})[i][j]
+      }
+      double acc = 0.0;
+      for (int t = 0; t < n; ++t) acc = fma(sA[i * n + t], X[t * w + c], acc);
+      Xn[e] = acc;
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------
+// pre-pass 2: d[r] = (Mg . given)[r] for every workspace row: a wavefront per row, lanes over
+// the given columns.
+// ---------------------------------------------------------------------------
+constexpr int D_ROWS_PER_WAVE = 4;
+
+__global__ __launch_bounds__(BLOCK) void compose_d_kernel(PlanDev p, SrcTable src,
+                                                          const double* __restrict__ given,
+                                                          double* __restrict__ work,
+                                                          long long work_stride, int nrb) {
+  __shared__ const double* s_base[NSTREAM];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const long inst = blockIdx.x / nrb;
+  const int rb = blockIdx.x - inst * nrb;
+  stream_bases(p, src, inst, s_base, tid);
+  __syncthreads();
+  const int32_t* rowptr = p.itab + p.off_rowptr;
+  const int32_t* entbase = p.itab + p.off_entbase;
+  const int32_t* entk = p.itab + p.off_entk;
+  const double* coef = p.dtab + p.doff_entcoef;
+  const int2* cig = reinterpret_cast<const int2*>(p.itab + p.off_t_cig);
+  const double* g = given + inst * p.ng;
+  double* d = work + inst * work_stride;
+  const int r0 = (rb * WAVES + wave) * D_ROWS_PER_WAVE;
+  for (int r = r0; r < min(r0 + D_ROWS_PER_WAVE, p.rtot); ++r) {
+    double part = 0.0;
+    for (int e = rowptr[r]; e < rowptr[r + 1]; ++e) {
+      const int b = entbase[e], k = entk[e];
+      const double cf = coef[e];
+      for (int c = lane; c < p.ng; c += 64) {
+        const int2 ci = cig[(size_t)b * p.ng + c];
+        const double v = s_base[(unsigned)ci.y >> 24][(long)ci.x + (long)k * sext24(ci.y)];
+        part = fma(cf * v, g[c], part);
+      }
+    }
+    part = wave_sum(part);
+    if (lane == 0) d[r] = part;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// the tiled kernel
+// ---------------------------------------------------------------------------
+// what two adjacent columns of one base variable read (from the column table)
+struct ColRef {
+  const double* p0;
+  const double* p1;
+  int rs0, rs1;
+};
+
+__device__ __forceinline__ ColRef load_colref(const int32_t* __restrict__ cio, int nop, int base,
+                                              int col, const double* const* s_base) {
+  const int4 v = *reinterpret_cast<const int4*>(cio + ((size_t)base * nop + col) * 2);
+  ColRef r;
+  r.p0 = s_base[(unsigned)v.y >> 24] + v.x;
+  r.rs0 = sext24(v.y);
+  r.p1 = s_base[(unsigned)v.w >> 24] + v.z;
+  r.rs1 = sext24(v.w);
+  return r;
+}
+
+__device__ __forceinline__ double2 colref_at(const ColRef& c, int k) {
+  double2 v;
+  v.x = c.p0[(long)k * c.rs0];
+  v.y = c.p1[(long)k * c.rs1];
+  return v;
+}
+
+struct RowTables {
+  const int32_t* rowptr;
+  const int32_t* entbase;
+  const int32_t* entk;
+  const double* coef;
+  const int32_t* cio;
+  int nop;
+};
+
+// two adjacent columns of workspace row r (wave-uniform): sum over the row's entries
+__device__ __forceinline__ double2 compose_row2(const RowTables& t, int r, int col,
+                                                const double* const* s_base, int& cur_base,
+                                                ColRef& cr) {
+  double2 acc{0.0, 0.0};
+  const int e1 = t.rowptr[r + 1];
+  for (int e = t.rowptr[r]; e < e1; ++e) {
+    const int b = t.entbase[e];
+    if (b != cur_base) {
+      cr = load_colref(t.cio, t.nop, b, col, s_base);
+      cur_base = b;
+    }
+    const double cf = t.coef[e];
+    const double2 v = colref_at(cr, t.entk[e]);
+    acc.x = fma(cf, v.x, acc.x);
+    acc.y = fma(cf, v.y, acc.y);
+  }
+  return acc;
+}
+
+// the 8 tiles of block b out of a stage's 64-bit tile mask (tiles beyond 62 fold onto bit 63)
+__device__ __forceinline__ unsigned block_tiles(unsigned lo, unsigned hi, int b) {
+  const unsigned long long m = ((unsigned long long)hi << 32) | lo;
+  if (8 * b + 7 < 63) return (unsigned)(m >> (8 * b)) & 0xFFu;
+  unsigned out = 0;
+  for (int j = 0; j < 8; ++j) out |= (unsigned)((m >> min(8 * b + j, 63)) & 1ull) << j;
+  return out;
+}
+
+// the products of the first NA x NB tiles of a wavefront's quadrant over the 16 rows of a stage;
+// at / bt: the lane's element of row lk in the A / B tile (lane map of v_mfma_f64_16x16x4_f64:
+// A[i = lane & 15][k = lane >> 4], B[k][j = lane & 15])
+template <int NA, int NB>
+__device__ __forceinline__ void mfma_tiles(f64x4 (&acc)[4][4], const double* at, const double* bt) {
+#pragma unroll
+  for (int kk = 0; kk < TK; kk += 4) {
+    double a[NA], b[NB];
+#pragma unroll
+    for (int t = 0; t < NA; ++t) a[t] = at[kk * TLD + t * 16];
+#pragma unroll
+    for (int t = 0; t < NB; ++t) b[t] = bt[kk * TLD + t * 16];
+#pragma unroll
+    for (int ta = 0; ta < NA; ++ta)
+#pragma unroll
+      for (int tb = 0; tb < NB; ++tb) acc[ta][tb] = mfma_f64_16x16x4(a[ta], b[tb], acc[ta][tb]);
+  }
+}
+
+struct Stage {
+  int arow, brow, drow, nrows, flags, base_a, base_b;
+  int cls;  // 0: no Hessian part; n = 1..4: the first n x n tiles of every wavefront's quadrant
+  int wslot, aimslot;
+  // rows wave, wave + 4, wave + 8, wave + 12 of the stage (this wavefront's): base row and
+  // coefficient of simple A / B rows, the rows of G riding on the A rows
+  int ka[TK / WAVES], kb[TK / WAVES];
+  double ca[TK / WAVES], cb[TK / WAVES];
+  int4 pig[TK / WAVES];
+};
+
+// a value every lane loads from the same address, through the vector memory path: it counts in
+// vmcnt (in order, waited for where it is used) instead of the scalar cache's lgkmcnt, which every
+// LDS wait of the matrix-core phase would have to include
+__device__ __forceinline__ double uniform_load(const double* p, int vzero) { return p[vzero]; }
+
+__global__ __launch_bounds__(BLOCK, 2) void tiled_assemble_kernel(
+    PlanDev p, SrcTable src, const double* __restrict__ params, const double* __restrict__ work,
+    long long work_stride, double* __restrict__ P, double* __restrict__ q, double* __restrict__ G,
+    double* __restrict__ h, int nb, int npairs, int sym, int batch) {
+  __shared__ __attribute__((aligned(16))) double As[2][TK * TLD];
+  __shared__ __attribute__((aligned(16))) double Bs[2][TK * TLD];
+  __shared__ const double* s_base[NSTREAM];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // the blocks of one instance go to ONE XCD (workgroups x, x + 8, x + 16 ... share an L2):
+  // they read the same sources and tables
+  const unsigned xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const long inst = (long)(slot / npairs) * 8 + xcd;
+  int pr = slot % npairs;
+  if (inst >= batch) return;
+  int bi = 0, bj = 0;
+  if (sym) {  // pair index -> (bi <= bj)
+    int rowlen = nb;
+    while (pr >= rowlen) {
+      pr -= rowlen;
+      --rowlen;
+      ++bi;
+    }
+    bj = bi + pr;
+  } else {
+    bi = pr / nb;
+    bj = pr - bi * nb;
+  }
+  const bool diag = bi == bj;
+  if (!P && !diag) return;  // only the constraints are wanted: the diagonal workgroups write them
+  stream_bases(p, src, inst, s_base, tid);
+  const int no = p.no;
+  const double* pb = params + (size_t)inst * p.nparams;
+  const double* dvec = work + inst * work_stride;
+  int vzero;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
+  // (the instance's parameters are read through the scalar cache below: bring their lines in now)
+  if (tid * 8 < p.nparams) asm volatile("" ::"v"(pb[tid * 8]));
+  __syncthreads();
+
+  RowTables rt;
+  rt.rowptr = p.itab + p.off_rowptr;
+  rt.entbase = p.itab + p.off_entbase;
+  rt.entk = p.itab + p.off_entk;
+  rt.coef = p.dtab + p.doff_entcoef;
+  rt.cio = p.itab + p.off_t_cio;
+  rt.nop = p.t_nop;
+  const int32_t* stages = p.itab + p.off_t_stage;
+  const int32_t* srow = p.itab + p.off_t_srow;
+  const double* scoef = p.dtab + p.t_doff_scoef;
+  const int4* pigs = reinterpret_cast<const int4*>(p.itab + p.off_t_pig);
+  const int li = lane & 15, lk = lane >> 4;
+  const int wr = wave >> 1, wc = wave & 1;
+  // compose role: wavefront `wave` takes rows wave, wave + 4, ... of a stage, lane `lane` two columns
+  const int scol = lane * 2;
+  const int colA = bi * T_BLOCK + scol, colB = bj * T_BLOCK + scol;
+  const bool want_g = G != nullptr && diag;
+
+  f64x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
+  double2 qacc{0.0, 0.0};
+
+  int baseA = -1, baseB = -1;
+  ColRef crA, crB;
+  crA.p0 = crA.p1 = crB.p0 = crB.p1 = p.dtab;
+  crA.rs0 = crA.rs1 = crB.rs0 = crB.rs1 = 0;
+
+  // ---- stages (sorted by class in the plan) ---------------------------------------------
+  int s = -1;
+  Stage cur;
+  auto next_stage = [&]() __attribute__((always_inline)) -> bool {
+    for (++s; s < p.t_nstage; ++s) {
+      const int32_t* rec = stages + s * T_STAGE_WORDS;
+      const int info = rec[TS_INFO];
+      const int fl = (info >> 8) & 255;
+      const unsigned ta = block_tiles((unsigned)rec[TS_MASKA_LO], (unsigned)rec[TS_MASKA_HI], bi);
+      const unsigned tb = block_tiles((unsigned)rec[TS_MASKB_LO], (unsigned)rec[TS_MASKB_HI], bj);
+      const bool for_p = P && (fl & TS_FLAG_P) && ta && tb;
+      // the diagonal workgroup also takes the stage for the gradient (when its A rows reach this
+      // column block at all) and for the rows of G that ride on it (zeros included)
+      const bool for_diag = diag && ((P && ta) || (want_g && (fl & TS_FLAG_G)));
+      if (!for_p && !for_diag) continue;
+      cur.arow = rec[TS_AROW];
+      cur.brow = rec[TS_BROW];
+      cur.drow = rec[TS_DROW];
+      cur.nrows = info & 255;
+      cur.flags = for_p ? fl : (fl & ~TS_FLAG_P);
+      cur.base_a = rec[TS_BASE] & 0xFFFF;
+      cur.base_b = (unsigned)rec[TS_BASE] >> 16;
+      cur.cls = info >> 16;  // (the plan's: the stages come sorted by it)
+      cur.wslot = rec[TS_WPARAM];
+      cur.aimslot = rec[TS_AIMPARAM];
+#pragma unroll
+      for (int rr = 0; rr < TK / WAVES; ++rr) {
+        const int i = wave + WAVES * rr;
+        cur.ka[rr] = srow[(s * 2 + 0) * TK + i];
+        cur.kb[rr] = srow[(s * 2 + 1) * TK + i];
+        cur.ca[rr] = scoef[(s * 2 + 0) * TK + i];
+        cur.cb[rr] = scoef[(s * 2 + 1) * TK + i];
+        cur.pig[rr] = pigs[s * TK + i];
+      }
+      return true;
+    }
+    return false;
+  };
+
+  // values of the stage's rows in this thread's columns (simple rows: the entry's coefficient
+  // still apart; the loads are in flight while the matrix core works on the stage before), the
+  // stage's weight, aim and the d of its rows
+  double2 va[TK / WAVES], vb[TK / WAVES];
+  auto compose_tile = [&](int row0, int nrows, bool simple, int base, const int* ks, int col,
+                          int& cur_base, ColRef& cr, double2* v) __attribute__((always_inline)) {
+    if (simple) {
+      if (base != cur_base) {
+        cr = load_colref(rt.cio, rt.nop, base, col, s_base);
+        cur_base = base;
+      }
+#pragma unroll
+      for (int rr = 0; rr < TK / WAVES; ++rr) v[rr] = colref_at(cr, ks[rr]);
+    } else {
+#pragma unroll
+      for (int rr = 0; rr < TK / WAVES; ++rr) {
+        const int i = wave + WAVES * rr;
+        v[rr] = compose_row2(rt, row0 + (i < nrows ? i : 0), col, s_base, cur_base, cr);
+      }
+    }
+  };
+  auto compose_stage = [&]() __attribute__((always_inline)) {
+    compose_tile(cur.arow, cur.nrows, cur.flags & TS_FLAG_SIMPLE_A, cur.base_a, cur.ka, colA, baseA, crA, va);
+    if ((cur.flags & TS_FLAG_P) && !(diag && (cur.flags & TS_FLAG_SAME)))
+      compose_tile(cur.brow, cur.nrows, cur.flags & TS_FLAG_SIMPLE_B, cur.base_b, cur.kb, colB, baseB, crB, vb);
+  };
+  // registers -> LDS tiles (the A rows weighted); on the way the diagonal workgroup adds the
+  // weighted rows into the gradient and writes the rows of G that are arrow * (an A row)
+  auto store_stage = [&](int buf) __attribute__((always_inline)) {
+    const bool same = diag && (cur.flags & TS_FLAG_SAME);
+    const bool simple_a = cur.flags & TS_FLAG_SIMPLE_A, simple_b = cur.flags & TS_FLAG_SIMPLE_B;
+    const double scale = (cur.flags & TS_FLAG_HALF) ? 0.5 : 1.0;
+    // (wave-uniform, through the scalar cache: the parameters' lines were brought in at the start)
+    const double vw = P ? pb[cur.wslot] : 0.0, vaim = pb[cur.aimslot];
+    double vd[TK / WAVES];
+#pragma unroll
+    for (int rr = 0; rr < TK / WAVES; ++rr) {
+      const int i = wave + WAVES * rr;
+      vd[rr] = (diag && P) ? dvec[cur.drow + (i < cur.nrows ? i : 0)] : 0.0;
+    }
+#pragma unroll
+    for (int rr = 0; rr < TK / WAVES; ++rr) {
+      const int i = wave + WAVES * rr;
+      const bool valid = i < cur.nrows;
+      const double fa = simple_a ? cur.ca[rr] : (valid ? 1.0 : 0.0);
+      double2 a = va[rr];
+      a.x *= fa;
+      a.y *= fa;
+      if (want_g && (cur.flags & TS_FLAG_G) && colA < no) {
+        const int4 pg = cur.pig[rr];
+        if (pg.x >= 0) {
+          const double ar = pb[pg.y];
+          store_result(reinterpret_cast<double2*>(G + ((size_t)inst * p.nc + pg.x) * no + colA),
+                       double2{ar * a.x, ar * a.y});
+        }
+        if (pg.z >= 0) {
+          const double ar = pb[pg.w];
+          store_result(reinterpret_cast<double2*>(G + ((size_t)inst * p.nc + pg.z) * no + colA),
+                       double2{ar * a.x, ar * a.y});
+        }
+      }
+      if (!P) continue;
+      double2 b;
+      if (same) {
+        b = a;
+      } else {
+        const double fb = simple_b ? cur.cb[rr] : (valid ? 1.0 : 0.0);
+        b = vb[rr];
+        b.x *= fb;
+        b.y *= fb;
+      }
+      a.x *= vw;
+      a.y *= vw;
+      if (diag) {
+        const double r = scale * (vd[rr] - vaim);
+        qacc.x = fma(a.x, r, qacc.x);
+        qacc.y = fma(a.y, r, qacc.y);
+      }
+      if (cur.flags & TS_FLAG_P) {
+        *reinterpret_cast<double2*>(As[buf] + i * TLD + scol) = a;
+        *reinterpret_cast<double2*>(Bs[buf] + i * TLD + scol) = b;
+      }
+    }
+  };
+
+  bool more = next_stage();
+  if (more) {
+    compose_stage();
+    store_stage(0);
+  }
+  int buf = 0;
+  lds_barrier();
+  auto run_class = [&](auto cls_tag) __attribute__((always_inline)) {
+    constexpr int N = decltype(cls_tag)::value;
+    while (more && cur.cls == N) {
+      const bool mult = cur.flags & TS_FLAG_P;  // (not when this block's columns are zero in it)
+      const bool have_next = next_stage();      // (the stage in the tiles has class N)
+      if (have_next) compose_stage();           // in flight while this stage is multiplied
+      if constexpr (N > 0)
+        if (mult)
+          mfma_tiles<N, N>(acc, As[buf] + lk * TLD + wr * 64 + li, Bs[buf] + lk * TLD + wc * 64 + li);
+      if (have_next) store_stage(buf ^ 1);
+      if constexpr (N > 0) {
+        lds_barrier();
+        buf ^= 1;
+      } else {
+        // (no tile was read: only a stage of a Hessian class that has just been stored needs
+        // the barrier before it is multiplied)
+        if (have_next && cur.cls > 0) {
+          lds_barrier();
+          buf ^= 1;
+        }
+      }
+      more = have_next;
+    }
+  };
+  run_class(std::integral_constant<int, 0>{});
+  run_class(std::integral_constant<int, 1>{});
+  run_class(std::integral_constant<int, 2>{});
+  run_class(std::integral_constant<int, 3>{});
+  run_class(std::integral_constant<int, 4>{});
+
+  // ---- rows of G that ride on no stage, h ------------------------------------------------
+  if (want_g) {
+    const int32_t* grow = p.itab + p.off_t_grow;
+    const int32_t* rrw = p.itab + p.off_rs_rr;
+    const int32_t* grest = p.itab + p.off_t_grest;
+    int baseG = -1;
+    ColRef crG = crA;
+    for (int x0 = wave; x0 < p.t_ngrest; x0 += WAVES) {
+      const int R = grest[x0];
+      const int32_t* x = rrw + (size_t)R * RS_RR_WORDS;
+      const int naxes = x[RR_NAXES];
+      double2 out{0.0, 0.0};
+      for (int ax = 0; ax < naxes; ++ax) {
+        const double ar = pb[x[RR_ARROW + ax]];
+        const double2 v = compose_row2(rt, grow[R * RS_AXMAX + ax], colA, s_base, baseG, crG);
+        out.x = fma(ar, v.x, out.x);
+        out.y = fma(ar, v.y, out.y);
+      }
+      if (colA < no)
+        store_result(reinterpret_cast<double2*>(G + ((size_t)inst * p.nc + R) * no + colA), out);
+    }
+    if (bi == 0)  // h: (extreme + arrow . center) - arrow . d
+      for (int R = tid; R < p.nc; R += BLOCK) {
+        const int32_t* x = rrw + (size_t)R * RS_RR_WORDS;
+        double ac = 0.0, ad = 0.0;
+        for (int ax = 0; ax < x[RR_NAXES]; ++ax) {
+          const double ar = pb[x[RR_ARROW + ax]];
+          ac += ar * pb[x[RR_CENTER + ax]];
+          ad = fma(ar, dvec[grow[R * RS_AXMAX + ax]], ad);
+        }
+        h[(size_t)inst * p.nc + R] = (pb[x[RR_EXTREME]] + ac) - ad;
+      }
+  }
+  if (!P) return;
+
+  // ---- results ---------------------------------------------------------------------------
+  double* Pb = P + (size_t)inst * no * no;
+  const bool mirror = sym && !diag;
+#pragma unroll
+  for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+    for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int row = bi * T_BLOCK + wr * 64 + ta * 16 + lk + 4 * reg;
+        const int col = bj * T_BLOCK + wc * 64 + tb * 16 + li;
+        if (row < no && col < no) {
+          double v = acc[ta][tb][reg];
+          if (row == col) {
+            double dP, dq;
+            diagonal_terms(p, pb, row, dP, dq);
+            v += dP;
+          }
+          Pb[(size_t)row * no + col] = v;
+          if (mirror) Pb[(size_t)col * no + row] = v;
+        }
+      }
+  if (diag) {  // the gradient: the four wavefronts hold the sums over their rows
+    double* part = As[0];
+    lds_barrier();
+    part[wave * T_BLOCK + scol] = qacc.x;
+    part[wave * T_BLOCK + scol + 1] = qacc.y;
+    lds_barrier();
+    if (tid < T_BLOCK) {
+      const int c = bi * T_BLOCK + tid;
+      if (c < no) {
+        double sum = 0.0;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) sum += part[w * T_BLOCK + tid];
+        double dP, dq;
+        diagonal_terms(p, pb, c, dP, dq);
+        q[(size_t)inst * no + c] = sum + dq;
+      }
+    }
+  }
+}
+
+inline unsigned ceil_div(unsigned a, unsigned b) { return (a + b - 1) / b; }
+
+}  // namespace
+
+bool tiled_eligible(const PlanDev& p) { return p.t_ok != 0 && p.no >= T_BLOCK; }
+
+size_t tiled_workspace_bytes(const PlanDev& p, int batch) {
+  return (size_t)batch * p.t_work * sizeof(double);
+}
+
+int launch_assemble_tiled(const PlanDev& p, const SrcTable& src, const double* params,
+                          const double* given, double* P, double* q, double* G, double* h,
+                          void* work, int batch, hipStream_t stream, hipError_t* err,
+                          const int32_t* h_itab) {
+  double* w = static_cast<double*>(work);
+  const long long stride = p.t_work;
+  SrcTable eff = src;
+  if (p.t_nlti > 0) {
+    if (h_itab == nullptr) return MPCASM_ERR_ARG;
+    for (int g = 0; g < p.t_nlti; ++g) {
+      const int32_t* rec = h_itab + p.off_t_lti + g * T_LTI_WORDS;
+      const int n = rec[TL_N], m = rec[TL_M];
+      if (n * (m + n) > LTI_XMAX || n > 64) return MPCASM_ERR_LIMIT;
+      const int32_t* ids = h_itab + p.off_t_lti_ids + rec[TL_IDS];
+      for (int j = 0; j < m; ++j) {
+        eff.ptr[ids[j]] = w + rec[TL_TB];
+        eff.stride[ids[j]] = stride;
+      }
+      eff.ptr[ids[m]] = w + rec[TL_TA];
+      eff.stride[ids[m]] = stride;
+    }
+    hipLaunchKernelGGL(lti_tables_kernel, dim3((unsigned)batch * p.t_nlti), dim3(BLOCK), 0, stream,
+                       p, src, w, stride);
+  }
+  if (p.rtot > 0) {
+    const unsigned nrb = ceil_div(p.rtot, WAVES * D_ROWS_PER_WAVE);
+    hipLaunchKernelGGL(compose_d_kernel, dim3(nrb * batch), dim3(BLOCK), 0, stream, p, eff, given, w,
+                       stride, (int)nrb);
+  }
+  const int nb = (int)ceil_div(p.no, T_BLOCK);
+  const int sym = p.rs_sym_any;
+  const int npairs = sym ? nb * (nb + 1) / 2 : nb * nb;
+  const unsigned groups = ceil_div((unsigned)batch, 8u);
+  hipLaunchKernelGGL(tiled_assemble_kernel, dim3(groups * 8 * (unsigned)npairs), dim3(BLOCK), 0,
+                     stream, p, eff, params, w, stride, P, q, G, h, nb, npairs, sym, batch);
+  *err = hipGetLastError();
+  return *err == hipSuccess ? MPCASM_OK : MPCASM_ERR_HIP;
+}
+
+}  // namespace mpcasm

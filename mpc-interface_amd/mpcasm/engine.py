@@ -158,11 +158,8 @@ class Assembler:
         base = torch.as_tensor(p.params, dtype=torch.float64, device=self.device)
         self.params = base.unsqueeze(0).repeat(self.batch, 1).contiguous()
 
-        nbytes = ctypes.c_size_t()
-        capi.check(lib.mpcasm_workspace_bytes(self._handle, self.batch, ctypes.byref(nbytes)),
-                   "mpcasm_workspace_bytes")
-        self._work = torch.empty(max(nbytes.value // 8, 1), dtype=torch.float64,
-                                 device=self.device)
+        self._work = None
+        self._workspace()
         self._out = None
         self._csc = {}
 
@@ -174,6 +171,19 @@ class Assembler:
             except Exception:
                 pass
             self._handle = None
+
+    def _workspace(self):
+        """The scratch buffer of a launch, as large as the kernels the options in force pick
+        ask for (``mpcasm_workspace_bytes``: a wide problem needs a few KB per instance on the
+        tiled kernel, its whole preview-matrix workspace on the staged pipeline)."""
+        nbytes = ctypes.c_size_t()
+        capi.check(capi.load().mpcasm_workspace_bytes(self._handle, self.batch, ctypes.byref(nbytes)),
+                   "mpcasm_workspace_bytes")
+        need = max(nbytes.value // 8, 1)
+        if self._work is None or self._work.numel() < need:
+            self._work = None
+            self._work = self._torch.empty(need, dtype=self._torch.float64, device=self.device)
+        return self._work
 
     def set_option(self, option, value):
         """This assembler's own kernel path (``capi.OPT_PATH``), per-plan compilation
@@ -313,10 +323,11 @@ class Assembler:
             G = h = None
         ptrs, strides = self._src_args()
         ptr = lambda t: t.data_ptr() if t is not None else None
+        work = self._workspace()
         with torch.cuda.device(self.device):
             rc = capi.load().mpcasm_assemble(
                 self._handle, ptrs, strides, self.params.data_ptr(), ptr(g), ptr(P), ptr(q),
-                ptr(G), ptr(h), self._work.data_ptr(), n_run, _stream_handle(torch, stream))
+                ptr(G), ptr(h), work.data_ptr(), n_run, _stream_handle(torch, stream))
         capi.check(rc, "mpcasm_assemble")
         return P, q, G, h
 

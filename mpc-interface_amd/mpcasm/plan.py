@@ -17,7 +17,7 @@ import numpy as np
 import scipy.sparse as sp
 
 PLAN_MAGIC = 0x4D504341
-PLAN_VERSION = 20
+PLAN_VERSION = 21
 
 # header words (csrc/plan_tables.h, enum HeaderWord)
 _H = {name: i for i, name in enumerate([
@@ -36,8 +36,11 @@ _H = {name: i for i, name in enumerate([
     "RS_NGDESC", "OFF_RS_GDESC", "PM_NFD", "OFF_PM_MAP", "OFF_PM_FDPTR", "OFF_PM_OP", "PM_NOPS",
     "DOFF_PM_POOL", "PM_NPOOL", "RS_NZBLK", "OFF_RS_ZBLK", "RS_GSINGLE",
     "CSC_PNNZ", "OFF_CSC_P", "CSC_GNNZ", "OFF_CSC_G", "CSC_GSINGLE",
+    "T_CI_OK", "T_NOP", "OFF_T_CIG", "OFF_T_CIO", "T_DOFF_DELTA", "T_NDELTA",
+    "T_OK", "T_NSTAGE", "OFF_T_STAGE", "T_NLTI", "OFF_T_LTI", "OFF_T_LTI_IDS", "T_WORK",
+    "OFF_T_GROW", "OFF_T_SROW", "T_DOFF_SCOEF", "OFF_T_PIG", "T_NGREST", "OFF_T_GREST",
 ])}
-H_WORDS = 96
+H_WORDS = 112
 assert len(_H) <= H_WORDS
 RS_NW, RS_NT = 4, 512                     # matrix wavefronts (they fetch the inputs), threads per instance
 RS_WAVES = RS_NT // 64
@@ -67,6 +70,10 @@ FUSED_MAX_ARENA = 1 << 14         # doubles
 SEG_GATHER, SEG_IDENTITY = 0, 1
 GT_FLAG_P, GT_FLAG_HALF, GT_FLAG_DIAG = 1, 2, 4
 MAX_SOURCES = 32
+# tiled kernel (csrc/tiled.hip, plan_tables.h T_* / TS_* / TL_*)
+T_BLOCK, T_SID_CONST, T_STAGE_WORDS, T_LTI_WORDS = 128, 32, 12, 8
+TS_FLAG_P, TS_FLAG_HALF, TS_FLAG_SIMPLE_A, TS_FLAG_SIMPLE_B, TS_FLAG_SAME, TS_FLAG_G = 1, 2, 4, 8, 16, 32
+T_PIG_MAX = 2
 
 
 class Source:
@@ -923,6 +930,205 @@ def _resident_program(fused, gterms, no, ldv, image, ng, nparams, nc_rows):
     return out
 
 
+def causal_sources(form, sources, groups=()):
+    """Ids of the sources that are the ``U_j`` of an ExtendedSystem and hold exact zeros above
+    the diagonal: ``U_j[k][l] = A^(k-l) B`` for ``l <= k``, else 0 (tools.py:27-31).  The tables
+    a plan derives from this (tile masks, CSC patterns) hold for every instance as long as the
+    tensors bound per instance are causal as well -- what ``tools.extend_matrices`` and
+    ``mpcasm_fill_su`` produce.  Sources generated on chip are causal by construction."""
+    out = {i for g in groups for i in g["ids"][:-1]}
+    for sid, src in enumerate(sources):
+        key = src.key
+        if sid in out or len(key) != 2 or key[0] not in form.dynamics or src.array.ndim != 3:
+            continue
+        m = len(getattr(form.dynamics[key[0]], "matrices", [])) - 1
+        N = src.array.shape[0]
+        if key[1] < m and src.array.shape[1] == N:
+            kk, ll = np.meshgrid(np.arange(N), np.arange(N), indexing="ij")
+            if not np.any(src.array[ll > kk]):
+                out.add(sid)
+    return out
+
+
+def _segments_of_base(b):
+    out = [[] for _ in b.base_rows]
+    for bid, colseg in enumerate(b.colseg):
+        for sg in sorted(set(int(x) for x in colseg if x >= 0)):
+            out[bid].append(b.segments[sg])
+    return out
+
+
+def _column_tables(b, groups, nop):
+    """``ci[base][column][2]`` over the columns ``[given | unknowns padded to nop]``
+    (csrc/plan_tables.h, H_T_CI_OK): element offset for base row 0 and ``rs | stream << 24``.
+    Offsets into the stream that is the plan's dtab are relative to the delta table here
+    (``compile_plan`` adds its position).  Also returns the delta table and ok."""
+    ng, no = b.ng, b.no
+    nbase = len(b.base_rows)
+    L = max([seg[5] for seg in b.segments if seg[6] == SEG_IDENTITY] + [0])
+    delta = np.zeros(2 * L + 2)
+    delta[1 + L] = 1.0                                  # delta[1 + L + j - k] = (j == k)
+    ci = np.zeros((nbase, ng + nop, 2), dtype=np.int64)
+    ci[:, :, 1] = T_SID_CONST << 24                     # no segment: the 0.0 at delta[0], rs = 0
+    gen = {}
+    for g in groups:
+        for j, sid in enumerate(g["ids"][:-1]):
+            gen[sid] = (g, j)
+    ok = True
+    for bid, segs in enumerate(_segments_of_base(b)):
+        for sid, off0, rs, es, dst0, length, kind, _ in segs:
+            j = np.arange(length, dtype=np.int64)
+            cols = dst0 + j                              # (a domain variable is all given or all optim)
+            if kind == SEG_IDENTITY:
+                off, stream, step = 1 + L + j, T_SID_CONST, -1
+            elif sid in gen:
+                # U_j[k][l][i] = TB[i][j][N + k - l] (plan_tables.h TL_*): offset for k = 0 and one
+                # element per base row
+                g, jj = gen[sid]
+                n, m, N = g["n"], g["m"], g["N"]
+                if rs != N * n or es != n or length != N or not 0 <= off0 < n:
+                    ok = False
+                    continue
+                off, stream, step = (off0 * m + jj) * 2 * N + N - j, sid, 1
+            else:
+                off, stream, step = off0 + j * es, sid, rs
+            if abs(step) >= 1 << 23 or off.max(initial=0) >= 1 << 31 or off.min(initial=0) < 0:
+                ok = False
+                continue
+            ci[bid, cols, 0] = off
+            ci[bid, cols, 1] = (step & 0xFFFFFF) | (stream << 24)
+    return ci, delta, ok
+
+
+def _row_tile_masks(b, rowptr, entbase, entk, rtot, causal):
+    """Per workspace row: bit t set when 16-column tile t of the unknowns can hold a non-zero
+    (tiles beyond 62 fold onto bit 63).  A causal source contributes columns l <= k only."""
+    ng = b.ng
+    segs_of_base = _segments_of_base(b)
+    masks = [0] * max(rtot, 1)
+    for r in range(rtot):
+        m = 0
+        for e in range(rowptr[r], rowptr[r + 1]):
+            u, k = int(entbase[e]), int(entk[e])
+            for sid, off0, rs, es, dst0, length, kind, _ in segs_of_base[u]:
+                if dst0 < ng or length == 0:
+                    continue
+                c0 = dst0 - ng
+                if kind == SEG_IDENTITY:
+                    if k >= length:
+                        continue
+                    lo = hi = c0 + k
+                elif sid in causal:
+                    lo, hi = c0, c0 + min(k, length - 1)
+                else:
+                    lo, hi = c0, c0 + length - 1
+                for t in range(lo // 16, hi // 16 + 1):
+                    m |= 1 << min(t, 63)
+        masks[r] = m
+    return masks
+
+
+def _tiled_program(b, form, gterms, rowptr, entbase, entk, entcoef, rtot, groups, rr_ok, g_rows):
+    """Tables of the tiled kernel (csrc/tiled.hip): the column tables, the stage list of the
+    Hessian / gradient terms with their structural tile masks, and the groups of horizon
+    tables a pre-pass generates from per-instance (A, B)."""
+    ng, no = b.ng, b.no
+    nop = -(-max(no, 1) // T_BLOCK) * T_BLOCK
+    ci, delta, ci_ok = _column_tables(b, groups, nop)
+    causal = causal_sources(form, b.sources, groups)
+    masks = _row_tile_masks(b, rowptr, entbase, entk, rtot, causal)
+    nent_of = np.diff(rowptr) if rtot else np.zeros(0, dtype=np.int64)
+
+    def simple(row0, n):
+        """The common base of rows that are one entry each, else -1."""
+        if n == 0 or np.any(nent_of[row0:row0 + n] != 1):
+            return -1
+        bases = entbase[rowptr[row0:row0 + n]]
+        return int(bases[0]) if np.all(bases == bases[0]) else -1
+
+    def ormask(row0, n):
+        m = 0
+        for r in range(row0, row0 + n):
+            m |= masks[r]
+        return m
+
+    def quarter_class(m):
+        """Smallest n such that in every 64-column quarter only the first n tiles are set."""
+        n = 0
+        while m:
+            n = max(n, (m & 15).bit_length())
+            m >>= 4
+        return n
+
+    # rows of G that are arrow * (one workspace row): they ride on the first stage whose A rows
+    # hold that row (g_rows: per row of G the workspace rows of its axes)
+    riders = {}
+    for R, axes in enumerate(g_rows):
+        if len(axes) == 1:
+            riders.setdefault(axes[0][0], []).append((R, axes[0][1]))
+    stages, srow, scoef, pig = [], [], [], []
+    for g in gterms:
+        aoff, boff, nrows, wparam, doff, aimparam, flags = g[:7]
+        if flags & GT_FLAG_DIAG:
+            continue
+        has_p = bool(flags & GT_FLAG_P)
+        for k0 in range(0, nrows, 16):
+            n = min(16, nrows - k0)
+            arow, drow = aoff + k0, doff + k0
+            brow = boff + k0 if has_p else arow
+            fl = (TS_FLAG_P if has_p else 0) | (TS_FLAG_HALF if flags & GT_FLAG_HALF else 0)
+            ba, bb = simple(arow, n), simple(brow, n)
+            if 0 <= ba < 65536:
+                fl |= TS_FLAG_SIMPLE_A
+            if 0 <= bb < 65536:
+                fl |= TS_FLAG_SIMPLE_B
+            if brow == arow:
+                fl |= TS_FLAG_SAME
+            ma, mb = ormask(arow, n), ormask(brow, n)
+            cls = max(1, quarter_class(ma), quarter_class(mb)) if has_p else 0
+            ks, cs = np.zeros((2, 16), dtype=np.int64), np.zeros((2, 16))
+            for side, (row0, smp) in enumerate(((arow, ba), (brow, bb))):
+                if 0 <= smp < 65536:
+                    ks[side, :n] = entk[rowptr[row0:row0 + n]]
+                    cs[side, :n] = entcoef[rowptr[row0:row0 + n]]
+            pg = -np.ones((16, T_PIG_MAX, 2), dtype=np.int64)
+            for i in range(n):
+                take = riders.get(arow + i, [])[:T_PIG_MAX]
+                for t, (R, slot) in enumerate(take):
+                    pg[i, t] = (R, slot)
+                    fl |= TS_FLAG_G
+                if take:
+                    riders[arow + i] = riders[arow + i][len(take):]
+            stages.append([arow, brow, drow, n | (fl << 8) | (cls << 16), wparam, aimparam,
+                           ma & 0xFFFFFFFF, ma >> 32, mb & 0xFFFFFFFF, mb >> 32,
+                           (max(ba, 0) & 0xFFFF) | ((max(bb, 0) & 0xFFFF) << 16), 0])
+            srow.append(ks)
+            scoef.append(cs)
+            pig.append(pg)
+    order = sorted(range(len(stages)), key=lambda i: stages[i][3] >> 16)     # by class, stable
+    stages = [stages[i] for i in order]
+    srow, scoef, pig = ([x[i] for i in order] for x in (srow, scoef, pig))
+    riding = {int(R) for pg in pig for R in pg[:, :, 0].ravel() if R >= 0}
+    grest = np.asarray([R for R in range(len(g_rows)) if R not in riding], dtype=np.int64)
+    d_len = rtot + (rtot & 1)
+    work = d_len
+    lti, ids = [], []
+    for g in groups:
+        n, m, N = g["n"], g["m"], g["N"]
+        lti.append([n, m, N, len(ids), work, work + N * n * n, 0, 0])
+        work += N * n * n + n * m * 2 * N
+        ids.extend(g["ids"])
+    ok = int(ci_ok and rr_ok and no >= T_BLOCK and no % 2 == 0 and len(b.base_rows) > 0
+             and len(b.sources) <= MAX_SOURCES and rtot < (1 << 24))
+    return dict(ok=ok, ci_ok=int(ci_ok), nop=nop, ci=ci, delta=delta, masks=masks,
+                srow=np.asarray(srow, dtype=np.int64).reshape(-1),
+                scoef=np.asarray(scoef, dtype=np.float64).reshape(-1),
+                pig=np.asarray(pig, dtype=np.int64).reshape(-1), grest=grest,
+                stages=np.asarray(stages, dtype=np.int64).reshape(-1, T_STAGE_WORDS),
+                lti=np.asarray(lti, dtype=np.int64).reshape(-1, T_LTI_WORDS),
+                lti_ids=np.asarray(ids, dtype=np.int64), work=work)
+
+
 def _structural_patterns(form, b, fused, gterms, limit_recs, lax_recs, rtot, ldv, no, nc):
     """Which entries of P (no x no) and of the stacked G (nc x no) can be non-zero at all:
     from the structurally non-zero elements of the workspace (an element with at least one
@@ -1264,6 +1470,37 @@ def compile_plan(form, costs=None, limits=None, lti=(), csc=None):
                         p_flat=p_flat, g_flat=g_flat)
     pmprog = _preview_program(b, pm_rowptr, pm_entbase, pm_entk, pm_entcoef, pmrows)
     sections += [("OFF_CSC_P", csc_p), ("OFF_CSC_G", csc_g)]
+    # ---- column tables + tiled program (wide problems) ------------------------------------
+    g_rows = []           # per row of G: (workspace row, arrow's parameter slot) of every axis
+    for out0, nrows, naxes, lax0, p_a, a_rows, *_ in limit_recs:
+        for r in range(nrows):
+            g_rows.append([(lax_recs[lax0 + ax][0] + (0 if lax_recs[lax0 + ax][1] == 1 else r),
+                            p_a + (0 if a_rows == 1 else r) * naxes + ax) for ax in range(naxes)])
+    tiled = _tiled_program(b, form, gterms, rowptr, entbase, entk, entcoef, rtot, groups, rr_ok,
+                           g_rows)
+    ndt0 = (entcoef.size + pm_entcoef.size + fused["coefpool"].size + resident["coef"].size
+            + diag_coefs.size)
+    doff_delta = ndt0 + (ndt0 & 1) + 4 + rs_dcoef.size + pmprog["pool"].size
+    ci = tiled["ci"]
+    own = (ci[:, :, 1] >> 24) == T_SID_CONST          # offsets into the plan's own dtab
+    ci[:, :, 0] += np.where(own, doff_delta, 0)
+    ci32 = ci.astype(np.uint32).view(np.int32) if ci.size else np.zeros((0, 0, 2), np.int32)
+    sections += [("OFF_T_CIG", np.ascontiguousarray(ci32[:, :b.ng]).reshape(-1)),
+                 ("OFF_T_CIO", np.ascontiguousarray(ci32[:, b.ng:]).reshape(-1)),
+                 ("OFF_T_STAGE", tiled["stages"].astype(np.uint32).view(np.int32).reshape(-1)),
+                 ("OFF_T_LTI", tiled["lti"].astype(np.int32).reshape(-1)),
+                 ("OFF_T_LTI_IDS", tiled["lti_ids"].astype(np.int32))]
+    t_grow = -np.ones((nc, RS_AXMAX), dtype=np.int32)
+    if rr_ok:
+        for out0, nrows, naxes, lax0, *_ in limit_recs:
+            for r in range(nrows):
+                for ax in range(naxes):
+                    off, rs = lax_recs[lax0 + ax]
+                    t_grow[out0 + r, ax] = off + (0 if rs == 1 else r)
+    sections += [("OFF_T_GROW", t_grow.reshape(-1)),
+                 ("OFF_T_SROW", tiled["srow"].astype(np.int32)),
+                 ("OFF_T_PIG", tiled["pig"].astype(np.int32)),
+                 ("OFF_T_GREST", tiled["grest"].astype(np.int32))]
     sections += [("OFF_RS_DPAR", rs_dpar.reshape(-1)), ("OFF_RS_GDESC", rs_gdesc),
                  ("OFF_PM_MAP", pmprog["map"]), ("OFF_PM_FDPTR", pmprog["fd_ptr"]),
                  ("OFF_PM_OP", pmprog["ops"])]
@@ -1277,7 +1514,8 @@ def compile_plan(form, costs=None, limits=None, lti=(), csc=None):
             parts.append(np.zeros(1, dtype=np.int32))
             off += 1
         if name in ("OFF_RS_RR", "OFF_RS_INMETA", "OFF_RS_ABMETA", "OFF_RS_DPAR",
-                    "OFF_RS_GDESC", "OFF_CSC_G") and off & 3:   # ... 16-byte quads
+                    "OFF_RS_GDESC", "OFF_CSC_G", "OFF_T_CIG", "OFF_T_CIO",
+                    "OFF_T_STAGE", "OFF_T_GROW", "OFF_T_SROW", "OFF_T_PIG") and off & 3:   # ... 16-byte quads
             pad = 4 - (off & 3)
             parts.append(np.zeros(pad, dtype=np.int32))
             off += pad
@@ -1300,6 +1538,15 @@ def compile_plan(form, costs=None, limits=None, lti=(), csc=None):
     dparts.append(pmprog["pool"])
     header[_H["PM_NFD"]], header[_H["PM_NOPS"]] = pmprog["nfd"], pmprog["ops"].size // 2
     header[_H["PM_NPOOL"]] = pmprog["pool"].size
+    assert sum(part.size for part in dparts) == doff_delta
+    dparts.append(tiled["delta"])
+    header[_H["T_DOFF_DELTA"]], header[_H["T_NDELTA"]] = doff_delta, tiled["delta"].size
+    header[_H["T_DOFF_SCOEF"]] = doff_delta + tiled["delta"].size
+    dparts.append(tiled["scoef"])
+    header[_H["T_NGREST"]] = tiled["grest"].size
+    header[_H["T_CI_OK"]], header[_H["T_NOP"]] = tiled["ci_ok"], tiled["nop"]
+    header[_H["T_OK"]], header[_H["T_NSTAGE"]] = tiled["ok"], tiled["stages"].shape[0]
+    header[_H["T_NLTI"]], header[_H["T_WORK"]] = tiled["lti"].shape[0], tiled["work"]
     dtab = np.concatenate(dparts).astype(np.float64)
     params = np.asarray(b.params, dtype=np.float64)
     header[_H["MAGIC"]], header[_H["VERSION"]] = PLAN_MAGIC, PLAN_VERSION
@@ -1358,4 +1605,5 @@ def compile_plan(form, costs=None, limits=None, lti=(), csc=None):
     plan.P_pattern, plan.G_pattern = P_pattern, G_pattern
     plan.csc = csc_info
     plan.lti = [dict(name=g["name"], n=g["n"], m=g["m"], N=g["N"], ids=list(g["ids"])) for g in groups]
+    plan.tiled = tiled
     return plan

@@ -380,3 +380,177 @@ def run_resident(plan, given, params=None, sources=None):
     Vrc[:, no + 1] = 0.0                                   # (not part of the row-set program's V)
     out["V"] = Vrc[:plan.rtot]
     return out
+
+
+def _tiled_streams(plan, srcs, ab):
+    """The streams the column tables address: the launch's sources -- with the horizon tables of
+    every generated group in the places of its U_j (TB, plan_tables.h TL_*) and of its S (TA),
+    built from the group's (A, B) by the reference's recurrence -- and, last, the plan's dtab."""
+    it, dt = plan.itab, plan.dtab
+    streams = [np.ascontiguousarray(a, dtype=np.float64).ravel() for a in srcs]
+    streams += [None] * (P.T_SID_CONST - len(streams)) + [dt]
+    lti = _section(it, "OFF_T_LTI", it[H["T_NLTI"]] * P.T_LTI_WORDS).reshape(-1, P.T_LTI_WORDS)
+    for g, (n, m, N, ids0, _ta, _tb, _p0, _p1) in enumerate(lti):
+        ids = _section(it, "OFF_T_LTI_IDS", ids0 + m + 1)[ids0:]
+        Am, Bm = (np.asarray(x, dtype=float) for x in ab[g])
+        TA = np.zeros((N, n, n))
+        TB = np.zeros((n, m, 2 * N))
+        X = np.hstack([Bm, Am])                      # X_d = A^d [B | A]
+        for d in range(N):
+            TB[:, :, N + d] = X[:, :m]
+            TA[d] = X[:, m:].T                       # S[k][j][i] = (A^{k+1})[i][j]
+            X = Am @ X
+        for j in range(m):
+            streams[ids[j]] = TB.ravel()
+        streams[ids[m]] = TA.ravel()
+    return streams
+
+
+def _sext24(x):
+    x = np.asarray(x, dtype=np.int64) & 0xFFFFFF
+    return np.where(x >= 1 << 23, x - (1 << 24), x)
+
+
+def run_tiled(plan, given, params=None, sources=None, ab=None):
+    """P, q, G, h of one instance from the tables of the tiled kernel (csrc/tiled.hip): rows
+    composed through the column tables, the Hessian accumulated stage by stage on the 16-column
+    tiles the stage's masks admit (a mask that hides a non-zero tile shows as a wrong P), the
+    gradient from the same weighted rows and d = Mg . given, G and h from the row records."""
+    it, dt = plan.itab, plan.dtab
+    ng, no, nc, ldv = plan.ng, plan.no, plan.nc, plan.ldv
+    assert it[H["T_CI_OK"]] == 1
+    srcs = [s.array for s in plan.sources] if sources is None else sources
+    params = plan.params if params is None else np.asarray(params, dtype=float)
+    g = np.asarray(given, dtype=float).ravel()
+    streams = _tiled_streams(plan, srcs, ab)
+    nbase, nop = int(it[H["NBASE"]]), int(it[H["T_NOP"]])
+    cig = _section(it, "OFF_T_CIG", nbase * ng * 2).view(np.uint32).astype(np.int64).reshape(nbase, ng, 2)
+    cio = _section(it, "OFF_T_CIO", nbase * nop * 2).view(np.uint32).astype(np.int64).reshape(nbase, nop, 2)
+    assert it[H["OFF_T_CIO"]] % 4 == 0
+    rtot, nent = int(it[H["RTOT"]]), int(it[H["NENT"]])
+    rowptr = _section(it, "OFF_ROWPTR", rtot + 1)
+    entbase, entk = _section(it, "OFF_ENTBASE", nent), _section(it, "OFF_ENTK", nent)
+    coef = dt[it[H["DOFF_ENTCOEF"]]:it[H["DOFF_ENTCOEF"]] + nent]
+
+    def base_row(ci, u, k):
+        off, meta = ci[u, :, 0], ci[u, :, 1]
+        sid, rs = meta >> 24, _sext24(meta)
+        out = np.zeros(off.size)
+        for s in np.unique(sid):
+            pick = sid == s
+            out[pick] = streams[s][off[pick] + k * rs[pick]]
+        return out
+
+    def row(ci, r):
+        out = np.zeros(ci.shape[1])
+        for e in range(rowptr[r], rowptr[r + 1]):
+            out += coef[e] * base_row(ci, entbase[e], entk[e])
+        return out
+
+    Vo = np.stack([row(cio, r) for r in range(rtot)]) if rtot else np.zeros((0, nop))
+    assert not Vo[:, no:].any()                                  # the pad columns read 0.0
+    d = np.asarray([row(cig, r) @ g for r in range(rtot)]) if ng else np.zeros(rtot)
+
+    Pm, q = np.zeros((nop, nop)), np.zeros(nop)
+    nblk = nop // P.T_BLOCK
+    nstage = int(it[H["T_NSTAGE"]])
+    stages = _section(it, "OFF_T_STAGE", nstage * P.T_STAGE_WORDS).view(np.uint32) \
+        .astype(np.int64).reshape(-1, P.T_STAGE_WORDS)
+    srow = _section(it, "OFF_T_SROW", nstage * 32).reshape(nstage, 2, 16)
+    scoef = dt[it[H["T_DOFF_SCOEF"]]:it[H["T_DOFF_SCOEF"]] + nstage * 32].reshape(nstage, 2, 16)
+    pig = _section(it, "OFF_T_PIG", nstage * 16 * P.T_PIG_MAX * 2).reshape(nstage, 16, P.T_PIG_MAX, 2)
+    G, h = np.full((nc, no), np.nan), np.zeros(nc)
+    prm0 = np.append(params, 0.0)
+
+    def blockbits(m, b):                                  # the 8 tiles of block b (fold onto bit 63)
+        return [(m >> min(8 * b + j, 63)) & 1 for j in range(8)]
+
+    last_cls = 0
+    for sx, (arow, brow, drow, info, pw, pa, mal, mah, mbl, mbh, base, _) in enumerate(stages):
+        n, fl, cls = info & 255, (info >> 8) & 255, info >> 16
+        assert cls >= last_cls and (cls > 0) == bool(fl & P.TS_FLAG_P)   # sorted by class
+        last_cls = cls
+        ma, mb = mal | (mah << 32), mbl | (mbh << 32)
+        w, aim = params[pw], params[pa]
+        scale = 0.5 if fl & P.TS_FLAG_HALF else 1.0
+        assert bool(fl & P.TS_FLAG_SAME) == (arow == brow)
+
+        def rows(side, row0, flag, ci=cio):               # the stage's rows as the kernel composes them
+            if fl & flag:
+                b_ = (base & 0xFFFF) if side == 0 else (base >> 16)
+                out = np.stack([scoef[sx, side, i] * base_row(ci, b_, srow[sx, side, i]) for i in range(n)])
+                assert not scoef[sx, side, n:].any()
+                return out
+            return np.stack([row(ci, r) for r in range(row0, row0 + n)])
+
+        Au = rows(0, arow, P.TS_FLAG_SIMPLE_A)
+        assert np.array_equal(Au, Vo[arow:arow + n])
+        B = rows(1, brow, P.TS_FLAG_SIMPLE_B)
+        assert np.array_equal(B, Vo[brow:brow + n])
+        A = w * Au
+        r = scale * (d[drow:drow + n] - aim)
+        for bi in range(nblk):
+            ca = slice(bi * P.T_BLOCK, (bi + 1) * P.T_BLOCK)
+            hit_a = any(blockbits(ma, bi))
+            if hit_a:                                      # (diagonal workgroup of block bi)
+                q[ca] += A[:, ca].T @ r
+            else:
+                assert not A[:, ca].any()
+            if hit_a or fl & P.TS_FLAG_G:                  # rows of G riding on the A rows
+                for i in range(n):
+                    for R, slot in pig[sx, i]:
+                        if R >= 0:
+                            assert np.isnan(G[R, ca.start:min(ca.stop, no)]).all()    # written once
+                            G[R, ca.start:min(ca.stop, no)] = (prm0[slot] * Au[i, ca])[:min(ca.stop, no) - ca.start]
+            if not (fl & P.TS_FLAG_P) or not hit_a:
+                continue
+            for bj in range(nblk):
+                if not any(blockbits(mb, bj)):
+                    continue
+                for ta in range(8):
+                    for tb in range(8):
+                        if ta % 4 < cls and tb % 4 < cls:
+                            ra = slice(bi * P.T_BLOCK + 16 * ta, bi * P.T_BLOCK + 16 * ta + 16)
+                            cb = slice(bj * P.T_BLOCK + 16 * tb, bj * P.T_BLOCK + 16 * tb + 16)
+                            Pm[ra, cb] += A[:, ra].T @ B[:, cb]
+        # what the masks and the class promise: nothing outside the multiplied tiles
+        for t in range(nop // 16):
+            if not ((ma >> min(t, 63)) & 1 and t % 4 < max(cls, 1 if not fl & P.TS_FLAG_P else cls)):
+                assert not Au[:, 16 * t:16 * t + 16].any() or not (fl & P.TS_FLAG_P)
+            if fl & P.TS_FLAG_P and not ((mb >> min(t, 63)) & 1 and t % 4 < cls):
+                assert not B[:, 16 * t:16 * t + 16].any()
+    Pm, q = Pm[:no, :no], q[:no]
+    gt = _section(it, "OFF_GTERM", it[H["NGTERM"]] * P.GT_WORDS).reshape(-1, P.GT_WORDS)
+    want = 0
+    for a, b, n, pw, dd, pa, flags, _ma, _mb, _pad in gt:
+        if flags & P.GT_FLAG_DIAG:
+            cf = dt[it[H["DOFF_DIAGCOEF"]] + b:it[H["DOFF_DIAGCOEF"]] + b + n]
+            idx = np.arange(a, a + n)
+            Pm[idx, idx] += (params[pw] * cf) * cf
+            q[idx] += params[pw] * (cf * (0.0 - params[pa]))
+        else:
+            want += -(-n // 16)
+    assert want == nstage
+
+    rr = _section(it, "OFF_RS_RR", nc * P.RS_RR_WORDS).reshape(nc, P.RS_RR_WORDS)
+    grow = _section(it, "OFF_T_GROW", nc * P.RS_AXMAX).reshape(nc, P.RS_AXMAX)
+    grest = _section(it, "OFF_T_GREST", it[H["T_NGREST"]])
+    for R in range(nc):
+        x = rr[R]
+        ac = ad = 0.0
+        row_sum = np.zeros(no)
+        for ax in range(x[12]):
+            assert x[ax] == grow[R, ax] * ldv
+            r = grow[R, ax]
+            row_sum += prm0[x[4 + ax]] * Vo[r, :no]
+            ac += prm0[x[4 + ax]] * prm0[x[8 + ax]]
+            ad += prm0[x[4 + ax]] * d[r]
+        assert (grow[R, x[12]:] == -1).all()
+        h[R] = (prm0[x[13]] + ac) - ad
+        if R in grest:
+            assert np.isnan(G[R]).all()
+            G[R] = row_sum
+        else:
+            assert np.array_equal(G[R], row_sum)              # the riding rows: the same numbers
+    assert not np.isnan(G).any()
+    return {"P": Pm, "q": q, "G": G, "h": h, "d": d, "Vo": Vo[:, :no]}

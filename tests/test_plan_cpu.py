@@ -33,6 +33,11 @@ def check_plan(form, given, tol=1e-12):
         block = out["PM"][r0:r0 + rows]
         assert_close(block[:, :plan.ng], PM[var][0], tol, var + " Mg")
         assert_close(block[:, plan.ng:], PM[var][1], tol, var + " Mo")
+    # the column tables / stage list of the tiled kernel (built for every plan)
+    assert plan.itab[_H["T_CI_OK"]] == 1
+    til = plan_emulator.run_tiled(plan, given)
+    for key, ref in (("P", Q), ("q", q.ravel()), ("G", A), ("h", h.ravel())):
+        assert_close(til[key], ref, tol, "tiled " + key)
     # the tables of the persistent kernel, when the problem fits it
     if plan.itab[_H["RS_OK"]]:
         res = plan_emulator.run_resident(plan, given)
