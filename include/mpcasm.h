@@ -194,6 +194,29 @@ int mpcasm_preview_matrices(const mpcasm_plan* plan, const double* const* h_src,
 int mpcasm_preview(const double* d_PM, const double* d_given, const double* d_optim,
                    double* d_out, int batch, int rows, int ng, int no, void* stream);
 
+/* f2, straight from the sources: the same rows without a preview matrix in memory.
+ * Replaces Formulation.preview(given, optim, variable)   body.py:209-219
+ * for every definition at once: d_out[batch][preview_rows] = Mg @ given + Mo @ optim, every row
+ * evaluated as its combination of base rows (rows of the horizon matrices times [given ; optim],
+ * kept on chip).  h_src / h_src_stride as for mpcasm_assemble; a plan compiled with lti=[...]
+ * takes the groups' (A, B) in the same slots and needs d_work (mpcasm_workspace_bytes) for the
+ * horizon tables it generates first. */
+int mpcasm_preview_direct(const mpcasm_plan* plan, const double* const* h_src,
+                          const int64_t* h_src_stride, const double* d_given, const double* d_optim,
+                          double* d_out, void* d_work, int batch, void* stream);
+
+/* f2  goal distances --------------------------------------------------------------
+ * Replaces Formulation.goal_distance(given, optim, goal_name)   body.py:221-228
+ * (and full_goal_distance, :230-234: the sum over the goals) for a batch, from the rows
+ * mpcasm_preview_direct / mpcasm_preview wrote:
+ *   d_out[b][g] = sum over the terms t of goal g (one per axis)
+ *                 sum_{r < rows_t} (d_preview[b][row0_t + r] - d_params[b][aim_t])^2
+ * d_terms: nterms records of 4 int32 -- goal, row0, rows, aim's parameter slot.  As in the
+ * reference the whole variable counts, whatever the goal's schedule or L. */
+int mpcasm_goal_distance(const double* d_preview, int64_t preview_stride, const double* d_params,
+                         int64_t n_params, const int32_t* d_terms, int nterms, int ngoals,
+                         double* d_out, int batch, void* stream);
+
 /* f3  sparse hand-off -----------------------------------------------------------
  * Replaces the dense -> CSC conversion in front of the solver call of the walking loop
  *   Q = scipy.sparse.csc_matrix(Q); A = scipy.sparse.csc_matrix(A)

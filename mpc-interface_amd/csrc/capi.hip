@@ -100,6 +100,14 @@ int validate_tiled(const int32_t* it, const double* h_dtab, int64_t n, int64_t n
   if (!scan(it[H_OFF_ENTBASE], it[H_OFF_ENTK], it[H_NENT]) ||
       !scan(it[H_OFF_PM_ENTBASE], it[H_OFF_PM_ENTK], it[H_PM_NENT]))
     return MPCASM_ERR_PLAN;
+  {  // first rows of the base variables: ascending, every row some program reads lies inside
+    if (!in_range(it[H_OFF_T_BROW0], nbase + 1, n, H_WORDS)) return MPCASM_ERR_PLAN;
+    const int32_t* r0 = it + it[H_OFF_T_BROW0];
+    if (r0[0] != 0) return MPCASM_ERR_PLAN;
+    for (int64_t b = 0; b < nbase; ++b)
+      if (r0[b + 1] < r0[b] || (r0[b + 1] > r0[b] ? kmax[b] >= r0[b + 1] - r0[b] : kmax[b] != 0))
+        return MPCASM_ERR_PLAN;
+  }
   auto table_ok = [&](const int32_t* ci, int64_t cols) {
     for (int64_t b = 0; b < nbase; ++b)
       for (int64_t c = 0; c < cols; ++c) {
@@ -658,7 +666,8 @@ void plan_dev_from_tables(const int32_t* it, PlanDev* out) {
   d.off_t_lti = it[H_OFF_T_LTI]; d.off_t_lti_ids = it[H_OFF_T_LTI_IDS]; d.t_work = it[H_T_WORK];
   d.off_t_grow = it[H_OFF_T_GROW];
   d.off_t_srow = it[H_OFF_T_SROW]; d.t_doff_scoef = it[H_T_DOFF_SCOEF]; d.off_t_pig = it[H_OFF_T_PIG];
-  d.t_ngrest = it[H_T_NGREST]; d.off_t_grest = it[H_OFF_T_GREST];
+  d.t_ngrest = it[H_T_NGREST]; d.off_t_grest = it[H_OFF_T_GREST]; d.off_t_brow0 = it[H_OFF_T_BROW0];
+  d.t_nbrow = d.t_ci_ok ? it[d.off_t_brow0 + d.nbase] : 0;
   d.pm_nfd = it[H_PM_NFD]; d.off_pm_map = it[H_OFF_PM_MAP]; d.off_pm_fdptr = it[H_OFF_PM_FDPTR];
   d.off_pm_op = it[H_OFF_PM_OP]; d.doff_pm_pool = it[H_DOFF_PM_POOL];
   d.rs_src16 = 0;
@@ -884,7 +893,9 @@ int mpcasm_workspace_bytes(const mpcasm_plan* plan, int batch, size_t* out_bytes
     *out_bytes = std::max(tiled_workspace_bytes(plan->dev, batch), stamps);
     return MPCASM_OK;
   }
-  *out_bytes = std::max(assemble_workspace_bytes(plan->dev, batch), stamps);
+  // (the generated horizon tables of mpcasm_preview_direct fit in either case)
+  *out_bytes = std::max(std::max(assemble_workspace_bytes(plan->dev, batch),
+                                 tiled_workspace_bytes(plan->dev, batch)), stamps);
   return MPCASM_OK;
 }
 
@@ -942,6 +953,41 @@ int mpcasm_preview(const double* d_PM, const double* d_given, const double* d_op
   hipError_t err;
   const int rc = launch_preview(d_PM, d_given, d_optim, d_out, batch, rows, ng, no,
                                 static_cast<hipStream_t>(stream), &err);
+  if (rc == MPCASM_ERR_HIP) g_last_hip = (int)err;
+  return rc;
+}
+
+int mpcasm_preview_direct(const mpcasm_plan* plan, const double* const* h_src,
+                          const int64_t* h_src_stride, const double* d_given, const double* d_optim,
+                          double* d_out, void* d_work, int batch, void* stream) {
+  if (!plan || !d_out || batch < 0) return MPCASM_ERR_ARG;
+  const PlanDev& d = plan->dev;
+  if ((d.nsrc && (!h_src || !h_src_stride)) || (d.ng && !d_given) || (d.no && !d_optim))
+    return MPCASM_ERR_ARG;
+  if (batch == 0 || d.pmrows == 0) return MPCASM_OK;
+  if (d.t_nlti != 0 && !d_work) return MPCASM_ERR_ARG;
+  SrcTable src, eff;
+  int rc = make_src_table(plan, h_src, h_src_stride, &src);
+  if (rc != MPCASM_OK) return rc;
+  hipError_t err;
+  rc = launch_lti_tables(d, src, static_cast<double*>(d_work), batch, plan->h_itab.data(), &eff,
+                         static_cast<hipStream_t>(stream));
+  if (rc != MPCASM_OK) return rc;
+  rc = launch_preview_direct(d, eff, d_given, d_optim, d_out, batch, plan->num_cus,
+                             static_cast<hipStream_t>(stream), &err);
+  if (rc == MPCASM_ERR_HIP) g_last_hip = (int)err;
+  return rc;
+}
+
+int mpcasm_goal_distance(const double* d_preview, int64_t preview_stride, const double* d_params,
+                         int64_t n_params, const int32_t* d_terms, int nterms, int ngoals,
+                         double* d_out, int batch, void* stream) {
+  if (batch < 0 || nterms < 0 || ngoals < 0 || preview_stride < 0 || n_params < 0) return MPCASM_ERR_ARG;
+  if (batch == 0 || ngoals == 0) return MPCASM_OK;
+  if (!d_preview || !d_out || (nterms && (!d_terms || !d_params))) return MPCASM_ERR_ARG;
+  hipError_t err;
+  const int rc = launch_goal_distance(d_preview, preview_stride, d_params, n_params, d_terms, nterms,
+                                      ngoals, d_out, batch, static_cast<hipStream_t>(stream), &err);
   if (rc == MPCASM_ERR_HIP) g_last_hip = (int)err;
   return rc;
 }

@@ -26,6 +26,15 @@ int launch_assemble_tiled(const PlanDev& p, const SrcTable& src, const double* p
                           const double* given, double* P, double* q, double* G, double* h,
                           void* work, int batch, hipStream_t stream, hipError_t* err,
                           const int32_t* h_itab);
+int launch_lti_tables(const PlanDev& p, const SrcTable& src, double* work, int batch,
+                      const int32_t* h_itab, SrcTable* eff, hipStream_t stream);
+// preview.hip
+int launch_preview_direct(const PlanDev& p, const SrcTable& eff, const double* given,
+                          const double* optim, double* out, int batch, int num_cus,
+                          hipStream_t stream, hipError_t* err);
+int launch_goal_distance(const double* preview, long long preview_stride, const double* params,
+                         long long nparams, const int32_t* terms, int nterms, int ngoals,
+                         double* out, int batch, hipStream_t stream, hipError_t* err);
 // fused.hip
 size_t fused_lds_bytes(const PlanDev& p, int nw);
 int launch_assemble_fused(const PlanDev& p, const SrcTable& src, const double* params,

@@ -180,9 +180,10 @@ enum HeaderWord : int {
                     //    arrow's parameter slot (-1: none); every such row of G is listed once
   H_T_NGREST,       // rows of G that ride on no stage (several axes, rows no cost reads ...)
   H_OFF_T_GREST,    // [T_NGREST] their indices, ascending
+  H_OFF_T_BROW0,    // [NBASE + 1] first row of every base variable among all base rows; [NBASE] = total
   H_WORDS = 112
 };
-static_assert(H_OFF_T_GREST < H_WORDS, "plan header");
+static_assert(H_OFF_T_BROW0 < H_WORDS, "plan header");
 
 constexpr int T_BLOCK = 128;       // columns of a block of P (tiled kernel)
 constexpr int T_SID_CONST = 32;    // the stream that is the plan's own dtab

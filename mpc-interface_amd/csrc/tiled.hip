@@ -561,29 +561,42 @@ size_t tiled_workspace_bytes(const PlanDev& p, int batch) {
   return (size_t)batch * p.t_work * sizeof(double);
 }
 
+// The horizon tables of the plan's generated groups, from the (A, B) in the slots of each group's
+// first two sources, into the scratch (t_work doubles per instance); `eff`: the launch's sources
+// with those tables in the places of the groups' U_j and S -- what the column tables address.
+int launch_lti_tables(const PlanDev& p, const SrcTable& src, double* w, int batch,
+                      const int32_t* h_itab, SrcTable* eff, hipStream_t stream) {
+  *eff = src;
+  if (p.t_nlti == 0) return MPCASM_OK;
+  if (h_itab == nullptr || w == nullptr) return MPCASM_ERR_ARG;
+  const long long stride = p.t_work;
+  for (int g = 0; g < p.t_nlti; ++g) {
+    const int32_t* rec = h_itab + p.off_t_lti + g * T_LTI_WORDS;
+    const int n = rec[TL_N], m = rec[TL_M];
+    if (n * (m + n) > LTI_XMAX || n > 64) return MPCASM_ERR_LIMIT;
+    const int32_t* ids = h_itab + p.off_t_lti_ids + rec[TL_IDS];
+    for (int j = 0; j < m; ++j) {
+      eff->ptr[ids[j]] = w + rec[TL_TB];
+      eff->stride[ids[j]] = stride;
+    }
+    eff->ptr[ids[m]] = w + rec[TL_TA];
+    eff->stride[ids[m]] = stride;
+  }
+  hipLaunchKernelGGL(lti_tables_kernel, dim3((unsigned)batch * p.t_nlti), dim3(BLOCK), 0, stream, p,
+                     src, w, stride);
+  return MPCASM_OK;
+}
+
 int launch_assemble_tiled(const PlanDev& p, const SrcTable& src, const double* params,
                           const double* given, double* P, double* q, double* G, double* h,
                           void* work, int batch, hipStream_t stream, hipError_t* err,
                           const int32_t* h_itab) {
   double* w = static_cast<double*>(work);
   const long long stride = p.t_work;
-  SrcTable eff = src;
-  if (p.t_nlti > 0) {
-    if (h_itab == nullptr) return MPCASM_ERR_ARG;
-    for (int g = 0; g < p.t_nlti; ++g) {
-      const int32_t* rec = h_itab + p.off_t_lti + g * T_LTI_WORDS;
-      const int n = rec[TL_N], m = rec[TL_M];
-      if (n * (m + n) > LTI_XMAX || n > 64) return MPCASM_ERR_LIMIT;
-      const int32_t* ids = h_itab + p.off_t_lti_ids + rec[TL_IDS];
-      for (int j = 0; j < m; ++j) {
-        eff.ptr[ids[j]] = w + rec[TL_TB];
-        eff.stride[ids[j]] = stride;
-      }
-      eff.ptr[ids[m]] = w + rec[TL_TA];
-      eff.stride[ids[m]] = stride;
-    }
-    hipLaunchKernelGGL(lti_tables_kernel, dim3((unsigned)batch * p.t_nlti), dim3(BLOCK), 0, stream,
-                       p, src, w, stride);
+  SrcTable eff;
+  {
+    const int rc = launch_lti_tables(p, src, w, batch, h_itab, &eff, stream);
+    if (rc != MPCASM_OK) return rc;
   }
   if (p.rtot > 0) {
     const unsigned nrb = ceil_div(p.rtot, WAVES * D_ROWS_PER_WAVE);

@@ -178,7 +178,15 @@ class Formulation:
         limits += [l for box in self.constraint_boxes.values() for l in box.constraints]
         return limits
 
-    _ASM_CACHE_MAX = 24
+    _ASM_CACHE_MIN = 24
+
+    def _asm_cache_size(self):
+        """Plans kept: room for the whole problem and every single cost / limit (the per-part
+        calls of generate_qp_cost / generate_qp_constraint) in three structures -- the walking
+        loop alternates between that many (SURVEY: QP 34 / 36 wide) -- and never fewer than
+        ``_ASM_CACHE_MIN``."""
+        parts = 1 + len(self.goals) + len(self._all_limits())
+        return max(self._ASM_CACHE_MIN, 3 * parts)
 
     def _assembler(self, costs=None, limits=None):
         """Assembler (batch 1) for the whole problem, or for the given costs / limits, carrying
@@ -198,6 +206,7 @@ class Formulation:
         key = (whole, formulation_key(self), structure_fingerprint(use_costs, use_limits))
         entry = self._asm_cache.get(key)
         if entry is not None:
+            self._asm_cache[key] = self._asm_cache.pop(key)          # most recently used: last
             asm, bound_at = entry
             if bound_at != self._tick and not asm.rebind_sources(self, self._frozen):
                 entry = None
@@ -206,8 +215,9 @@ class Formulation:
             else:
                 entry[1] = self._tick
         if entry is None:
-            if len(self._asm_cache) >= self._ASM_CACHE_MAX:
-                self._asm_cache.pop(next(iter(self._asm_cache)))      # oldest first
+            self._asm_cache.pop(key, None)                            # (a stale entry of this key)
+            while len(self._asm_cache) >= self._asm_cache_size():
+                self._asm_cache.pop(next(iter(self._asm_cache)))      # least recently used first
             asm = (Assembler(self, batch=1, device=self._device) if whole else
                    Assembler(self, batch=1, device=self._device, costs=use_costs, limits=use_limits))
             asm.rebind_sources(self, self._frozen)
@@ -247,13 +257,22 @@ class Formulation:
         asm = self._assembler()
         return asm.plan.pm_rows[variable]
 
+    def _preview_rows(self, given, optim):
+        """Every row of every definition at ``(given, optim)``: device tensor ``(1, rows)`` from
+        ``mpcasm_preview_direct`` (no preview matrix is built), kept until the tick or the point
+        changes -- the walking loop reads one variable after the other at the same point."""
+        asm = self._assembler()
+        g = np.ascontiguousarray(given, dtype=float).reshape(1, -1)
+        x = np.ascontiguousarray(optim, dtype=float).reshape(1, -1)
+        key = (id(asm), self._tick, g.tobytes(), x.tobytes())
+        if getattr(self, "_rows_dev", (None,))[0] != key:
+            self._rows_dev = (key, asm.preview_rows(g, x))
+        return asm, self._rows_dev[1]
+
     def preview(self, given, optim, variable, axes=None):
         """``Mg @ given + Mo @ optim`` (body.py:209-219), on the device."""
-        asm = self._assembler()
-        if getattr(self, "_pm_dev", (None, None))[:2] != (asm, self._tick):
-            self._pm_dev = (asm, self._tick, asm.preview_matrices())
-        values = asm.preview(self._pm_dev[2], np.asarray(given, dtype=float).reshape(1, -1),
-                             np.asarray(optim, dtype=float).reshape(1, -1))[0].cpu().numpy()
+        asm, rows = self._preview_rows(given, optim)
+        values = rows[0].cpu().numpy()
 
         def rows_of(name):
             r0, rows = asm.plan.pm_rows[name]
@@ -263,17 +282,25 @@ class Formulation:
             return rows_of(variable)
         return np.hstack([rows_of(variable + axis) for axis in axes])
 
+    def _goal_distances(self, given, optim):
+        asm, rows = self._preview_rows(given, optim)
+        values = asm.goal_distance(self, rows)[0].cpu().numpy()
+        return dict(zip(asm.goal_terms(self)[1], values))
+
     def goal_distance(self, given, optim, goal_name):
-        """Squared distance of a goal's variable to its aim (body.py:221-228)."""
-        goal = self.goals[goal_name]
-        value = 0
-        for i, axis in enumerate(goal.axes):
-            v = self.preview(given, optim, goal.variable + axis) - goal.aim[:, i]
-            value += (v.T @ v).item()
-        return float(value)
+        """Squared distance of a goal's variable to its aim (body.py:221-228): reduced on the
+        device (``mpcasm_goal_distance``) from the rows of :meth:`preview`."""
+        if goal_name not in self.goals:
+            raise KeyError(goal_name)
+        return float(self._goal_distances(given, optim)[goal_name])
 
     def full_goal_distance(self, given, optim):
-        return sum(self.goal_distance(given, optim, name) for name in self.goals.keys())
+        """Sum over the goals (body.py:230-234)."""
+        dist = self._goal_distances(given, optim)
+        value = 0
+        for name in self.goals.keys():
+            value += float(dist[name])
+        return value
 
     # ---- QP blocks (body.py:236-348) ----------------------------------------------
     @staticmethod

@@ -58,6 +58,12 @@ SIGNATURES = {
                                                ctypes.c_int, _void_p]),
     "mpcasm_preview": (ctypes.c_int, [_void_p, _void_p, _void_p, _void_p, ctypes.c_int,
                                       ctypes.c_int, ctypes.c_int, ctypes.c_int, _void_p]),
+    "mpcasm_preview_direct": (ctypes.c_int, [_void_p, ctypes.POINTER(_void_p),
+                                             ctypes.POINTER(ctypes.c_int64), _void_p, _void_p,
+                                             _void_p, _void_p, ctypes.c_int, _void_p]),
+    "mpcasm_goal_distance": (ctypes.c_int, [_void_p, ctypes.c_int64, _void_p, ctypes.c_int64,
+                                            _void_p, ctypes.c_int, ctypes.c_int, _void_p,
+                                            ctypes.c_int, _void_p]),
     "mpcasm_gather": (ctypes.c_int, [_void_p, ctypes.c_int64, _void_p, ctypes.c_int, _void_p,
                                      ctypes.c_int, _void_p]),
     "mpcasm_box_transform": (ctypes.c_int, [_void_p, ctypes.c_int64, ctypes.c_int, _void_p,

@@ -386,6 +386,64 @@ class Assembler:
         capi.check(rc, "mpcasm_preview_matrices")
         return PM
 
+    def preview_rows(self, given, optim, out=None, stream=None, count=None):
+        """``Mg @ given + Mo @ optim`` for every row of every definition (body.py:209-219)
+        without a preview matrix in memory (``mpcasm_preview_direct``): ``(B, preview_rows)``;
+        rows of definition ``v`` are ``plan.pm_rows[v]``.  ``given``: ``(B, ng)``, ``optim``:
+        ``(B, no)`` (the solver's answer)."""
+        torch = self._torch
+        n = self.batch if count is None else int(count)
+        g = _as_device(torch, given, self.device).reshape(-1, self.ng) if self.ng else None
+        x = _as_device(torch, optim, self.device).reshape(-1, self.no) if self.no else None
+        for t, name in ((g, "given"), (x, "optim")):
+            if t is not None and t.shape[0] < n:
+                raise ValueError("%s must have %d rows, got %d" % (name, n, t.shape[0]))
+        if out is None:
+            out = torch.empty((self.batch, self.plan.pmrows), dtype=torch.float64, device=self.device)
+        ptrs, strides = self._src_args()
+        work = self._workspace()
+        with torch.cuda.device(self.device):
+            rc = capi.load().mpcasm_preview_direct(
+                self._handle, ptrs, strides, g.data_ptr() if g is not None else None,
+                x.data_ptr() if x is not None else None, out.data_ptr(), work.data_ptr(), n,
+                _stream_handle(torch, stream))
+        capi.check(rc, "mpcasm_preview_direct")
+        return out
+
+    def goal_terms(self, form):
+        """Device table of ``mpcasm_goal_distance`` for ``form.goals`` (the plan's costs): one
+        record ``(goal, first preview row, rows, aim's parameter slot)`` per goal and axis;
+        returns ``(table, goal names)``."""
+        if getattr(self, "_goal_terms", None) is None:
+            names, recs = list(form.goals.keys()), []
+            for gi, name in enumerate(names):
+                goal = form.goals[name]
+                aim0 = self.plan.param_slots[("cost", name, "aim")][0]
+                for i, axis in enumerate(goal.axes):
+                    r0, rows = self.plan.pm_rows[goal.variable + axis]
+                    recs.append([gi, r0, rows, aim0 + i])
+            table = self._torch.as_tensor(np.asarray(recs, dtype=np.int32).reshape(-1, 4),
+                                          device=self.device)
+            self._goal_terms = (table, names)
+        return self._goal_terms
+
+    def goal_distance(self, form, rows, out=None, stream=None, count=None):
+        """Squared distance of every goal's variable to its aim (body.py:221-228), per instance:
+        ``(B, n_goals)`` from the rows of :meth:`preview_rows`; the row sum over the goals is
+        ``full_goal_distance`` (:230-234).  Aims are read from :attr:`params`."""
+        torch = self._torch
+        table, names = self.goal_terms(form)
+        n = self.batch if count is None else int(count)
+        if out is None:
+            out = torch.empty((self.batch, len(names)), dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = capi.load().mpcasm_goal_distance(
+                rows.data_ptr(), rows.shape[1], self.params.data_ptr(), self.params.shape[1],
+                table.data_ptr(), table.shape[0], len(names), out.data_ptr(), n,
+                _stream_handle(torch, stream))
+        capi.check(rc, "mpcasm_goal_distance")
+        return out
+
     def preview(self, PM, given, optim, stream=None):
         """``Mg @ given + Mo @ optim`` for every definition row (body.py:209-219):
         ``(B, preview_rows)``."""

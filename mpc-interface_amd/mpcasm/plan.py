@@ -38,7 +38,7 @@ _H = {name: i for i, name in enumerate([
     "CSC_PNNZ", "OFF_CSC_P", "CSC_GNNZ", "OFF_CSC_G", "CSC_GSINGLE",
     "T_CI_OK", "T_NOP", "OFF_T_CIG", "OFF_T_CIO", "T_DOFF_DELTA", "T_NDELTA",
     "T_OK", "T_NSTAGE", "OFF_T_STAGE", "T_NLTI", "OFF_T_LTI", "OFF_T_LTI_IDS", "T_WORK",
-    "OFF_T_GROW", "OFF_T_SROW", "T_DOFF_SCOEF", "OFF_T_PIG", "T_NGREST", "OFF_T_GREST",
+    "OFF_T_GROW", "OFF_T_SROW", "T_DOFF_SCOEF", "OFF_T_PIG", "T_NGREST", "OFF_T_GREST", "OFF_T_BROW0",
 ])}
 H_WORDS = 112
 assert len(_H) <= H_WORDS
@@ -1500,7 +1500,8 @@ def compile_plan(form, costs=None, limits=None, lti=(), csc=None):
     sections += [("OFF_T_GROW", t_grow.reshape(-1)),
                  ("OFF_T_SROW", tiled["srow"].astype(np.int32)),
                  ("OFF_T_PIG", tiled["pig"].astype(np.int32)),
-                 ("OFF_T_GREST", tiled["grest"].astype(np.int32))]
+                 ("OFF_T_GREST", tiled["grest"].astype(np.int32)),
+                 ("OFF_T_BROW0", np.asarray(list(b.base_row0) + [b.total_base_rows], dtype=np.int32))]
     sections += [("OFF_RS_DPAR", rs_dpar.reshape(-1)), ("OFF_RS_GDESC", rs_gdesc),
                  ("OFF_PM_MAP", pmprog["map"]), ("OFF_PM_FDPTR", pmprog["fd_ptr"]),
                  ("OFF_PM_OP", pmprog["ops"])]

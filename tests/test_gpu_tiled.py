@@ -1,0 +1,224 @@
+"""GPU: the tiled kernel (csrc/tiled.hip) -- wide problems (no >= 128) without a workspace in
+HBM -- against the staged pipeline and the oracle; horizon tables generated from per-instance
+(A, B) against the K1 fill; C4 at its per-GPU batch of 8192 in ONE call."""
+import numpy as np
+import pytest
+
+from helpers import RTOL, RTOL_TIGHT, assert_close
+from mpcasm import problems
+from mpcasm.plan import _H
+from oracle import qp_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(x, ref):
+    import torch
+
+    scale = ref.abs().max()
+    err = (x - ref).abs().max()
+    return float(err / scale) if float(scale) > 0 else float(err)
+
+
+@pytest.fixture
+def torch_gpu():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    return torch
+
+
+@pytest.mark.parametrize("nx,nu,N,B,seed", [
+    (5, 3, 48, 37, 1),       # no = 144: the second column block is mostly padding
+    (4, 6, 40, 16, 2),       # no = 240: stages of 16, 16 and 8 rows
+    (12, 6, 64, 24, 20262),  # the C4 shape
+    (3, 2, 100, 9, 5),       # no = 200, N = 100: seven stages per term, the last of 4 rows
+])
+def test_tiled_against_staged_and_oracle(gpu_api, torch_gpu, nx, nu, N, B, seed):
+    torch = torch_gpu
+    from mpcasm import capi, engine
+
+    rng = np.random.default_rng(seed)
+    form = problems.random_lti(gpu_api, rng, nx=nx, nu=nu, N=N)
+    given = torch.as_tensor(rng.normal(0, 0.3, [B, form.given_len]), device="cuda")
+    w = rng.uniform(0.1, 1.0, [B, 1, 1])
+    til = engine.Assembler(form, batch=B)
+    assert til.plan.itab[_H["T_OK"]] == 1                   # this plan runs on the tiled kernel
+    til.set_param("cost", "track s0", "weight", w)
+    # garbage in the result buffers first: every element must be written, zeros included
+    out = tuple(torch.full_like(t, float("nan")) for t in til.assemble(given))
+    Pt, qt, Gt, ht = (t.clone() for t in til.assemble(given, out=out))
+    assert not any(torch.isnan(t).any().item() for t in (Pt, qt, Gt, ht))
+    ref = engine.Assembler(form, batch=B)
+    ref.set_option(capi.OPT_PATH, 2)                          # the staged pipeline
+    ref.set_param("cost", "track s0", "weight", w)
+    Ps, qs, Gs, hs = ref.assemble(given)
+    assert max(_rel(Pt, Ps), _rel(qt, qs), _rel(Gt, Gs), _rel(ht, hs)) <= RTOL_TIGHT
+    goal = form.goals["track s0"]
+    w0 = goal.weight
+    try:
+        for b in (0, B - 1):
+            goal.update(weight=float(w[b, 0, 0]))
+            Ao, ho, Qo, qo = orc.assemble(form, given[b].cpu().numpy().reshape(-1, 1))
+            assert_close(Pt[b].cpu().numpy(), Qo, RTOL_TIGHT), assert_close(qt[b].cpu().numpy(), qo.ravel(), RTOL_TIGHT)
+            assert_close(Gt[b].cpu().numpy(), Ao, RTOL_TIGHT), assert_close(ht[b].cpu().numpy(), ho.ravel(), RTOL_TIGHT)
+    finally:
+        goal.update(weight=w0)
+    # one half at a time: the same numbers
+    P2, q2, _, _ = til.assemble(given, want_constraints=False)
+    assert torch.equal(P2, Pt) and torch.equal(q2, qt)
+    out = tuple(torch.full_like(t, float("nan")) for t in (Pt, qt, Gt, ht))
+    _, _, G2, h2 = til.assemble(given, out=out, want_cost=False)
+    assert torch.equal(G2, Gt) and torch.equal(h2, ht)
+
+
+@pytest.mark.parametrize("nx,nu,N,B,seed", [(5, 3, 48, 19, 11), (12, 6, 64, 24, 12)])
+def test_horizon_tables_from_the_systems_own_matrices(gpu_api, torch_gpu, nx, nu, N, B, seed):
+    """Plans compiled with lti=[...] on the tiled kernel: a pre-pass builds S and the compact
+    Toeplitz tables of U from per-instance (A, B) by the reference's recurrence (tools.py:24-29);
+    against the staged pipeline fed the K1 fill's S, U of the same systems, and the oracle."""
+    torch = torch_gpu
+    from mpcasm import capi, engine
+
+    rng = np.random.default_rng(seed)
+    form = problems.random_lti(gpu_api, rng, nx=nx, nu=nu, N=N)
+    given = torch.as_tensor(rng.normal(0, 0.3, [B, form.given_len]), device="cuda")
+    As, Bs = zip(*(problems.random_lti_matrices(rng, nx, nu) for _ in range(B)))
+    A, Bm = np.stack(As), np.stack(Bs)
+    At, Bt = torch.as_tensor(A, device="cuda"), torch.as_tensor(Bm, device="cuda")
+    lti = engine.Assembler(form, batch=B, lti=["plant"])
+    lti.bind_lti("plant", At, Bt)
+    out = tuple(torch.full_like(t, float("nan")) for t in lti.assemble(given))
+    Pl, ql, Gl, hl = (t.clone() for t in lti.assemble(given, out=out))
+    assert not any(torch.isnan(t).any().item() for t in (Pl, ql, Gl, hl))
+    ref = engine.Assembler(form, batch=B)
+    ref.set_option(capi.OPT_PATH, 2)
+    S, U = engine.fill_su(At, Bt, N)
+    for j in range(nu):
+        ref.bind_source(("plant", j), U[:, j])
+    ref.bind_source(("plant", nu), S)
+    Ps, qs, Gs, hs = ref.assemble(given)
+    assert max(_rel(Pl, Ps), _rel(ql, qs), _rel(Gl, Gs), _rel(hl, hs)) <= 1e-12
+    dyn = form.dynamics["plant"]
+    saved = list(dyn.matrices)
+    try:
+        for b in (0, B - 1):
+            So, Uo = orc.extend_matrices(N, A[b], Bm[b])
+            dyn.matrices = Uo + [So]
+            dyn.update_definitions()
+            Ao, ho, Qo, qo = orc.assemble(form, given[b].cpu().numpy().reshape(-1, 1))
+            assert_close(Pl[b].cpu().numpy(), Qo, RTOL), assert_close(ql[b].cpu().numpy(), qo.ravel(), RTOL)
+            assert_close(Gl[b].cpu().numpy(), Ao, RTOL), assert_close(hl[b].cpu().numpy(), ho.ravel(), RTOL)
+    finally:
+        dyn.matrices = saved
+        dyn.update_definitions()
+
+
+def test_crossed_cost_and_two_axis_constraint_on_the_tiled_kernel(gpu_api, torch_gpu):
+    """What the random LTI problems do not have: a crossed cost (A != B rows, non-symmetric P:
+    every block pair is computed), a derived variable (rows of several entries: the general
+    compose path), a constraint over two axes (rows of G that ride on no stage) and an L."""
+    torch = torch_gpu
+    from mpcasm import capi, engine
+
+    api = gpu_api
+    rng = np.random.default_rng(77)
+    N, nx, nu = 32, 4, 5
+    A, Bm = problems.random_lti_matrices(rng, nx, nu)
+    axes = ["_x", "_y"]
+    inputs = ["u%d" % j for j in range(nu)]
+    states = ["s%d" % i for i in range(nx)]
+    system = api.ControlSystem(inputs, states, A, Bm, axes=axes)
+    ext = api.ExtendedSystem.from_cotrol_system(system, "x", N)
+    form = api.Formulation()
+    form.incorporate_dynamics("plant", ext)
+    for ax in axes:
+        form.incorporate_definition("mix" + ax, api.LineCombo(
+            {"s0" + ax: 1.0, "s1" + ax: np.diag(rng.standard_normal(N)), "u0" + ax: 0.5}))
+    form.incorporate_goal("track", api.Cost("s0", 0.7, aim=[0.3, -0.2], axes=axes))
+    form.incorporate_goal("crossed", api.Cost("mix", 0.4, aim=[0.1, 0.0], axes=axes,
+                                              cross="s2", cross_aim=[0.0, 0.5]))
+    form.incorporate_goal("effort", api.Cost("u1", 0.2, axes=axes))
+    L = [rng.standard_normal((6, N)), rng.standard_normal((6, N))]
+    form.incorporate_constraint("cone", [
+        api.Constraint("s3", 4.0, axes=axes, arrow=[0.6, 0.8]),
+        api.Constraint("mix", 2.0, axes=axes, arrow=rng.standard_normal((6, 2)), L=L),
+        api.Constraint("s1", 3.0, axes=["_x"], arrow=[-1]),
+    ])
+    form.identify_qp_domain([u + ax for ax in axes for u in inputs])
+    form.make_preview_matrices()
+    assert form.optim_len == 2 * nu * N
+    B = 13
+    given = torch.as_tensor(rng.normal(0, 0.3, [B, form.given_len]), device="cuda")
+    til = engine.Assembler(form, batch=B)
+    out = tuple(torch.full_like(t, float("nan")) for t in til.assemble(given))
+    Pt, qt, Gt, ht = (t.clone() for t in til.assemble(given, out=out))
+    assert not any(torch.isnan(t).any().item() for t in (Pt, qt, Gt, ht))
+    ref = engine.Assembler(form, batch=B)
+    ref.set_option(capi.OPT_PATH, 2)
+    Ps, qs, Gs, hs = ref.assemble(given)
+    assert max(_rel(Pt, Ps), _rel(qt, qs), _rel(Gt, Gs), _rel(ht, hs)) <= RTOL_TIGHT
+    assert _rel(Pt.transpose(1, 2), Pt) > 1e-3                # the crossed cost: P is not symmetric
+    for b in (0, B - 1):
+        Ao, ho, Qo, qo = orc.assemble(form, given[b].cpu().numpy().reshape(-1, 1))
+        assert_close(Pt[b].cpu().numpy(), Qo, RTOL_TIGHT), assert_close(qt[b].cpu().numpy(), qo.ravel(), RTOL_TIGHT)
+        assert_close(Gt[b].cpu().numpy(), Ao, RTOL_TIGHT), assert_close(ht[b].cpu().numpy(), ho.ravel(), RTOL_TIGHT)
+
+
+def test_c4_at_its_per_gpu_batch_in_one_call(gpu_api, torch_gpu):
+    """C4 (nx=12 nu=6 N=64: no=384, nc=1536) at 8192 instances in ONE call -- P 9.7 GB, G 38.7 GB,
+    no workspace -- with a different system in every instance: P symmetric, G = [+V; -V] per state,
+    q and h affine in `given`, P affine in a per-instance weight, instances against the oracle."""
+    torch = torch_gpu
+    from mpcasm import engine
+
+    nx, nu, N, B = 12, 6, 64, 8192
+    if torch.cuda.get_device_properties(0).total_memory < 120e9:
+        pytest.skip("needs 60 GB of device memory")
+    rng = np.random.default_rng(20262)
+    form = problems.random_lti(gpu_api, rng, nx=nx, nu=nu, N=N)
+    base = [problems.random_lti_matrices(rng, nx, nu) for _ in range(64)]
+    scale = 1.0 - 0.05 * rng.random(B)
+    A = np.stack([base[b % 64][0] * scale[b] for b in range(B)])
+    Bm = np.stack([base[b % 64][1] * (2.0 - scale[b]) for b in range(B)])
+    asm = engine.Assembler(form, batch=B, lti=["plant"])
+    asm.bind_lti("plant", torch.as_tensor(A, device="cuda"), torch.as_tensor(Bm, device="cuda"))
+    w = rng.uniform(0.1, 1.0, [B, 1, 1])
+    asm.set_param("cost", "track s0", "weight", w)
+    g0 = torch.as_tensor(rng.normal(0, 0.3, [B, form.given_len]), device="cuda")
+    g1 = torch.as_tensor(rng.normal(0, 0.3, [B, form.given_len]), device="cuda")
+    P, q, G, h = asm.assemble(g0)
+    assert P.shape == (B, 384, 384) and G.shape == (B, 1536, 384)
+    q0, h0 = q.clone(), h.clone()
+    # symmetric, block by block (chunks of instances: no 10 GB temporaries)
+    for lo in range(0, B, 512):
+        blk = P[lo:lo + 512]
+        assert _rel(blk.transpose(1, 2), blk) <= RTOL_TIGHT
+    # every state's limits: rows [+V (64); -V (64)]
+    Gv = G.view(B, nx, 2, N, 384)
+    for lo in range(0, B, 256):
+        assert torch.equal(Gv[lo:lo + 256, :, 0], -Gv[lo:lo + 256, :, 1])
+    # three instances against the oracle (their own systems and weights)
+    dyn, goal = form.dynamics["plant"], form.goals["track s0"]
+    saved, w0 = list(dyn.matrices), goal.weight
+    try:
+        for b in (0, 4097, B - 1):
+            So, Uo = orc.extend_matrices(N, A[b], Bm[b])
+            dyn.matrices = Uo + [So]
+            dyn.update_definitions()
+            goal.update(weight=float(w[b, 0, 0]))
+            Ao, ho, Qo, qo = orc.assemble(form, g0[b].cpu().numpy().reshape(-1, 1))
+            assert_close(P[b].cpu().numpy(), Qo, RTOL), assert_close(q[b].cpu().numpy(), qo.ravel(), RTOL)
+            assert_close(G[b].cpu().numpy(), Ao, RTOL), assert_close(h[b].cpu().numpy(), ho.ravel(), RTOL)
+    finally:
+        dyn.matrices = saved
+        dyn.update_definitions()
+        goal.update(weight=w0)
+    # q, h affine in given: f(g0) + f(g1) = f(g0 + g1) + f(0); P, G do not depend on it
+    Pa = P[::1024].clone()
+    _, q1, _, h1 = (t.clone() for t in asm.assemble(g1))
+    _, qz, _, hz = (t.clone() for t in asm.assemble(torch.zeros_like(g0)))
+    Pb, qs, _, hs = asm.assemble(g0 + g1)
+    assert torch.equal(Pb[::1024], Pa)
+    assert _rel(q0 + q1, qs + qz) <= 1e-12 and _rel(h0 + h1, hs + hz) <= 1e-12
