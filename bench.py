@@ -56,7 +56,8 @@ METRIC = "QP assemblies/sec (P,q,G,h), biped N=16 batched"
 
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="GPUs (= ranks) of this node; default: WORLD_SIZE under a launcher, else 1")
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--settle-ms", type=float, default=40.0,
@@ -78,6 +79,10 @@ def parse_args(argv=None):
                          "default single launch that builds the horizon matrices on chip")
     ap.add_argument("--fused", action="store_true", help="(the default; kept for scripts)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--dist-at-world-1", action="store_true",
+                    help="with ONE rank, still initialise the process group (nccl = RCCL) and run the "
+                         "barriers, the MAX reduction and the gather of the assembled QPs through it: "
+                         "RCCL start-up, stream semantics and the record plumbing on the hardware at hand")
     ap.add_argument("--stub-fail-rank", type=int, default=-1, help="TEST ONLY: this rank exits 3")
     ap.add_argument("--stub-kernels", action="store_true",
                     help="TEST ONLY (tests/test_bench_launcher.py): no GPU, no kernels -- exercises "
@@ -96,40 +101,54 @@ def _free_port():
 
 def launch_ranks(args, argv):
     """Start ``args.gpus`` ranks of this script as child processes (one per GPU) and wait.
-    The parent never initialises the GPU; rank 0's stdout (the JSON line) passes through.
-    Returns the exit code: non-zero if any rank failed (the others are stopped)."""
-    n = args.gpus
-    if not args.stub_kernels:
-        import torch
+    The parent never initialises the GPU -- it counts devices from the kernel driver's topology,
+    not through torch or HIP -- and rank 0's stdout (the JSON line) passes through.  Returns the
+    exit code: non-zero if any rank failed (the others are stopped); the ranks are stopped too
+    when the parent is interrupted or terminated."""
+    import signal
 
-        have = torch.cuda.device_count()        # (counting devices does not initialise HIP)
-        if have < n and args.backend == "nccl":
-            print("bench.py: --gpus %d but only %d HIP device(s) visible" % (n, have),
-                  file=sys.stderr)
+    n = args.gpus
+    if not args.stub_kernels and args.backend == "nccl":
+        from mpcasm.dist import visible_gpus
+
+        have = visible_gpus()
+        if have is not None and have < n:
+            print("bench.py: --gpus %d but only %d GPU(s) visible" % (n, have), file=sys.stderr)
             return 2
     port = _free_port()
     procs = []
-    for rank in range(n):
-        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=None if rank == 0 else subprocess.DEVNULL))
+
+    def stop_all(*_):
+        for proc in procs:
+            if proc.poll() is None:
+                proc.terminate()
+
+    previous = signal.signal(signal.SIGTERM, lambda *a: (stop_all(), sys.exit(143)))
     rc = 0
-    pending = set(range(n))
-    while pending:
-        for r in sorted(pending):
-            code = procs[r].poll()
-            if code is None:
-                continue
-            pending.discard(r)
-            if code != 0 and rc == 0:
-                rc = code if code > 0 else 1
-                print("bench.py: rank %d exited with %d; stopping the others" % (r, code),
-                      file=sys.stderr)
-                for o in pending:
-                    procs[o].terminate()
-        time.sleep(0.05)
+    try:
+        for rank in range(n):
+            env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                       HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                          stdout=None if rank == 0 else subprocess.DEVNULL))
+        pending = set(range(n))
+        while pending:
+            for r in sorted(pending):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    print("bench.py: rank %d exited with %d; stopping the others" % (r, code),
+                          file=sys.stderr)
+                    for o in pending:
+                        procs[o].terminate()
+            time.sleep(0.05)
+    finally:
+        stop_all()
+        signal.signal(signal.SIGTERM, previous)
     return rc
 
 
@@ -192,6 +211,29 @@ def cpu_baseline(work, budget_s=12.0):
     return done / elapsed, done, elapsed
 
 
+def cpu_fill_compiled(budget_s=2.0):
+    """K1 on one host core, compiled: oracle/extend_matrices.c (plain C restatement of
+    tools.extend_matrices, reference twin cpp/src/tools.cc:83-144) on the C2 and C4 shapes."""
+    from oracle import c_oracle
+
+    out = []
+    rng = np.random.default_rng(6)
+    for name, n, m, N, count in (("C2 biped LIPM n=3 m=1 N=16", 3, 1, 16, 4096),
+                                 ("C4 random LTI n=12 m=6 N=64", 12, 6, 64, 16)):
+        A = rng.standard_normal((count, n, n)) / np.sqrt(n) * 0.9
+        B = rng.standard_normal((count, n, m))
+        c_oracle.extend_matrices_batch(A, B, N)
+        done, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < budget_s:
+            c_oracle.extend_matrices_batch(A, B, N)
+            done += count
+        secs = time.perf_counter() - t0
+        out.append({"shape": name, "systems_per_s": done / secs, "cores": 1,
+                    "GBps": fill_bytes(n, m, N, False) * done / secs / 1e9,
+                    "sample": "%d systems in %.1f s" % (done, secs)})
+    return out
+
+
 def _cpu_worker(args):
     """One process of the multi-core baseline: its own formulation (horizon matrices from the
     oracle, this process never touches the GPU), its own slice of the instances."""
@@ -208,11 +250,12 @@ def _cpu_worker(args):
 
 
 def cpu_baseline_all_cores(budget_s=10.0):
-    """The same oracle loop in P processes, P = this box's CPU share (at most 16)."""
+    """The same oracle loop in P processes, P = the cores this process may run on (at most 64:
+    beyond that the pool's start-up outweighs the 10 s sample)."""
     import multiprocessing as mp
 
-    procs = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity")
-                       else (os.cpu_count() or 1)))
+    share = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    procs = max(1, min(64, share))
     with mp.get_context("spawn").Pool(procs) as pool:
         results = pool.map(_cpu_worker, [(1000 + i, budget_s) for i in range(procs)])
     done = sum(r[0] for r in results)
@@ -296,12 +339,14 @@ def run_stub(args, world, rank):
 
     if rank == args.stub_fail_rank:
         sys.exit(3)
-    if world > 1:
+    use_dist = world > 1 or args.dist_at_world_1
+    if use_dist:
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
         dist.init_process_group(args.backend, rank=rank, world_size=world)
     B, no, nc = args.batch, 36, 76
     lo, hi = mdist.shard_bounds(world * B, world, rank)
     P = torch.full((hi - lo, no, no), float(rank), dtype=torch.float64)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -309,8 +354,9 @@ def run_stub(args, world, rank):
     elapsed = time.perf_counter() - t0
     record = {"metric": METRIC, "unit": "assemblies/s", "n_gpus": world, "steps": args.steps,
               "warmup": args.warmup, "stub": True,
+              "n_ranks_seen": dist.get_world_size() if use_dist else 1,
               "config": {"batch_per_gpu": B, "global_batch": B * world}}
-    if world > 1:
+    if use_dist:
         elapsed = mdist.max_over_ranks(elapsed)
         allP = mdist.gather_batch(P, world * B)
         assert allP.shape[0] == world * B
@@ -327,6 +373,8 @@ def run_rank(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus is None:
+        args.gpus = world                   # (under a launcher: the ranks it started)
     if args.gpus != world:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE %d" % (args.gpus, world))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -343,9 +391,10 @@ def run_rank(args):
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.dist_at_world_1:
         import torch.distributed as dist
 
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
         dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     B = args.batch
@@ -478,17 +527,32 @@ def run_rank(args):
             traffic = pmc["traffic_bytes_per_launch"]
     except (OSError, ValueError, KeyError):
         pass
-    kernel_name = "mpcasm_assemble -> resident_spec_kernel: the persistent kernel (%sK2 compose + K3 " \
-                  "hessian_mfma + K4 constraint_stack in one launch) compiled for this plan by hiprtc; " \
-                  "resident_assemble_kernel (ahead of time) when libhiprtc.so is missing" \
-                  % ("K1 horizon tables + " if fused else "")
+    # (which kernel really ran: the per-plan compiled one falls back to the ahead-of-time kernel
+    # when libhiprtc.so is missing or the compilation fails)
+    kernel_name = "mpcasm_assemble -> %s: %sK2 compose + K3 hessian_mfma + K4 constraint_stack in one " \
+                  "launch" % (asm.last_kernel(), "K1 horizon tables + " if fused else "")
+    ranks_seen = dist.get_world_size() if dist is not None else 1
+    devices = [torch.cuda.get_device_name(local_rank)]
+    if dist is not None:
+        names = [None] * ranks_seen
+        dist.all_gather_object(names, "rank %d: %s (cuda:%d)" % (rank, devices[0], local_rank))
+        devices = names
+    timed_ms = elapsed * 1e3
+    if timed_ms < 5.0 and rank == 0:
+        print("bench.py: the timed region is only %.2f ms (%d steps): a few launches of jitter move "
+              "`value` by several per cent -- use --steps %d or more for a steady number"
+              % (timed_ms, args.steps, int(np.ceil(50.0 / max(timed_ms / args.steps, 1e-6)))),
+              file=sys.stderr)
     record = {
         "metric": METRIC,
         "value": value,
         "unit": "assemblies/s",
         "n_gpus": world,
+        "n_ranks_seen": ranks_seen,
+        "devices": devices,
         "steps": args.steps,
         "warmup": args.warmup,
+        "timed_region_ms": timed_ms,
         "settle": {"ms": args.settle_ms, "untimed_steps_before_warmup": settle_steps},
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
@@ -515,6 +579,9 @@ def run_rank(args):
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS,
             "traffic": traffic,
+            "traffic_source": "profiles/pmc_traffic.json (static: rocprofv3 --pmc passes of this command "
+                              "at this batch, committed with the round's profiles; null at any other "
+                              "batch) -- not measured in this run",
             "algorithmic_bytes_per_launch": bytes_asm * B,
             "algorithmic_bytes_per_assembly": bytes_asm,
             "avg_launch_ms": asm_ms,
@@ -552,7 +619,7 @@ def run_rank(args):
                 gather()
             sync_all()
             g_ms = mdist.max_over_ranks((time.perf_counter() - t0) / reps * 1e3, device=dev)
-            recv = bytes_out * B * (world - 1)
+            recv = bytes_out * B * max(world - 1, 1)   # (one rank: its own slice, device to device)
             record["gather"] = {
                 "what": "all-gather of P,q,G,h of every rank onto every rank (mpcasm.dist.gather_batch), "
                         "after the assembly; not part of `value`",
@@ -593,12 +660,17 @@ def run_rank(args):
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         rate1, count1, secs1 = cpu_baseline(work, 6.0)
         rate, count, procs = cpu_baseline_all_cores(10.0)
+        try:
+            compiled = cpu_fill_compiled()
+        except (OSError, RuntimeError) as exc:       # (oracle/liboracle.so not built)
+            compiled = "unavailable: %s" % exc
         record["cpu_baseline"] = {
             "value": rate,
             "unit": "assemblies/s",
             "cores": procs,
             "kind": "port",
             "single_core_value": rate1,
+            "compiled_fill_single_thread": compiled,
             "sample": "%d assemblies of the same workload in 10 s on %d processes (one formulation "
                       "each): oracle/qp_oracle.py (extend_matrices + preview matrices + all QP "
                       "blocks per instance; the per-tick update() callback of the reference's "
@@ -615,8 +687,11 @@ def run_rank(args):
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     args = parse_args(argv)
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(launch_ranks(args, argv))
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus is None:
+            args.gpus = 1
+        if args.gpus > 1:
+            sys.exit(launch_ranks(args, argv))
     run_rank(args)
 
 

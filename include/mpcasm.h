@@ -177,6 +177,14 @@ int mpcasm_assemble(const mpcasm_plan* plan, const double* const* h_src,
                     const double* d_given, double* d_P, double* d_q, double* d_G,
                     double* d_h, void* d_work, int batch, void* stream);
 
+/* Which kernels the latest successful mpcasm_assemble on this plan launched (a record for
+ * benchmarks and tests; 0 before the first launch): the persistent kernel ahead of time / compiled
+ * for the plan, the per-instance fused kernel, the staged K2 -> K3 -> K4 pipeline, the tiled
+ * kernel for wide problems. */
+enum { MPCASM_KERNEL_NONE = 0, MPCASM_KERNEL_RESIDENT = 1, MPCASM_KERNEL_RESIDENT_JIT = 2,
+       MPCASM_KERNEL_FUSED = 3, MPCASM_KERNEL_STAGED = 4, MPCASM_KERNEL_TILED = 5 };
+int mpcasm_plan_last_kernel(const mpcasm_plan* plan);
+
 /* K2 alone  preview matrices ------------------------------------------------
  * Replaces Formulation.make_preview_matrices   body.py:149-193
  * d_PM [batch][preview_rows][ng+no]: for every definition, in definition

@@ -32,6 +32,7 @@ struct mpcasm_plan {
   // mpcasm_plan_set_option: this plan's own choice of path / per-plan compilation / workgroups
   // per CU (-1: the process-wide value of mpcasm_set_option)
   int opt_path = -1, opt_jit = -1, opt_per_cu = -1;
+  mutable int last_kernel = 0;  // mpcasm_plan_last_kernel: what the latest mpcasm_assemble launched
 };
 
 namespace {
@@ -927,8 +928,11 @@ int mpcasm_assemble(const mpcasm_plan* plan, const double* const* h_src,
                        plan->num_cus, static_cast<hipStream_t>(stream), &err, plan->h_itab.data(),
                        plan->device);
   if (rc == MPCASM_ERR_HIP) g_last_hip = (int)err;
+  if (rc == MPCASM_OK) plan->last_kernel = t_last_kernel;
   return rc;
 }
+
+int mpcasm_plan_last_kernel(const mpcasm_plan* plan) { return plan ? plan->last_kernel : MPCASM_ERR_ARG; }
 
 int mpcasm_preview_matrices(const mpcasm_plan* plan, const double* const* h_src,
                             const int64_t* h_src_stride, double* d_PM, int batch, void* stream) {
@@ -1044,6 +1048,7 @@ int g_path = 0;  // test hook (MPCASM_OPT_PATH): 0 best, 1 no resident kernel, 2
 int g_resident_per_cu = 0;  // tuning aid (MPCASM_OPT_RESIDENT_PER_CU): 0 = automatic
 // the values in force for the launch this thread is making (mpcasm_assemble sets them)
 thread_local int t_path = 0, t_jit = 0, t_per_cu = 0;
+thread_local int t_last_kernel = 0;
 
 // dispatch: fused single launch when the problem fits on chip, else staged
 int launch_assemble(const PlanDev& plan, const SrcTable& src, const double* params,
@@ -1061,21 +1066,29 @@ int launch_assemble(const PlanDev& plan, const SrcTable& src, const double* para
       resident_inputs_aligned(p, src, params, given)) {
     // large batches: the same kernel compiled for this very plan (jit.hip), when available
     if (h_itab != nullptr)
-      if (const void* k = jit_kernel_for(p, h_itab, device, batch, rs))
+      if (const void* k = jit_kernel_for(p, h_itab, device, batch, rs)) {
+        t_last_kernel = MPCASM_KERNEL_RESIDENT_JIT;
         return jit_launch(k, p, src, params, given, P, q, G, h, batch, num_cus, t_per_cu,
                           work, stream, err);
+      }
+    t_last_kernel = MPCASM_KERNEL_RESIDENT;
     return launch_assemble_resident(p, src, params, given, P, q, G, h, work, batch, rs, num_cus,
                                     stream, err);
   }
   // wide problems: one workgroup per block of P, rows composed straight into the LDS tiles
-  if (tiled_eligible(p) && t_path != 2 && p.csc_pnnz == 0 && p.csc_gnnz == 0)
+  if (tiled_eligible(p) && t_path != 2 && p.csc_pnnz == 0 && p.csc_gnnz == 0) {
+    t_last_kernel = MPCASM_KERNEL_TILED;
     return launch_assemble_tiled(p, src, params, given, P, q, G, h, work, batch, stream, err, h_itab);
+  }
   // elsewhere, horizon matrices generated from (A, B) and the CSC form of the results exist in the
   // persistent kernel only
   if (p.rs_nlti != 0 || p.csc_pnnz != 0 || p.csc_gnnz != 0) return MPCASM_ERR_LIMIT;
   const size_t lds = fused_lds_bytes(p, 4);
-  if (lds != 0 && lds <= FUSED_LDS_LIMIT && t_path <= 1)
+  if (lds != 0 && lds <= FUSED_LDS_LIMIT && t_path <= 1) {
+    t_last_kernel = MPCASM_KERNEL_FUSED;
     return launch_assemble_fused(p, src, params, given, P, q, G, h, batch, lds, stream, err);
+  }
+  t_last_kernel = MPCASM_KERNEL_STAGED;
   return launch_assemble_staged(p, src, params, given, P, q, G, h, work, batch, stream, err);
 }
 

@@ -7,6 +7,8 @@ become per-instance device parameters of the batched assembly
 """
 import numpy as np
 
+from ._fields import per_axis_matrices
+
 
 class Cost:
     """Bring ``V = L @ v[schedule]`` towards ``aim`` with some ``weight``.
@@ -48,49 +50,34 @@ class Cost:
 
     def arrange_L(self, L):
         """One matrix per axis; needs an up-to-date schedule (goal.py:88-104)."""
-        per_axis = L if isinstance(L, list) else [L]
-        if len(per_axis) == 1:
-            per_axis = per_axis * self.axes_len
-        elif len(per_axis) not in (self.axes_len, 0):
-            raise IndexError(
-                "'L' must have 0, 1 or len(axes) = {} elements".format(self.axes_len)
-            )
-        if self.schedule and np.any([l.shape[-1] != self.t for l in per_axis]):
-            raise ValueError(
-                "arrays in L must have {} columns, which is given by the "
-                "'schedule'.".format(self.t)
-            )
-        return per_axis
+        matrices, problem = per_axis_matrices(L, self.axes_len, self.t if self.schedule else None)
+        if problem is not None:
+            raise problem
+        return matrices
 
     def update(self, aim=None, weight=None, L=None, schedule=None,
                cross_aim=None, cross_L=None):
-        """goal.py:106-136 (same ordering: schedule, L, cross_L, aim, weight,
-        cross_aim)."""
+        """Replace any of the fields (goal.py:106-136).  The schedule goes first (the L's are
+        checked against it); then, in the reference's order, every given field is stored --
+        a plain cost keeps its ``cross_*`` twin pointing at the same object, and refuses a
+        ``cross_*`` of its own."""
         if schedule is not None:
             self.schedule = schedule
-
-        if L is not None:
-            self.L = self.arrange_L(L)
-            if not self.crossed:
-                self.cross_L = self.L
-
-        if cross_L is not None:
-            if not self.crossed:
+        # field, new value, how it is stored, the twin a plain cost mirrors it into
+        steps = (("L", L, self.arrange_L, "cross_L"),
+                 ("cross_L", cross_L, self.arrange_L, None),
+                 ("aim", aim, self._as_rows, "cross_aim"),
+                 ("weight", weight, None, None),
+                 ("cross_aim", cross_aim, None, None))
+        for field, value, store, twin in steps:
+            if value is None:
+                continue
+            if field.startswith("cross_") and not self.crossed:
                 raise KeyError("Trying to set cross_aim in a non-crossed cost")
-            self.cross_L = self.arrange_L(cross_L)
-
-        if aim is not None:
-            self.aim = np.array(aim).reshape([-1, self.axes_len])
-            if not self.crossed:
-                self.cross_aim = self.aim
-
-        if weight is not None:
-            self.weight = weight
-
-        if cross_aim is not None:
-            if not self.crossed:
-                raise KeyError("Trying to set cross_aim in a non-crossed cost")
-            self.cross_aim = cross_aim
+            kept = store(value) if store else value
+            setattr(self, field, kept)
+            if twin and not self.crossed:
+                setattr(self, twin, kept)
 
     @property
     def t(self):

@@ -8,6 +8,8 @@ polytope with Qhull at set-up time (kept on the host so that the facet order
 stays the reference's, SURVEY.md section 8a quirk vii).
 """
 import numpy as np
+
+from ._fields import as_rows, per_axis_matrices
 import scipy.spatial as sp
 
 from . import tools as use
@@ -42,19 +44,11 @@ class Constraint:
 
     # ---- structure -------------------------------------------------------
     def arrange_L(self, L):
-        """One matrix per axis; needs an up-to-date schedule (restrictions.py:75-90)."""
-        self.L = L if isinstance(L, list) else [L]
-        if len(self.L) == 1:
-            self.L = self.L * self.axes_len
-        elif len(self.L) not in (self.axes_len, 0):
-            raise IndexError(
-                "'L' must have 0, 1 or len(axes) = {} elements".format(self.axes_len)
-            )
-        if self.schedule and np.any([l.shape[-1] != self.t for l in self.L]):
-            raise ValueError(
-                "arrays in L must have {} columns, which is given by the "
-                "'schedule'.".format(self.t)
-            )
+        """One matrix per axis; needs an up-to-date schedule (restrictions.py:75-90).  As in
+        the reference the new list is stored before it is found wanting."""
+        self.L, problem = per_axis_matrices(L, self.axes_len, self.t if self.schedule else None)
+        if problem is not None:
+            raise problem
 
     @property
     def m(self):
@@ -156,24 +150,23 @@ class Constraint:
         return self.extreme + (self.arrow * self.center).sum(axis=1).reshape([-1, 1])
 
     def update(self, extreme=None, arrow=None, center=None, L=None, schedule=None):
-        """restrictions.py:201-219."""
+        """Replace any of the fields (restrictions.py:201-219): schedule first (L is checked
+        against it), then the numbers; new geometry is checked, and normalised when a sign may
+        have changed (new ``extreme`` or ``arrow``)."""
         if schedule is not None:
             self.schedule = schedule
         if L is not None:
             self.arrange_L(L)
-
-        if extreme is not None:
-            self.extreme = np.array(extreme).reshape([-1, 1])
-        if arrow is not None:
-            self.arrow = np.array(arrow).reshape([-1, self.axes_len])
-        if center is not None:
-            self.center = np.array(center).reshape([-1, self.axes_len])
-
-        if extreme is not None or arrow is not None:
+        numbers = {"extreme": (extreme, 1), "arrow": (arrow, self.axes_len),
+                   "center": (center, self.axes_len)}
+        changed = [name for name, (value, _) in numbers.items() if value is not None]
+        for name in changed:
+            value, columns = numbers[name]
+            setattr(self, name, as_rows(value, columns))
+        if changed:
             self.check_geometry()
-            self.normalize()
-        elif center is not None:
-            self.check_geometry()
+            if "extreme" in changed or "arrow" in changed:
+                self.normalize()
 
     # ---- feasibility checks (restrictions.py:221-257) ----------------------
     def is_feasible(self, points, space="SS"):

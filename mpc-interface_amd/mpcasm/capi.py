@@ -16,7 +16,7 @@ OPT_PATH = 1
 OPT_PHASE_MASK = 2
 OPT_RESIDENT_PER_CU = 3
 OPT_P_DIRECT = 5     # the persistent kernel writes P 1: straight to HBM, 2: through LDS when it fits, 0: by the launch's size (read at plan creation)
-OPT_JIT = 4            # 0: specialise the persistent kernel for batches >= 1024, 1: always, 2: never
+OPT_JIT = 4            # 0: specialise the persistent kernel for batches >= 512, 1: always, 2: never
 PHASE_DEFAULT = 0xBF   # every phase on, cycle stamps (bit 6) off
 PHASE_STAMPS = 0x40
 STATUS = {
@@ -48,6 +48,7 @@ SIGNATURES = {
     "mpcasm_plan_sizes": (ctypes.c_int, [_void_p, ctypes.POINTER(ctypes.c_int64)]),
     "mpcasm_plan_csc_sizes": (ctypes.c_int, [_void_p, ctypes.POINTER(ctypes.c_int64)]),
     "mpcasm_plan_set_option": (ctypes.c_int, [_void_p, ctypes.c_int, ctypes.c_int]),
+    "mpcasm_plan_last_kernel": (ctypes.c_int, [_void_p]),
     "mpcasm_workspace_bytes": (ctypes.c_int, [_void_p, ctypes.c_int,
                                               ctypes.POINTER(ctypes.c_size_t)]),
     "mpcasm_assemble": (ctypes.c_int, [_void_p, ctypes.POINTER(_void_p),
@@ -73,6 +74,10 @@ SIGNATURES = {
                                                ctypes.c_int, ctypes.c_int, _void_p, ctypes.c_int,
                                                ctypes.c_int, _void_p, ctypes.c_int64, _void_p]),
 }
+KERNEL_NAMES = {0: "none", 1: "resident_assemble_kernel (persistent, ahead of time)",
+                2: "resident_spec_kernel (persistent, compiled for the plan by hiprtc)",
+                3: "fused_assemble_kernel", 4: "staged pipeline (compose_rowsets / hessian / constraints)",
+                5: "tiled_assemble_kernel"}
 BOX_RECENTER, BOX_TRANSLATE, BOX_ROTATE, BOX_SCALE, BOX_MARGIN = range(5)
 
 

@@ -28,23 +28,33 @@ def local_shard(array, world_size, rank):
 def gather_batch(local, batch, group=None):
     """All-gather per-instance tensors sharded by :func:`shard_bounds` back into
     batch order on every rank.  ``local``: tensor ``(hi - lo, ...)``; returns
-    ``(batch, ...)``.  Ragged shards are padded to the largest shard for the
-    collective and trimmed afterwards."""
+    ``(batch, ...)``.
+
+    Equal shards (the usual case: the batch is a multiple of the world size) go straight into
+    the result with ONE ``all_gather_into_tensor`` -- every rank's slice lands at its final
+    place, no staging copy, no concatenation.  Ragged shards are padded to the largest one
+    for the collective and trimmed afterwards."""
     import torch
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
     sizes = [b - a for a, b in (shard_bounds(batch, world, r) for r in range(world))]
     longest = max(sizes)
+    on_host = local.is_cuda and dist.get_backend(group) == "gloo"
+    if min(sizes) == longest and not on_host:
+        local = local.contiguous()
+        out = torch.empty((batch,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, local, group=group)
+        return out
     padded = local
     if local.shape[0] < longest:
         pad = torch.zeros((longest - local.shape[0],) + tuple(local.shape[1:]),
                           dtype=local.dtype, device=local.device)
         padded = torch.cat([local, pad])
     padded = padded.contiguous()
-    if padded.is_cuda and dist.get_backend(group) == "gloo":
+    if on_host:
         # gloo has no all-gather of device tensors: stage through the host (rehearsals of the
-        # multi-rank path on a box whose ranks share one GPU; RCCL takes the branch below)
+        # multi-rank path on a box whose ranks share one GPU; RCCL takes the branches above / below)
         host = padded.cpu()
         parts = [torch.empty_like(host) for _ in range(world)]
         dist.all_gather(parts, host, group=group)
@@ -52,6 +62,33 @@ def gather_batch(local, batch, group=None):
     parts = [torch.empty_like(padded) for _ in range(world)]
     dist.all_gather(parts, padded, group=group)
     return torch.cat([p[:n] for p, n in zip(parts, sizes)])
+
+
+def visible_gpus():
+    """Number of GPUs this process could use, WITHOUT touching the HIP runtime (a parent that
+    starts one rank per GPU must not initialise the device it hands out): the compute nodes of
+    the kernel driver's topology, narrowed by ``HIP_VISIBLE_DEVICES`` / ``ROCR_VISIBLE_DEVICES``
+    when set.  ``None`` when the topology cannot be read (let the ranks find out)."""
+    import glob
+    import os
+
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        value = os.environ.get(var)
+        if value is not None:
+            return len([x for x in value.split(",") if x.strip() != ""])
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not nodes:
+        return None
+    count = 0
+    for path in nodes:
+        try:
+            with open(path) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+        except OSError:
+            return None
+        if int(props.get("simd_count", "0")) > 0:      # (CPU nodes have none)
+            count += 1
+    return count
 
 
 def max_over_ranks(value, device=None, group=None):

@@ -331,6 +331,10 @@ class Assembler:
         capi.check(rc, "mpcasm_assemble")
         return P, q, G, h
 
+    def last_kernel(self):
+        """Name of the kernel(s) the latest :meth:`assemble` launched (``mpcasm_plan_last_kernel``)."""
+        return capi.KERNEL_NAMES.get(capi.load().mpcasm_plan_last_kernel(self._handle), "?")
+
     # ---- sparse hand-off (f3) ------------------------------------------------------
     def csc_pattern(self, which, upper=False):
         """``(indptr, indices)`` (numpy int32) of the batch-wide CSC pattern of ``"P"`` or

@@ -180,18 +180,55 @@ def g2_body():
 # --------------------------------------------------------------------------
 # G3  biped walking ticks (both QP widths), N=16 and N=24
 # --------------------------------------------------------------------------
+EXAMPLE = "/root/reference/python/use_examples/simple_functional_example"
+
+
+def reference_example(step_samples):
+    """The reference's OWN example formulation, ``formulate_biped(conf)`` of
+    use_examples/simple_functional_example/biped_formulation.py:23-191, on its
+    biped_configuration with ``step_samples`` overridden (8: N = 16, BASELINE configs C1 / C2;
+    12: the example as shipped, N = 24).  Imported read-only, never written into a fixture."""
+    import types
+
+    if EXAMPLE not in sys.path:
+        sys.path.insert(3, EXAMPLE)
+    import biped_configuration
+    import biped_formulation
+
+    conf = types.SimpleNamespace(**{k: v for k, v in vars(biped_configuration).items()
+                                    if not k.startswith("_")})
+    conf.step_samples = step_samples
+    conf.horizon_lenght = conf.num_steps * step_samples
+    return biped_formulation.formulate_biped(conf), conf
+
+
+def same_problem(form, ref_form, given, where):
+    """``problems.biped`` builds the very problem of the reference's example: identical index
+    maps and (A, h, Q, q), bit for bit."""
+    assert list(form.optim_ID.items()) == list(ref_form.optim_ID.items()), where
+    assert list(form.given_ID.items()) == list(ref_form.given_ID.items()), where
+    mine = form.generate_all_qp_matrices(given)
+    theirs = ref_form.generate_all_qp_matrices(given)
+    for a, b, name in zip(mine, theirs, "AhQq"):
+        assert a.shape == b.shape and np.array_equal(a, b), (where, name)
+
+
 def g3_biped():
     for step_samples, keep in ((8, (0, 1, 6, 7, 8, 9, 15, 17)), (12, (0, 10, 11, 12, 17))):
         out = {}
         conf = problems.BipedConfig(step_samples=step_samples)
         form = problems.biped(api, conf)
+        ref_form, ref_conf = reference_example(step_samples)
+        assert ref_conf.horizon_lenght == conf.horizon_lenght
         clock = problems.StepClock(conf.step_samples, form.domain["Ds_x"])
         rng = np.random.default_rng(20260 + step_samples)
         shapes = []
         for tick in range(18):
             form.update(step_times=clock.step_times, step_count=clock.step_count)
+            ref_form.update(step_times=clock.step_times, step_count=clock.step_count)
             collector = problems.biped_given_collector(form, rng, bias_sigma=0.01)
             given = form.arrange_given(collector)
+            same_problem(form, ref_form, given, "biped N=%d tick %d" % (conf.horizon_lenght, tick))
             if tick in keep:
                 p = "tick%02d/" % tick
                 out[p + "step_times"] = clock.step_times.copy()
