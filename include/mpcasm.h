@@ -53,8 +53,10 @@ const char* mpcasm_status_string(int status);
 /* Process-wide options.  MPCASM_OPT_PATH selects the assembly kernels: 0 = best
  * available (persistent fused kernel when one instance fits on chip), 1 = never
  * the persistent kernel (per-instance fused kernel if it fits), 2 = always the
- * staged K2 -> K3 -> K4 pipeline with the workspace in HBM.  The parity tests use
- * it to exercise every path; all paths give the same results. */
+ * staged K2 -> K3 -> K4 pipeline with the workspace in HBM, 3 = as 1, and a wide problem whose
+ * rows are windows of generated horizon tables still composes its tiles (the tiled kernel's
+ * general form instead of its Toeplitz form).  The parity tests use it to exercise every path;
+ * all paths give the same results. */
 enum { MPCASM_OPT_PATH = 1, MPCASM_OPT_PHASE_MASK = 2, MPCASM_OPT_RESIDENT_PER_CU = 3, MPCASM_OPT_JIT = 4,
        MPCASM_OPT_P_DIRECT = 5 };
 /* MPCASM_OPT_PHASE_MASK is a profiling aid (timing-only ablation of the fused

@@ -134,6 +134,14 @@ int validate_tiled(const int32_t* it, const double* h_dtab, int64_t n, int64_t n
       !in_range(it[H_OFF_RS_RR], nc * RS_RR_WORDS, n, H_WORDS) ||
       !in_range(it[H_OFF_ROWPTR], rtot + 1, n, H_WORDS))
     return MPCASM_ERR_PLAN;
+  {  // the per-column table of the diagonal gterms (read when no column has more than RS_DIAG_MAX)
+    if (!in_range(it[H_OFF_RS_DPAR], no * 2 * RS_DIAG_MAX, n, H_WORDS) || it[H_OFF_RS_DPAR] % 4 ||
+        !in_range(it[H_DOFF_RS_DCOEF], no * RS_DIAG_MAX, nd, 0) || it[H_DOFF_RS_DCOEF] % 2)
+      return MPCASM_ERR_PLAN;
+    const int32_t* dp = it + it[H_OFF_RS_DPAR];
+    for (int64_t i = 0; i < no * 2 * RS_DIAG_MAX; ++i)
+      if (dp[i] < 0 || dp[i] > it[H_NPARAMS]) return MPCASM_ERR_PLAN;
+  }
   const int64_t ngrest = it[H_T_NGREST];
   if (!in_range(it[H_OFF_T_SROW], nstage * 2 * 16, n, H_WORDS) ||
       !in_range(it[H_T_DOFF_SCOEF], nstage * 2 * 16, nd, 0) ||
@@ -187,7 +195,7 @@ int validate_tiled(const int32_t* it, const double* h_dtab, int64_t n, int64_t n
           return MPCASM_ERR_PLAN;
         g_written[R] = 1;
       }
-    if (rows < 1 || rows > 16 || (fl & ~63) || x[TS_AROW] < 0 ||
+    if (rows < 1 || rows > 16 || (fl & ~127) || x[TS_AROW] < 0 ||
         x[TS_AROW] + rows > rtot || x[TS_BROW] < 0 || x[TS_BROW] + rows > rtot || x[TS_DROW] < 0 ||
         x[TS_DROW] + rows > rtot || x[TS_WPARAM] < 0 || x[TS_WPARAM] >= it[H_NPARAMS] ||
         x[TS_AIMPARAM] < 0 || x[TS_AIMPARAM] >= it[H_NPARAMS] ||
@@ -203,6 +211,59 @@ int validate_tiled(const int32_t* it, const double* h_dtab, int64_t n, int64_t n
         if (rowptr[r + 1] - rowptr[r] != 1 || rowptr[r] < 0 || rowptr[r] >= it[H_NENT] ||
             entbase[rowptr[r]] != base)
           return MPCASM_ERR_PLAN;
+    }
+  }
+  // Toeplitz form: all stages or none; one generated group; every stage's rows are consecutive
+  // rows of one of its states with one coefficient, and -- what lets the kernel keep ONE set of
+  // per-lane column offsets -- a column's table offset less the state's own part is the same for
+  // every state, inside the group's TB table together with the window
+  if (it[H_T_TOEPLITZ] & ~1) return MPCASM_ERR_PLAN;
+  {
+    int64_t ntoep = 0;
+    for (int64_t sx = 0; sx < nstage; ++sx)
+      ntoep += ((it + it[H_OFF_T_STAGE] + sx * T_STAGE_WORDS)[TS_INFO] >> 8) & TS_FLAG_TOEPLITZ ? 1 : 0;
+    if (it[H_T_TOEPLITZ] ? (ntoep != nstage || nstage == 0 || nlti != 1) : false) return MPCASM_ERR_PLAN;
+  }
+  if (it[H_T_TOEPLITZ]) {
+    const int32_t* g = it + it[H_OFF_T_LTI];
+    const int64_t gn = g[TL_N], gm = g[TL_M], gN = g[TL_HORIZON], tbn = gn * gm * 2 * gN;
+    const int32_t* ids = it + it[H_OFF_T_LTI_IDS] + g[TL_IDS];
+    const double* sc = h_dtab + it[H_T_DOFF_SCOEF];
+    const int32_t* cio = it + it[H_OFF_T_CIO];
+    const int32_t* x0 = it + it[H_OFF_T_STAGE];
+    const int64_t base0 = x0[TS_BASE] & 0xFFFF, sb0 = x0[TS_SBOFFA];
+    if (base0 >= nbase) return MPCASM_ERR_PLAN;
+    auto is_u = [&](int64_t sid) {
+      for (int64_t j = 0; j < gm; ++j)
+        if (ids[j] == sid) return true;
+      return false;
+    };
+    for (int64_t sx = 0; sx < nstage; ++sx) {
+      const int32_t* x = it + it[H_OFF_T_STAGE] + sx * T_STAGE_WORDS;
+      const int rows = x[TS_INFO] & 255, fl = (x[TS_INFO] >> 8) & 255;
+      for (int side = 0; side < ((fl & TS_FLAG_P) ? 2 : 1); ++side) {
+        if (!(fl & (side ? TS_FLAG_SIMPLE_B : TS_FLAG_SIMPLE_A))) return MPCASM_ERR_PLAN;
+        const int64_t base = side ? (int64_t)((uint32_t)x[TS_BASE] >> 16) : (x[TS_BASE] & 0xFFFF);
+        const int64_t sb = x[side ? TS_SBOFFB : TS_SBOFFA], U = x[side ? TS_UB : TS_UA];
+        const int32_t* ks = srow + (sx * 2 + side) * 16;
+        if (base >= nbase || sb < 0 || sb % (gm * 2 * gN) || sb / (gm * 2 * gN) >= gn || U != sb + ks[0])
+          return MPCASM_ERR_PLAN;
+        for (int i = 0; i < rows; ++i)
+          if (ks[i] != ks[0] + i || sc[(sx * 2 + side) * 16 + i] != sc[(sx * 2 + side) * 16])
+            return MPCASM_ERR_PLAN;
+        for (int64_t c = 0; c < nop; ++c) {
+          const int32_t* e = cio + (base * nop + c) * 2;
+          const int32_t* e0 = cio + (base0 * nop + c) * 2;
+          const int64_t sid = (uint32_t)e[1] >> 24, sid0 = (uint32_t)e0[1] >> 24;
+          const bool valid = sid != T_SID_CONST;
+          if (valid != (sid0 != T_SID_CONST)) return MPCASM_ERR_PLAN;
+          if (!valid) continue;
+          const int64_t part = (int64_t)(uint32_t)e[0] - sb;
+          if (!is_u(sid) || ((e[1] << 8) >> 8) != 1 || part != (int64_t)(uint32_t)e0[0] - sb0 ||
+              part + U < 0 || part + U + 15 + 3 >= tbn + 16)
+            return MPCASM_ERR_PLAN;
+        }
+      }
     }
   }
   {  // every row of G is written exactly once: riding on a stage or listed in the rest
@@ -667,7 +728,7 @@ void plan_dev_from_tables(const int32_t* it, PlanDev* out) {
   d.off_t_lti = it[H_OFF_T_LTI]; d.off_t_lti_ids = it[H_OFF_T_LTI_IDS]; d.t_work = it[H_T_WORK];
   d.off_t_grow = it[H_OFF_T_GROW];
   d.off_t_srow = it[H_OFF_T_SROW]; d.t_doff_scoef = it[H_T_DOFF_SCOEF]; d.off_t_pig = it[H_OFF_T_PIG];
-  d.t_ngrest = it[H_T_NGREST]; d.off_t_grest = it[H_OFF_T_GREST]; d.off_t_brow0 = it[H_OFF_T_BROW0];
+  d.t_ngrest = it[H_T_NGREST]; d.off_t_grest = it[H_OFF_T_GREST]; d.off_t_brow0 = it[H_OFF_T_BROW0]; d.t_toeplitz = it[H_T_TOEPLITZ];
   d.t_nbrow = d.t_ci_ok ? it[d.off_t_brow0 + d.nbase] : 0;
   d.pm_nfd = it[H_PM_NFD]; d.off_pm_map = it[H_OFF_PM_MAP]; d.off_pm_fdptr = it[H_OFF_PM_FDPTR];
   d.off_pm_op = it[H_OFF_PM_OP]; d.doff_pm_pool = it[H_DOFF_PM_POOL];
@@ -684,6 +745,19 @@ void plan_dev_from_tables(const int32_t* it, PlanDev* out) {
     const int32_t* r = it + it[H_OFF_GTERM] + g * GT_WORDS;
     if (r[GT_FLAGS] & GT_FLAG_DIAG) ++d.ndiag;
     if ((r[GT_FLAGS] & GT_FLAG_P) && r[GT_AOFF] != r[GT_BOFF]) d.rs_sym_any = 0;
+  }
+  // the per-column table of the diagonal gterms holds them all when no column carries more than
+  // RS_DIAG_MAX (its sections are laid out for every plan)
+  d.rs_diag_table = 1;
+  {
+    std::vector<int> on(std::max(d.no, 1), 0);
+    for (int g = 0; g < it[H_NGTERM]; ++g) {
+      const int32_t* r = it + it[H_OFF_GTERM] + g * GT_WORDS;
+      if (!(r[GT_FLAGS] & GT_FLAG_DIAG)) continue;
+      for (int k = 0; k < r[GT_NROWS]; ++k)
+        if (++on[r[GT_AOFF] + k] > RS_DIAG_MAX) d.rs_diag_table = 0;
+    }
+    if (it[H_OFF_RS_DPAR] % 4 || it[H_DOFF_RS_DCOEF] % 2) d.rs_diag_table = 0;
   }
   d.max_axes = 0;
   for (int l = 0; l < it[H_NLIMIT]; ++l) {
@@ -713,7 +787,7 @@ int mpcasm_last_hip(void) { return g_last_hip; }
 
 int mpcasm_set_option(int option, int value) {
   if (option == MPCASM_OPT_PATH) {
-    if (value < 0 || value > 2) return MPCASM_ERR_ARG;
+    if (value < 0 || value > 3) return MPCASM_ERR_ARG;
     g_path = value;
     return MPCASM_OK;
   }
@@ -741,7 +815,7 @@ int mpcasm_set_option(int option, int value) {
 
 int mpcasm_plan_set_option(mpcasm_plan* plan, int option, int value) {
   if (!plan) return MPCASM_ERR_ARG;
-  if (option == MPCASM_OPT_PATH && value >= -1 && value <= 2) plan->opt_path = value;
+  if (option == MPCASM_OPT_PATH && value >= -1 && value <= 3) plan->opt_path = value;
   else if (option == MPCASM_OPT_JIT && value >= -1 && value <= 2) plan->opt_jit = value;
   else if (option == MPCASM_OPT_RESIDENT_PER_CU && value >= -1 && value <= 16) plan->opt_per_cu = value;
   else return MPCASM_ERR_ARG;

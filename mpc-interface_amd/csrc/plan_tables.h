@@ -181,9 +181,11 @@ enum HeaderWord : int {
   H_T_NGREST,       // rows of G that ride on no stage (several axes, rows no cost reads ...)
   H_OFF_T_GREST,    // [T_NGREST] their indices, ascending
   H_OFF_T_BROW0,    // [NBASE + 1] first row of every base variable among all base rows; [NBASE] = total
+  H_T_TOEPLITZ,     // 1: every stage is TS_FLAG_TOEPLITZ (one generated group): the kernel keeps the
+                    //    group's TB table in LDS and reads the matrix core's operands out of it
   H_WORDS = 112
 };
-static_assert(H_OFF_T_BROW0 < H_WORDS, "plan header");
+static_assert(H_T_TOEPLITZ < H_WORDS, "plan header");
 
 constexpr int T_BLOCK = 128;       // columns of a block of P (tiled kernel)
 constexpr int T_SID_CONST = 32;    // the stream that is the plan's own dtab
@@ -195,10 +197,17 @@ constexpr int T_SID_CONST = 32;    // the stream that is the plan's own dtab
 // non-zero, so a wavefront multiplies the first n x n tiles of its 64 x 64 quadrant.  TS_BASE =
 // base of the A rows | base of the B rows << 16 when every row of the stage is ONE entry of one
 // base (TS_FLAG_SIMPLE_*).  TS_FLAG_G: some A row carries rows of G (H_OFF_T_PIG).
+// TS_FLAG_TOEPLITZ (every stage of a plan, or none: H_T_TOEPLITZ): the A rows (and the B rows of a
+// Hessian stage) are rows k0 .. k0 + rows - 1 of ONE state of the plan's single generated group
+// with one coefficient (H_T_DOFF_SCOEF[stage][side][0]); TS_UA / TS_UB = (state * m) * 2N + k0:
+// with the group's TB table (TL_*) in LDS, row r of the stage reads, in a column whose table entry is
+// (offset, rs = 1) of one of the group's U_j, the element TB[offset - state * m * 2N + TS_U + r] --
+// a window of a Toeplitz table, no tile is ever built.
 enum { TS_AROW = 0, TS_BROW, TS_DROW, TS_INFO, TS_WPARAM, TS_AIMPARAM, TS_MASKA_LO, TS_MASKA_HI,
-       TS_MASKB_LO, TS_MASKB_HI, TS_BASE, TS_PAD, T_STAGE_WORDS = 12 };
+       TS_MASKB_LO, TS_MASKB_HI, TS_BASE, TS_PAD, TS_UA, TS_UB, TS_SBOFFA, TS_SBOFFB,
+       T_STAGE_WORDS = 16 };
 enum { TS_FLAG_P = 1, TS_FLAG_HALF = 2, TS_FLAG_SIMPLE_A = 4, TS_FLAG_SIMPLE_B = 8, TS_FLAG_SAME = 16,
-       TS_FLAG_G = 32 };
+       TS_FLAG_G = 32, TS_FLAG_TOEPLITZ = 64 };
 constexpr int T_PIG_MAX = 2;
 // generated group: sizes, where its source ids start in T_LTI_IDS, scratch offsets (doubles, per
 // instance) of TA = S itself [N][n][n] and of TB [n][m][2N]: row (i, j) holds N zeros, then

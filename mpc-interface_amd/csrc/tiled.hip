@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
 #include <type_traits>
 
 #include "device_common.h"
@@ -224,6 +225,24 @@ __device__ __forceinline__ void mfma_tiles(f64x4 (&acc)[4][4], const double* at,
     for (int ta = 0; ta < NA; ++ta)
 #pragma unroll
       for (int tb = 0; tb < NB; ++tb) acc[ta][tb] = mfma_f64_16x16x4(a[ta], b[tb], acc[ta][tb]);
+  }
+}
+
+// P[c][c] and q[c] of the diagonal gterms on column c (a cost on a free variable itself): from
+// the plan's per-column table when no column carries more than RS_DIAG_MAX of them
+// (H_OFF_RS_DPAR: weight, aim slots; H_DOFF_RS_DCOEF), else by walking the gterm list
+__device__ __forceinline__ void diagonal_of_column(const PlanDev& p, const double* pb, int c,
+                                                   double& dP, double& dq) {
+  if (p.rs_diag_table) {
+    const int4 sl = *reinterpret_cast<const int4*>(p.itab + p.off_rs_dpar + 4 * c);
+    const double* cf = p.dtab + p.doff_rs_dcoef + 2 * c;
+    // (a free slot points at the parameter behind the last: read as 0 weight through its 0 coefficient)
+    const double w0 = sl.x < p.nparams ? pb[sl.x] : 0.0, a0 = sl.y < p.nparams ? pb[sl.y] : 0.0;
+    const double w1 = sl.z < p.nparams ? pb[sl.z] : 0.0, a1 = sl.w < p.nparams ? pb[sl.w] : 0.0;
+    dP = (w0 * cf[0]) * cf[0] + (w1 * cf[1]) * cf[1];
+    dq = w0 * (cf[0] * (0.0 - a0)) + w1 * (cf[1] * (0.0 - a1));
+  } else {
+    diagonal_terms(p, pb, c, dP, dq);
   }
 }
 
@@ -510,6 +529,18 @@ __global__ __launch_bounds__(BLOCK, 2) void tiled_assemble_kernel(
   if (!P) return;
 
   // ---- results ---------------------------------------------------------------------------
+  double* part = As[0];  // (the tiles are no longer needed)
+  // the diagonal gterms on column bi * T_BLOCK + tid (diagonal workgroups)
+  double dPc = 0.0, dqc = 0.0;
+  if (diag && tid < T_BLOCK && bi * T_BLOCK + tid < no)
+    diagonal_of_column(p, pb, bi * T_BLOCK + tid, dPc, dqc);
+  if (diag) {            // ... and the wavefronts' partial gradients, through LDS
+    lds_barrier();
+    if (tid < T_BLOCK) part[WAVES * T_BLOCK + tid] = dPc;
+    part[wave * T_BLOCK + scol] = qacc.x;
+    part[wave * T_BLOCK + scol + 1] = qacc.y;
+    lds_barrier();
+  }
   double* Pb = P + (size_t)inst * no * no;
   const bool mirror = sym && !diag;
 #pragma unroll
@@ -522,31 +553,297 @@ __global__ __launch_bounds__(BLOCK, 2) void tiled_assemble_kernel(
         const int col = bj * T_BLOCK + wc * 64 + tb * 16 + li;
         if (row < no && col < no) {
           double v = acc[ta][tb][reg];
-          if (row == col) {
-            double dP, dq;
-            diagonal_terms(p, pb, row, dP, dq);
-            v += dP;
-          }
+          if (diag && row == col) v += part[WAVES * T_BLOCK + (row - bi * T_BLOCK)];
           Pb[(size_t)row * no + col] = v;
           if (mirror) Pb[(size_t)col * no + row] = v;
         }
       }
-  if (diag) {  // the gradient: the four wavefronts hold the sums over their rows
-    double* part = As[0];
-    lds_barrier();
-    part[wave * T_BLOCK + scol] = qacc.x;
-    part[wave * T_BLOCK + scol + 1] = qacc.y;
-    lds_barrier();
-    if (tid < T_BLOCK) {
-      const int c = bi * T_BLOCK + tid;
-      if (c < no) {
-        double sum = 0.0;
+  if (diag && tid < T_BLOCK) {  // the gradient: the four wavefronts hold the sums over their rows
+    const int c = bi * T_BLOCK + tid;
+    if (c < no) {
+      double sum = 0.0;
 #pragma unroll
-        for (int w = 0; w < WAVES; ++w) sum += part[w * T_BLOCK + tid];
-        double dP, dq;
-        diagonal_terms(p, pb, c, dP, dq);
-        q[(size_t)inst * no + c] = sum + dq;
+      for (int w = 0; w < WAVES; ++w) sum += part[w * T_BLOCK + tid];
+      q[(size_t)inst * no + c] = sum + dqc;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Toeplitz form (plans whose every stage is TS_FLAG_TOEPLITZ: the rows of every cost are rows
+// of the states of ONE system x+ = A x + B u whose horizon tables the pre-pass generated): the
+// rows of a stage are windows of the group's table TB[i][j][.] (plan_tables.h TL_*), so the
+// workgroup copies TB (n m 2N doubles: 74 KB for C4) into LDS once and the matrix core's
+// operands are read straight out of it -- element (row r, column c) of the stage sits at
+// TB[colpart(c) + U + r].  No tile is composed, nothing is written to LDS in the loop, no barrier.
+// Diagonal workgroups read the same windows once more for the gradient and the riding rows of G.
+// LDS: TB | zeros (what columns outside the system's inputs read) | d.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double lds_f64(const char* lds, unsigned byte_off) {
+  return *reinterpret_cast<const double*>(lds + byte_off);
+}
+
+template <int N>
+__device__ __forceinline__ void mfma_toeplitz(f64x4 (&acc)[4][4], const char* lds,
+                                              const unsigned (&pa)[4], const unsigned (&pb)[4],
+                                              const unsigned (&ma)[4], const unsigned (&mb)[4],
+                                              unsigned ua, unsigned ub, double sa, double sb, int lk,
+                                              int nrows) {
+  unsigned aa[N], ab[N];
+#pragma unroll
+  for (int t = 0; t < N; ++t) {
+    aa[t] = pa[t] + (ua & ma[t]);
+    ab[t] = pb[t] + (ub & mb[t]);
+  }
+#pragma unroll
+  for (int kk = 0; kk < TK; kk += 4) {
+    const bool live = kk + lk < nrows;  // (a term's last stage may be short: rows behind it are zeros)
+    double a[N], b[N];
+#pragma unroll
+    for (int t = 0; t < N; ++t) {
+      const double va = lds_f64(lds, aa[t] + kk * 8) * sa, vb = lds_f64(lds, ab[t] + kk * 8) * sb;
+      a[t] = live ? va : 0.0;
+      b[t] = live ? vb : 0.0;
+    }
+#pragma unroll
+    for (int ta = 0; ta < N; ++ta)
+#pragma unroll
+      for (int tb = 0; tb < N; ++tb) acc[ta][tb] = mfma_f64_16x16x4(a[ta], b[tb], acc[ta][tb]);
+  }
+}
+
+__global__ __launch_bounds__(BLOCK, 2) void toeplitz_assemble_kernel(
+    PlanDev p, SrcTable src, const double* __restrict__ params, const double* __restrict__ work,
+    long long work_stride, double* __restrict__ P, double* __restrict__ q, double* __restrict__ G,
+    double* __restrict__ h, int nb, int npairs, int sym, int batch, int tbn, int nzero) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const long inst = (long)(slot / npairs) * 8 + xcd;
+  int pr = slot % npairs;
+  if (inst >= batch) return;
+  int bi = 0, bj = 0;
+  if (sym) {
+    int rowlen = nb;
+    while (pr >= rowlen) {
+      pr -= rowlen;
+      --rowlen;
+      ++bi;
+    }
+    bj = bi + pr;
+  } else {
+    bi = pr / nb;
+    bj = pr - bi * nb;
+  }
+  const bool diag = bi == bj;
+  if (!P && !diag) return;
+  const int no = p.no;
+  const double* pb = params + (size_t)inst * p.nparams;
+  const double* dvec = work + inst * work_stride;
+  const int32_t* stages = p.itab + p.off_t_stage;
+  const double* scoef = p.dtab + p.t_doff_scoef;
+  const int4* pigs = reinterpret_cast<const int4*>(p.itab + p.off_t_pig);
+  const int32_t* grp = p.itab + p.off_t_lti;  // the one generated group
+  const int32_t* ids = p.itab + p.off_t_lti_ids + grp[TL_IDS];
+  const int first_u = ids[0];
+  // ---- the table, the zeros and d into LDS ------------------------------------------------
+  {
+    const double* tb = src.ptr[first_u] + inst * src.stride[first_u];  // (16-byte aligned: the scratch)
+    double2* dst = reinterpret_cast<double2*>(lds);
+    const double2* from = reinterpret_cast<const double2*>(tb);
+    for (int e = tid; e < tbn / 2; e += BLOCK) dst[e] = from[e];
+    double* z = reinterpret_cast<double*>(lds) + tbn;
+    for (int e = tid; e < nzero; e += BLOCK) z[e] = 0.0;
+    double* dl = z + nzero;
+    if (diag && P)
+      for (int e = tid; e < p.rtot; e += BLOCK) dl[e] = dvec[e];
+    if (tid * 8 < p.nparams) asm volatile("" ::"v"(pb[tid * 8]));  // (parameters: lines into L2)
+  }
+  const unsigned zero_off = (unsigned)tbn * 8u, d_off = (unsigned)(tbn + nzero) * 8u;
+  const int li = lane & 15, lk = lane >> 4;
+  const int wr = wave >> 1, wc = wave & 1;
+  // ---- per lane: where its columns sit in the table (state-independent part) ---------------
+  const int32_t* cio = p.itab + p.off_t_cio;
+  const int base0 = stages[TS_BASE] & 0xFFFF, sboff0 = stages[TS_SBOFFA];
+  auto column = [&](int col, unsigned extra, unsigned& part, unsigned& mask) __attribute__((always_inline)) {
+    const int2 ci = *reinterpret_cast<const int2*>(cio + ((size_t)base0 * p.t_nop + col) * 2);
+    const bool valid = ((unsigned)ci.y >> 24) != (unsigned)T_SID_CONST;
+    part = valid ? (unsigned)(ci.x - sboff0) * 8u + extra : zero_off + extra;
+    mask = valid ? 0xFFFFFFFFu : 0u;
+  };
+  unsigned pa[4], pbt[4], ma[4], mb[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    column(bi * T_BLOCK + wr * 64 + t * 16 + li, (unsigned)lk * 8u, pa[t], ma[t]);
+    column(bj * T_BLOCK + wc * 64 + t * 16 + li, (unsigned)lk * 8u, pbt[t], mb[t]);
+  }
+  // the diagonal workgroup's second role: wavefront `wave` takes rows wave, wave + 4, ... of a stage,
+  // lane `lane` two columns of block bi
+  const int colA = bi * T_BLOCK + lane * 2;
+  unsigned pq0, pq1, mq0, mq1;
+  column(colA, 0u, pq0, mq0);
+  column(colA + 1, 0u, pq1, mq1);
+  const bool want_g = G != nullptr && diag;
+  __syncthreads();
+
+  f64x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
+  double2 qacc{0.0, 0.0};
+
+  int s = 0;
+  auto run_class = [&](auto cls_tag) __attribute__((always_inline)) {
+    constexpr int N = decltype(cls_tag)::value;
+    for (; s < p.t_nstage; ++s) {
+      const int32_t* rec = stages + s * T_STAGE_WORDS;
+      const int info = rec[TS_INFO];
+      if ((info >> 16) != N) break;
+      const int fl = (info >> 8) & 255, nrows = info & 255;
+      const unsigned ta = block_tiles((unsigned)rec[TS_MASKA_LO], (unsigned)rec[TS_MASKA_HI], bi);
+      const unsigned tb = block_tiles((unsigned)rec[TS_MASKB_LO], (unsigned)rec[TS_MASKB_HI], bj);
+      const bool for_p = P && (fl & TS_FLAG_P) && ta && tb;
+      const bool for_q = diag && P && ta, for_g = want_g && (fl & TS_FLAG_G);
+      if (!for_p && !for_q && !for_g) continue;
+      const unsigned ua = (unsigned)rec[TS_UA] * 8u, ub = (unsigned)rec[TS_UB] * 8u;
+      const double ca = scoef[(s * 2 + 0) * TK], cb = scoef[(s * 2 + 1) * TK];
+      const double w = P ? pb[rec[TS_WPARAM]] : 0.0;
+      if (for_q || for_g) {
+        const double aim = pb[rec[TS_AIMPARAM]];
+        const double scale = (fl & TS_FLAG_HALF) ? 0.5 : 1.0;
+        const int drow = rec[TS_DROW];
+        // this wavefront's four rows: the riding rows of G and their arrows first, all at once
+        // (two dependent trips through the scalar cache for the lot, not two per row)
+        int4 pg[TK / WAVES];
+        double ar0[TK / WAVES], ar1[TK / WAVES];
+#pragma unroll
+        for (int rr = 0; rr < TK / WAVES; ++rr) {
+          const int i = wave + WAVES * rr;
+          pg[rr] = (for_g && i < nrows) ? pigs[s * TK + i] : int4{-1, 0, -1, 0};
+        }
+#pragma unroll
+        for (int rr = 0; rr < TK / WAVES; ++rr) {
+          ar0[rr] = pb[pg[rr].x >= 0 ? pg[rr].y : 0];
+          ar1[rr] = pb[pg[rr].z >= 0 ? pg[rr].w : 0];
+        }
+#pragma unroll
+        for (int rr = 0; rr < TK / WAVES; ++rr) {
+          const int i = wave + WAVES * rr;
+          if (i >= nrows) break;
+          double2 a;
+          a.x = lds_f64(lds, pq0 + (ua & mq0) + i * 8) * ca;
+          a.y = lds_f64(lds, pq1 + (ua & mq1) + i * 8) * ca;
+          if (colA < no) {
+            if (pg[rr].x >= 0)
+              store_result(reinterpret_cast<double2*>(G + ((size_t)inst * p.nc + pg[rr].x) * no + colA),
+                           double2{ar0[rr] * a.x, ar0[rr] * a.y});
+            if (pg[rr].z >= 0)
+              store_result(reinterpret_cast<double2*>(G + ((size_t)inst * p.nc + pg[rr].z) * no + colA),
+                           double2{ar1[rr] * a.x, ar1[rr] * a.y});
+          }
+          if (for_q) {
+            const double r = scale * (lds_f64(lds, d_off + (unsigned)(drow + i) * 8u) - aim);
+            qacc.x = fma(w * a.x, r, qacc.x);
+            qacc.y = fma(w * a.y, r, qacc.y);
+          }
+        }
       }
+      if constexpr (N > 0)
+        if (for_p) mfma_toeplitz<N>(acc, lds, pa, pbt, ma, mb, ua, ub, w * ca, cb, lk, nrows);
+    }
+  };
+  run_class(std::integral_constant<int, 0>{});
+  run_class(std::integral_constant<int, 1>{});
+  run_class(std::integral_constant<int, 2>{});
+  run_class(std::integral_constant<int, 3>{});
+  run_class(std::integral_constant<int, 4>{});
+
+  // ---- rows of G that ride on no stage, h ------------------------------------------------
+  if (want_g) {
+    const int32_t* grow = p.itab + p.off_t_grow;
+    const int32_t* rrw = p.itab + p.off_rs_rr;
+    if (p.t_ngrest > 0) {  // (through the column tables, from the scratch)
+      __shared__ const double* s_base[NSTREAM];
+      stream_bases(p, src, inst, s_base, tid);
+      __syncthreads();
+      RowTables rt;
+      rt.rowptr = p.itab + p.off_rowptr;
+      rt.entbase = p.itab + p.off_entbase;
+      rt.entk = p.itab + p.off_entk;
+      rt.coef = p.dtab + p.doff_entcoef;
+      rt.cio = cio;
+      rt.nop = p.t_nop;
+      const int32_t* grest = p.itab + p.off_t_grest;
+      int baseG = -1;
+      ColRef crG;
+      crG.p0 = crG.p1 = p.dtab;
+      crG.rs0 = crG.rs1 = 0;
+      for (int x0 = wave; x0 < p.t_ngrest; x0 += WAVES) {
+        const int R = grest[x0];
+        const int32_t* x = rrw + (size_t)R * RS_RR_WORDS;
+        const int naxes = x[RR_NAXES];
+        double2 out{0.0, 0.0};
+        for (int ax = 0; ax < naxes; ++ax) {
+          const double ar = pb[x[RR_ARROW + ax]];
+          const double2 v = compose_row2(rt, grow[R * RS_AXMAX + ax], colA, s_base, baseG, crG);
+          out.x = fma(ar, v.x, out.x);
+          out.y = fma(ar, v.y, out.y);
+        }
+        if (colA < no)
+          store_result(reinterpret_cast<double2*>(G + ((size_t)inst * p.nc + R) * no + colA), out);
+      }
+    }
+    if (bi == 0)  // h: (extreme + arrow . center) - arrow . d
+      for (int R = tid; R < p.nc; R += BLOCK) {
+        const int32_t* x = rrw + (size_t)R * RS_RR_WORDS;
+        double ac = 0.0, ad = 0.0;
+        for (int ax = 0; ax < x[RR_NAXES]; ++ax) {
+          const double ar = pb[x[RR_ARROW + ax]];
+          ac += ar * pb[x[RR_CENTER + ax]];
+          ad = fma(ar, dvec[grow[R * RS_AXMAX + ax]], ad);
+        }
+        h[(size_t)inst * p.nc + R] = (pb[x[RR_EXTREME]] + ac) - ad;
+      }
+  }
+  if (!P) return;
+
+  double* part = reinterpret_cast<double*>(lds);  // (the table is no longer needed)
+  double dPc = 0.0, dqc = 0.0;  // the diagonal gterms on column bi * T_BLOCK + tid
+  if (diag && tid < T_BLOCK && bi * T_BLOCK + tid < no)
+    diagonal_of_column(p, pb, bi * T_BLOCK + tid, dPc, dqc);
+  if (diag) {  // ... and the wavefronts' partial gradients, through LDS
+    __syncthreads();
+    if (tid < T_BLOCK) part[WAVES * T_BLOCK + tid] = dPc;
+    part[wave * T_BLOCK + lane * 2] = qacc.x;
+    part[wave * T_BLOCK + lane * 2 + 1] = qacc.y;
+    __syncthreads();
+  }
+  double* Pb = P + (size_t)inst * no * no;
+  const bool mirror = sym && !diag;
+#pragma unroll
+  for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+    for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int row = bi * T_BLOCK + wr * 64 + ta * 16 + lk + 4 * reg;
+        const int col = bj * T_BLOCK + wc * 64 + tb * 16 + li;
+        if (row < no && col < no) {
+          double v = acc[ta][tb][reg];
+          if (diag && row == col) v += part[WAVES * T_BLOCK + (row - bi * T_BLOCK)];
+          Pb[(size_t)row * no + col] = v;
+          if (mirror) Pb[(size_t)col * no + row] = v;
+        }
+      }
+  if (diag && tid < T_BLOCK) {  // the gradient: the four wavefronts hold the sums over their rows
+    const int c = bi * T_BLOCK + tid;
+    if (c < no) {
+      double sum = 0.0;
+#pragma unroll
+      for (int w = 0; w < WAVES; ++w) sum += part[w * T_BLOCK + tid];
+      q[(size_t)inst * no + c] = sum + dqc;
     }
   }
 }
@@ -607,6 +904,26 @@ int launch_assemble_tiled(const PlanDev& p, const SrcTable& src, const double* p
   const int sym = p.rs_sym_any;
   const int npairs = sym ? nb * (nb + 1) / 2 : nb * nb;
   const unsigned groups = ceil_div((unsigned)batch, 8u);
+  if (p.t_toeplitz && p.t_nlti == 1 && h_itab != nullptr && t_path != 3) {
+    // every stage is a window of the one generated group's table: operands straight out of LDS
+    const int32_t* rec = h_itab + p.off_t_lti;
+    const int tbn = rec[TL_N] * rec[TL_M] * 2 * rec[TL_HORIZON];
+    const int nzero = std::max(rec[TL_HORIZON], 16) + 16;
+    const size_t lds = ((size_t)tbn + nzero + p.rtot + (p.rtot & 1)) * sizeof(double);
+    if (lds <= (size_t)RESIDENT_LDS_LIMIT && (rec[TL_TB] & 1) == 0 && (stride & 1) == 0) {
+      static thread_local size_t granted = 0;
+      if (lds > granted) {
+        *err = hipFuncSetAttribute(reinterpret_cast<const void*>(toeplitz_assemble_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, RESIDENT_LDS_LIMIT);
+        if (*err != hipSuccess) return MPCASM_ERR_HIP;
+        granted = RESIDENT_LDS_LIMIT;
+      }
+      hipLaunchKernelGGL(toeplitz_assemble_kernel, dim3(groups * 8 * (unsigned)npairs), dim3(BLOCK), lds,
+                         stream, p, eff, params, w, stride, P, q, G, h, nb, npairs, sym, batch, tbn, nzero);
+      *err = hipGetLastError();
+      return *err == hipSuccess ? MPCASM_OK : MPCASM_ERR_HIP;
+    }
+  }
   hipLaunchKernelGGL(tiled_assemble_kernel, dim3(groups * 8 * (unsigned)npairs), dim3(BLOCK), 0,
                      stream, p, eff, params, w, stride, P, q, G, h, nb, npairs, sym, batch);
   *err = hipGetLastError();

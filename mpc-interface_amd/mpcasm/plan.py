@@ -38,7 +38,7 @@ _H = {name: i for i, name in enumerate([
     "CSC_PNNZ", "OFF_CSC_P", "CSC_GNNZ", "OFF_CSC_G", "CSC_GSINGLE",
     "T_CI_OK", "T_NOP", "OFF_T_CIG", "OFF_T_CIO", "T_DOFF_DELTA", "T_NDELTA",
     "T_OK", "T_NSTAGE", "OFF_T_STAGE", "T_NLTI", "OFF_T_LTI", "OFF_T_LTI_IDS", "T_WORK",
-    "OFF_T_GROW", "OFF_T_SROW", "T_DOFF_SCOEF", "OFF_T_PIG", "T_NGREST", "OFF_T_GREST", "OFF_T_BROW0",
+    "OFF_T_GROW", "OFF_T_SROW", "T_DOFF_SCOEF", "OFF_T_PIG", "T_NGREST", "OFF_T_GREST", "OFF_T_BROW0", "T_TOEPLITZ",
 ])}
 H_WORDS = 112
 assert len(_H) <= H_WORDS
@@ -71,8 +71,8 @@ SEG_GATHER, SEG_IDENTITY = 0, 1
 GT_FLAG_P, GT_FLAG_HALF, GT_FLAG_DIAG = 1, 2, 4
 MAX_SOURCES = 32
 # tiled kernel (csrc/tiled.hip, plan_tables.h T_* / TS_* / TL_*)
-T_BLOCK, T_SID_CONST, T_STAGE_WORDS, T_LTI_WORDS = 128, 32, 12, 8
-TS_FLAG_P, TS_FLAG_HALF, TS_FLAG_SIMPLE_A, TS_FLAG_SIMPLE_B, TS_FLAG_SAME, TS_FLAG_G = 1, 2, 4, 8, 16, 32
+T_BLOCK, T_SID_CONST, T_STAGE_WORDS, T_LTI_WORDS = 128, 32, 16, 8
+TS_FLAG_P, TS_FLAG_HALF, TS_FLAG_SIMPLE_A, TS_FLAG_SIMPLE_B, TS_FLAG_SAME, TS_FLAG_G, TS_FLAG_TOEPLITZ = 1, 2, 4, 8, 16, 32, 64
 T_PIG_MAX = 2
 
 
@@ -222,6 +222,20 @@ class _Builder:
             colseg[dst0:dst0 + length] = len(self.segments)
             self.segments.append(seg)
         self.colseg.append(colseg)
+
+    def lti_state_of(self, group):
+        """``{base id: state index}`` of the bases that are states of the generated group: every
+        segment of such a base reads one of the group's sources at element offset = its state."""
+        ids = set(group["ids"])
+        out = {}
+        for var, bid in self.base_ids.items():
+            segs = [self.segments[sg] for sg in sorted(set(int(x) for x in self.colseg[bid] if x >= 0))]
+            gather = [sg for sg in segs if sg[6] == SEG_GATHER]
+            if gather and len(gather) == len(segs) and all(sg[0] in ids for sg in gather):
+                states = {sg[1] for sg in gather}
+                if len(states) == 1:
+                    out[bid] = states.pop()
+        return out
 
     # ---- flattened definition graph (body.py:179-193) ----------------------
     def flatten_definitions(self):
@@ -1099,9 +1113,31 @@ def _tiled_program(b, form, gterms, rowptr, entbase, entk, entcoef, rtot, groups
                     fl |= TS_FLAG_G
                 if take:
                     riders[arow + i] = riders[arow + i][len(take):]
+            # a window of the group's Toeplitz table: rows k0 .. k0 + n - 1 of one generated state,
+            # one coefficient (plan_tables.h TS_FLAG_TOEPLITZ)
+            ua = ub = sba = sbb = 0
+            if len(groups) == 1:
+                g0 = groups[0]
+                state_of = {bid: dyn_state for bid, dyn_state in b.lti_state_of(g0).items()}
+
+                def window(side, smp):
+                    if not 0 <= smp < 65536 or smp not in state_of:
+                        return None
+                    k, c = ks[side, :n], cs[side, :n]
+                    if np.any(k != k[0] + np.arange(n)) or np.any(c != c[0]):
+                        return None
+                    sboff = state_of[smp] * g0["m"] * 2 * g0["N"]
+                    return sboff + int(k[0]), sboff
+
+                wa = window(0, ba)
+                wb = window(1, bb) if has_p else wa
+                if wa is not None and wb is not None:
+                    fl |= TS_FLAG_TOEPLITZ
+                    (ua, sba), (ub, sbb) = wa, wb
             stages.append([arow, brow, drow, n | (fl << 8) | (cls << 16), wparam, aimparam,
                            ma & 0xFFFFFFFF, ma >> 32, mb & 0xFFFFFFFF, mb >> 32,
-                           (max(ba, 0) & 0xFFFF) | ((max(bb, 0) & 0xFFFF) << 16), 0])
+                           (max(ba, 0) & 0xFFFF) | ((max(bb, 0) & 0xFFFF) << 16), 0,
+                           ua, ub, sba, sbb])
             srow.append(ks)
             scoef.append(cs)
             pig.append(pg)
@@ -1120,7 +1156,8 @@ def _tiled_program(b, form, gterms, rowptr, entbase, entk, entcoef, rtot, groups
         ids.extend(g["ids"])
     ok = int(ci_ok and rr_ok and no >= T_BLOCK and no % 2 == 0 and len(b.base_rows) > 0
              and len(b.sources) <= MAX_SOURCES and rtot < (1 << 24))
-    return dict(ok=ok, ci_ok=int(ci_ok), nop=nop, ci=ci, delta=delta, masks=masks,
+    toeplitz = int(bool(ok and stages and all((st[3] >> 8) & TS_FLAG_TOEPLITZ for st in stages)))
+    return dict(ok=ok, toeplitz=toeplitz, ci_ok=int(ci_ok), nop=nop, ci=ci, delta=delta, masks=masks,
                 srow=np.asarray(srow, dtype=np.int64).reshape(-1),
                 scoef=np.asarray(scoef, dtype=np.float64).reshape(-1),
                 pig=np.asarray(pig, dtype=np.int64).reshape(-1), grest=grest,
@@ -1548,6 +1585,7 @@ def compile_plan(form, costs=None, limits=None, lti=(), csc=None):
     header[_H["T_CI_OK"]], header[_H["T_NOP"]] = tiled["ci_ok"], tiled["nop"]
     header[_H["T_OK"]], header[_H["T_NSTAGE"]] = tiled["ok"], tiled["stages"].shape[0]
     header[_H["T_NLTI"]], header[_H["T_WORK"]] = tiled["lti"].shape[0], tiled["work"]
+    header[_H["T_TOEPLITZ"]] = tiled["toeplitz"]
     dtab = np.concatenate(dparts).astype(np.float64)
     params = np.asarray(b.params, dtype=np.float64)
     header[_H["MAGIC"]], header[_H["VERSION"]] = PLAN_MAGIC, PLAN_VERSION

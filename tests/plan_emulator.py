@@ -466,8 +466,31 @@ def run_tiled(plan, given, params=None, sources=None, ab=None):
         return [(m >> min(8 * b + j, 63)) & 1 for j in range(8)]
 
     last_cls = 0
-    for sx, (arow, brow, drow, info, pw, pa, mal, mah, mbl, mbh, base, _) in enumerate(stages):
+    nlti = int(it[H["T_NLTI"]])
+    toeplitz_plan = bool(it[H["T_TOEPLITZ"]])
+    for sx, (arow, brow, drow, info, pw, pa, mal, mah, mbl, mbh, base, _, ua, ub, sba, sbb) in enumerate(stages):
         n, fl, cls = info & 255, (info >> 8) & 255, info >> 16
+        assert not toeplitz_plan or fl & P.TS_FLAG_TOEPLITZ
+        if fl & P.TS_FLAG_TOEPLITZ:
+            # the window of the group's Toeplitz table the kernel reads instead of composing rows:
+            # element (row r, column c) = coef * TB[offset(c) - sboff + U + r] where column c's table
+            # entry is one of the group's U_j with one element per base row, else 0
+            assert nlti == 1
+            lti = _section(it, "OFF_T_LTI", P.T_LTI_WORDS)
+            ids = set(_section(it, "OFF_T_LTI_IDS", lti[3] + lti[1] + 1)[lti[3]:lti[3] + lti[1]])
+            for side, (row0, U, sb) in enumerate(((arow, ua, sba), (brow, ub, sbb))):
+                if side == 1 and not fl & P.TS_FLAG_P:
+                    continue
+                b_ = (base & 0xFFFF) if side == 0 else (base >> 16)
+                off, meta = cio[b_, :, 0], cio[b_, :, 1]
+                sid, rs = meta >> 24, _sext24(meta)
+                valid = np.isin(sid, list(ids))
+                assert np.all(rs[valid] == 1) and np.all(sid[~valid] == P.T_SID_CONST) and np.all(rs[~valid] == 0)
+                tb = streams[next(iter(ids))]
+                win = np.zeros((n, nop))
+                for r in range(n):
+                    win[r, valid] = scoef[sx, side, 0] * tb[off[valid] - sb + U + r]
+                assert np.array_equal(win, Vo[row0:row0 + n]), "Toeplitz window"
         assert cls >= last_cls and (cls > 0) == bool(fl & P.TS_FLAG_P)   # sorted by class
         last_cls = cls
         ma, mb = mal | (mah << 32), mbl | (mbh << 32)

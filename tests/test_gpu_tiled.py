@@ -73,11 +73,14 @@ def test_tiled_against_staged_and_oracle(gpu_api, torch_gpu, nx, nu, N, B, seed)
     assert torch.equal(G2, Gt) and torch.equal(h2, ht)
 
 
-@pytest.mark.parametrize("nx,nu,N,B,seed", [(5, 3, 48, 19, 11), (12, 6, 64, 24, 12)])
-def test_horizon_tables_from_the_systems_own_matrices(gpu_api, torch_gpu, nx, nu, N, B, seed):
+@pytest.mark.parametrize("path", [0, 3], ids=["toeplitz", "general"])
+@pytest.mark.parametrize("nx,nu,N,B,seed", [(5, 3, 48, 19, 11), (12, 6, 64, 24, 12), (3, 4, 40, 9, 13)])
+def test_horizon_tables_from_the_systems_own_matrices(gpu_api, torch_gpu, nx, nu, N, B, seed, path):
     """Plans compiled with lti=[...] on the tiled kernel: a pre-pass builds S and the compact
-    Toeplitz tables of U from per-instance (A, B) by the reference's recurrence (tools.py:24-29);
-    against the staged pipeline fed the K1 fill's S, U of the same systems, and the oracle."""
+    Toeplitz tables of U from per-instance (A, B) by the reference's recurrence (tools.py:24-29).
+    Both forms of the kernel -- operands read out of the table in LDS (every cost row is a window
+    of it), and the general form that composes tiles (MPCASM_OPT_PATH 3) -- against the staged
+    pipeline fed the K1 fill's S, U of the same systems, and the oracle."""
     torch = torch_gpu
     from mpcasm import capi, engine
 
@@ -88,10 +91,19 @@ def test_horizon_tables_from_the_systems_own_matrices(gpu_api, torch_gpu, nx, nu
     A, Bm = np.stack(As), np.stack(Bs)
     At, Bt = torch.as_tensor(A, device="cuda"), torch.as_tensor(Bm, device="cuda")
     lti = engine.Assembler(form, batch=B, lti=["plant"])
+    assert lti.plan.itab[_H["T_TOEPLITZ"]] == 1
+    lti.set_option(capi.OPT_PATH, path)
     lti.bind_lti("plant", At, Bt)
     out = tuple(torch.full_like(t, float("nan")) for t in lti.assemble(given))
     Pl, ql, Gl, hl = (t.clone() for t in lti.assemble(given, out=out))
     assert not any(torch.isnan(t).any().item() for t in (Pl, ql, Gl, hl))
+    assert "tiled" in lti.last_kernel()
+    # one half at a time: the same numbers
+    P2, q2, _, _ = lti.assemble(given, want_constraints=False)
+    assert torch.equal(P2, Pl) and torch.equal(q2, ql)
+    out = tuple(torch.full_like(t, float("nan")) for t in (Pl, ql, Gl, hl))
+    _, _, G2, h2 = lti.assemble(given, out=out, want_cost=False)
+    assert torch.equal(G2, Gl) and torch.equal(h2, hl)
     ref = engine.Assembler(form, batch=B)
     ref.set_option(capi.OPT_PATH, 2)
     S, U = engine.fill_su(At, Bt, N)
