@@ -91,6 +91,20 @@ int mpcasm_plan_set_option(mpcasm_plan* plan, int option, int value);
 int mpcasm_jit_check(const int32_t* h_itab, size_t n_itab, const double* h_dtab, size_t n_dtab,
                      char* log, size_t log_capacity);
 
+/* Compile ahead of the first launch what a launch of `batch` instances of this plan would
+ * compile (the persistent kernel specialised for the plan, MPCASM_OPT_JIT): a control loop calls
+ * it once with the plan's capacity, so that no tick ever blocks for a compilation; launches of
+ * fewer instances then run the compiled kernel too.  Other plans keep launching meanwhile (the
+ * compilation holds no lock).  Code objects are kept on disk -- $MPCASM_CACHE_DIR, else
+ * $XDG_CACHE_HOME/mpcasm, else ~/.cache/mpcasm; MPCASM_NO_DISK_CACHE=1: never -- named by a hash of
+ * everything the compiler sees, so every later process (and the other ranks of a node) loads
+ * instead of compiling.  MPCASM_OK also when nothing needs compiling or hiprtc is missing (the
+ * ahead-of-time kernel runs then); MPCASM_ERR_ARG when the current device is not the plan's. */
+int mpcasm_plan_prepare(const mpcasm_plan* plan, int batch);
+/* Diagnostic: out[0] = kernels compiled by this process so far, out[1] = code objects loaded from
+ * the disk cache, out[2] = code objects written to it. */
+int mpcasm_jit_stats(int64_t out[3]);
+
 /* K1  horizon extension ---------------------------------------------------
  * Replaces tools.extend_matrices(N, A, B)      python/mpc_interface/tools.py:14-33
  * (C++ twin gecko::tools::extend_matrices      cpp/src/tools.cc:83-144),

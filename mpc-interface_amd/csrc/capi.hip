@@ -915,17 +915,49 @@ int mpcasm_jit_check(const int32_t* h_itab, size_t n_itab, const double* h_dtab,
   // (both forms of the P hand-over when the size of a launch picks one)
   const int small = resident_p_direct_for(d, 1), large = resident_p_direct_for(d, 1 << 30);
   int out = MPCASM_OK;
-  for (int form : {small, large}) {
-    if (form == large && small != large && out != MPCASM_OK) break;
-    d.rs_p_direct = form;
-    out = jit_compile(jit_spec_header(d, h_itab), &code, &text);
-    if (small == large) break;
+  if (!jit_available()) {
+    text = "libhiprtc.so could not be loaded";
+    out = MPCASM_ERR_LIMIT;
+  } else {
+    for (int form : {small, large}) {
+      if (form == large && small != large && out != MPCASM_OK) break;
+      d.rs_p_direct = form;
+      // (through the disk cache, as a launch would: a second check of the same plan compiles nothing)
+      out = jit_code_for(jit_spec_header(d, h_itab), false, 0xBF, &code, &text) ? MPCASM_OK : MPCASM_ERR_HIP;
+      if (small == large) break;
+    }
   }
   if (log && log_capacity) {
     strncpy(log, text.c_str(), log_capacity - 1);
     log[log_capacity - 1] = 0;
   }
   return out;
+}
+
+int mpcasm_jit_stats(int64_t out[3]) {
+  if (!out) return MPCASM_ERR_ARG;
+  long v[3];
+  jit_stats(v);
+  out[0] = v[0];
+  out[1] = v[1];
+  out[2] = v[2];
+  return MPCASM_OK;
+}
+
+int mpcasm_plan_prepare(const mpcasm_plan* plan, int batch) {
+  if (!plan || batch < 0) return MPCASM_ERR_ARG;
+  int current = -1;
+  if (hipGetDevice(&current) != hipSuccess || current != plan->device) return MPCASM_ERR_ARG;
+  PlanDev p = plan->dev;
+  if (!p.rs_ok) return MPCASM_OK;  // (nothing is compiled per plan for the other kernels)
+  p.rs_p_direct = resident_p_direct_for(plan->dev, batch);
+  const size_t rs = resident_lds_bytes(p);
+  if (rs == 0 || rs > RESIDENT_LDS_LIMIT) return MPCASM_OK;
+  t_path = plan->opt_path >= 0 ? plan->opt_path : g_path;
+  t_jit = plan->opt_jit >= 0 ? plan->opt_jit : g_jit;
+  if (t_path != 0 && p.rs_nlti == 0 && p.csc_pnnz == 0 && p.csc_gnnz == 0) return MPCASM_OK;
+  (void)jit_kernel_for(p, plan->h_itab.data(), plan->device, batch, rs);  // (a failure: the ahead-of-time kernel)
+  return MPCASM_OK;
 }
 
 int mpcasm_plan_destroy(mpcasm_plan* plan) {
@@ -986,6 +1018,10 @@ int mpcasm_assemble(const mpcasm_plan* plan, const double* const* h_src,
   if ((d_P == nullptr) != (d_q == nullptr) || (d_G == nullptr) != (d_h == nullptr))
     return MPCASM_ERR_ARG;
   if (d.rtot && !d_work) return MPCASM_ERR_ARG;
+  {  // the plan's tables (and its compiled kernel) live on the device it was created on
+    int current = -1;
+    if (hipGetDevice(&current) != hipSuccess || current != plan->device) return MPCASM_ERR_ARG;
+  }
   // results leave the chip in 16-byte stores
   if ((reinterpret_cast<uintptr_t>(d_P) | reinterpret_cast<uintptr_t>(d_q) |
        reinterpret_cast<uintptr_t>(d_G) | reinterpret_cast<uintptr_t>(d_h)) & 15)

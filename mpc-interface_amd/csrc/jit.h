@@ -22,6 +22,13 @@ int jit_compile(const std::string& header, std::vector<char>* code, std::string*
 // the compiled kernel of (plan structure, device), or nullptr: use the ahead-of-time kernel
 const void* jit_kernel_for(const PlanDev& d, const int32_t* h_itab, int device, int batch,
                            size_t lds_bytes);
+// the code object of a generated header: from the disk cache ($MPCASM_CACHE_DIR, $XDG_CACHE_HOME/mpcasm
+// or ~/.cache/mpcasm; MPCASM_NO_DISK_CACHE=1: never), else compiled and stored there
+bool jit_code_for(const std::string& header, bool stamps, int phases, std::vector<char>* code,
+                  std::string* log);
+bool jit_available();
+// compilations, code objects read from / written to the disk cache, in this process so far
+void jit_stats(long out[3]);
 // (called when a plan is destroyed: compiled kernels are remembered by the plan's device tables)
 void jit_forget(const void* itab);
 int jit_launch(const void* kernel, const PlanDev& p, const SrcTable& src, const double* params,

@@ -49,6 +49,8 @@ SIGNATURES = {
     "mpcasm_plan_csc_sizes": (ctypes.c_int, [_void_p, ctypes.POINTER(ctypes.c_int64)]),
     "mpcasm_plan_set_option": (ctypes.c_int, [_void_p, ctypes.c_int, ctypes.c_int]),
     "mpcasm_plan_last_kernel": (ctypes.c_int, [_void_p]),
+    "mpcasm_plan_prepare": (ctypes.c_int, [_void_p, ctypes.c_int]),
+    "mpcasm_jit_stats": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int64)]),
     "mpcasm_workspace_bytes": (ctypes.c_int, [_void_p, ctypes.c_int,
                                               ctypes.POINTER(ctypes.c_size_t)]),
     "mpcasm_assemble": (ctypes.c_int, [_void_p, ctypes.POINTER(_void_p),

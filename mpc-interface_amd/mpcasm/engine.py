@@ -161,6 +161,9 @@ class Assembler:
         self._work = None
         self._workspace()
         self._out = None
+        # what a launch at this capacity would compile, now (not in the middle of a control loop)
+        with torch.cuda.device(self.device):
+            capi.check(lib.mpcasm_plan_prepare(self._handle, self.batch), "mpcasm_plan_prepare")
         self._csc = {}
 
     def __del__(self):

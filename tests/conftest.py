@@ -24,6 +24,12 @@ for path in (os.path.join(_ROOT, "mpc-interface_amd"), _ROOT, os.path.dirname(__
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a HIP device (MI355X)")
+    # compiled code objects of this test session go to a scratch directory of their own (the
+    # library's default is ~/.cache/mpcasm), unless the caller chose one
+    if "MPCASM_CACHE_DIR" not in os.environ:
+        import tempfile
+
+        os.environ["MPCASM_CACHE_DIR"] = tempfile.mkdtemp(prefix="mpcasm-test-cache-")
 
 
 @pytest.fixture

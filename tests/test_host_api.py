@@ -301,3 +301,42 @@ def test_formulation_bookkeeping(cpu_api):
             form.generate_all_qp_matrices(given)
         with pytest.raises(RuntimeError):
             form.PM["CoM_x"]
+
+
+def test_compiled_plans_are_kept_least_recently_used(cpu_api, monkeypatch):
+    """Formulation._assembler keeps compiled plans by structure: room for the whole problem and
+    every single cost / limit in three structures (what a per-part sweep over the walking loop's
+    phases needs), the least recently used entry goes first."""
+    import mpcasm.engine as engine
+    from mpcasm import problems
+
+    built = []
+
+    class FakeAssembler:
+        def __init__(self, form, batch=1, device=None, costs=None, limits=None):
+            built.append((None if costs is None else tuple(costs), None if limits is None else len(limits)))
+
+        def rebind_sources(self, form, frozen):
+            return True
+
+        def refresh_params(self):
+            return True
+
+    monkeypatch.setattr(engine, "Assembler", FakeAssembler)
+    form = problems.biped(cpu_api, problems.BipedConfig(step_samples=8))
+    parts = 1 + len(form.goals) + len(form._all_limits())
+    assert form._asm_cache_size() == max(24, 3 * parts) and parts == 19
+    form._ASM_CACHE_MIN = 3                                     # a small cache for the test
+    monkeypatch.setattr(type(form), "_asm_cache_size", lambda self: 3)
+    names = list(form.goals)
+    a = form._assembler(costs={"cost": form.goals[names[0]]})
+    b = form._assembler(costs={"cost": form.goals[names[1]]})
+    c = form._assembler(costs={"cost": form.goals[names[2]]})
+    assert len(built) == 3 and len(form._asm_cache) == 3
+    assert form._assembler(costs={"cost": form.goals[names[0]]}) is a and len(built) == 3   # a hit
+    d = form._assembler(costs={"cost": form.goals[names[3]]})   # evicts b: the least recently used
+    assert len(built) == 4 and len(form._asm_cache) == 3
+    assert form._assembler(costs={"cost": form.goals[names[0]]}) is a and len(built) == 4
+    assert form._assembler(costs={"cost": form.goals[names[2]]}) is c and len(built) == 4
+    assert form._assembler(costs={"cost": form.goals[names[1]]}) is not b and len(built) == 5
+    assert d is not None

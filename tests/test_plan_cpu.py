@@ -394,3 +394,42 @@ def test_the_persistent_kernel_compiles_for_a_plan_without_a_device(cpu_api):
     if big.itab[_H["RS_OK"]] == 0:
         assert lib.mpcasm_jit_check(big.itab.ctypes.data, big.itab.size, big.dtab.ctypes.data,
                                     big.dtab.size, None, 0) == -5
+
+
+def test_compiled_kernels_are_kept_on_disk(cpu_api, tmp_path, monkeypatch):
+    """The per-plan code object is named by a hash of everything the compiler sees and kept in
+    MPCASM_CACHE_DIR: the second request of the same plan (a later process, another rank) reads
+    the file instead of compiling; MPCASM_NO_DISK_CACHE=1 compiles every time."""
+    lib = capi.load()
+    form = problems.biped(cpu_api, problems.BipedConfig(step_samples=8))
+    form.update(step_times=np.array([6, 14]), step_count=0)
+    plan = compile_plan(form, lti=["LIP"])
+    monkeypatch.setenv("MPCASM_CACHE_DIR", str(tmp_path / "cache"))
+
+    def stats():
+        out = (ctypes.c_int64 * 3)()
+        assert lib.mpcasm_jit_stats(out) == 0
+        return list(out)
+
+    def check():
+        log = ctypes.create_string_buffer(4096)
+        return lib.mpcasm_jit_check(plan.itab.ctypes.data, plan.itab.size, plan.dtab.ctypes.data,
+                                    plan.dtab.size, log, len(log))
+
+    s0 = stats()
+    rc = check()
+    if rc == -5:
+        pytest.skip("no libhiprtc.so")
+    assert rc == 0
+    s1 = stats()
+    built = s1[0] - s0[0]
+    assert built >= 1 and s1[2] - s0[2] == built and s1[1] == s0[1]
+    files = sorted((tmp_path / "cache").glob("*.co"))
+    assert len(files) == built and all(f.stat().st_size > 1000 for f in files)
+    assert check() == 0                                      # ... the second time: from the files
+    s2 = stats()
+    assert s2[0] == s1[0] and s2[1] - s1[1] == built
+    monkeypatch.setenv("MPCASM_NO_DISK_CACHE", "1")
+    assert check() == 0
+    s3 = stats()
+    assert s3[0] - s2[0] == built and s3[1] == s2[1]
