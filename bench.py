@@ -155,14 +155,16 @@ def launch_ranks(args, argv):
 # --------------------------------------------------------------------------
 # workload
 # --------------------------------------------------------------------------
-def build_workload(batch, seed):
-    """The biped formulation in its 36-wide phase + per-instance synthetic inputs."""
+def build_workload(batch, seed, step_times=(6, 14), reduced=False):
+    """The biped formulation in its 36-wide phase + per-instance synthetic inputs.
+    ``step_times`` (7, 15): the phase with ONE previewed step -- the 34-wide bucket;
+    ``reduced``: without the zero-weight terminal cost and the terminal box."""
     from mpcasm import engine, problems
 
     api = problems.load_api("mpc_interface")
     conf = problems.BipedConfig(step_samples=8)               # N = 16
-    form = problems.biped(api, conf)
-    form.update(step_times=np.array([6, 14]), step_count=0)   # phase phi=1: no=36, nc=76
+    form = problems.biped(api, conf, reduced=reduced)
+    form.update(step_times=np.array(step_times), step_count=0)   # phase phi=1: no=36, nc=76
     N = conf.horizon_lenght
 
     rng = np.random.default_rng(seed)
@@ -249,13 +251,34 @@ def _cpu_worker(args):
     return done, elapsed
 
 
+def cpu_share():
+    """Cores this process may really use: its affinity mask, cut down to the cgroup's CPU quota
+    when there is one (a container on a 256-core host is often given 16)."""
+    share = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                fields = f.read().split()
+            if path.endswith("cpu.max"):
+                quota, period = fields[0], float(fields[1])
+            else:
+                quota = fields[0]
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                    period = float(g.read().split()[0])
+            if quota not in ("max", "-1") and period > 0:
+                share = min(share, max(1, int(float(quota) / period + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return share
+
+
 def cpu_baseline_all_cores(budget_s=10.0):
     """The same oracle loop in P processes, P = the cores this process may run on (at most 64:
     beyond that the pool's start-up outweighs the 10 s sample)."""
     import multiprocessing as mp
 
-    share = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    procs = max(1, min(64, share))
+    procs = max(1, min(64, cpu_share()))
     with mp.get_context("spawn").Pool(procs) as pool:
         results = pool.map(_cpu_worker, [(1000 + i, budget_s) for i in range(procs)])
     done = sum(r[0] for r in results)
@@ -321,6 +344,102 @@ def fill_records(torch, engine, dev, batch, reps=30):
         del A, Bm, S, U
     torch.cuda.empty_cache()
     return out
+
+
+def variant_records(torch, dev, batch, seed):
+    """The same step on the other shapes SURVEY.md 8d names for C2: the 34-wide bucket (the walking
+    phase with one previewed step: no=34, nc=72) and the reduced formulation of the north star
+    ("3 costs, 2 box constraints": no terminal cost, no terminal box), both widths."""
+    out = []
+    for name, kw in (("34-wide bucket (one previewed step)", dict(step_times=(7, 15))),
+                     ("reduced: 3 cost kinds, 2 boxes; 36-wide", dict(reduced=True)),
+                     ("reduced: 3 cost kinds, 2 boxes; 34-wide", dict(reduced=True, step_times=(7, 15)))):
+        work = build_workload(batch, seed, **kw)
+        engine, form = work["engine"], work["form"]
+        asm = engine.Assembler(form, batch=batch, device=dev, lti=["LIP"])
+        asm.bind_lti("LIP", torch.as_tensor(work["A"], device=dev), torch.as_tensor(work["B"], device=dev))
+        asm.set_param("cost", "track vel_x", "aim", work["aims"])
+        given = torch.as_tensor(work["given"], device=dev)
+        f = dict(dtype=torch.float64, device=dev)
+        sets = [(torch.empty((batch, asm.no, asm.no), **f), torch.empty((batch, asm.no), **f),
+                 torch.empty((batch, asm.nc, asm.no), **f), torch.empty((batch, asm.nc), **f))
+                for _ in range(4)]
+        k = [0]
+
+        def step():
+            asm.assemble(given, out=sets[k[0] % 4])
+            k[0] += 1
+
+        ms = _event_ms(torch, step, 200)
+        nbytes = 8 * (asm.no * asm.no + asm.no + asm.nc * asm.no + asm.nc) \
+            + 8 * (asm.ng + int(asm.params.shape[1]) + 12)
+        gbps = nbytes * batch / (ms * 1e-3) / 1e9
+        out.append({"workload": "C2 biped N=16, %s" % name, "no": asm.no, "nc": asm.nc,
+                    "costs": len(form.goals), "boxes": len(form.constraint_boxes),
+                    "batch_per_gpu": batch, "kernel": asm.last_kernel(), "avg_launch_ms": ms,
+                    "assemblies_per_s": batch / (ms * 1e-3), "algorithmic_bytes_per_assembly": nbytes,
+                    "achieved": gbps, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS})
+        del asm, sets, given
+    torch.cuda.empty_cache()
+    return out
+
+
+F64_MFMA_PEAK_TFLOPS = 78.6    # dense fp64 matrix peak of gfx950 (v_mfma_f64_16x16x4_f64: 32 flop/clk/SIMD)
+
+
+def c4_record(torch, dev, batch=8192, reps=3):
+    """BASELINE config C4 (random LTI nx=12 nu=6 N=64: no=384, nc=1536) at its per-GPU batch in ONE
+    call on the tiled kernel, a different system in every instance (horizon tables generated from
+    (A, B): no S, U in memory, no workspace).  Bound: the fp64 matrix core for the Hessian, HBM for
+    the results; both fractions are reported."""
+    from mpcasm import engine, problems
+
+    nx, nu, N = 12, 6, 64
+    need = 8 * batch * (384 * 384 + 384 + 1536 * 384 + 1536) * 1.05
+    free = torch.cuda.mem_get_info(dev)[0]
+    while need > 0.8 * free and batch > 256:
+        batch //= 2
+        need /= 2
+    api = problems.load_api("mpc_interface")
+    rng = np.random.default_rng(20262)
+    form = problems.random_lti(api, rng, nx=nx, nu=nu, N=N)
+    base = [problems.random_lti_matrices(rng, nx, nu) for _ in range(64)]
+    scale = 1.0 - 0.05 * rng.random(batch)
+    A = np.stack([base[b % 64][0] * scale[b] for b in range(batch)])
+    Bm = np.stack([base[b % 64][1] * (2.0 - scale[b]) for b in range(batch)])
+    asm = engine.Assembler(form, batch=batch, device=dev, lti=["plant"])
+    asm.bind_lti("plant", torch.as_tensor(A, device=dev), torch.as_tensor(Bm, device=dev))
+    asm.set_param("cost", "track s0", "weight", rng.uniform(0.1, 1.0, [batch, 1, 1]))
+    given = torch.as_tensor(rng.normal(0, 0.3, [batch, form.given_len]), device=dev)
+    ms = _event_ms(torch, lambda: asm.assemble(given), reps, warm=1, settle_ms=0.0)
+    no, nc = asm.no, asm.nc
+    out_bytes = 8 * (no * no + no + nc * no + nc)
+    in_bytes = 8 * (asm.ng + int(asm.params.shape[1]) + nx * nx + nx * nu)
+    gbps = (out_bytes + in_bytes) * batch / (ms * 1e-3) / 1e9
+    # executed matrix-core work, from the plan: a stage of class n multiplies n x n tiles per
+    # wavefront, 4 wavefronts per block of P, 4 k-steps of v_mfma_f64_16x16x4_f64 (2048 flop) each
+    stages = asm.plan.tiled["stages"]
+    nb = -(-no // 128)
+    blocks = nb * (nb + 1) // 2                     # (P symmetric: block pairs bi <= bj)
+    mfma = int(sum(((int(st[3]) >> 16) ** 2) * 4 * 4 for st in stages if (int(st[3]) >> 8) & 1)) * blocks
+    tflops = mfma * 2048 * batch / (ms * 1e-3) / 1e12
+    rec = {"workload": "C4: random LTI nx=12 nu=6 N=64, no=%d nc=%d, per-instance (A,B), weight, given; "
+                       "B=%d in one call" % (no, nc, batch),
+           "kernel": asm.last_kernel() + (" (Toeplitz form: operands out of the TB table in LDS)"
+                                          if int(asm.plan.tiled["toeplitz"]) else ""),
+           "batch_per_gpu": batch, "ms_per_call": ms, "assemblies_per_s": batch / (ms * 1e-3),
+           "algorithmic_bytes_per_assembly": out_bytes + in_bytes,
+           "hbm": {"achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS},
+           "mfma": {"executed_mfma_per_assembly": mfma, "achieved": tflops, "peak": F64_MFMA_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": tflops / F64_MFMA_PEAK_TFLOPS,
+                    "note": "structurally zero 16-column tiles of the block-lower-triangular horizon "
+                            "matrices are not multiplied: %.0f%% of the dense symmetric count"
+                            % (100.0 * mfma / max(1, blocks * sum(1 for st in stages if (int(st[3]) >> 8) & 1)
+                                                  * 16 * 4 * 4))},
+           "workspace_bytes_per_instance": 8 * int(asm.plan.tiled["work"])}
+    del asm, given
+    torch.cuda.empty_cache()
+    return rec
 
 
 def tiled(x, times):
@@ -629,8 +748,15 @@ def run_rank(args):
             }
             del gathered
             torch.cuda.empty_cache()
+        # the other C2 shapes (34-wide bucket, the north star's reduced formulation)
+        record["variants"] = variant_records(torch, dev, B, 20260 + rank)
         # K1 alone on the north-star shapes
         record["fill"] = fill_records(torch, engine, dev, B)
+        # C4 on the tiled kernel at its per-GPU batch
+        try:
+            record["c4"] = c4_record(torch, dev)
+        except Exception as exc:        # (never at the cost of the main line)
+            record["c4"] = {"error": repr(exc)}
         # the same step at B=65536: 2.2 GB of outputs per step, no cache can hold it
         big = 65536
         times = (big + B - 1) // B

@@ -75,8 +75,12 @@ class BipedConfig:
         }
 
 
-def biped(api, conf=None):
+def biped(api, conf=None, reduced=False):
     """Walking formulation: steps + LIPM + bias, 3 boxes, 6 costs.
+
+    ``reduced``: without the zero-weight terminal cost and the terminal box of the example
+    (biped_formulation.py:95-105, 129-131) -- the "3 costs, 2 box constraints" BASELINE.json's
+    north star counts (cost kinds: relax ankles, minimize jerk, track velocity).
 
     Domain per axis: ``Ds`` (next step displacements, width changes with the
     walking phase), ``s0`` (current support), ``CoM_dddot`` (jerk, unknown),
@@ -145,10 +149,12 @@ def biped(api, conf=None):
     form.incorporate_dynamics("bias", bias)
     form.incorporate_definitions(outputs)
     for name, goal in goals.items():
-        form.incorporate_goal(name, goal)
+        if not (reduced and name == "terminal_cost"):
+            form.incorporate_goal(name, goal)
     form.incorporate_box("stepping area", stepping_area)
     form.incorporate_box("support_polygon", support_polygon)
-    form.incorporate_box("terminal_Constraint", terminal_box)
+    if not reduced:
+        form.incorporate_box("terminal_Constraint", terminal_box)
 
     form.identify_qp_domain(["CoM_dddot_x", "Ds_x", "CoM_dddot_y", "Ds_y"])
     form.make_preview_matrices()
