@@ -109,6 +109,18 @@ int validate_tiled(const int32_t* it, const double* h_dtab, int64_t n, int64_t n
       if (r0[b + 1] < r0[b] || (r0[b + 1] > r0[b] ? kmax[b] >= r0[b + 1] - r0[b] : kmax[b] != 0))
         return MPCASM_ERR_PLAN;
   }
+  {  // the covered columns of every base variable: ascending ranges of one list, inside [0, ng + no)
+    if (!in_range(it[H_OFF_T_BCOLPTR], nbase + 1, n, H_WORDS)) return MPCASM_ERR_PLAN;
+    const int32_t* cp = it + it[H_OFF_T_BCOLPTR];
+    if (cp[0] != 0 || cp[nbase] < 0 || !in_range(it[H_OFF_T_BCOLS], cp[nbase], n, H_WORDS))
+      return MPCASM_ERR_PLAN;
+    const int32_t* cl = it + it[H_OFF_T_BCOLS];
+    for (int64_t b = 0; b < nbase; ++b) {
+      if (cp[b + 1] < cp[b]) return MPCASM_ERR_PLAN;
+      for (int64_t i = cp[b]; i < cp[b + 1]; ++i)
+        if (cl[i] < 0 || cl[i] >= ng + no || (i > cp[b] && cl[i] <= cl[i - 1])) return MPCASM_ERR_PLAN;
+    }
+  }
   auto table_ok = [&](const int32_t* ci, int64_t cols) {
     for (int64_t b = 0; b < nbase; ++b)
       for (int64_t c = 0; c < cols; ++c) {
@@ -729,6 +741,7 @@ void plan_dev_from_tables(const int32_t* it, PlanDev* out) {
   d.off_t_grow = it[H_OFF_T_GROW];
   d.off_t_srow = it[H_OFF_T_SROW]; d.t_doff_scoef = it[H_T_DOFF_SCOEF]; d.off_t_pig = it[H_OFF_T_PIG];
   d.t_ngrest = it[H_T_NGREST]; d.off_t_grest = it[H_OFF_T_GREST]; d.off_t_brow0 = it[H_OFF_T_BROW0]; d.t_toeplitz = it[H_T_TOEPLITZ];
+  d.off_t_bcolptr = it[H_OFF_T_BCOLPTR]; d.off_t_bcols = it[H_OFF_T_BCOLS];
   d.t_nbrow = d.t_ci_ok ? it[d.off_t_brow0 + d.nbase] : 0;
   d.pm_nfd = it[H_PM_NFD]; d.off_pm_map = it[H_OFF_PM_MAP]; d.off_pm_fdptr = it[H_OFF_PM_FDPTR];
   d.off_pm_op = it[H_OFF_PM_OP]; d.doff_pm_pool = it[H_DOFF_PM_POOL];

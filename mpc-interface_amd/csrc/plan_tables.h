@@ -29,7 +29,7 @@
 namespace mpcasm {
 
 constexpr int32_t PLAN_MAGIC = 0x4D504341;  // 'MPCA'
-constexpr int32_t PLAN_VERSION = 21;
+constexpr int32_t PLAN_VERSION = 22;
 
 enum HeaderWord : int {
   H_MAGIC = 0,
@@ -181,9 +181,11 @@ enum HeaderWord : int {
   H_T_NGREST,       // rows of G that ride on no stage (several axes, rows no cost reads ...)
   H_OFF_T_GREST,    // [T_NGREST] their indices, ascending
   H_OFF_T_BROW0,    // [NBASE + 1] first row of every base variable among all base rows; [NBASE] = total
+  H_OFF_T_BCOLPTR,  // [NBASE + 1] per base variable: its columns some segment covers, as a range of ...
+  H_OFF_T_BCOLS,    // ... this list of column indices in [given | unknowns] (ascending per base)
   H_T_TOEPLITZ,     // 1: every stage is TS_FLAG_TOEPLITZ (one generated group): the kernel keeps the
                     //    group's TB table in LDS and reads the matrix core's operands out of it
-  H_WORDS = 112
+  H_WORDS = 128
 };
 static_assert(H_T_TOEPLITZ < H_WORDS, "plan header");
 

@@ -103,44 +103,42 @@ __global__ __launch_bounds__(BLOCK) void lti_tables_kernel(PlanDev p, SrcTable s
 }
 
 // ---------------------------------------------------------------------------
-// pre-pass 2: d[r] = (Mg . given)[r] for every workspace row: a wavefront per row, lanes over
-// the given columns.
+// pre-pass 2: d[r] = (Mg . given)[r] for every workspace row: a thread per row (a wavefront per
+// row, lanes over the dozen given columns of a wide problem, spent 6 % of a C4 call here), the
+// given vector in LDS; the row's entries and the column tables are the same for every instance
+// (L2), a thread's loads of one entry independent of each other.
 // ---------------------------------------------------------------------------
-constexpr int D_ROWS_PER_WAVE = 4;
-
 __global__ __launch_bounds__(BLOCK) void compose_d_kernel(PlanDev p, SrcTable src,
                                                           const double* __restrict__ given,
                                                           double* __restrict__ work,
                                                           long long work_stride, int nrb) {
   __shared__ const double* s_base[NSTREAM];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  extern __shared__ __attribute__((aligned(16))) double s_given[];
+  const int tid = threadIdx.x;
   const long inst = blockIdx.x / nrb;
   const int rb = blockIdx.x - inst * nrb;
   stream_bases(p, src, inst, s_base, tid);
+  for (int c = tid; c < p.ng; c += BLOCK) s_given[c] = given[inst * p.ng + c];
   __syncthreads();
+  const int r = rb * BLOCK + tid;
+  if (r >= p.rtot) return;
   const int32_t* rowptr = p.itab + p.off_rowptr;
   const int32_t* entbase = p.itab + p.off_entbase;
   const int32_t* entk = p.itab + p.off_entk;
   const double* coef = p.dtab + p.doff_entcoef;
   const int2* cig = reinterpret_cast<const int2*>(p.itab + p.off_t_cig);
-  const double* g = given + inst * p.ng;
-  double* d = work + inst * work_stride;
-  const int r0 = (rb * WAVES + wave) * D_ROWS_PER_WAVE;
-  for (int r = r0; r < min(r0 + D_ROWS_PER_WAVE, p.rtot); ++r) {
+  double acc = 0.0;
+  for (int e = rowptr[r]; e < rowptr[r + 1]; ++e) {
+    const int k = entk[e];
+    const int2* row = cig + (size_t)entbase[e] * p.ng;
     double part = 0.0;
-    for (int e = rowptr[r]; e < rowptr[r + 1]; ++e) {
-      const int b = entbase[e], k = entk[e];
-      const double cf = coef[e];
-      for (int c = lane; c < p.ng; c += 64) {
-        const int2 ci = cig[(size_t)b * p.ng + c];
-        const double v = s_base[(unsigned)ci.y >> 24][(long)ci.x + (long)k * sext24(ci.y)];
-        part = fma(cf * v, g[c], part);
-      }
+    for (int c = 0; c < p.ng; ++c) {
+      const int2 ci = row[c];
+      part = fma(s_base[(unsigned)ci.y >> 24][(long)ci.x + (long)k * sext24(ci.y)], s_given[c], part);
     }
-    part = wave_sum(part);
-    if (lane == 0) d[r] = part;
+    acc = fma(coef[e], part, acc);
   }
+  work[inst * work_stride + r] = acc;
 }
 
 // ---------------------------------------------------------------------------
@@ -896,9 +894,10 @@ int launch_assemble_tiled(const PlanDev& p, const SrcTable& src, const double* p
     if (rc != MPCASM_OK) return rc;
   }
   if (p.rtot > 0) {
-    const unsigned nrb = ceil_div(p.rtot, WAVES * D_ROWS_PER_WAVE);
-    hipLaunchKernelGGL(compose_d_kernel, dim3(nrb * batch), dim3(BLOCK), 0, stream, p, eff, given, w,
-                       stride, (int)nrb);
+    const unsigned nrb = ceil_div(p.rtot, BLOCK);
+    if ((size_t)p.ng * sizeof(double) > 48 * 1024) return MPCASM_ERR_LIMIT;
+    hipLaunchKernelGGL(compose_d_kernel, dim3(nrb * batch), dim3(BLOCK), (size_t)p.ng * sizeof(double),
+                       stream, p, eff, given, w, stride, (int)nrb);
   }
   const int nb = (int)ceil_div(p.no, T_BLOCK);
   const int sym = p.rs_sym_any;

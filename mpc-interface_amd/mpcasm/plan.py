@@ -17,7 +17,7 @@ import numpy as np
 import scipy.sparse as sp
 
 PLAN_MAGIC = 0x4D504341
-PLAN_VERSION = 21
+PLAN_VERSION = 22
 
 # header words (csrc/plan_tables.h, enum HeaderWord)
 _H = {name: i for i, name in enumerate([
@@ -38,9 +38,9 @@ _H = {name: i for i, name in enumerate([
     "CSC_PNNZ", "OFF_CSC_P", "CSC_GNNZ", "OFF_CSC_G", "CSC_GSINGLE",
     "T_CI_OK", "T_NOP", "OFF_T_CIG", "OFF_T_CIO", "T_DOFF_DELTA", "T_NDELTA",
     "T_OK", "T_NSTAGE", "OFF_T_STAGE", "T_NLTI", "OFF_T_LTI", "OFF_T_LTI_IDS", "T_WORK",
-    "OFF_T_GROW", "OFF_T_SROW", "T_DOFF_SCOEF", "OFF_T_PIG", "T_NGREST", "OFF_T_GREST", "OFF_T_BROW0", "T_TOEPLITZ",
+    "OFF_T_GROW", "OFF_T_SROW", "T_DOFF_SCOEF", "OFF_T_PIG", "T_NGREST", "OFF_T_GREST", "OFF_T_BROW0", "OFF_T_BCOLPTR", "OFF_T_BCOLS", "T_TOEPLITZ",
 ])}
-H_WORDS = 112
+H_WORDS = 128
 assert len(_H) <= H_WORDS
 RS_NW, RS_NT = 4, 512                     # matrix wavefronts (they fetch the inputs), threads per instance
 RS_WAVES = RS_NT // 64
@@ -1539,6 +1539,10 @@ def compile_plan(form, costs=None, limits=None, lti=(), csc=None):
                  ("OFF_T_PIG", tiled["pig"].astype(np.int32)),
                  ("OFF_T_GREST", tiled["grest"].astype(np.int32)),
                  ("OFF_T_BROW0", np.asarray(list(b.base_row0) + [b.total_base_rows], dtype=np.int32))]
+    # the columns some segment of every base variable covers (everywhere else its rows are zero)
+    bcols = [np.flatnonzero(colseg >= 0) for colseg in b.colseg]
+    sections += [("OFF_T_BCOLPTR", np.cumsum([0] + [c.size for c in bcols]).astype(np.int32)),
+                 ("OFF_T_BCOLS", (np.concatenate(bcols) if bcols else np.zeros(0)).astype(np.int32))]
     sections += [("OFF_RS_DPAR", rs_dpar.reshape(-1)), ("OFF_RS_GDESC", rs_gdesc),
                  ("OFF_PM_MAP", pmprog["map"]), ("OFF_PM_FDPTR", pmprog["fd_ptr"]),
                  ("OFF_PM_OP", pmprog["ops"])]

@@ -10,6 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "mpc-interface_amd"))
 sys.path.insert(0, ROOT)
 
+import numpy as np
 import torch  # noqa: E402
 
 import bench  # noqa: E402
@@ -54,7 +55,23 @@ def main():
     t = timed(lambda: fleet.tick(g_fleet), 64, warm=4 * fleet.conf.step_samples + 4)
     print("   from hipGraphs %6d walkers  %8.3f ms per tick  %10.0f walker-ticks/s" % (B, t * 1e3, B / t))
 
-    # f2: Mg.given + Mo.optim for every definition (body.py:209-219)
+    # f2 (round 3): every row of every definition and every goal's distance straight from the
+    # sources -- no preview matrix in memory (mpcasm_preview_direct, mpcasm_goal_distance)
+    optim0 = torch.as_tensor(np.random.default_rng(1).normal(0, 0.5, [B, asm.no]), device="cuda")
+    for label, kw in (("shared S, U", {}), ("tables from per-instance (A, B)", dict(lti=["LIP"]))):
+        a2 = engine.Assembler(form, batch=B, **kw)
+        if kw:
+            a2.bind_lti("LIP", torch.as_tensor(work["A"], device="cuda"), torch.as_tensor(work["B"], device="cuda"))
+        rows = a2.preview_rows(given, optim0)
+        t = timed(lambda: a2.preview_rows(given, optim0, out=rows), 100)
+        td = timed(lambda: a2.goal_distance(form, rows), 100)
+        algo = 8 * (asm.ng + asm.no + a2.plan.pmrows) + (8 * 12 if kw else 0)
+        print("f2 rows of all definitions, %-32s %6d x %d rows  %8.3f ms  %10.0f instances/s  %6.0f GB/s "
+              "(algorithmic: given + optim%s read, rows written)"
+              % (label + ":", B, a2.plan.pmrows, t * 1e3, B / t, algo * B / t / 1e9, " + A, B" if kw else ""))
+        print("   goal distances (%d goals)   %8.3f ms" % (len(form.goals), td * 1e3))
+        del a2
+    # ... against round 2's two passes: the preview matrices through HBM, then a GEMV
     PM = asm.preview_matrices()
     optim = torch.zeros((B, asm.no), dtype=torch.float64, device="cuda")
     t = timed(lambda: asm.preview(PM, given, optim), 50)

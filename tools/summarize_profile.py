@@ -28,7 +28,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def short(name):
     for key in ("resident_spec_kernel", "resident_assemble_kernel", "fused_assemble_kernel",
                 "fill_lti_quad_kernel", "fill_ltv_row_kernel", "fill_lti_tiny_kernel",
-                "fill_lti_kernel", "fill_ltv_wave_kernel", "fill_ltv_kernel", "compose_rowsets_kernel", "hessian_kernel",
+                "toeplitz_assemble_kernel", "tiled_assemble_kernel", "preview_direct_kernel", "goal_distance_kernel", "fill_lti_kernel", "fill_ltv_wave_kernel", "fill_ltv_kernel", "compose_rowsets_kernel", "hessian_kernel",
                 "constraints_kernel", "compose_preview_kernel", "preview_kernel"):
         if key in name:
             return key
