@@ -1231,29 +1231,44 @@ int launch_jc(const PlanDev& p, const SrcTable& src, const double* params, const
   auto kernel = (g_phase_mask & 64) ? resident_assemble_kernel<JC, true, true>
                 : p.rs_nlti != 0    ? resident_assemble_kernel<JC, false, true>
                                     : resident_assemble_kernel<JC, false, false>;
-  // residency of this instantiation at this LDS size: queried once, then cached (the
-  // launch path itself makes no other runtime call, so it can be graph-captured)
-  static thread_local size_t cached_lds[3] = {0, 0, 0};
-  static thread_local int cached_per_cu[3] = {0, 0, 0}, cached_device[3] = {-1, -1, -1};
+  // residency of this instantiation at this LDS size: queried once per (instantiation, device,
+  // size) and kept -- plans of different LDS sizes that share the instantiation (the 34- and
+  // 36-unknown buckets of a walker fleet) alternate without another runtime call, so the launch
+  // path can be graph-captured.  The dynamic-LDS attribute of the function is only ever RAISED, to
+  // the largest size seen: a replayed graph node of the larger plan must not meet a lowered limit.
+  struct Residency {
+    int device;
+    size_t lds;
+    int per_cu;
+  };
+  constexpr int KEPT = 8;
+  static thread_local Residency kept[3][KEPT];
+  static thread_local int nkept[3] = {0, 0, 0};
+  static thread_local size_t granted[3][16];  // per device (the first 16): attribute in force
   const int slot = (g_phase_mask & 64) ? 2 : (p.rs_nlti != 0 ? 1 : 0);
   int device = 0;
   (void)hipGetDevice(&device);  // (the attribute and the occupancy belong to one device)
-  if (cached_lds[slot] != lds_bytes || cached_device[slot] != device) {
-    if (lds_bytes > 64 * 1024) {
+  int found = -1;
+  for (int i = 0; i < nkept[slot]; ++i)
+    if (kept[slot][i].device == device && kept[slot][i].lds == lds_bytes) found = kept[slot][i].per_cu;
+  if (found < 0) {
+    size_t& have = granted[slot][device & 15];
+    if (lds_bytes > 64 * 1024 && lds_bytes > have) {
       *err = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
       if (*err != hipSuccess) return MPCASM_ERR_HIP;
+      have = lds_bytes;
     }
     int n = 0;
     *err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, NT, lds_bytes);
     if (*err != hipSuccess) return MPCASM_ERR_HIP;
-    cached_per_cu[slot] = n;
-    cached_lds[slot] = lds_bytes;
-    cached_device[slot] = device;
+    found = n;
+    const int at = nkept[slot] < KEPT ? nkept[slot]++ : (int)(lds_bytes % KEPT);  // (full: replace one)
+    kept[slot][at] = Residency{device, lds_bytes, n};
   }
   // persistent grid: exactly the workgroups that are resident at once, never more
   // than there are instances
-  int per_cu = cached_per_cu[slot];
+  int per_cu = found;
   if (per_cu < 1) return MPCASM_ERR_LIMIT;
   if (t_per_cu > 0 && t_per_cu < per_cu) per_cu = t_per_cu;
   long grid = (long)num_cus * per_cu;

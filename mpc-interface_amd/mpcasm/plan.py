@@ -401,11 +401,22 @@ def formulation_key(form):
                     tuple(np.shape(M) for M in getattr(dyn, "matrices", ()))))
     for var, combo in form.definitions.items():
         if var in form.of:
+            dyn = form.dynamics[form.of[var]]
+            state_ID, domain_ID = getattr(dyn, "state_ID", {}), getattr(dyn, "domain_ID", {})
             items = []
             for dep, m in combo.items():
                 m = np.asarray(m, dtype=np.float64)
                 eye = m.ndim == 2 and m.shape[0] == m.shape[1] and np.array_equal(m, np.eye(m.shape[0]))
-                items.append((dep, m.shape, eye))
+                # what add_base decides from the numbers: the coefficient IS the slice of the
+                # dynamics' horizon matrix (a rebindable source) or a block of its own (a constant
+                # source, re-read from the definition) -- a plan compiled for one is wrong for the other
+                gather = False
+                if var in state_ID and dep in domain_ID:
+                    src = np.asarray(dyn.matrices[domain_ID[dep]])
+                    sID = state_ID[var]
+                    gather = bool(src.ndim == 3 and sID < src.shape[2] and m.shape == src.shape[:2]
+                                  and np.array_equal(m, src[..., sID]))
+                items.append((dep, m.shape, eye, gather))
             key.append((var, form.of[var], tuple(items)))
         else:
             key.append((var, tuple((dep, _digest(m)) for dep, m in combo.items())))
