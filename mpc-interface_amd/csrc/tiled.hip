@@ -581,13 +581,34 @@ __device__ __forceinline__ double lds_f64(const char* lds, unsigned byte_off) {
   return *reinterpret_cast<const double*>(lds + byte_off);
 }
 
-template <int N>
+// Which of a wavefront's 4 x 4 tiles a stage of class N multiplies, by the wavefront's role:
+//   FULL  every pair of the first N tiles (a block off the diagonal);
+//   TRI   pairs ta <= tb only: a quadrant ON the diagonal of a diagonal block of a symmetric P (the
+//         other triangle is its mirror image: written, not computed);
+//   TOP / BOT  the quadrant above the diagonal of a diagonal block, shared by the wavefront that owns
+//         it (tile rows 0, 1) and the one whose own quadrant -- below the diagonal -- is a mirror
+//         image (tile rows 2, 3).
+// A diagonal block then takes 2 N^2 + N products per four k-steps instead of 4 N^2.
+enum Role { ROLE_FULL = 0, ROLE_TRI = 1, ROLE_TOP = 2, ROLE_BOT = 3 };
+template <int ROLE, int N>
+struct TileRange {
+  static constexpr int a0 = ROLE == ROLE_BOT ? (N < 2 ? N : 2) : 0;
+  static constexpr int a1 = ROLE == ROLE_TOP ? (N < 2 ? N : 2) : N;
+  static constexpr bool tri = ROLE == ROLE_TRI;
+  __device__ static constexpr bool has(int ta, int tb) {
+    return ta >= a0 && ta < a1 && tb < N && (!tri || ta <= tb);
+  }
+};
+
+template <int ROLE, int N>
 __device__ __forceinline__ void mfma_toeplitz(f64x4 (&acc)[4][4], const char* lds,
                                               const unsigned (&pa)[4], const unsigned (&pb)[4],
                                               const unsigned (&ma)[4], const unsigned (&mb)[4],
                                               unsigned ua, unsigned ub, double sa, double sb, int lk,
                                               int nrows) {
-  unsigned aa[N], ab[N];
+  using R = TileRange<ROLE, N>;
+  if constexpr (R::a0 >= R::a1) return;
+  unsigned aa[4], ab[4];
 #pragma unroll
   for (int t = 0; t < N; ++t) {
     aa[t] = pa[t] + (ua & ma[t]);
@@ -596,17 +617,21 @@ __device__ __forceinline__ void mfma_toeplitz(f64x4 (&acc)[4][4], const char* ld
 #pragma unroll
   for (int kk = 0; kk < TK; kk += 4) {
     const bool live = kk + lk < nrows;  // (a term's last stage may be short: rows behind it are zeros)
-    double a[N], b[N];
+    double a[4], b[4];
+#pragma unroll
+    for (int t = R::a0; t < R::a1; ++t) {
+      const double va = lds_f64(lds, aa[t] + kk * 8) * sa;
+      a[t] = live ? va : 0.0;
+    }
 #pragma unroll
     for (int t = 0; t < N; ++t) {
-      const double va = lds_f64(lds, aa[t] + kk * 8) * sa, vb = lds_f64(lds, ab[t] + kk * 8) * sb;
-      a[t] = live ? va : 0.0;
+      const double vb = lds_f64(lds, ab[t] + kk * 8) * sb;
       b[t] = live ? vb : 0.0;
     }
 #pragma unroll
-    for (int ta = 0; ta < N; ++ta)
+    for (int ta = R::a0; ta < R::a1; ++ta)
 #pragma unroll
-      for (int tb = 0; tb < N; ++tb) acc[ta][tb] = mfma_f64_16x16x4(a[ta], b[tb], acc[ta][tb]);
+      for (int tb = R::tri ? ta : 0; tb < N; ++tb) acc[ta][tb] = mfma_f64_16x16x4(a[ta], b[tb], acc[ta][tb]);
   }
 }
 
@@ -660,7 +685,12 @@ __global__ __launch_bounds__(BLOCK, 2) void toeplitz_assemble_kernel(
   }
   const unsigned zero_off = (unsigned)tbn * 8u, d_off = (unsigned)(tbn + nzero) * 8u;
   const int li = lane & 15, lk = lane >> 4;
-  const int wr = wave >> 1, wc = wave & 1;
+  // the wavefront's role and the 64 x 64 quadrant (wr, wc) of the block its tiles belong to: in a
+  // diagonal block of a symmetric P the quadrant below the diagonal is a mirror image, so its
+  // wavefront helps with the one above (tile rows 2, 3)
+  const bool tri_block = diag && sym;
+  const int role = !tri_block ? ROLE_FULL : (wave == 0 || wave == 3 ? ROLE_TRI : (wave == 1 ? ROLE_TOP : ROLE_BOT));
+  const int wr = (tri_block && wave == 2) ? 0 : wave >> 1, wc = (tri_block && wave == 2) ? 1 : wave & 1;
   // ---- per lane: where its columns sit in the table (state-independent part) ---------------
   const int32_t* cio = p.itab + p.off_t_cio;
   const int base0 = stages[TS_BASE] & 0xFFFF, sboff0 = stages[TS_SBOFFA];
@@ -693,7 +723,8 @@ __global__ __launch_bounds__(BLOCK, 2) void toeplitz_assemble_kernel(
   double2 qacc{0.0, 0.0};
 
   int s = 0;
-  auto run_class = [&](auto cls_tag) __attribute__((always_inline)) {
+  auto run_class = [&](auto role_tag, auto cls_tag) __attribute__((always_inline)) {
+    constexpr int ROLE = decltype(role_tag)::value;
     constexpr int N = decltype(cls_tag)::value;
     for (; s < p.t_nstage; ++s) {
       const int32_t* rec = stages + s * T_STAGE_WORDS;
@@ -749,14 +780,32 @@ __global__ __launch_bounds__(BLOCK, 2) void toeplitz_assemble_kernel(
         }
       }
       if constexpr (N > 0)
-        if (for_p) mfma_toeplitz<N>(acc, lds, pa, pbt, ma, mb, ua, ub, w * ca, cb, lk, nrows);
+        if (for_p) mfma_toeplitz<ROLE, N>(acc, lds, pa, pbt, ma, mb, ua, ub, w * ca, cb, lk, nrows);
     }
   };
-  run_class(std::integral_constant<int, 0>{});
-  run_class(std::integral_constant<int, 1>{});
-  run_class(std::integral_constant<int, 2>{});
-  run_class(std::integral_constant<int, 3>{});
-  run_class(std::integral_constant<int, 4>{});
+  // which tiles of acc hold results, by role (what the epilogue writes): every class's union
+  unsigned computed = 0;  // bit ta * 4 + tb
+  auto run_role = [&](auto role_tag) __attribute__((always_inline)) {
+    constexpr int ROLE = decltype(role_tag)::value;
+    run_class(role_tag, std::integral_constant<int, 0>{});
+    run_class(role_tag, std::integral_constant<int, 1>{});
+    run_class(role_tag, std::integral_constant<int, 2>{});
+    run_class(role_tag, std::integral_constant<int, 3>{});
+    run_class(role_tag, std::integral_constant<int, 4>{});
+#pragma unroll
+    for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+      for (int tb = 0; tb < 4; ++tb)
+        if (TileRange<ROLE, 4>::has(ta, tb)) computed |= 1u << (ta * 4 + tb);
+  };
+  if (role == ROLE_FULL)
+    run_role(std::integral_constant<int, ROLE_FULL>{});
+  else if (role == ROLE_TRI)
+    run_role(std::integral_constant<int, ROLE_TRI>{});
+  else if (role == ROLE_TOP)
+    run_role(std::integral_constant<int, ROLE_TOP>{});
+  else
+    run_role(std::integral_constant<int, ROLE_BOT>{});
 
   // ---- rows of G that ride on no stage, h ------------------------------------------------
   if (want_g) {
@@ -819,11 +868,14 @@ __global__ __launch_bounds__(BLOCK, 2) void toeplitz_assemble_kernel(
     __syncthreads();
   }
   double* Pb = P + (size_t)inst * no * no;
-  const bool mirror = sym && !diag;
+  // mirror images: everything of a block off the diagonal of a symmetric P; in a diagonal block
+  // the tiles above the tile diagonal (a tile ON it holds both of its triangles)
 #pragma unroll
   for (int ta = 0; ta < 4; ++ta)
 #pragma unroll
-    for (int tb = 0; tb < 4; ++tb)
+    for (int tb = 0; tb < 4; ++tb) {
+      if (!((computed >> (ta * 4 + tb)) & 1u)) continue;
+      const bool mirror = sym && (!diag || wr != wc || ta != tb);
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
         const int row = bi * T_BLOCK + wr * 64 + ta * 16 + lk + 4 * reg;
@@ -835,6 +887,7 @@ __global__ __launch_bounds__(BLOCK, 2) void toeplitz_assemble_kernel(
           if (mirror) Pb[(size_t)col * no + row] = v;
         }
       }
+    }
   if (diag && tid < T_BLOCK) {  // the gradient: the four wavefronts hold the sums over their rows
     const int c = bi * T_BLOCK + tid;
     if (c < no) {
