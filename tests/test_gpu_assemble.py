@@ -198,6 +198,18 @@ def test_biped_batch_c2(gpu_api):
     # aims here, so it is the same matrix for every instance, and symmetric
     assert np.abs(P - P[0]).max() == 0.0
     assert np.abs(P[0] - P[0].T).max() <= 1e-12 * np.abs(P[0]).max()
+    # ... G does not depend on given either, and q, h are affine in it, for EVERY instance (its own
+    # aims and centres): f(g) + f(g') = f(g + g') + f(0)
+    import torch
+
+    rng = np.random.default_rng(77)
+    g1 = rng.normal(0, 0.1, given.shape)
+    _, q1, G1, h1 = (t.cpu().numpy().copy() for t in asm.assemble(g1))
+    _, q0, _, h0 = (t.cpu().numpy().copy() for t in asm.assemble(np.zeros_like(g1)))
+    _, qs, Gs, hs = (t.cpu().numpy().copy() for t in asm.assemble(given + g1))
+    assert np.array_equal(G1, G) and np.array_equal(Gs, G)
+    assert np.abs((q + q1) - (qs + q0)).max() <= 1e-12 * np.abs(qs).max()
+    assert np.abs((h + h1) - (hs + h0)).max() <= 1e-12 * np.abs(hs).max()
 
 
 def test_biped_batch_per_instance_dynamics(gpu_api):
