@@ -59,46 +59,60 @@ __device__ __forceinline__ void stream_bases(const PlanDev& p, const SrcTable& s
 // ---------------------------------------------------------------------------
 constexpr int LTI_XMAX = 2048;  // n (m + n) doubles of one X
 
+constexpr int LTI_HIST = 16;  // steps of the input columns kept in LDS before they are written out
+
 __global__ __launch_bounds__(BLOCK) void lti_tables_kernel(PlanDev p, SrcTable src,
                                                            double* __restrict__ work,
                                                            long long work_stride) {
-  __shared__ double sA[LTI_XMAX];
-  __shared__ double sX[2][LTI_XMAX];
+  // dynamic LDS, sized for the group at hand: A | X twice | the input columns of LTI_HIST steps
+  extern __shared__ __attribute__((aligned(16))) double lti_lds[];
   const int tid = threadIdx.x;
   const long inst = blockIdx.x / p.t_nlti;
   const int g = blockIdx.x - inst * p.t_nlti;
   const int32_t* rec = p.itab + p.off_t_lti + g * T_LTI_WORDS;
   const int n = rec[TL_N], m = rec[TL_M], N = rec[TL_HORIZON];
+  double* sA = lti_lds;
+  double* sX0 = lti_lds + n * n;
+  double* sX1 = sX0 + n * (m + n);
+  double* hist = sX1 + n * (m + n);  // [n m][LTI_HIST]
   const int32_t* ids = p.itab + p.off_t_lti_ids + rec[TL_IDS];
   const double* A = src.ptr[ids[0]] + inst * src.stride[ids[0]];
   const double* B = src.ptr[ids[1]] + inst * src.stride[ids[1]];
   double* TA = work + inst * work_stride + rec[TL_TA];
   double* TB = work + inst * work_stride + rec[TL_TB];
-  const int w = m + n, elems = n * w;
+  const int w = m + n, elems = n * w, nm = n * m;
   for (int e = tid; e < n * n; e += BLOCK) sA[e] = A[e];
   for (int e = tid; e < elems; e += BLOCK) {
     const int i = e / w, c = e - i * w;
-    sX[0][e] = c < m ? B[i * m + c] : A[i * n + (c - m)];
+    sX0[e] = c < m ? B[i * m + c] : A[i * n + (c - m)];
   }
+  // the zeros in front of every row of TB: whole runs of N doubles
+  for (int e = tid; e < nm * N; e += BLOCK) TB[(size_t)(e / N) * 2 * N + (e % N)] = 0.0;
   __syncthreads();
   for (int d = 0; d < N; ++d) {
-    const double* X = sX[d & 1];
-    double* Xn = sX[(d + 1) & 1];
+    const double* X = (d & 1) ? sX1 : sX0;
+    double* Xn = (d & 1) ? sX0 : sX1;
     for (int e = tid; e < elems; e += BLOCK) {
       const int i = e / w, c = e - i * w;
       const double v = X[e];
-      if (c < m) {
-        double* row = TB + (size_t)(i * m + c) * 2 * N;
-        row[N + d] = v;
-        row[N - 1 - d] = 0.0;
-      } else {
-        TA[(size_t)d * n * n + (size_t)(c - m) * n + i] = v;  // S[k][j][i] = (A^{k+1})[i][j]
-      }
+      if (c < m)
+        hist[(i * m + c) * LTI_HIST + (d % LTI_HIST)] = v;  // (A^d B)[i][c], written out below
+      else
+        TA[(size_t)d * n * n + (size_t)(c - m) * n + i] = v;  // S[k][j][i] = (A^{k+1})[i][j]: a contiguous block per step
       double acc = 0.0;
       for (int t = 0; t < n; ++t) acc = fma(sA[i * n + t], X[t * w + c], acc);
       Xn[e] = acc;
     }
-    __syncthreads();
+    lds_barrier();  // (orders LDS only: the step's stores to the scratch stream on behind it)
+    if ((d + 1) % LTI_HIST == 0 || d + 1 == N) {
+      // LTI_HIST steps of every row of TB at once: whole cache lines instead of one double per step
+      const int d0 = d - d % LTI_HIST, cnt = d + 1 - d0;
+      for (int e = tid; e < nm * cnt; e += BLOCK) {
+        const int row = e / cnt, k = e - row * cnt;
+        TB[(size_t)row * 2 * N + N + d0 + k] = hist[row * LTI_HIST + k];
+      }
+      lds_barrier();
+    }
   }
 }
 
@@ -577,6 +591,20 @@ __global__ __launch_bounds__(BLOCK, 2) void tiled_assemble_kernel(
 // Diagonal workgroups read the same windows once more for the gradient and the riding rows of G.
 // LDS: TB | zeros (what columns outside the system's inputs read) | d.
 // ---------------------------------------------------------------------------
+// One LDS-DMA load (global_load_lds_dwordx4): every active lane's 16 bytes from its own global
+// address to lds_base + lane * 16, no register in between.  M0 carries the LDS base; it is
+// compiler-reserved, so it is saved, set and restored inside the one statement.  The compiler does
+// not count this load: the issuing wave waits for it itself (s_waitcnt vmcnt(0)).
+__device__ __forceinline__ void lds_dma16(const void* gsrc, unsigned lds_base) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_base)
+      : "memory");
+}
+
 __device__ __forceinline__ double lds_f64(const char* lds, unsigned byte_off) {
   return *reinterpret_cast<const double*>(lds + byte_off);
 }
@@ -638,29 +666,17 @@ __device__ __forceinline__ void mfma_toeplitz(f64x4 (&acc)[4][4], const char* ld
 __global__ __launch_bounds__(BLOCK, 2) void toeplitz_assemble_kernel(
     PlanDev p, SrcTable src, const double* __restrict__ params, const double* __restrict__ work,
     long long work_stride, double* __restrict__ P, double* __restrict__ q, double* __restrict__ G,
-    double* __restrict__ h, int nb, int npairs, int sym, int batch, int tbn, int nzero) {
+    double* __restrict__ h, int nb, int npairs, int sym, int batch, int tbn, int nzero, int phases) {
+  // (phases: MPCASM_OPT_PHASE_MASK, a timing-only ablation for profiles -- bit 1 the matrix-core
+  // products, bit 2 the gradient, bit 3 the rows of G, bit 5 the stores of P; all set in production)
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const unsigned xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const long inst = (long)(slot / npairs) * 8 + xcd;
-  int pr = slot % npairs;
+  // ONE workgroup per instance: it takes the blocks of P one after the other, with the table (and
+  // everything else of the set-up) in LDS once -- a workgroup per block paid the 74 KB copy, the
+  // column look-ups and the launch six times per C4 instance (a fifth of a call)
+  const long inst = blockIdx.x;
   if (inst >= batch) return;
-  int bi = 0, bj = 0;
-  if (sym) {
-    int rowlen = nb;
-    while (pr >= rowlen) {
-      pr -= rowlen;
-      --rowlen;
-      ++bi;
-    }
-    bj = bi + pr;
-  } else {
-    bi = pr / nb;
-    bj = pr - bi * nb;
-  }
-  const bool diag = bi == bj;
-  if (!P && !diag) return;
   const int no = p.no;
   const double* pb = params + (size_t)inst * p.nparams;
   const double* dvec = work + inst * work_stride;
@@ -672,26 +688,33 @@ __global__ __launch_bounds__(BLOCK, 2) void toeplitz_assemble_kernel(
   const int first_u = ids[0];
   // ---- the table, the zeros and d into LDS ------------------------------------------------
   {
-    const double* tb = src.ptr[first_u] + inst * src.stride[first_u];  // (16-byte aligned: the scratch)
-    double2* dst = reinterpret_cast<double2*>(lds);
-    const double2* from = reinterpret_cast<const double2*>(tb);
-    for (int e = tid; e < tbn / 2; e += BLOCK) dst[e] = from[e];
+    // LDS-DMA: the wavefronts take the table's 1 KB chunks in turn, every load in flight at once
+    // (copied through registers a thread's 18 loads came back one after the other: 38 us of a
+    // workgroup's ~200)
+    const char* tb = reinterpret_cast<const char*>(src.ptr[first_u] + inst * src.stride[first_u]);
+    const unsigned lds0 = (unsigned)(uintptr_t)lds;  // (the LDS byte address: low half of the flat one)
+    const unsigned tb_bytes = (unsigned)tbn * 8u;    // (a multiple of 16; the scratch is 16-byte aligned)
+    for (unsigned c0 = (unsigned)wave * 1024u; c0 < tb_bytes; c0 += WAVES * 1024u) {
+      const unsigned off = c0 + (unsigned)lane * 16u;
+      if (off < tb_bytes) lds_dma16(tb + off, __builtin_amdgcn_readfirstlane(lds0 + c0));
+    }
     double* z = reinterpret_cast<double*>(lds) + tbn;
     for (int e = tid; e < nzero; e += BLOCK) z[e] = 0.0;
-    double* dl = z + nzero;
-    if (diag && P)
-      for (int e = tid; e < p.rtot; e += BLOCK) dl[e] = dvec[e];
     if (tid * 8 < p.nparams) asm volatile("" ::"v"(pb[tid * 8]));  // (parameters: lines into L2)
   }
   const unsigned zero_off = (unsigned)tbn * 8u, d_off = (unsigned)(tbn + nzero) * 8u;
+  // d (behind the table and the zeros; the same LDS serves the gradient's reduction at the end of
+  // a diagonal block, so it is fetched again before the next one)
+  auto fetch_d = [&]() __attribute__((always_inline)) {
+    const char* dsrc = reinterpret_cast<const char*>(dvec);
+    const unsigned d_bytes = (unsigned)(p.rtot + (p.rtot & 1)) * 8u, d0 = (unsigned)(uintptr_t)lds + d_off;
+    for (unsigned c0 = (unsigned)wave * 1024u; c0 < d_bytes; c0 += WAVES * 1024u) {
+      const unsigned off = c0 + (unsigned)lane * 16u;
+      if (off < d_bytes) lds_dma16(dsrc + off, __builtin_amdgcn_readfirstlane(d0 + c0));
+    }
+  };
+  bool d_stale = P != nullptr;
   const int li = lane & 15, lk = lane >> 4;
-  // the wavefront's role and the 64 x 64 quadrant (wr, wc) of the block its tiles belong to: in a
-  // diagonal block of a symmetric P the quadrant below the diagonal is a mirror image, so its
-  // wavefront helps with the one above (tile rows 2, 3)
-  const bool tri_block = diag && sym;
-  const int role = !tri_block ? ROLE_FULL : (wave == 0 || wave == 3 ? ROLE_TRI : (wave == 1 ? ROLE_TOP : ROLE_BOT));
-  const int wr = (tri_block && wave == 2) ? 0 : wave >> 1, wc = (tri_block && wave == 2) ? 1 : wave & 1;
-  // ---- per lane: where its columns sit in the table (state-independent part) ---------------
   const int32_t* cio = p.itab + p.off_t_cio;
   const int base0 = stages[TS_BASE] & 0xFFFF, sboff0 = stages[TS_SBOFFA];
   auto column = [&](int col, unsigned extra, unsigned& part, unsigned& mask) __attribute__((always_inline)) {
@@ -700,6 +723,37 @@ __global__ __launch_bounds__(BLOCK, 2) void toeplitz_assemble_kernel(
     part = valid ? (unsigned)(ci.x - sboff0) * 8u + extra : zero_off + extra;
     mask = valid ? 0xFFFFFFFFu : 0u;
   };
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's LDS-DMA loads have landed
+
+  for (int job = 0; job < npairs; ++job) {
+  int bi = 0, bj = 0;
+  if (sym) {  // job -> block pair (bi <= bj)
+    int pr = job, rowlen = nb;
+    while (pr >= rowlen) {
+      pr -= rowlen;
+      --rowlen;
+      ++bi;
+    }
+    bj = bi + pr;
+  } else {
+    bi = job / nb;
+    bj = job - bi * nb;
+  }
+  const bool diag = bi == bj;
+  if (!P && !diag) continue;  // only the constraints are wanted: diagonal blocks write them
+  if (diag && d_stale) {
+    __syncthreads();  // (nobody still reads the partial sums of the diagonal block before)
+    fetch_d();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    d_stale = false;
+  }
+  // the wavefront's role and the 64 x 64 quadrant (wr, wc) of the block its tiles belong to: in a
+  // diagonal block of a symmetric P the quadrant below the diagonal is a mirror image, so its
+  // wavefront helps with the one above (tile rows 2, 3)
+  const bool tri_block = diag && sym;
+  const int role = !tri_block ? ROLE_FULL : (wave == 0 || wave == 3 ? ROLE_TRI : (wave == 1 ? ROLE_TOP : ROLE_BOT));
+  const int wr = (tri_block && wave == 2) ? 0 : wave >> 1, wc = (tri_block && wave == 2) ? 1 : wave & 1;
+  // ---- per lane: where its columns sit in the table (state-independent part) ---------------
   unsigned pa[4], pbt[4], ma[4], mb[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
@@ -713,7 +767,7 @@ __global__ __launch_bounds__(BLOCK, 2) void toeplitz_assemble_kernel(
   column(colA, 0u, pq0, mq0);
   column(colA + 1, 0u, pq1, mq1);
   const bool want_g = G != nullptr && diag;
-  __syncthreads();
+  __syncthreads();  // (the table and d are in place; the block before is done with the LDS it borrowed)
 
   f64x4 acc[4][4];
 #pragma unroll
@@ -722,27 +776,49 @@ __global__ __launch_bounds__(BLOCK, 2) void toeplitz_assemble_kernel(
     for (int b = 0; b < 4; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
   double2 qacc{0.0, 0.0};
 
+  // The stage records are read one stage ahead (a record is 64 bytes through the scalar cache: its
+  // trip is over by the time the stage before has been multiplied; read where they are used, the
+  // 288 records of a C4 instance's six blocks cost a tenth of the call in waits alone).
+  struct Rec {
+    int4 a, b, c, d;  // the 16 words (TS_*)
+    double ca, cb;
+  };
+  auto load_rec = [&](int sx) __attribute__((always_inline)) {
+    const int4* r4 = reinterpret_cast<const int4*>(stages + (size_t)sx * T_STAGE_WORDS);
+    Rec r;
+    r.a = r4[0];
+    r.b = r4[1];
+    r.c = r4[2];
+    r.d = r4[3];
+    r.ca = scoef[(sx * 2 + 0) * TK];
+    r.cb = scoef[(sx * 2 + 1) * TK];
+    return r;
+  };
   int s = 0;
+  Rec cur = load_rec(0);
   auto run_class = [&](auto role_tag, auto cls_tag) __attribute__((always_inline)) {
     constexpr int ROLE = decltype(role_tag)::value;
     constexpr int N = decltype(cls_tag)::value;
-    for (; s < p.t_nstage; ++s) {
-      const int32_t* rec = stages + s * T_STAGE_WORDS;
-      const int info = rec[TS_INFO];
+    while (s < p.t_nstage) {
+      const int info = cur.a.w;  // TS_INFO
       if ((info >> 16) != N) break;
+      const Rec rec = cur;
+      ++s;
+      cur = load_rec(s < p.t_nstage ? s : 0);  // (in flight while this stage is worked on)
+      const int sx = s - 1;
       const int fl = (info >> 8) & 255, nrows = info & 255;
-      const unsigned ta = block_tiles((unsigned)rec[TS_MASKA_LO], (unsigned)rec[TS_MASKA_HI], bi);
-      const unsigned tb = block_tiles((unsigned)rec[TS_MASKB_LO], (unsigned)rec[TS_MASKB_HI], bj);
-      const bool for_p = P && (fl & TS_FLAG_P) && ta && tb;
-      const bool for_q = diag && P && ta, for_g = want_g && (fl & TS_FLAG_G);
+      const unsigned ta = block_tiles((unsigned)rec.b.z, (unsigned)rec.b.w, bi);  // TS_MASKA_*
+      const unsigned tb = block_tiles((unsigned)rec.c.x, (unsigned)rec.c.y, bj);  // TS_MASKB_*
+      const bool for_p = P && (fl & TS_FLAG_P) && ta && tb && (phases & 2);
+      const bool for_q = diag && P && ta && (phases & 4), for_g = want_g && (fl & TS_FLAG_G) && (phases & 8);
       if (!for_p && !for_q && !for_g) continue;
-      const unsigned ua = (unsigned)rec[TS_UA] * 8u, ub = (unsigned)rec[TS_UB] * 8u;
-      const double ca = scoef[(s * 2 + 0) * TK], cb = scoef[(s * 2 + 1) * TK];
-      const double w = P ? pb[rec[TS_WPARAM]] : 0.0;
+      const unsigned ua = (unsigned)rec.d.x * 8u, ub = (unsigned)rec.d.y * 8u;  // TS_UA, TS_UB
+      const double ca = rec.ca, cb = rec.cb;
+      const double w = P ? pb[rec.b.x] : 0.0;  // TS_WPARAM
       if (for_q || for_g) {
-        const double aim = pb[rec[TS_AIMPARAM]];
+        const double aim = pb[rec.b.y];  // TS_AIMPARAM
         const double scale = (fl & TS_FLAG_HALF) ? 0.5 : 1.0;
-        const int drow = rec[TS_DROW];
+        const int drow = rec.a.z;  // TS_DROW
         // this wavefront's four rows: the riding rows of G and their arrows first, all at once
         // (two dependent trips through the scalar cache for the lot, not two per row)
         int4 pg[TK / WAVES];
@@ -750,7 +826,7 @@ __global__ __launch_bounds__(BLOCK, 2) void toeplitz_assemble_kernel(
 #pragma unroll
         for (int rr = 0; rr < TK / WAVES; ++rr) {
           const int i = wave + WAVES * rr;
-          pg[rr] = (for_g && i < nrows) ? pigs[s * TK + i] : int4{-1, 0, -1, 0};
+          pg[rr] = (for_g && i < nrows) ? pigs[sx * TK + i] : int4{-1, 0, -1, 0};
         }
 #pragma unroll
         for (int rr = 0; rr < TK / WAVES; ++rr) {
@@ -798,7 +874,9 @@ __global__ __launch_bounds__(BLOCK, 2) void toeplitz_assemble_kernel(
       for (int tb = 0; tb < 4; ++tb)
         if (TileRange<ROLE, 4>::has(ta, tb)) computed |= 1u << (ta * 4 + tb);
   };
-  if (role == ROLE_FULL)
+  if (!(phases & 1))
+    ;  // (profiling: no stage loop at all)
+  else if (role == ROLE_FULL)
     run_role(std::integral_constant<int, ROLE_FULL>{});
   else if (role == ROLE_TRI)
     run_role(std::integral_constant<int, ROLE_TRI>{});
@@ -854,14 +932,15 @@ __global__ __launch_bounds__(BLOCK, 2) void toeplitz_assemble_kernel(
         h[(size_t)inst * p.nc + R] = (pb[x[RR_EXTREME]] + ac) - ad;
       }
   }
-  if (!P) return;
+  if (!P) continue;
 
-  double* part = reinterpret_cast<double*>(lds);  // (the table is no longer needed)
+  double* part = reinterpret_cast<double*>(lds + d_off);  // (d is no longer needed by this block)
   double dPc = 0.0, dqc = 0.0;  // the diagonal gterms on column bi * T_BLOCK + tid
   if (diag && tid < T_BLOCK && bi * T_BLOCK + tid < no)
     diagonal_of_column(p, pb, bi * T_BLOCK + tid, dPc, dqc);
   if (diag) {  // ... and the wavefronts' partial gradients, through LDS
     __syncthreads();
+    d_stale = true;
     if (tid < T_BLOCK) part[WAVES * T_BLOCK + tid] = dPc;
     part[wave * T_BLOCK + lane * 2] = qacc.x;
     part[wave * T_BLOCK + lane * 2 + 1] = qacc.y;
@@ -874,7 +953,7 @@ __global__ __launch_bounds__(BLOCK, 2) void toeplitz_assemble_kernel(
   for (int ta = 0; ta < 4; ++ta)
 #pragma unroll
     for (int tb = 0; tb < 4; ++tb) {
-      if (!((computed >> (ta * 4 + tb)) & 1u)) continue;
+      if (!((computed >> (ta * 4 + tb)) & 1u) || !(phases & 32)) continue;
       const bool mirror = sym && (!diag || wr != wc || ta != tb);
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
@@ -897,11 +976,14 @@ __global__ __launch_bounds__(BLOCK, 2) void toeplitz_assemble_kernel(
       q[(size_t)inst * no + c] = sum + dqc;
     }
   }
+  }  // (the next block of this instance)
 }
 
 inline unsigned ceil_div(unsigned a, unsigned b) { return (a + b - 1) / b; }
 
 }  // namespace
+
+extern int g_phase_mask;  // fused.hip (MPCASM_OPT_PHASE_MASK)
 
 bool tiled_eligible(const PlanDev& p) { return p.t_ok != 0 && p.no >= T_BLOCK; }
 
@@ -930,7 +1012,13 @@ int launch_lti_tables(const PlanDev& p, const SrcTable& src, double* w, int batc
     eff->ptr[ids[m]] = w + rec[TL_TA];
     eff->stride[ids[m]] = stride;
   }
-  hipLaunchKernelGGL(lti_tables_kernel, dim3((unsigned)batch * p.t_nlti), dim3(BLOCK), 0, stream, p,
+  size_t lds = 0;
+  for (int g = 0; g < p.t_nlti; ++g) {
+    const int32_t* rec = h_itab + p.off_t_lti + g * T_LTI_WORDS;
+    const size_t n = rec[TL_N], m = rec[TL_M];
+    lds = std::max(lds, (n * n + 2 * n * (m + n) + n * m * LTI_HIST) * sizeof(double));
+  }
+  hipLaunchKernelGGL(lti_tables_kernel, dim3((unsigned)batch * p.t_nlti), dim3(BLOCK), lds, stream, p,
                      src, w, stride);
   return MPCASM_OK;
 }
@@ -960,8 +1048,10 @@ int launch_assemble_tiled(const PlanDev& p, const SrcTable& src, const double* p
     // every stage is a window of the one generated group's table: operands straight out of LDS
     const int32_t* rec = h_itab + p.off_t_lti;
     const int tbn = rec[TL_N] * rec[TL_M] * 2 * rec[TL_HORIZON];
-    const int nzero = std::max(rec[TL_HORIZON], 16) + 16;
-    const size_t lds = ((size_t)tbn + nzero + p.rtot + (p.rtot & 1)) * sizeof(double);
+    const int nzero = (std::max(rec[TL_HORIZON], 16) + 16 + 1) & ~1;  // (even: what follows stays 16-byte aligned)
+    // (behind the table and the zeros: d, and at the end of a diagonal block the gradient's partial
+    // sums of four wavefronts + the diagonal gterms of its T_BLOCK columns)
+    const size_t lds = ((size_t)tbn + nzero + std::max(p.rtot + (p.rtot & 1), (WAVES + 1) * T_BLOCK)) * sizeof(double);
     if (lds <= (size_t)RESIDENT_LDS_LIMIT && (rec[TL_TB] & 1) == 0 && (stride & 1) == 0) {
       static thread_local size_t granted = 0;
       if (lds > granted) {
@@ -970,8 +1060,9 @@ int launch_assemble_tiled(const PlanDev& p, const SrcTable& src, const double* p
         if (*err != hipSuccess) return MPCASM_ERR_HIP;
         granted = RESIDENT_LDS_LIMIT;
       }
-      hipLaunchKernelGGL(toeplitz_assemble_kernel, dim3(groups * 8 * (unsigned)npairs), dim3(BLOCK), lds,
-                         stream, p, eff, params, w, stride, P, q, G, h, nb, npairs, sym, batch, tbn, nzero);
+      hipLaunchKernelGGL(toeplitz_assemble_kernel, dim3((unsigned)batch), dim3(BLOCK), lds,
+                         stream, p, eff, params, w, stride, P, q, G, h, nb, npairs, sym, batch, tbn, nzero,
+                         g_phase_mask);
       *err = hipGetLastError();
       return *err == hipSuccess ? MPCASM_OK : MPCASM_ERR_HIP;
     }
