@@ -75,8 +75,8 @@ enum { MPCASM_OPT_PATH = 1, MPCASM_OPT_PHASE_MASK = 2, MPCASM_OPT_RESIDENT_PER_C
  * for the compilation, a second or two); 1 = for every batch; 2 = never.
  * MPCASM_OPT_P_DIRECT (read by mpcasm_plan_create): how the persistent kernel writes P -- 1: its
  * 4x4 blocks go from the matrix core straight to HBM; 2: collected in LDS and copied out with
- * 16-byte stores whenever P fits there beside the workspace; 0 (default): as 2 for launches whose
- * outputs stream to HBM (200 MB and more), as 1 for smaller ones.
+ * 16-byte stores whenever P fits there beside the workspace; 0 (default): as 1 when P in LDS would
+ * cost a workgroup per CU or the launch writes less than ~0.55 GB, else as 2.
  * These options are process-wide test / tuning hooks, not part of a launch's state: set them
  * before other threads start launching. */
 int mpcasm_set_option(int option, int value);

@@ -1295,15 +1295,26 @@ int resident_choose_p_direct(const PlanDev& p, int option) {
   return (!fits || option == 1) ? 1 : (option == 2 ? 0 : 2);
 }
 
-// ... for one launch: while the outputs of a launch stay in the 256 MiB Infinity Cache the direct
-// stores are 4 % faster (no read-out phase, 10 KB less LDS traffic per instance on C2: 35.1
-// against 36.6 us at B = 4096); once they stream to HBM the short runs cost a fifth of the
-// write rate (588 against 465 us at B = 65536; tools/microbench/store_rate3.hip shows the same
-// on the bare store pattern).
+// ... for one launch.  Two things decide (round 3, tools/ab_n24.py: same box, one process):
+// * whether P in LDS costs a workgroup per CU: the biped at N = 24 needs 85 KB with P beside the
+//   workspace and 64 KB without -- one workgroup per CU or two -- and is faster with the direct
+//   stores at EVERY batch size (B = 8192: 0.76 against 0.46 of 8 TB/s; 65536: 0.58 against 0.48);
+// * else the size of the launch: the 32-byte runs of the direct stores merge on their way to HBM
+//   while a launch writes less than ~0.55 GB (C2 at B = 16384: 0.73 direct against 0.65 through
+//   LDS; round 2 switched at 0.2 GB already), beyond that they cost a third of the write rate
+//   (B = 32768: 0.46 against 0.68; tools/microbench/store_rate3.hip shows the same on the bare
+//   store pattern).
 int resident_p_direct_for(const PlanDev& p, int batch) {
   if (p.rs_p_direct != 2) return p.rs_p_direct;
+  PlanDev q = p;
+  q.rs_p_direct = 0;
+  const size_t with_p = (size_t)resident_layout(q).total_doubles * sizeof(double);
+  q.rs_p_direct = 1;
+  const size_t without = (size_t)resident_layout(q).total_doubles * sizeof(double);
+  constexpr size_t HALF_CU = 80 * 1024;  // two workgroups share a CU's 160 KB
+  if (with_p > HALF_CU && without <= HALF_CU) return 1;
   const double out_bytes = 8.0 * ((double)p.no * p.no + p.no + (double)p.nc * p.no + p.nc) * batch;
-  return out_bytes < 200e6 ? 1 : 0;
+  return out_bytes < 560e6 ? 1 : 0;
 }
 
 // 0 when the resident kernel cannot take this plan, else its dynamic LDS bytes
