@@ -152,7 +152,9 @@ __global__ __launch_bounds__(BLOCK) void fill_lti_kernel(const double* __restric
           Sb[(size_t)d * n * n + (e - n * m)] = v;
       });
     }
-    __syncthreads();
+    // (LDS only: __syncthreads() would also wait, in every step, for the step's stores of S to be
+    // acknowledged by memory -- N - 1 round trips per system before the first row of U leaves)
+    lds_barrier();
   }
 
   if (!live) return;

@@ -234,3 +234,91 @@ def test_c4_at_its_per_gpu_batch_in_one_call(gpu_api, torch_gpu):
     Pb, qs, _, hs = asm.assemble(g0 + g1)
     assert torch.equal(Pb[::1024], Pa)
     assert _rel(q0 + q1, qs + qz) <= 1e-12 and _rel(h0 + h1, hs + hz) <= 1e-12
+
+
+def _two_systems(api, rng, N, nx1, nu1, nx2, nu2, optim_second=True):
+    """Two independent LTI plants in one formulation (inputs u*, v*), tracking + bounds on states of
+    both; with ``optim_second`` False the second plant's inputs are GIVEN (they enter d, h, q only)."""
+    A1, B1 = problems.random_lti_matrices(rng, nx1, nu1)
+    A2, B2 = problems.random_lti_matrices(rng, nx2, nu2)
+    s1 = api.ControlSystem(["u%d" % j for j in range(nu1)], ["s%d" % i for i in range(nx1)], A1, B1)
+    s2 = api.ControlSystem(["v%d" % j for j in range(nu2)], ["r%d" % i for i in range(nx2)], A2, B2)
+    e1 = api.ExtendedSystem.from_cotrol_system(s1, "x", N)
+    e2 = api.ExtendedSystem.from_cotrol_system(s2, "z", N)
+    form = api.Formulation()
+    form.incorporate_dynamics("first", e1)
+    form.incorporate_dynamics("second", e2)
+    for i in range(nx1):
+        form.incorporate_goal("track s%d" % i, api.Cost("s%d" % i, float(rng.uniform(0.1, 1)), aim=[float(rng.normal())]))
+    for i in range(nx2):
+        form.incorporate_goal("track r%d" % i, api.Cost("r%d" % i, float(rng.uniform(0.1, 1)), aim=[float(rng.normal())]))
+    form.incorporate_goal("effort", api.Cost("u0", 0.3))
+    form.incorporate_constraint("bounds", [api.Constraint("s0", 4.0), api.Constraint("r0", 3.0, arrow=[-1]),
+                                           api.Constraint("r1", 2.0)])
+    optim = ["u%d" % j for j in range(nu1)] + (["v%d" % j for j in range(nu2)] if optim_second else [])
+    form.identify_qp_domain(optim)
+    form.make_preview_matrices()
+    return form, (A1, B1), (A2, B2)
+
+
+@pytest.mark.parametrize("lti,optim_second", [((), True), (("first", "second"), True), (("first",), False),
+                                              (("first", "second"), False)])
+def test_two_plants_in_one_wide_problem(gpu_api, torch_gpu, lti, optim_second):
+    """Two systems side by side: columns of one plant's inputs are structural zeros in the rows of
+    the other's states (tile masks per 64-column quarter), two generated groups (the general form of
+    the kernel: the Toeplitz form is for a single group), and inputs that are GIVEN instead of
+    unknown (their horizon tables are read through the given columns of the column tables)."""
+    torch = torch_gpu
+    from mpcasm import capi, engine
+
+    rng = np.random.default_rng(31)
+    N, nx1, nu1, nx2, nu2 = 48, 3, 3, 2, 2
+    form, ab1, ab2 = _two_systems(gpu_api, rng, N, nx1, nu1, nx2, nu2, optim_second)
+    assert form.optim_len == N * (nu1 + (nu2 if optim_second else 0))
+    B = 11
+    given = torch.as_tensor(rng.normal(0, 0.3, [B, form.given_len]), device="cuda")
+    til = engine.Assembler(form, batch=B, lti=list(lti))
+    assert til.plan.itab[_H["T_OK"]] == 1
+    for name, (A, Bm) in (("first", ab1), ("second", ab2)):
+        if name in lti:
+            til.bind_lti(name, torch.as_tensor(A, device="cuda"), torch.as_tensor(Bm, device="cuda"))
+    out = tuple(torch.full_like(t, float("nan")) for t in til.assemble(given))
+    Pt, qt, Gt, ht = (t.clone() for t in til.assemble(given, out=out))
+    assert not any(torch.isnan(t).any().item() for t in (Pt, qt, Gt, ht))
+    assert "tiled" in til.last_kernel()
+    ref = engine.Assembler(form, batch=B)
+    ref.set_option(capi.OPT_PATH, 2)
+    Ps, qs, Gs, hs = ref.assemble(given)
+    assert max(_rel(Pt, Ps), _rel(qt, qs), _rel(Gt, Gs), _rel(ht, hs)) <= 1e-12
+    for b in (0, B - 1):
+        Ao, ho, Qo, qo = orc.assemble(form, given[b].cpu().numpy().reshape(-1, 1))
+        assert_close(Pt[b].cpu().numpy(), Qo, RTOL), assert_close(qt[b].cpu().numpy(), qo.ravel(), RTOL)
+        assert_close(Gt[b].cpu().numpy(), Ao, RTOL), assert_close(ht[b].cpu().numpy(), ho.ravel(), RTOL)
+    # the preview of every definition through the same tables
+    x = torch.as_tensor(rng.normal(0, 0.5, [B, form.optim_len]), device="cuda")
+    rows = til.preview_rows(given, x).cpu().numpy()
+    PM = orc.preview_matrices(form)
+    for var, (r0, n) in til.plan.pm_rows.items():
+        want = (PM[var][0] @ given[3].cpu().numpy().reshape(-1, 1) + PM[var][1] @ x[3].cpu().numpy().reshape(-1, 1)).ravel()
+        assert_close(rows[3, r0:r0 + n], want, 1e-11, var)
+
+
+def test_odd_width_falls_back_to_the_staged_pipeline(gpu_api, torch_gpu):
+    """129 unknowns: rows of G are not 16-byte aligned, the tiled kernel does not take the plan
+    (T_OK = 0); the staged pipeline does, same numbers as the oracle."""
+    torch = torch_gpu
+    from mpcasm import engine
+
+    rng = np.random.default_rng(5)
+    form = problems.random_lti(gpu_api, rng, nx=3, nu=3, N=43)
+    assert form.optim_len == 129
+    asm = engine.Assembler(form, batch=5)
+    assert asm.plan.itab[_H["T_OK"]] == 0 and asm.plan.itab[_H["T_CI_OK"]] == 1
+    given = rng.normal(0, 0.3, [5, form.given_len])
+    P, q, G, h = (t.cpu().numpy() for t in asm.assemble(given))
+    assert "staged" in asm.last_kernel()
+    Ao, ho, Qo, qo = orc.assemble(form, given[2].reshape(-1, 1))
+    assert_close(P[2], Qo, RTOL_TIGHT), assert_close(q[2], qo.ravel(), RTOL_TIGHT)
+    assert_close(G[2], Ao, RTOL_TIGHT), assert_close(h[2], ho.ravel(), RTOL_TIGHT)
+    with pytest.raises(Exception):
+        engine.Assembler(form, batch=5, lti=["plant"]).assemble(given)   # nowhere to generate the tables
