@@ -541,6 +541,31 @@ int validate_plan(const int32_t* it, const double* h_dtab, size_t n_itab, size_t
           const bool swapped = (uint32_t)gd[2 * e] == (v1 | (v0 << 16)) && (uint32_t)gd[2 * e + 1] == (a1 | (a0 << 16));
           if (!as_is && !swapped) return MPCASM_ERR_PLAN;
         }
+        // per thread, the second axis of at most one of its pieces: the same numbers as the
+        // second half of that piece's descriptor
+        const int64_t nfix = it[H_RS_NGFIX];
+        if (nfix < 0 || nfix > RS_GDESC_THREADS) return MPCASM_ERR_PLAN;
+        if (nfix != 0) {
+          if (!in_range(it[H_OFF_RS_GFIX], RS_GDESC_THREADS * 2, n, H_WORDS) || it[H_OFF_RS_GFIX] % 2)
+            return MPCASM_ERR_PLAN;
+          const int32_t* gf = it + it[H_OFF_RS_GFIX];
+          int64_t seen = 0;
+          for (int64_t t = 0; t < RS_GDESC_THREADS; ++t) {
+            const uint32_t w = (uint32_t)gf[2 * t], u = w >> 16, arrow = (uint32_t)gf[2 * t + 1];
+            if (u == (uint32_t)RS_GFIX_NONE) {
+              if ((w & 0xFFFF) != 0 || arrow != (uint32_t)it[H_NPARAMS]) return MPCASM_ERR_PLAN;
+              continue;
+            }
+            const int64_t e = t + (int64_t)u * RS_GDESC_THREADS;
+            if (u >= (uint32_t)RS_GDESC_PIECES || e >= pieces || (w & 0xFFFF) != ((uint32_t)gd[2 * e] >> 16) ||
+                arrow != ((uint32_t)gd[2 * e + 1] >> 16))
+              return MPCASM_ERR_PLAN;
+            ++seen;
+          }
+          if (seen != nfix) return MPCASM_ERR_PLAN;
+        }
+      } else if (it[H_RS_NGFIX] != 0) {
+        return MPCASM_ERR_PLAN;
       }
     }
     if (it[H_CSC_PNNZ] != 0 || it[H_CSC_GNNZ] != 0) {  // the CSC hand-off tables
@@ -742,6 +767,7 @@ void plan_dev_from_tables(const int32_t* it, PlanDev* out) {
   d.off_t_srow = it[H_OFF_T_SROW]; d.t_doff_scoef = it[H_T_DOFF_SCOEF]; d.off_t_pig = it[H_OFF_T_PIG];
   d.t_ngrest = it[H_T_NGREST]; d.off_t_grest = it[H_OFF_T_GREST]; d.off_t_brow0 = it[H_OFF_T_BROW0]; d.t_toeplitz = it[H_T_TOEPLITZ];
   d.off_t_bcolptr = it[H_OFF_T_BCOLPTR]; d.off_t_bcols = it[H_OFF_T_BCOLS];
+  d.rs_ngfix = it[H_RS_NGFIX]; d.off_rs_gfix = it[H_OFF_RS_GFIX];
   d.t_nbrow = d.t_ci_ok ? it[d.off_t_brow0 + d.nbase] : 0;
   d.pm_nfd = it[H_PM_NFD]; d.off_pm_map = it[H_OFF_PM_MAP]; d.off_pm_fdptr = it[H_OFF_PM_FDPTR];
   d.off_pm_op = it[H_OFF_PM_OP]; d.doff_pm_pool = it[H_DOFF_PM_POOL];

@@ -29,7 +29,7 @@
 namespace mpcasm {
 
 constexpr int32_t PLAN_MAGIC = 0x4D504341;  // 'MPCA'
-constexpr int32_t PLAN_VERSION = 22;
+constexpr int32_t PLAN_VERSION = 23;
 
 enum HeaderWord : int {
   H_MAGIC = 0,
@@ -185,9 +185,15 @@ enum HeaderWord : int {
   H_OFF_T_BCOLS,    // ... this list of column indices in [given | unknowns] (ascending per base)
   H_T_TOEPLITZ,     // 1: every stage is TS_FLAG_TOEPLITZ (one generated group): the kernel keeps the
                     //    group's TB table in LDS and reads the matrix core's operands out of it
+  H_RS_NGFIX,       // pieces of G (descriptor table) that need both of their axes while the rest of their
+                    //    round needs one, at most one per stream-wave thread: the round adds the second
+                    //    axis for that lane alone; 0: the table below is absent
+  H_OFF_RS_GFIX,    // [RS_GDESC_THREADS][2] per thread: workspace index of the second axis (as in RS_GDESC)
+                    //    | u << 16 -- the piece is its e = t + u RS_GDESC_THREADS --, the second arrow's
+                    //    parameter slot; a thread without such a piece: 0 | RS_GFIX_NONE << 16, NPARAMS
   H_WORDS = 128
 };
-static_assert(H_T_TOEPLITZ < H_WORDS, "plan header");
+static_assert(H_OFF_RS_GFIX < H_WORDS, "plan header");
 
 constexpr int T_BLOCK = 128;       // columns of a block of P (tiled kernel)
 constexpr int T_SID_CONST = 32;    // the stream that is the plan's own dtab
@@ -255,6 +261,7 @@ constexpr int RS_LTI_MAX = 4;
 // first two axes packed once more: voff0 | voff1 << 16, arrow0 | arrow1 << 16
 constexpr int RS_AXMAX = 4, RS_RR_WORDS = 16;
 constexpr int RS_GDESC_PIECES = 6, RS_GDESC_THREADS = RS_NT - RS_NW * 64;  // pieces per stream-wave thread
+constexpr int RS_GFIX_NONE = 7;   // (H_OFF_RS_GFIX: no round of this thread has a two-axis piece)
 constexpr int32_t RS_DST_ACC = 1 << 30;
 // The Hessian and the gradient are accumulated in 4x4 blocks (v_mfma_f64_4x4x4_4b_f64: four
 // independent 4x4 blocks per instruction, 4 rows of the workspace per k-step): block (bi, bj)

@@ -115,7 +115,7 @@ struct ResidentLayout {
   int v, pl, ql, dvec, dcoef, dpar, img, ab, streams, ints, total_doubles;
   int ldp;                                            // leading dimension of P in LDS
   int p_direct;  // 1: P does not fit beside the workspace -- its blocks go straight to HBM
-  int i_rr, i_meta, i_wtrip, i_split, i_lti, i_abmeta, i_gdesc, i_cscp;  // offsets in ints inside the int region
+  int i_rr, i_meta, i_wtrip, i_split, i_lti, i_abmeta, i_gdesc, i_gfix, i_cscp;  // offsets in ints inside the int region
 };
 
 template <class PlanT>
@@ -142,6 +142,8 @@ __host__ __device__ inline ResidentLayout resident_layout(const PlanT& p) {
   // per-thread piece descriptors of G; CSC hand-off: per-entry descriptors of G, then where the
   // stored entries of P sit in its LDS copy
   L.i_gdesc = i;  i += resident_g_mode(p) == 2 ? GU * WT * 2 : (resident_g_mode(p) == 3 ? 2 * p.csc_gnnz : 0);
+  // per stream-wave thread: the second axis of the one piece of its that needs both (H_RS_NGFIX)
+  L.i_gfix = i;   i += resident_g_mode(p) == 2 && p.rs_ngfix != 0 ? 2 * WT : 0;
   L.i_cscp = i;   i += resident_g_mode(p) == 3 ? p.csc_pnnz : 0;
   L.i_wtrip = i; i += RS_WAVES * 2;
   L.i_split = i; i += p.rs_nsplit;
@@ -263,10 +265,15 @@ __device__ __forceinline__ void spec_trip(TripState& s) {
     }
   }
   if constexpr ((WORD >> RT_LAST) & 1) {  // the pack is complete: into P and q in LDS
-    const int row = 4 * s.bi + s.lk, col = 4 * s.bj + s.lx;
+    // (opaque copies again: a pack whose four blocks share a block row has a constant s.bi, and
+    // its row offsets and bounds tests would be kept in registers across instances -- with a
+    // width that is no multiple of 4 that is what made the kernel spill)
+    int lk_ = s.lk, lx_ = s.lx;
+    asm volatile("" : "+v"(lk_), "+v"(lx_));
+    const int row = 4 * s.bi + lk_, col = 4 * s.bj + lx_;
     if (s.live && row < PC::no) {
       if (s.isq) {
-        if (s.lx == 0) s.ql[row] = s.acc + s.dvec[ldp + row];
+        if (lx_ == 0) s.ql[row] = s.acc + s.dvec[ldp + row];
       } else if (col < PC::no) {
         const double val = s.acc + (row == col ? s.dvec[col] : 0.0);
         // (to LDS or, block by block, to HBM: ordinary stores -- the 32-byte runs of a block
@@ -342,6 +349,7 @@ __device__ __forceinline__ void resident_body(
   int* lti = itb + L.i_lti;
   int2* abmeta = reinterpret_cast<int2*>(itb + L.i_abmeta);
   int2* gdesc = reinterpret_cast<int2*>(itb + L.i_gdesc);  // [GU][WT]
+  int2* gfix = reinterpret_cast<int2*>(itb + L.i_gfix);    // [WT]
   // LDS byte address of the image double buffer (the low half of a flat LDS address)
   const unsigned img_lds = (unsigned)(uintptr_t)(lds + L.img);  // (rs_img doubles each, rs_img_dma of them loaded)
   const int unit = p.rs_unit, nchunk = p.rs_nchunk;
@@ -647,6 +655,7 @@ __device__ __forceinline__ void resident_body(
     if (own_gd) {
 #pragma unroll
       for (int u = 0; u < GU; ++u) gdesc[u * WT + wt_] = v_gd[u];
+      if (p.rs_ngfix != 0) gfix[wt_] = reinterpret_cast<const int2*>(plan_itab + p.off_rs_gfix)[wt_];
     }
     if (own_diag) {
       dpar[ct] = v_dpar;
@@ -820,6 +829,13 @@ __device__ __forceinline__ void resident_body(
 #endif
           static_assert(GU % GB == 0, "batches of pieces");
           const bool h_mine = wt_ < nc;
+          // one piece of this thread may need its second axis in a round of one-axis pieces
+          // (H_RS_NGFIX): requested with the first batch, added in its round for this lane alone
+          int fix_u = RS_GFIX_NONE;
+          double fa1 = 0.0;
+          double2 fv1{0.0, 0.0};
+          int2 fd{0, 0};
+          if (p.rs_ngfix != 0) fd = gfix[wt_];
           const int4 hc4 = reinterpret_cast<const int4*>(rr)[h_mine ? wt_ : 0];  // compact record
           const int4 hr = int4{0, hc4.w, hc4.x, hc4.y};  // -, extreme, packed rows, packed arrows
           const int2 hc = int2{hc4.z & 0xFFFF, (int)((unsigned)hc4.z >> 16)};
@@ -829,6 +845,11 @@ __device__ __forceinline__ void resident_body(
             int2 ds[GB];
 #pragma unroll
             for (int u = 0; u < GB; ++u) ds[u] = gdesc[(u0 + u) * WT + wt_];
+            if (u0 == 0 && p.rs_ngfix != 0) {
+              fix_u = (unsigned)fd.x >> 16;
+              fa1 = prm[fd.y];
+              fv1 = *reinterpret_cast<const double2*>(V + (fd.x & 0xFFFF));
+            }
             if (u0 == 0) {
               ha0 = prm[hr.w & 0xFFFF];
               ha1 = prm[(unsigned)hr.w >> 16];
@@ -862,11 +883,16 @@ __device__ __forceinline__ void resident_body(
               if (one[u]) {
                 r.x = a0[u] * v0[u].x;
                 r.y = a0[u] * v0[u].y;
+                if (p.rs_ngfix != 0 && u0 + u == fix_u) {
+                  r.x = fma(fa1, fv1.x, r.x);
+                  r.y = fma(fa1, fv1.y, r.y);
+                }
               } else {
                 r.x = fma(a1[u], v1[u].x, a0[u] * v0[u].x);
                 r.y = fma(a1[u], v1[u].y, a0[u] * v0[u].y);
               }
-              if (e < gtotal) store_result(&G2[e], r);
+              if (e < gtotal && !((phases & 512) && r.x == r.x))
+                store_result(&G2[e], r);  // (bit 9, A/B aid: G computed, not written)
             }
             if (u0 == 0 && h_mine) {  // h = (extreme + arrow . center) - arrow . d   (body.py:264)
               double ac = ha0 * hc0, ad = ha0 * hd0;

@@ -17,7 +17,7 @@ import numpy as np
 import scipy.sparse as sp
 
 PLAN_MAGIC = 0x4D504341
-PLAN_VERSION = 22
+PLAN_VERSION = 23
 
 # header words (csrc/plan_tables.h, enum HeaderWord)
 _H = {name: i for i, name in enumerate([
@@ -39,6 +39,7 @@ _H = {name: i for i, name in enumerate([
     "T_CI_OK", "T_NOP", "OFF_T_CIG", "OFF_T_CIO", "T_DOFF_DELTA", "T_NDELTA",
     "T_OK", "T_NSTAGE", "OFF_T_STAGE", "T_NLTI", "OFF_T_LTI", "OFF_T_LTI_IDS", "T_WORK",
     "OFF_T_GROW", "OFF_T_SROW", "T_DOFF_SCOEF", "OFF_T_PIG", "T_NGREST", "OFF_T_GREST", "OFF_T_BROW0", "OFF_T_BCOLPTR", "OFF_T_BCOLS", "T_TOEPLITZ",
+    "RS_NGFIX", "OFF_RS_GFIX",
 ])}
 H_WORDS = 128
 assert len(_H) <= H_WORDS
@@ -63,6 +64,7 @@ RS_DIAG_MAX = 2                           # diagonal gterms per column (persiste
 RS_AXMAX = 4                              # axes per constraint row record
 RS_DST_ACC = 1 << 30                      # compose destination shared by two threads
 RS_GDESC_PIECES, RS_GDESC_THREADS = 6, 256   # descriptor table of G: pieces per stream-wave thread
+RS_GFIX_NONE = 7
 RS_RR_WORDS = 16                          # row record: voff[4], arrow param[4], center param[4], naxes, extreme param, pad
 SEG_WORDS, GT_WORDS, LM_WORDS, LX_WORDS = 8, 10, 12, 2
 FUSED_MAX_OPS = 1 << 18           # beyond this the staged pipeline is used
@@ -1440,7 +1442,8 @@ def compile_plan(form, costs=None, limits=None, lti=(), csc=None):
     # ... and, for small problems, the descriptor of every 16-byte piece of G a stream-wave
     # thread owns: piece e = t + u RS_GDESC_THREADS, columns 2cp, 2cp+1 of row R = e // (no/2):
     # rs_index(row0, 2cp) | rs_index(row1, 2cp) << 16, arrow0 | arrow1 << 16
-    rs_gdesc = np.zeros(0, dtype=np.int32)
+    rs_gdesc = rs_gfix = np.zeros(0, dtype=np.int32)
+    rs_ngfix = 0
     rs_gsingle = 0
     rr_ok = rs_rr.size == nc * RS_RR_WORDS
     packed_ok = (rr_ok and no % 2 == 0 and nc > 0 and (b.rtot + 8) * ldv < 65536
@@ -1474,6 +1477,23 @@ def compile_plan(form, costs=None, limits=None, lti=(), csc=None):
         word0 = (v0 + 2 * cp) | ((v1 + 2 * cp) << 16)    # rs_index(row, 2 cp)
         word1 = a0 | (a1 << 16)
         rs_gdesc = np.stack([word0, word1], axis=1).astype(np.uint32).view(np.int32).reshape(-1)
+        # A few pieces with two live axes among many with one (the biped's 34-wide phase: x ends
+        # and y begins inside one piece of every two-axis row) would turn every round they sit in
+        # into a two-axis round.  Instead the round stays a one-axis round and adds the second axis
+        # for that lane alone; a thread holds the second axis of at most one of its pieces (RS_GFIX).
+        # (Writing such pieces apart, behind the rounds, leaves 16-byte holes in the lines the
+        # rounds write: partial lines cost the write stream half its rate, tools/run_variant.py.)
+        both = np.flatnonzero(~single)
+        in_mixed_rounds = int((~single.reshape(-1, 64).all(axis=1)).sum()) * 64
+        owners = both % RS_GDESC_THREADS
+        if (both.size and 4 * both.size <= in_mixed_rounds and np.unique(owners).size == both.size
+                and not _os.environ.get('MPCASM_NO_GFIX')):
+            fix = np.zeros((RS_GDESC_THREADS, 2), dtype=np.int64)
+            fix[:, 0], fix[:, 1] = RS_GFIX_NONE << 16, len(b.params)
+            fix[owners, 0] = (v1 + 2 * cp)[both] | ((both // RS_GDESC_THREADS) << 16)
+            fix[owners, 1] = a1[both]
+            rs_gfix, rs_ngfix = fix.astype(np.uint32).view(np.int32).reshape(-1), int(both.size)
+            single = np.ones_like(single)
         rounds = single.reshape(RS_GDESC_PIECES, RS_GDESC_THREADS // 64, 64).all(axis=2)
         rs_gsingle = int(sum(1 << (u * (RS_GDESC_THREADS // 64) + w)
                              for u in range(RS_GDESC_PIECES) for w in range(RS_GDESC_THREADS // 64)
@@ -1555,6 +1575,7 @@ def compile_plan(form, costs=None, limits=None, lti=(), csc=None):
     sections += [("OFF_T_BCOLPTR", np.cumsum([0] + [c.size for c in bcols]).astype(np.int32)),
                  ("OFF_T_BCOLS", (np.concatenate(bcols) if bcols else np.zeros(0)).astype(np.int32))]
     sections += [("OFF_RS_DPAR", rs_dpar.reshape(-1)), ("OFF_RS_GDESC", rs_gdesc),
+                 ("OFF_RS_GFIX", rs_gfix),
                  ("OFF_PM_MAP", pmprog["map"]), ("OFF_PM_FDPTR", pmprog["fd_ptr"]),
                  ("OFF_PM_OP", pmprog["ops"])]
     header = np.zeros(H_WORDS, dtype=np.int32)
@@ -1567,7 +1588,7 @@ def compile_plan(form, costs=None, limits=None, lti=(), csc=None):
             parts.append(np.zeros(1, dtype=np.int32))
             off += 1
         if name in ("OFF_RS_RR", "OFF_RS_INMETA", "OFF_RS_ABMETA", "OFF_RS_DPAR",
-                    "OFF_RS_GDESC", "OFF_CSC_G", "OFF_T_CIG", "OFF_T_CIO",
+                    "OFF_RS_GDESC", "OFF_RS_GFIX", "OFF_CSC_G", "OFF_T_CIG", "OFF_T_CIO",
                     "OFF_T_STAGE", "OFF_T_GROW", "OFF_T_SROW", "OFF_T_PIG") and off & 3:   # ... 16-byte quads
             pad = 4 - (off & 3)
             parts.append(np.zeros(pad, dtype=np.int32))
@@ -1587,6 +1608,7 @@ def compile_plan(form, costs=None, limits=None, lti=(), csc=None):
     header[_H["DOFF_RS_DCOEF"]] = ndt + (ndt & 1) + 4
     dparts.append(rs_dcoef.reshape(-1))
     header[_H["RS_NGDESC"]] = rs_gdesc.size // 2
+    header[_H["RS_NGFIX"]] = rs_ngfix
     header[_H["DOFF_PM_POOL"]] = ndt + (ndt & 1) + 4 + rs_dcoef.size
     dparts.append(pmprog["pool"])
     header[_H["PM_NFD"]], header[_H["PM_NOPS"]] = pmprog["nfd"], pmprog["ops"].size // 2

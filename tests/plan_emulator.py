@@ -336,6 +336,11 @@ def run_resident(plan, given, params=None, sources=None):
     if it[H["RS_NGDESC"]]:                              # descriptors of the 16-byte pieces of G
         gd = _section(it, "OFF_RS_GDESC", it[H["RS_NGDESC"]] * 2).view(np.uint32).reshape(-1, 2)
         assert it[H["RR_PACKED"]] and len(gd) >= nc * (no // 2)
+        gfix = _section(it, "OFF_RS_GFIX", 2 * P.RS_GDESC_THREADS if it[H["RS_NGFIX"]] else 0) \
+            .view(np.uint32).reshape(-1, 2)
+        fixed = {t + int(w >> 16) * P.RS_GDESC_THREADS for t, (w, _) in enumerate(gfix)
+                 if w >> 16 != P.RS_GFIX_NONE}
+        assert len(fixed) == it[H["RS_NGFIX"]]
         for e in range(nc * (no // 2)):
             R, cp = divmod(e, no // 2)
             v0, v1, a0, a1 = rr[R, 0] + 2 * cp, rr[R, 1] + 2 * cp, rr[R, 4], rr[R, 5]
@@ -344,10 +349,32 @@ def run_resident(plan, given, params=None, sources=None):
             assert as_is or swapped
             # a round marked "one axis": the second of the descriptor is structurally zero here
             u, w = divmod(e // 64, P.RS_GDESC_THREADS // 64)
-            if (int(it[H["RS_GSINGLE"]]) >> (u * (P.RS_GDESC_THREADS // 64) + w)) & 1:
+            if (int(it[H["RS_GSINGLE"]]) >> (u * (P.RS_GDESC_THREADS // 64) + w)) & 1 and e not in fixed:
                 second, arrow = int(gd[e, 0] >> 16), int(gd[e, 1] >> 16)
                 # ... or absent (the always-zero parameter slot)
                 assert (V[second] == 0.0 and V[second + 1] == 0.0) or arrow == nparams
+    Gdesc = None
+    if it[H["RS_NGDESC"]]:
+        # ... and G as the descriptor path writes it: rounds of one-axis pieces read the first axis
+        # only; the thread that owns a piece on the list RS_GFIX adds that piece's second axis
+        T, U = P.RS_GDESC_THREADS, P.RS_GDESC_PIECES
+        pieces = nc * (no // 2)
+        Gflat = np.full(pieces * 2, np.nan)
+        for e in range(pieces):
+            u, t = divmod(e, T)
+            d = gd[e]
+            v0, v1, a0, a1 = int(d[0] & 0xFFFF), int(d[0] >> 16), int(d[1] & 0xFFFF), int(d[1] >> 16)
+            val = prm[a0] * V[v0:v0 + 2]
+            if not (int(it[H["RS_GSINGLE"]]) >> (u * (T // 64) + t // 64)) & 1:
+                val = prm[a1] * V[v1:v1 + 2] + val
+            elif len(gfix) and gfix[t, 0] >> 16 == u:
+                assert (int(gfix[t, 0] & 0xFFFF), int(gfix[t, 1])) == (v1, a1)
+                val = prm[a1] * V[v1:v1 + 2] + val
+            Gflat[2 * e:2 * e + 2] = val
+        for t, (w, arrow) in enumerate(gfix):
+            assert w >> 16 == P.RS_GFIX_NONE and (w & 0xFFFF, arrow) == (0, nparams) \
+                or t + int(w >> 16) * T < pieces
+        Gdesc = Gflat.reshape(nc, no)
     for R in range(nc):
         rec = rr[R]
         ac = ad = 0.0
@@ -361,6 +388,9 @@ def run_resident(plan, given, params=None, sources=None):
         for ax in range(rec[12], P.RS_AXMAX):       # the kernel's fast path reads two axes
             assert prm[rec[4 + ax]] == 0.0
         h[R] = (prm[rec[13]] + ac) - ad
+    if Gdesc is not None:
+        assert np.allclose(Gdesc, G, rtol=1e-15, atol=0)
+        G = Gdesc
     out = {"P": Pm, "q": q, "G": G, "h": h}
     if it[H["CSC_PNNZ"]] or it[H["CSC_GNNZ"]]:      # the CSC hand-off: data arrays as the kernel writes them
         ldp = no + (no & 1)

@@ -193,7 +193,13 @@ def test_biped_plan_over_ticks(cpu_api, step_samples):
         form.update(step_times=clock.step_times, step_count=clock.step_count)
         given = form.arrange_given(problems.biped_given_collector(form, rng, 0.01))
         if tick in (0, 1, 7, 8, 9):
-            check_plan(form, given)
+            it = check_plan(form, given).itab
+            if step_samples == 8:
+                # one previewed step: x ends and y begins inside one 16-byte piece of every row
+                # with two axes -- those pieces are on the list the rounds leave out, every round
+                # of the descriptor path stays a one-axis round
+                assert (it[_H["RS_NGFIX"]] > 0) == (form.optim_len == 34)
+                assert it[_H["RS_GSINGLE"]] == (1 << 24) - 1
         widths.add(form.optim_len)
         clock.tick()
     assert len(widths) == 2      # ragged QP width across walking phases

@@ -20,7 +20,8 @@ NAMES = ["barA", "compose+B", "tiles", "G,h", "barC", "dma wait", "Pq out", "fet
 
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-    work = bench.build_workload(B, 1)
+    times = os.environ.get("MPCASM_STEP_TIMES")      # e.g. "7,15": the 34-wide bucket
+    work = bench.build_workload(B, 1, step_times=[int(x) for x in times.split(",")] if times else (6, 14))
     engine, form = work["engine"], work["form"]
     lti = os.environ.get("MPCASM_LTI") == "1"   # horizon matrices generated on chip
     asm = engine.Assembler(form, batch=B, lti=["LIP"] if lti else ())
