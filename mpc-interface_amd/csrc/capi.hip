@@ -428,7 +428,18 @@ int validate_plan(const int32_t* it, const double* h_dtab, size_t n_itab, size_t
       const double* c = h_dtab + it[H_DOFF_RS_CONST];
       if (c[0] != 1.0 || c[1] != 1.0 || c[2] != 0.0 || c[3] != 0.0) return MPCASM_ERR_PLAN;
     }
-    const int64_t vsize = (int64_t)it[H_RTOT] * it[H_LDV];
+    // the workspace's geometry (plan_tables.h H_RS_COMPACT): dense = the fused kernel's, or compact
+    const int64_t vldv = it[H_RS_LDV], vd = it[H_RS_VD], vrow0 = it[H_RS_VROW0];
+    const int64_t vrows = vrow0 + it[H_RTOT];
+    if (it[H_RS_COMPACT] == 0) {
+      if (vldv != it[H_LDV] || vd != no || vrow0 != 0) return MPCASM_ERR_PLAN;
+    } else {
+      if (it[H_RS_COMPACT] != 1 || vldv < 6 || vldv % 4 != 2 || vd != vldv - 2 || vd > no + 3 || vrow0 < 0 ||
+          vrow0 % 4 || vrow0 > 1024 || !it[H_RR_PACKED] || it[H_CSC_PNNZ] != 0 || it[H_CSC_GNNZ] != 0 ||
+          !in_range(it[H_OFF_RS_RRWIN], nc, n, H_WORDS))
+        return MPCASM_ERR_PLAN;
+    }
+    const int64_t vsize = vrows * vldv;
     const int32_t* ts = it + it[H_OFF_RS_SRC];
     const int32_t* tg = it + it[H_OFF_RS_GIDX];
     const int32_t* td = it + it[H_OFF_RS_DST];
@@ -448,7 +459,7 @@ int validate_plan(const int32_t* it, const double* h_dtab, size_t n_itab, size_t
     const int32_t* tr = it + it[H_OFF_RS_TRIP];
     for (int i = 0; i < 2 * RS_TRIP_WORDS; ++i)
       if (tr[it[H_RS_NTRIP] * RS_TRIP_WORDS + i] != 0) return MPCASM_ERR_PLAN;
-    const int64_t row_bytes = (int64_t)it[H_LDV] * 8;
+    const int64_t row_bytes = vldv * 8;
     if (it[H_LDV] < no + 2) return MPCASM_ERR_PLAN;  // columns: unknowns, d, ones
     for (int i = 0; i < it[H_RS_NTRIP]; ++i) {
       const int32_t* x = tr + i * RS_TRIP_WORDS;
@@ -464,12 +475,26 @@ int validate_plan(const int32_t* it, const double* h_dtab, size_t n_itab, size_t
       for (int g = 0; g < 4; ++g)  // (all four groups load, live or not)
         if (((x[RT_BI] >> (8 * g)) & 255) >= nb || ((x[RT_BJ] >> (8 * g)) & 255) >= nb)
           return MPCASM_ERR_PLAN;
-      // offsets: whole rows on group boundaries (the d offset: column `no` of its row); a trip
+      // offsets: whole rows on group boundaries (the d offset: column RS_VD of its row); a trip
       // reads `rows` rows from each
-      const int64_t offs[3] = {x[RT_A], x[RT_B], (int64_t)x[RT_D] - (rows > 0 ? no * 8 : 0)};
-      for (int k = 0; k < 3; ++k)
-        if (offs[k] < 0 || offs[k] % (4 * row_bytes) || offs[k] / row_bytes + rows > it[H_RTOT])
-          return MPCASM_ERR_PLAN;
+      if (it[H_RS_COMPACT] == 0) {
+        const int64_t offs[3] = {x[RT_A], x[RT_B], (int64_t)x[RT_D] - (rows > 0 ? no * 8 : 0)};
+        for (int k = 0; k < 3; ++k)
+          if (offs[k] < 0 || offs[k] % (4 * row_bytes) || offs[k] / row_bytes + rows > it[H_RTOT])
+            return MPCASM_ERR_PLAN;
+      } else if (rows > 0) {
+        // compact: the offsets carry the window's first column; what every group really reads -- 32
+        // bytes at its block in each of the rows -- stays inside the workspace
+        const int64_t d = (int64_t)x[RT_D] - vd * 8;
+        if (d < 0 || d % (4 * row_bytes) || d / row_bytes + rows > vrows) return MPCASM_ERR_PLAN;
+        for (int g = 0; g < 4; ++g) {
+          const int64_t a = (int64_t)x[RT_A] + 32 * ((x[RT_BI] >> (8 * g)) & 255);
+          const int64_t b = (int64_t)x[RT_B] + 32 * ((x[RT_BJ] >> (8 * g)) & 255);
+          if (a < 0 || a % 32 || a + (rows - 1) * row_bytes + 32 > vsize * 8) return MPCASM_ERR_PLAN;
+          if (!((qmask >> g) & 1) && (b < 0 || b % 32 || b + (rows - 1) * row_bytes + 32 > vsize * 8))
+            return MPCASM_ERR_PLAN;
+        }
+      }
     }
     {  // every wavefront's trips: consecutive, whole packs (first ... last)
       const int32_t* wt = it + it[H_OFF_RS_WTRIP];
@@ -502,8 +527,8 @@ int validate_plan(const int32_t* it, const double* h_dtab, size_t n_itab, size_t
           x[RR_EXTREME] >= it[H_NPARAMS])
         return MPCASM_ERR_PLAN;
       for (int a = 0; a < RS_AXMAX; ++a)
-        if (x[RR_VOFF + a] < 0 || x[RR_VOFF + a] % it[H_LDV] != 0 ||
-            x[RR_VOFF + a] / it[H_LDV] >= std::max<int64_t>(it[H_RTOT], 1) || x[RR_ARROW + a] < 0 ||
+        if (x[RR_VOFF + a] < 0 || x[RR_VOFF + a] % vldv != 0 ||
+            x[RR_VOFF + a] / vldv >= std::max<int64_t>(vrows, 1) || x[RR_ARROW + a] < 0 ||
             x[RR_ARROW + a] > it[H_NPARAMS] || x[RR_CENTER + a] < 0 ||
             x[RR_CENTER + a] > it[H_NPARAMS])
           return MPCASM_ERR_PLAN;
@@ -516,6 +541,14 @@ int validate_plan(const int32_t* it, const double* h_dtab, size_t n_itab, size_t
         return MPCASM_ERR_PLAN;
     }
     if (it[H_RR_PACKED] != 0 && (it[H_RR_PACKED] != 1 || (no & 1) || nc < 1)) return MPCASM_ERR_PLAN;
+    if (it[H_RS_COMPACT]) {  // a window lies inside its row: first + count column pairs <= RS_VD / 2
+      const int32_t* win = it + it[H_OFF_RS_RRWIN];
+      for (int64_t R = 0; R < nc; ++R)
+        for (int a = 0; a < 2; ++a) {
+          const uint32_t w = ((uint32_t)win[R] >> (16 * a)) & 0xFFFF;
+          if (2 * (int64_t)(w >> 8) > vd) return MPCASM_ERR_PLAN;
+        }
+    }
     {  // the per-column tables of the diagonal gterms and the piece descriptors of G
       if (!in_range(it[H_OFF_RS_DPAR], no * 2 * RS_DIAG_MAX, n, H_WORDS) || it[H_OFF_RS_DPAR] % 4 ||
           !in_range(it[H_DOFF_RS_DCOEF], no * RS_DIAG_MAX, nd, 0) || it[H_DOFF_RS_DCOEF] % 2)
@@ -535,8 +568,17 @@ int validate_plan(const int32_t* it, const double* h_dtab, size_t n_itab, size_t
         for (int64_t e = 0; e < ngd; ++e) {  // the same numbers as the row record of the piece
           const int64_t R = e < pieces ? e / (no / 2) : 0, cp = e < pieces ? e % (no / 2) : 0;
           const int32_t* x = rrw + R * RS_RR_WORDS;
-          const uint32_t v0 = (uint32_t)x[RR_VOFF] + 2 * cp, v1 = (uint32_t)x[RR_VOFF + 1] + 2 * cp;
-          const uint32_t a0 = (uint32_t)x[RR_ARROW], a1 = (uint32_t)x[RR_ARROW + 1];
+          uint32_t v0 = (uint32_t)x[RR_VOFF] + 2 * cp, v1 = (uint32_t)x[RR_VOFF + 1] + 2 * cp;
+          uint32_t a0 = (uint32_t)x[RR_ARROW], a1 = (uint32_t)x[RR_ARROW + 1];
+          if (it[H_RS_COMPACT]) {  // ... the piece inside the axis' window, or row 0 and the zero arrow
+            const uint32_t win = (uint32_t)(it + it[H_OFF_RS_RRWIN])[R];
+            const uint32_t d0 = (uint32_t)cp - (win & 255), d1 = (uint32_t)cp - ((win >> 16) & 255);
+            const bool in0 = d0 < ((win >> 8) & 255), in1 = d1 < (win >> 24);
+            v0 = in0 ? (uint32_t)x[RR_VOFF] + 2 * d0 : 0;
+            a0 = in0 ? a0 : (uint32_t)it[H_NPARAMS];
+            v1 = in1 ? (uint32_t)x[RR_VOFF + 1] + 2 * d1 : (x[RR_NAXES] >= 2 ? 0 : (uint32_t)x[RR_VOFF + 1]);
+            a1 = in1 || x[RR_NAXES] < 2 ? a1 : (uint32_t)it[H_NPARAMS];
+          }
           const bool as_is = (uint32_t)gd[2 * e] == (v0 | (v1 << 16)) && (uint32_t)gd[2 * e + 1] == (a0 | (a1 << 16));
           const bool swapped = (uint32_t)gd[2 * e] == (v1 | (v0 << 16)) && (uint32_t)gd[2 * e + 1] == (a1 | (a0 << 16));
           if (!as_is && !swapped) return MPCASM_ERR_PLAN;
@@ -768,6 +810,8 @@ void plan_dev_from_tables(const int32_t* it, PlanDev* out) {
   d.t_ngrest = it[H_T_NGREST]; d.off_t_grest = it[H_OFF_T_GREST]; d.off_t_brow0 = it[H_OFF_T_BROW0]; d.t_toeplitz = it[H_T_TOEPLITZ];
   d.off_t_bcolptr = it[H_OFF_T_BCOLPTR]; d.off_t_bcols = it[H_OFF_T_BCOLS];
   d.rs_ngfix = it[H_RS_NGFIX]; d.off_rs_gfix = it[H_OFF_RS_GFIX];
+  d.rs_compact = it[H_RS_COMPACT]; d.rs_ldv = it[H_RS_LDV]; d.rs_vd = it[H_RS_VD];
+  d.rs_vrow0 = it[H_RS_VROW0]; d.off_rs_rrwin = it[H_OFF_RS_RRWIN];
   d.t_nbrow = d.t_ci_ok ? it[d.off_t_brow0 + d.nbase] : 0;
   d.pm_nfd = it[H_PM_NFD]; d.off_pm_map = it[H_OFF_PM_MAP]; d.off_pm_fdptr = it[H_OFF_PM_FDPTR];
   d.off_pm_op = it[H_OFF_PM_OP]; d.doff_pm_pool = it[H_DOFF_PM_POOL];

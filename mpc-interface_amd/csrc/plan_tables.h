@@ -29,7 +29,7 @@
 namespace mpcasm {
 
 constexpr int32_t PLAN_MAGIC = 0x4D504341;  // 'MPCA'
-constexpr int32_t PLAN_VERSION = 23;
+constexpr int32_t PLAN_VERSION = 24;
 
 enum HeaderWord : int {
   H_MAGIC = 0,
@@ -191,9 +191,21 @@ enum HeaderWord : int {
   H_OFF_RS_GFIX,    // [RS_GDESC_THREADS][2] per thread: workspace index of the second axis (as in RS_GDESC)
                     //    | u << 16 -- the piece is its e = t + u RS_GDESC_THREADS --, the second arrow's
                     //    parameter slot; a thread without such a piece: 0 | RS_GFIX_NONE << 16, NPARAMS
+  // The persistent kernel's workspace V (plan.py Workspace): row major, leading dimension RS_LDV,
+  // RS_VROW0 zero rows in front; a row holds its *window* of the unknowns -- dense (RS_COMPACT 0): all
+  // of them, RS_LDV = LDV, RS_VD = NO, RS_VROW0 = 0; compact: the 4-column blocks its row-set can be
+  // non-zero in, so that a wide problem of several axes fits two workgroups per CU -- then d in
+  // column RS_VD and the one behind it.  Trip offsets (RT_A, RT_B) have the window's first column
+  // taken off, so that block bi of the unknowns is found at + 32 bi all the same.
+  H_RS_COMPACT,
+  H_RS_LDV,
+  H_RS_VD,
+  H_RS_VROW0,
+  H_OFF_RS_RRWIN,   // [NC] (compact) per row of G the windows of its two axes in column pairs:
+                    //    first | count << 8, the second axis << 16 (a missing axis: 0)
   H_WORDS = 128
 };
-static_assert(H_OFF_RS_GFIX < H_WORDS, "plan header");
+static_assert(H_OFF_RS_RRWIN < H_WORDS, "plan header");
 
 constexpr int T_BLOCK = 128;       // columns of a block of P (tiled kernel)
 constexpr int T_SID_CONST = 32;    // the stream that is the plan's own dtab

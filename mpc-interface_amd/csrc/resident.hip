@@ -107,7 +107,7 @@ static_assert(GU == RS_GDESC_PIECES && WT == RS_GDESC_THREADS, "descriptor table
 // last row (the lanes of a block of q read two columns past the ones)
 template <class PlanT>
 __host__ __device__ inline int resident_v_doubles(const PlanT& p) {
-  return p.rtot * p.ldv + 16;
+  return (p.rs_vrow0 + p.rtot) * p.rs_ldv + 16;
 }
 
 struct ResidentLayout {
@@ -115,7 +115,7 @@ struct ResidentLayout {
   int v, pl, ql, dvec, dcoef, dpar, img, ab, streams, ints, total_doubles;
   int ldp;                                            // leading dimension of P in LDS
   int p_direct;  // 1: P does not fit beside the workspace -- its blocks go straight to HBM
-  int i_rr, i_meta, i_wtrip, i_split, i_lti, i_abmeta, i_gdesc, i_gfix, i_cscp;  // offsets in ints inside the int region
+  int i_rr, i_meta, i_wtrip, i_split, i_lti, i_abmeta, i_gdesc, i_gfix, i_rrwin, i_cscp;  // offsets in ints inside the int region
 };
 
 template <class PlanT>
@@ -144,6 +144,7 @@ __host__ __device__ inline ResidentLayout resident_layout(const PlanT& p) {
   L.i_gdesc = i;  i += resident_g_mode(p) == 2 ? GU * WT * 2 : (resident_g_mode(p) == 3 ? 2 * p.csc_gnnz : 0);
   // per stream-wave thread: the second axis of the one piece of its that needs both (H_RS_NGFIX)
   L.i_gfix = i;   i += resident_g_mode(p) == 2 && p.rs_ngfix != 0 ? 2 * WT : 0;
+  L.i_rrwin = i;  i += p.rs_compact ? p.nc : 0;  // windows of the rows of G (compact workspace)
   L.i_cscp = i;   i += resident_g_mode(p) == 3 ? p.csc_pnnz : 0;
   L.i_wtrip = i; i += RS_WAVES * 2;
   L.i_split = i; i += p.rs_nsplit;
@@ -209,7 +210,7 @@ __device__ __forceinline__ void spec_trip(TripState& s) {
   constexpr int A = spec::TRIPS[I][RT_A], B = spec::TRIPS[I][RT_B], D = spec::TRIPS[I][RT_D];
   constexpr int W = spec::TRIPS[I][RT_W], AIM = spec::TRIPS[I][RT_AIM], WORD = spec::TRIPS[I][RT_WORD];
   constexpr int BI = spec::TRIPS[I][RT_BI], BJ = spec::TRIPS[I][RT_BJ];
-  constexpr int row_bytes = PC::ldv * 8, ldp = (PC::no + 1) & ~1;
+  constexpr int row_bytes = PC::rs_ldv * 8, ldp = (PC::no + 1) & ~1;
   constexpr int qmask = (WORD >> RT_QMASK) & 15, livemask = (WORD >> RT_LIVE) & 15;
   constexpr bool nop = (WORD >> RT_NOP) & 1, half = (WORD >> RT_HALF) & 1;
   if constexpr ((WORD >> RT_FIRST) & 1) {  // a new pack: what this lane reads and owns
@@ -332,7 +333,7 @@ __device__ __forceinline__ void resident_body(
     t_prev = t_now;                                                \
   }
   const ResidentLayout L = resident_layout(p);
-  const int no = p.no, nc = p.nc, ldv = p.ldv, ldp = L.ldp;
+  const int no = p.no, nc = p.nc, ldv = p.rs_ldv, vd = p.rs_vd, ldp = L.ldp;  // (ldv, vd: plan_tables.h H_RS_LDV)
 
   double* V = lds + L.v;
   double* Pl = lds + L.pl;
@@ -350,6 +351,7 @@ __device__ __forceinline__ void resident_body(
   int2* abmeta = reinterpret_cast<int2*>(itb + L.i_abmeta);
   int2* gdesc = reinterpret_cast<int2*>(itb + L.i_gdesc);  // [GU][WT]
   int2* gfix = reinterpret_cast<int2*>(itb + L.i_gfix);    // [WT]
+  int* rrwin = itb + L.i_rrwin;                            // [nc]
   // LDS byte address of the image double buffer (the low half of a flat LDS address)
   const unsigned img_lds = (unsigned)(uintptr_t)(lds + L.img);  // (rs_img doubles each, rs_img_dma of them loaded)
   const int unit = p.rs_unit, nchunk = p.rs_nchunk;
@@ -556,7 +558,8 @@ __device__ __forceinline__ void resident_body(
   // writes -- four instances' q and h end on a line boundary for every even problem size, and
   // what one workgroup writes within a few microseconds merges in its L2
   // (tools/microbench/store_rate3.hip: +9 % on the C2 output pattern alone).
-  const int run_shift = (long)batch >= 16L * gridDim.x && !(phases & 256) ? 2 : 0;  // (bit 8: A/B aid)
+  const int run_over = (phases >> 10) & 7;  // (bits 10-12, A/B aid: runs of 2^k instances)
+  const int run_shift = run_over ? run_over : ((long)batch >= 16L * gridDim.x && !(phases & 256) ? 2 : 0);  // (bit 8: A/B aid)
   auto instance_at = [&](int n) -> long {
     return ((((long)(n >> run_shift) * gridDim.x + blockIdx.x)) << run_shift) + (n & ((1 << run_shift) - 1));
   };
@@ -637,6 +640,8 @@ __device__ __forceinline__ void resident_body(
       for (int k = 0; k < RRK; ++k)
         if (ct + k * CT < nrr) rr[ct + k * CT] = v_rr[k];
       for (int i = ct + RRK * CT; i < nrr; i += CT) rr[i] = trr[i];
+      if (p.rs_compact)
+        for (int R = ct; R < nc; R += CT) rrwin[R] = (plan_itab + p.off_rs_rrwin)[R];
       if (p.rr_packed)
         for (int R = ct; R < nc; R += CT) {
           const int32_t* g = trr + R * RR_WORDS;
@@ -666,7 +671,7 @@ __device__ __forceinline__ void resident_body(
   lds_barrier();
   SETUP_STAMP(5)
   // column no + 1 of the workspace: ones, for the whole launch (nothing composes into it)
-  for (int r = tid; r < p.rtot; r += NT) V[r * ldv + no + 1] = 1.0;
+  for (int r = tid; r < p.rtot; r += NT) V[(p.rs_vrow0 + r) * ldv + vd + 1] = 1.0;
 
   const bool lookahead = (phases & 128) != 0;  // diagnostic: off = fetch only when needed
   if (wave < MW) {
@@ -711,6 +716,65 @@ __device__ __forceinline__ void resident_body(
   const int g_first = wt >= 0 && npair > 0 ? ((wt / npair) << 16) | (wt % npair) : 0;
   const int g_dR = npair > 0 ? WT / npair : 0, g_dcp = npair > 0 ? WT % npair : 0;
 
+
+  // G by 16-byte pieces from the packed row records (g_mode 1): piece e = wt + u WT of G is columns
+  // 2cp, 2cp+1 of row R.  Per piece: the packed words of the row record -> arrows and workspace
+  // rows -> arithmetic -> one 16-byte store; the reads of three pieces are in flight together
+  const auto g_packed = [&](double* Gb, const double* V, const double* prm) __attribute__((always_inline)) {
+    double2* G2 = reinterpret_cast<double2*>(Gb);
+    int first = g_first;  // opaque copy: nothing derived from it is kept across instances
+    asm volatile("" : "+v"(first));
+    int R = first >> 16, cp = first & 0xFFFF;
+    for (int e0 = wt; e0 < gtotal; e0 += 3 * WT) {
+      int2 ds[3];
+      int c2[3], wn[3];
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int Rr = e0 + u * WT < gtotal ? R : 0;
+        ds[u] = *reinterpret_cast<const int2*>(rr + Rr * RR_COMPACT);
+        wn[u] = p.rs_compact ? rrwin[Rr] : 0;
+        c2[u] = 2 * cp;
+        cp += g_dcp;
+        R += g_dR;
+        if (cp >= npair) {
+          cp -= npair;
+          ++R;
+        }
+      }
+      double a0[3], a1[3];
+      double2 v0[3], v1[3];
+      if (p.rs_compact) {
+        // a row holds its window of the columns: a piece outside it is zero -- read the
+        // window's first piece and the always-zero parameter behind the others instead
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          const unsigned win = (unsigned)wn[u], cpair = (unsigned)c2[u] >> 1;
+          const unsigned d0 = cpair - (win & 255), d1 = cpair - ((win >> 16) & 255);
+          const bool in0 = d0 < ((win >> 8) & 255), in1 = d1 < (win >> 24);
+          a0[u] = prm[in0 ? ds[u].y & 0xFFFF : p.nparams];
+          a1[u] = prm[in1 ? (unsigned)ds[u].y >> 16 : p.nparams];
+          v0[u] = *reinterpret_cast<const double2*>(V + (ds[u].x & 0xFFFF) + (in0 ? 2 * d0 : 0));
+          v1[u] = *reinterpret_cast<const double2*>(V + ((unsigned)ds[u].x >> 16) + (in1 ? 2 * d1 : 0));
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          a0[u] = prm[ds[u].y & 0xFFFF];
+          a1[u] = prm[(unsigned)ds[u].y >> 16];
+          v0[u] = *reinterpret_cast<const double2*>(V + (ds[u].x & 0xFFFF) + c2[u]);
+          v1[u] = *reinterpret_cast<const double2*>(V + ((unsigned)ds[u].x >> 16) + c2[u]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int e = e0 + u * WT;
+        double2 r;
+        r.x = fma(a1[u], v1[u].x, a0[u] * v0[u].x);
+        r.y = fma(a1[u], v1[u].y, a0[u] * v0[u].y);
+        if (e < gtotal) store_result(&G2[e], r);
+      }
+    }
+  };
 
   if (STAMPS && stamping) t_prev = __builtin_amdgcn_s_memtime();
   int buf = 0, iter = 0;  // iter: instances this workgroup has started
@@ -855,8 +919,8 @@ __device__ __forceinline__ void resident_body(
               ha1 = prm[(unsigned)hr.w >> 16];
               hc0 = prm[hc.x];
               hc1 = prm[hc.y];
-              hd0 = V[(hr.z & 0xFFFF) + no];
-              hd1 = V[((unsigned)hr.z >> 16) + no];
+              hd0 = V[(hr.z & 0xFFFF) + vd];
+              hd1 = V[((unsigned)hr.z >> 16) + vd];
               hext = prm[hr.y];
             }
             // rounds whose pieces all have one axis that can be non-zero (p.rs_gsingle: known to
@@ -902,46 +966,7 @@ __device__ __forceinline__ void resident_body(
             }
           }
         } else if (g_mode == 1) {
-          // piece e = wt + u WT of G: columns 2cp, 2cp+1 of row R.  Per piece: the packed
-          // words of the row record -> arrows and workspace rows -> arithmetic -> one
-          // 16-byte store; the reads of three pieces are in flight together
-          double2* G2 = reinterpret_cast<double2*>(Gb);
-          int first = g_first;  // opaque copy: nothing derived from it is kept across instances
-          asm volatile("" : "+v"(first));
-          int R = first >> 16, cp = first & 0xFFFF;
-          for (int e0 = wt; e0 < gtotal; e0 += 3 * WT) {
-            int2 ds[3];
-            int c2[3];
-#pragma unroll
-            for (int u = 0; u < 3; ++u) {
-              const int Rr = e0 + u * WT < gtotal ? R : 0;
-              ds[u] = *reinterpret_cast<const int2*>(rr + Rr * RR_COMPACT);
-              c2[u] = 2 * cp;
-              cp += g_dcp;
-              R += g_dR;
-              if (cp >= npair) {
-                cp -= npair;
-                ++R;
-              }
-            }
-            double a0[3], a1[3];
-            double2 v0[3], v1[3];
-#pragma unroll
-            for (int u = 0; u < 3; ++u) {
-              a0[u] = prm[ds[u].y & 0xFFFF];
-              a1[u] = prm[(unsigned)ds[u].y >> 16];
-              v0[u] = *reinterpret_cast<const double2*>(V + (ds[u].x & 0xFFFF) + c2[u]);
-              v1[u] = *reinterpret_cast<const double2*>(V + ((unsigned)ds[u].x >> 16) + c2[u]);
-            }
-#pragma unroll
-            for (int u = 0; u < 3; ++u) {
-              const int e = e0 + u * WT;
-              double2 r;
-              r.x = fma(a1[u], v1[u].x, a0[u] * v0[u].x);
-              r.y = fma(a1[u], v1[u].y, a0[u] * v0[u].y);
-              if (e < gtotal) store_result(&G2[e], r);
-            }
-          }
+          g_packed(Gb, V, prm);
         } else if ((no & 1) == 0) {
           // (opaque copies of the thread index keep the general paths' per-thread constants
           // from being computed once and then held in registers for the whole launch)
@@ -998,9 +1023,9 @@ __device__ __forceinline__ void resident_body(
           if (p.rr_packed) {
             const int4 c = reinterpret_cast<const int4*>(rr)[R];
             const double a0 = prm[c.y & 0xFFFF], a1 = prm[(unsigned)c.y >> 16];
-            double ac = a0 * prm[c.z & 0xFFFF], ad = a0 * V[(c.x & 0xFFFF) + no];
+            double ac = a0 * prm[c.z & 0xFFFF], ad = a0 * V[(c.x & 0xFFFF) + vd];
             ac += a1 * prm[(unsigned)c.z >> 16];
-            ad = fma(a1, V[((unsigned)c.x >> 16) + no], ad);
+            ad = fma(a1, V[((unsigned)c.x >> 16) + vd], ad);
             hb[R] = (prm[c.w] + ac) - ad;
             continue;
           }
@@ -1010,7 +1035,7 @@ __device__ __forceinline__ void resident_body(
           for (int ax = 0; ax < naxes; ++ax) {
             const double a = prm[rec[RR_ARROW + ax]];
             ac += a * prm[rec[RR_CENTER + ax]];
-            ad = fma(a, V[rec[RR_VOFF + ax] + no], ad);
+            ad = fma(a, V[rec[RR_VOFF + ax] + vd], ad);
           }
           hb[R] = (prm[rec[RR_EXTREME]] + ac) - ad;
         }
@@ -1321,15 +1346,20 @@ int resident_choose_p_direct(const PlanDev& p, int option) {
   return (!fits || option == 1) ? 1 : (option == 2 ? 0 : 2);
 }
 
-// ... for one launch.  Two things decide (round 3, tools/ab_n24.py: same box, one process):
-// * whether P in LDS costs a workgroup per CU: the biped at N = 24 needs 85 KB with P beside the
-//   workspace and 64 KB without -- one workgroup per CU or two -- and is faster with the direct
-//   stores at EVERY batch size (B = 8192: 0.76 against 0.46 of 8 TB/s; 65536: 0.58 against 0.48);
-// * else the size of the launch: the 32-byte runs of the direct stores merge on their way to HBM
-//   while a launch writes less than ~0.55 GB (C2 at B = 16384: 0.73 direct against 0.65 through
-//   LDS; round 2 switched at 0.2 GB already), beyond that they cost a third of the write rate
-//   (B = 32768: 0.46 against 0.68; tools/microbench/store_rate3.hip shows the same on the bare
-//   store pattern).
+// ... for one launch.  What decides (round 3, tools/ab_n24.py, tools/ab_workspace.py: same box, one
+// process, interleaved rounds):
+// * the size of the launch: the 32-byte runs of the direct stores merge on their way to HBM while
+//   a launch writes less than ~0.55 GB (C2 at B = 16384: 0.73 direct against 0.65 through LDS;
+//   round 2 switched at 0.2 GB already), beyond that they reach memory as partial lines and cost a
+//   third of the write rate and more (C2 at B = 32768: 0.46 against 0.68; C3 at 16384 with the
+//   compact workspace: 0.54 direct against 0.82 through LDS although P is a sixth of its output;
+//   tools/microbench/store_rate3.hip shows the same on the bare store pattern);
+// * unless P in LDS costs a workgroup per CU AND an instance is small: the biped at N = 24 with the
+//   dense workspace needs 85 KB with P beside it and 64 KB without -- one workgroup per CU or two
+//   -- and is faster with the direct stores at EVERY batch size (B = 8192: 0.76 against 0.46 of
+//   8 TB/s; 65536: 0.58 against 0.48): eight wavefronts on 68 KB of output per instance leave the
+//   CU idle between phases.  C3's 226 KB per instance (92 trips, 9408 pieces of G) keep one
+//   workgroup's waves busy: there the size of the launch decides as everywhere else.
 int resident_p_direct_for(const PlanDev& p, int batch) {
   if (p.rs_p_direct != 2) return p.rs_p_direct;
   PlanDev q = p;
@@ -1338,15 +1368,15 @@ int resident_p_direct_for(const PlanDev& p, int batch) {
   q.rs_p_direct = 1;
   const size_t without = (size_t)resident_layout(q).total_doubles * sizeof(double);
   constexpr size_t HALF_CU = 80 * 1024;  // two workgroups share a CU's 160 KB
-  if (with_p > HALF_CU && without <= HALF_CU) return 1;
-  const double out_bytes = 8.0 * ((double)p.no * p.no + p.no + (double)p.nc * p.no + p.nc) * batch;
-  return out_bytes < 560e6 ? 1 : 0;
+  const double per_instance = 8.0 * ((double)p.no * p.no + p.no + (double)p.nc * p.no + p.nc);
+  if (with_p > HALF_CU && without <= HALF_CU && per_instance < 128.0 * 1024) return 1;
+  return per_instance * batch < 560e6 ? 1 : 0;
 }
 
 // 0 when the resident kernel cannot take this plan, else its dynamic LDS bytes
 size_t resident_lds_bytes(const PlanDev& p) {
   if (!p.rs_ok || p.rs_jc > RS_JC_MAX || p.no > WT || p.no < 1 || p.max_axes > AXMAX) return 0;
-  if ((long)p.rtot * p.ldv > (1 << 20)) return 0;
+  if ((long)(p.rs_vrow0 + p.rtot) * p.rs_ldv > (1 << 20)) return 0;
   return (size_t)resident_layout(p).total_doubles * sizeof(double);
 }
 

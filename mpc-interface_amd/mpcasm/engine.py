@@ -118,7 +118,8 @@ class Assembler:
         :meth:`bind_lti`.
     """
 
-    def __init__(self, form, batch=1, device=None, costs=None, limits=None, lti=(), csc=None):
+    def __init__(self, form, batch=1, device=None, costs=None, limits=None, lti=(), csc=None,
+                 workspace="auto"):
         torch = require_device()
         self._torch = torch
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None \
@@ -129,7 +130,8 @@ class Assembler:
         # pattern of :meth:`csc_pattern` -- written by the assembly kernel itself
         # (biped_mpc_loop.py:57-58 without a second pass).  ValueError / RuntimeError when the
         # problem does not run on the persistent kernel: assemble dense and use export_csc.
-        self.plan = compile_plan(form, costs=costs, limits=limits, lti=tuple(lti), csc=csc)
+        self.plan = compile_plan(form, costs=costs, limits=limits, lti=tuple(lti), csc=csc,
+                                 workspace=workspace)
         self.csc = self.plan.csc
         p = self.plan
         self.ng, self.no, self.nc = p.ng, p.no, p.nc
@@ -324,15 +326,19 @@ class Assembler:
             P = q = None
         if not want_constraints or nc == 0:
             G = h = None
+        self._launch(g, (P, q, G, h), n_run, stream)
+        return P, q, G, h
+
+    def _launch(self, g, out, n_run, stream):
+        torch = self._torch
         ptrs, strides = self._src_args()
         ptr = lambda t: t.data_ptr() if t is not None else None
         work = self._workspace()
         with torch.cuda.device(self.device):
             rc = capi.load().mpcasm_assemble(
-                self._handle, ptrs, strides, self.params.data_ptr(), ptr(g), ptr(P), ptr(q),
-                ptr(G), ptr(h), work.data_ptr(), n_run, _stream_handle(torch, stream))
+                self._handle, ptrs, strides, self.params.data_ptr(), ptr(g), *(ptr(t) for t in out),
+                work.data_ptr(), n_run, _stream_handle(torch, stream))
         capi.check(rc, "mpcasm_assemble")
-        return P, q, G, h
 
     def last_kernel(self):
         """Name of the kernel(s) the latest :meth:`assemble` launched (``mpcasm_plan_last_kernel``)."""

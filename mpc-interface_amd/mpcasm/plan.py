@@ -17,7 +17,7 @@ import numpy as np
 import scipy.sparse as sp
 
 PLAN_MAGIC = 0x4D504341
-PLAN_VERSION = 23
+PLAN_VERSION = 24
 
 # header words (csrc/plan_tables.h, enum HeaderWord)
 _H = {name: i for i, name in enumerate([
@@ -39,7 +39,7 @@ _H = {name: i for i, name in enumerate([
     "T_CI_OK", "T_NOP", "OFF_T_CIG", "OFF_T_CIO", "T_DOFF_DELTA", "T_NDELTA",
     "T_OK", "T_NSTAGE", "OFF_T_STAGE", "T_NLTI", "OFF_T_LTI", "OFF_T_LTI_IDS", "T_WORK",
     "OFF_T_GROW", "OFF_T_SROW", "T_DOFF_SCOEF", "OFF_T_PIG", "T_NGREST", "OFF_T_GREST", "OFF_T_BROW0", "OFF_T_BCOLPTR", "OFF_T_BCOLS", "T_TOEPLITZ",
-    "RS_NGFIX", "OFF_RS_GFIX",
+    "RS_NGFIX", "OFF_RS_GFIX", "RS_COMPACT", "RS_LDV", "RS_VD", "RS_VROW0", "OFF_RS_RRWIN",
 ])}
 H_WORDS = 128
 assert len(_H) <= H_WORDS
@@ -65,6 +65,7 @@ RS_AXMAX = 4                              # axes per constraint row record
 RS_DST_ACC = 1 << 30                      # compose destination shared by two threads
 RS_GDESC_PIECES, RS_GDESC_THREADS = 6, 256   # descriptor table of G: pieces per stream-wave thread
 RS_GFIX_NONE = 7
+RS_COMPACT_FROM_BYTES = 65536           # a dense workspace beyond this is compacted (tools/ab_workspace.py)
 RS_RR_WORDS = 16                          # row record: voff[4], arrow param[4], center param[4], naxes, extreme param, pad
 SEG_WORDS, GT_WORDS, LM_WORDS, LX_WORDS = 8, 10, 12, 2
 FUSED_MAX_OPS = 1 << 18           # beyond this the staged pipeline is used
@@ -336,9 +337,11 @@ class _Builder:
         the others are never materialised."""
         offsets, blocks = {}, []
         self.rtot = 0
+        self.spans = []                      # (first row, rows incl. the zero rows behind them)
         for rid, block in enumerate(self.rowset_rows):
             if rid in needed:
                 offsets[rid] = self.rtot
+                self.spans.append((self.rtot, block.shape[0] + -block.shape[0] % 4))
                 self.rtot += block.shape[0]
                 blocks.append(block)
                 pad = -block.shape[0] % 4
@@ -562,18 +565,75 @@ def _fused_program(b, rowptr, entbase, entk, entcoef, rtot, ldv):
                 row_tiles=row_tiles)
 
 
-def rs_index(r, c, ldv):
-    """Where the persistent kernel keeps element (r, c) of the workspace in LDS: row major,
-    ``V[r][c]`` with leading dimension ``ldv`` (columns: the unknowns, d = Mg.given, ones).  Rows
-    come in groups of four (row-sets start on a group, zero rows pad them): a 16-row trip feeds
-    lane row lk of the matrix core the rows ``base + (0, 8, 4, 12)[lk] + u``, u = k-step -- the two
-    lane rows an 8-byte LDS read serves together lie 8 rows apart, which with ldv = 2 (mod 4) is
-    half the banks -- and the two columns of a 16-byte piece of G are adjacent."""
-    return r * ldv + c
+class Workspace:
+    """Where the persistent kernel keeps the workspace V in LDS: row major with leading dimension
+    ``ldv``; a row holds the columns ``c0[r] .. c0[r] + w[r] - 1`` of the unknowns (its *window*),
+    d = Mg.given in column ``vd`` and a one behind it.  Rows come in groups of four (row-sets start
+    on a group, zero rows pad them): a 16-row trip feeds lane row lk of the matrix core the rows
+    ``base + (0, 8, 4, 12)[lk] + u``, u = k-step -- the two lane rows an 8-byte LDS read serves
+    together lie 8 rows apart, which with ldv = 2 (mod 4) is half the banks -- and the two columns
+    of a 16-byte piece of G are adjacent.
+
+    *Dense* (:meth:`dense`): every row holds all the unknowns (c0 = 0, vd = no).  *Compact*
+    (:meth:`windows`): a row-set holds only the 4-column blocks its rows can be non-zero in -- a
+    row-set of an x variable has no y columns -- which is what lets a three-axis problem (C3) fit two
+    workgroups per CU.  A trip adds ``- c0 * 8`` to its operand offsets, so that block ``bi`` of the
+    unknowns is still found at ``+ 32 bi``; ``row0`` zero rows in front keep those offsets
+    non-negative."""
+
+    def __init__(self, no, ldv, vd, row0, c0, w, compact):
+        self.no, self.ldv, self.vd, self.row0, self.compact = no, ldv, vd, row0, compact
+        self.c0, self.w = np.asarray(c0, dtype=np.int64), np.asarray(w, dtype=np.int64)
+        self.rtot = self.c0.size
+
+    @classmethod
+    def dense(cls, rtot, no, ldv):
+        return cls(no, ldv, no, 0, np.zeros(rtot), np.full(rtot, ldv - 2), 0)
+
+    @classmethod
+    def windows(cls, rtot, no, spans, el_row, el_col):
+        """Windows from the structural non-zeros ``(el_row, el_col)`` of the workspace, one per
+        row-set (``spans``: first row, rows incl. the zero rows behind it)."""
+        c0, w = np.zeros(rtot, dtype=np.int64), np.full(rtot, 4, dtype=np.int64)
+        keep = el_col < no
+        el_row, el_col = el_row[keep], el_col[keep]
+        for first, rows in spans:
+            cols = el_col[(el_row >= first) & (el_row < first + rows)]
+            if cols.size:
+                lo, hi = int(cols.min()) // 4 * 4, (int(cols.max()) + 4) // 4 * 4
+                c0[first:first + rows], w[first:first + rows] = lo, hi - lo
+        ldv = int(w.max()) + 2                                # = 2 mod 4
+        first_rows = np.asarray([f for f, _ in spans], dtype=np.int64)
+        short = int(max(0, (c0[first_rows] - first_rows * ldv).max())) if len(spans) else 0
+        row0 = -(-short // ldv)
+        row0 += -row0 % 4
+        return cls(no, ldv, int(w.max()), row0, c0, w, 1)
+
+    @property
+    def doubles(self):
+        return (self.row0 + self.rtot) * self.ldv
+
+    def rowstart(self, r):
+        """Index of the first stored element of row r (column c0[r])."""
+        return (self.row0 + r) * self.ldv
+
+    def index(self, r, c):
+        """Index of element (r, c): c < no an unknown inside the row's window, no: d, no + 1: the one."""
+        if c >= self.no:
+            return self.rowstart(r) + self.vd + (c - self.no)
+        assert self.c0[r] <= c < self.c0[r] + self.w[r], "outside the row's window"
+        return self.rowstart(r) + c - int(self.c0[r])
+
+    def origin(self, r):
+        """What a trip adds to 8 * 4 * block to find the block in row r: bytes."""
+        return (self.rowstart(r) - int(self.c0[r])) * 8
+
+    def holds_block(self, r, blk):
+        return self.c0[r] <= 4 * blk and 4 * blk + 4 <= self.c0[r] + self.w[r]
 
 
-def _resident_rows(limit_recs, lax_recs, nparams, ldv):
-    """Per row of the stacked G, 16 words: workspace index (:func:`rs_index`, column 0) of every axis' row [4], arrow
+def _resident_rows(limit_recs, lax_recs, nparams, ws):
+    """Per row of the stacked G, 16 words: workspace index (:meth:`Workspace.rowstart`) of every axis' row [4], arrow
     param of every axis [4], center param of every axis [4], naxes, extreme param, then
     the first two axes once more, packed: voff0 | voff1 << 16, arrow0 | arrow1 << 16 (zero
     where that does not fit); a missing axis points at workspace row 0 with the always-zero
@@ -586,7 +646,7 @@ def _resident_rows(limit_recs, lax_recs, nparams, ldv):
             for ax in range(RS_AXMAX):
                 if ax < naxes:
                     off, rs = lax_recs[lax0 + ax]
-                    voff.append(rs_index(off + (0 if rs == 1 else r), 0, ldv))
+                    voff.append(ws.rowstart(off + (0 if rs == 1 else r)))
                     ap.append(p_a + (0 if a_rows == 1 else r) * naxes + ax)
                     cp.append(p_c + (0 if c_rows == 1 else r) * naxes + ax)
                 else:
@@ -725,10 +785,12 @@ def _lti_table_offset(g, k, flat):
     return g["tab_b"] + ((kk - l) * n + i) * m + k
 
 
-def _resident_program(fused, gterms, no, ldv, image, ng, nparams, nc_rows):
+def _resident_program(fused, gterms, no, ldv, ws, image, ng, nparams, nc_rows):
     """Tables of the persistent fused kernel: the compose ops of ``_fused_program``
     dealt out to the RS_NT threads of a workgroup (kept in registers for the whole
-    launch) and the Hessian + gradient work split into per-wavefront lists of MFMA items."""
+    launch) and the Hessian + gradient work split into per-wavefront lists of MFMA items.
+    ``ldv``: the leading dimension ``fused["fd_idx"]`` is written in; ``ws``: where the kernel
+    keeps the element (:class:`Workspace`)."""
     import heapq
 
     NT, NW = RS_NT, RS_NW
@@ -788,7 +850,7 @@ def _resident_program(fused, gterms, no, ldv, image, ng, nparams, nc_rows):
             heapq.heappush(heap, (load + pc[1] - pc[0], t))
         if max((sum(pc[1] - pc[0] for pc in own) for own in trial), default=0) <= cap:
             owner = trial
-            split = sorted({rs_index(*divmod(int(fd_idx[pc[2]]), ldv), ldv) for pc in pieces if pc[3]})
+            split = sorted({ws.index(*divmod(int(fd_idx[pc[2]]), ldv)) for pc in pieces if pc[3]})
             break
     if owner is None:
         return out
@@ -807,7 +869,7 @@ def _resident_program(fused, gterms, no, ldv, image, ng, nparams, nc_rows):
                     gidx[j, t] = image["given"] + gi
                 coef[j, t] = pool[int(ops[o, 1]) & 0xFFFF]
                 j += 1
-            dst[j - 1, t] = rs_index(*divmod(int(fd_idx[i]), ldv), ldv) | (RS_DST_ACC if shared else 0)
+            dst[j - 1, t] = ws.index(*divmod(int(fd_idx[i]), ldv)) | (RS_DST_ACC if shared else 0)
     # ---- Hessian and gradient on the matrix core, in 4x4 blocks (plan_tables.h RT_*).
     # Block (bi, bj) of P exists when some term has structural non-zeros in columns 4bi.. of
     # its A rows and 4bj.. of its B rows; block bi of q when a term's A rows reach columns
@@ -851,11 +913,21 @@ def _resident_program(fused, gterms, no, ldv, image, ng, nparams, nc_rows):
         keys = by_sig[sig]
         for i in range(0, len(keys), 4):
             (packs if len(keys) - i >= 4 else partial).append((keys[i:i + 4], set(sig)))
+    def in_window(key, gi):
+        """Block ``key`` inside the windows of term gi's rows: what the term reads there are true
+        elements of the workspace (zeros where it does not reach), not some other row's."""
+        aoff, boff, flags = terms[gi][0], terms[gi][1], terms[gi][6]
+        if not ws.holds_block(aoff, key[0]):
+            return False
+        return key[1] < 0 or ws.holds_block(boff if flags & GT_FLAG_P else aoff, key[1])
+
     merged = []
     for keys, sig in sorted(partial, key=lambda p: (-len(p[0]), sorted(p[1]))):
         best = None
         for m in merged:
-            if len(m[0]) + len(keys) <= 4:
+            if len(m[0]) + len(keys) <= 4 and (not ws.compact or (
+                    all(in_window(k, gi) for k in keys for gi in m[1] - sig)
+                    and all(in_window(k, gi) for k in m[0] for gi in sig - m[1]))):
                 extra = len(m[1] | sig) * 2 - len(m[1]) - len(sig)
                 if best is None or extra < best[0]:
                     best = (extra, m)
@@ -874,7 +946,7 @@ def _resident_program(fused, gterms, no, ldv, image, ng, nparams, nc_rows):
         bi_bytes = sum(k[0] << (8 * j) for j, k in enumerate(grp))
         bj_bytes = sum(k[1] << (8 * j) for j, k in enumerate(grp))
         lst = []
-        row_bytes = ldv * 8
+        row_bytes = ws.ldv * 8
         for gi in sorted(tids):
             aoff, boff, nrows, wparam, doff, aimparam, flags = terms[gi][:7]
             half = 1 if flags & GT_FLAG_HALF else 0
@@ -887,8 +959,8 @@ def _resident_program(fused, gterms, no, ldv, image, ng, nparams, nc_rows):
                 # full trips of 16 rows (four groups, four k-steps); what is left goes group by
                 # group: *short* trips, one k-step each
                 rows = 16 if n4 - k0 >= 16 else 4
-                mine.append([(aoff + k0) * row_bytes, (brow + k0) * row_bytes,
-                             (doff + k0) * row_bytes + no * 8, wparam * 8, aimparam * 8,
+                mine.append([ws.origin(aoff) + k0 * row_bytes, ws.origin(brow) + k0 * row_bytes,
+                             (ws.rowstart(doff + k0) + ws.vd) * 8, wparam * 8, aimparam * 8,
                              rows | ((rows == 4) << RT_SHORT) | (half << RT_HALF) | (nop << RT_NOP),
                              bi_bytes, bj_bytes])
                 k0 += rows
@@ -916,6 +988,7 @@ def _resident_program(fused, gterms, no, ldv, image, ng, nparams, nc_rows):
     cost = [PACK_COST + sum(trip_cost(trip) for trip in lst) for lst in pack_trips]
     stream_threads = NT - NW * 64
     pieces = nc_rows * max(no // 2, 1)
+
     loads = []
     for w in range(RS_WAVES):
         if w < NW:
@@ -1238,7 +1311,7 @@ def csc_pattern(mask, upper=False):
     return indptr, rows_sorted.astype(np.int32), flat
 
 
-def compile_plan(form, costs=None, limits=None, lti=(), csc=None):
+def compile_plan(form, costs=None, limits=None, lti=(), csc=None, workspace="auto"):
     """Compile ``form`` (an up-to-date Formulation: sizes and IDs current).
 
     ``costs``: dict name -> Cost to include (default ``form.goals``);
@@ -1381,8 +1454,37 @@ def compile_plan(form, costs=None, limits=None, lti=(), csc=None):
         rec[8] = mask(rec[1], rec[2]) if rec[1] >= 0 else 0
     groups = _lti_groups(form, b.sources, lti)
     image = _resident_image(b.sources, b.ng, len(b.params), groups)
-    resident = _resident_program(fused, gterms, no, ldv, image, b.ng, len(b.params), nc)
-    rs_rr = _resident_rows(limit_recs, lax_recs, len(b.params), ldv)
+    # The persistent kernel's workspace: dense, or -- a wide problem whose row-sets each live in a
+    # part of the columns -- compact, when that is what lets a second workgroup share the CU's LDS.
+    # (Compact needs the 16-byte-piece paths of G: an even width, rows of at most two axes, no CSC.)
+    ws = Workspace.dense(rtot, no, ldv)
+    packed_like = csc is None and no % 2 == 0 and nc > 0 and all(rec[2] <= 2 for rec in limit_recs)
+    if workspace not in ("auto", "dense", "compact"):
+        raise ValueError("workspace: 'auto', 'dense' or 'compact'")
+    if _os.environ.get("MPCASM_NO_COMPACT"):              # (A/B aid: tools/ab_workspace.py)
+        workspace = "dense"
+    if packed_like and workspace != "dense" and (workspace == "compact"
+                                                 or 8 * ws.doubles > RS_COMPACT_FROM_BYTES):
+        cand = Workspace.windows(rtot, no, b.spans, fused["fd_idx"] // ldv, fused["fd_idx"] % ldv)
+        if ((workspace == "compact" or 3 * cand.doubles <= 2 * ws.doubles)
+                and (cand.row0 + rtot + 8) * cand.ldv < 65536 and len(b.params) < 65535):
+            ws = cand
+    resident = _resident_program(fused, gterms, no, ldv, ws, image, b.ng, len(b.params), nc)
+    rs_rr = _resident_rows(limit_recs, lax_recs, len(b.params), ws)
+    # per row of G the windows of its (at most two) axes, in column pairs: first | count << 8 of the
+    # first axis, the same << 16 of the second (compact workspace only; a missing axis: 0 | 0)
+    rs_rrwin = np.zeros(0, dtype=np.int32)
+    if ws.compact:
+        win = []
+        for out0, nrows, naxes, lax0, *_ in limit_recs:
+            for r in range(nrows):
+                word = 0
+                for ax in range(naxes):
+                    off, rs = lax_recs[lax0 + ax]
+                    row = off + (0 if rs == 1 else r)
+                    word |= (int(ws.c0[row]) // 2 | (int(ws.w[row]) // 2) << 8) << (16 * ax)
+                win.append(word)
+        rs_rrwin = np.asarray(win, dtype=np.int64).astype(np.uint32).view(np.int32)
     if any(rec[2] > RS_AXMAX for rec in limit_recs):
         rs_rr = np.zeros(0, dtype=np.int32)      # too many axes: no resident kernel
     pm_blocks, pm_rows, r0 = [], {}, 0
@@ -1441,14 +1543,15 @@ def compile_plan(form, costs=None, limits=None, lti=(), csc=None):
                 taken[c] += 1
     # ... and, for small problems, the descriptor of every 16-byte piece of G a stream-wave
     # thread owns: piece e = t + u RS_GDESC_THREADS, columns 2cp, 2cp+1 of row R = e // (no/2):
-    # rs_index(row0, 2cp) | rs_index(row1, 2cp) << 16, arrow0 | arrow1 << 16
+    # Workspace.index(row0, 2cp) | Workspace.index(row1, 2cp) << 16, arrow0 | arrow1 << 16
     rs_gdesc = rs_gfix = np.zeros(0, dtype=np.int32)
     rs_ngfix = 0
     rs_gsingle = 0
     rr_ok = rs_rr.size == nc * RS_RR_WORDS
-    packed_ok = (rr_ok and no % 2 == 0 and nc > 0 and (b.rtot + 8) * ldv < 65536
+    packed_ok = (rr_ok and no % 2 == 0 and nc > 0 and (ws.row0 + b.rtot + 8) * ws.ldv < 65536
                  and len(b.params) < 65535
                  and bool((rs_rr.reshape(nc, RS_RR_WORDS)[:, 12] <= 2).all()))
+    assert packed_ok or not ws.compact
     if packed_ok and nc * (no // 2) <= RS_GDESC_PIECES * RS_GDESC_THREADS:
         recs = rs_rr.reshape(nc, RS_RR_WORDS).astype(np.int64)
         e = np.arange(RS_GDESC_PIECES * RS_GDESC_THREADS)
@@ -1464,17 +1567,31 @@ def compile_plan(form, costs=None, limits=None, lti=(), csc=None):
         nz[fused["fd_idx"]] = True
         nz = nz.reshape(-1, ldv)
 
-        def can(voff, col):                              # voff = rs_index(row, 0)
-            return nz[voff // ldv, col] | nz[voff // ldv, col + 1]
+        def row_of(voff):                                # voff = Workspace.rowstart(row)
+            return np.clip(voff // ws.ldv - ws.row0, 0, max(rtot, 1) - 1)
+
+        def can(row, col):
+            return nz[row, col] | nz[row, col + 1]
+
+        def inside(row, col):                            # (windows are whole 4-column blocks)
+            return (ws.c0[row] <= col) & (col + 2 <= ws.c0[row] + ws.w[row])
 
         v0, v1, a0, a1 = recs[R, 0], recs[R, 1], recs[R, 4], recs[R, 5]
         two = recs[R, 12] >= 2
-        c0, c1 = can(v0, 2 * cp), two & can(v1, 2 * cp)
+        r0, r1 = row_of(v0), row_of(v1)
+        c0, c1 = can(r0, 2 * cp), two & can(r1, 2 * cp)
+        # the piece in the row's window: its index; outside (compact workspace): row 0, zero arrow
+        in0, in1 = inside(r0, 2 * cp), two & inside(r1, 2 * cp)
+        p0 = np.where(in0, v0 + 2 * cp - ws.c0[r0], 0)
+        p1 = np.where(in1 | ~two, v1 + np.where(two, 2 * cp - ws.c0[r1], 0), 0)
+        a0, a1 = np.where(in0, a0, len(b.params)), np.where(in1 | ~two, a1, len(b.params))
+        if not ws.compact:
+            p1 = v1 + 2 * cp                             # (a missing axis: row 0 + the piece's columns)
         swap = c1 & ~c0                                  # only the second axis can: it goes first
-        v0, v1 = np.where(swap, v1, v0), np.where(swap, v0, v1)
+        p0, p1 = np.where(swap, p1, p0), np.where(swap, p0, p1)
         a0, a1 = np.where(swap, a1, a0), np.where(swap, a0, a1)
         single = ~(c0 & c1) | ~live
-        word0 = (v0 + 2 * cp) | ((v1 + 2 * cp) << 16)    # rs_index(row, 2 cp)
+        word0 = p0 | (p1 << 16)                          # Workspace.index(row, 2 cp)
         word1 = a0 | (a1 << 16)
         rs_gdesc = np.stack([word0, word1], axis=1).astype(np.uint32).view(np.int32).reshape(-1)
         # A few pieces with two live axes among many with one (the biped's 34-wide phase: x ends
@@ -1490,7 +1607,7 @@ def compile_plan(form, costs=None, limits=None, lti=(), csc=None):
                 and not _os.environ.get('MPCASM_NO_GFIX')):
             fix = np.zeros((RS_GDESC_THREADS, 2), dtype=np.int64)
             fix[:, 0], fix[:, 1] = RS_GFIX_NONE << 16, len(b.params)
-            fix[owners, 0] = (v1 + 2 * cp)[both] | ((both // RS_GDESC_THREADS) << 16)
+            fix[owners, 0] = p1[both] | ((both // RS_GDESC_THREADS) << 16)
             fix[owners, 1] = a1[both]
             rs_gfix, rs_ngfix = fix.astype(np.uint32).view(np.int32).reshape(-1), int(both.size)
             single = np.ones_like(single)
@@ -1500,7 +1617,7 @@ def compile_plan(form, costs=None, limits=None, lti=(), csc=None):
                              if rounds[u, w]))
     # ---- CSC hand-off: where the stored entries sit (P: in the LDS copy of P, leading
     # dimension no rounded up to even) and, per stored entry (R, c) of G, what a 16-byte piece
-    # has for two columns: rs_index(row0, c) | rs_index(row1, c) << 16, arrow0 | arrow1 << 16
+    # has for two columns: Workspace.index(row0, c) | Workspace.index(row1, c) << 16, arrow0 | arrow1 << 16
     P_pattern, G_pattern = _structural_patterns(
         form, b, fused, gterms, limit_recs, lax_recs, rtot, ldv, no, nc)
     csc_p = csc_g = np.zeros(0, dtype=np.int32)
@@ -1575,7 +1692,7 @@ def compile_plan(form, costs=None, limits=None, lti=(), csc=None):
     sections += [("OFF_T_BCOLPTR", np.cumsum([0] + [c.size for c in bcols]).astype(np.int32)),
                  ("OFF_T_BCOLS", (np.concatenate(bcols) if bcols else np.zeros(0)).astype(np.int32))]
     sections += [("OFF_RS_DPAR", rs_dpar.reshape(-1)), ("OFF_RS_GDESC", rs_gdesc),
-                 ("OFF_RS_GFIX", rs_gfix),
+                 ("OFF_RS_GFIX", rs_gfix), ("OFF_RS_RRWIN", rs_rrwin),
                  ("OFF_PM_MAP", pmprog["map"]), ("OFF_PM_FDPTR", pmprog["fd_ptr"]),
                  ("OFF_PM_OP", pmprog["ops"])]
     header = np.zeros(H_WORDS, dtype=np.int32)
@@ -1609,6 +1726,8 @@ def compile_plan(form, costs=None, limits=None, lti=(), csc=None):
     dparts.append(rs_dcoef.reshape(-1))
     header[_H["RS_NGDESC"]] = rs_gdesc.size // 2
     header[_H["RS_NGFIX"]] = rs_ngfix
+    header[_H["RS_COMPACT"]], header[_H["RS_LDV"]] = ws.compact, ws.ldv
+    header[_H["RS_VD"]], header[_H["RS_VROW0"]] = ws.vd, ws.row0
     header[_H["DOFF_PM_POOL"]] = ndt + (ndt & 1) + 4 + rs_dcoef.size
     dparts.append(pmprog["pool"])
     header[_H["PM_NFD"]], header[_H["PM_NOPS"]] = pmprog["nfd"], pmprog["ops"].size // 2
@@ -1672,7 +1791,7 @@ def compile_plan(form, costs=None, limits=None, lti=(), csc=None):
     plan.param_getters = b.param_getters
     plan.fingerprint = structure_fingerprint(costs, limits)
     plan.pm_rows, plan.pmrows = pm_rows, pmrows
-    plan.rtot, plan.ldv = rtot, ldv
+    plan.rtot, plan.ldv, plan.workspace = rtot, ldv, ws
     plan.limit_rows = limit_rows
     plan.optim_ID = {v: form.optim_ID[v] for v in form.optim_variables}
     plan.given_ID = {v: form.given_ID[v] for v in form.given_variables}

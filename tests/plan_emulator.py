@@ -213,7 +213,13 @@ def run_resident(plan, given, params=None, sources=None):
     dst = _section(it, "OFF_RS_DST", jc * P.RS_NT).reshape(jc, P.RS_NT)
     cf = dt[it[H["DOFF_RS_COEF"]]:it[H["DOFF_RS_COEF"]] + jc * P.RS_NT].reshape(jc, P.RS_NT)
     assert plan.rtot % 4 == 0                           # row-sets are padded to groups of four
-    V = np.zeros(plan.rtot * ldv + 16)                  # the kernel's layout: row major
+    # the kernel's layout (plan.py Workspace): row major, leading dimension RS_LDV, RS_VROW0 zero rows
+    # in front, a row holds its window of the unknowns, d in column RS_VD and the one behind it
+    geo = plan.workspace
+    vldv, vd, vrow0 = int(it[H["RS_LDV"]]), int(it[H["RS_VD"]]), int(it[H["RS_VROW0"]])
+    assert (vldv, vd, vrow0, geo.compact) == (geo.ldv, geo.vd, geo.row0, it[H["RS_COMPACT"]])
+    assert geo.compact or (vldv, vd, vrow0) == (ldv, no, 0)
+    V = np.zeros((vrow0 + plan.rtot) * vldv + 16)
     split = _section(it, "OFF_RS_SPLIT", it[H["RS_NSPLIT"]])
     written = np.zeros(V.size, dtype=np.int64)
     for t in range(P.RS_NT):
@@ -233,10 +239,16 @@ def run_resident(plan, given, params=None, sources=None):
                     written[d] = 99
                 acc = 0.0
     assert all(written[d] in (1, 2) for d in split)
-    Vrc = V[:plan.rtot * ldv].reshape(plan.rtot, ldv).copy()
-    assert not Vrc[:, no + 1].any()
-    Vrc[:, no + 1] = 1.0                                       # the ones column (set once per launch)
-    assert ldv >= no + 2
+    rowstart = (vrow0 + np.arange(plan.rtot)) * vldv
+    assert not V[rowstart + vd + 1].any() and not V[:vrow0 * vldv].any()
+    V[rowstart + vd + 1] = 1.0                                 # the ones column (set once per launch)
+    assert ldv >= no + 2 and vldv % 4 == 2
+    # the same workspace as the fused kernel keeps it: dense, columns = unknowns, d, -
+    Vrc = np.zeros((plan.rtot, ldv))
+    for r in range(plan.rtot):
+        c0, w = int(geo.c0[r]), min(int(geo.w[r]), no - int(geo.c0[r]))
+        Vrc[r, c0:c0 + w] = V[rowstart[r]:rowstart[r] + w]
+        Vrc[r, no] = V[rowstart[r] + vd]
     # ---- Hessian and gradient: packs of four 4x4 blocks (plan_tables.h RT_*)
     nb = (no + 3) // 4
     TW = P.RS_TRIP_WORDS
@@ -264,7 +276,7 @@ def run_resident(plan, given, params=None, sources=None):
     Pm, q = np.full((no, no), np.nan), np.full(no, np.nan)
     four = np.arange(4)
     assert wtrip[:, 1].sum() == len(trips)
-    rbytes = ldv * 8
+    rbytes = vldv * 8
     for first_trip, count in wtrip:
         acc, open_pack, S = None, None, np.zeros((4, 4, 4))
         for x in trips[first_trip:first_trip + count]:
@@ -280,20 +292,26 @@ def run_resident(plan, given, params=None, sources=None):
             assert open_pack == pack
             assert rows or ((word >> P.RT_FIRST) & 1 and (word >> P.RT_LAST) & 1)
             w, aim = prm[x[P.RT_W] // 8], prm[x[P.RT_AIM] // 8]
-            assert x[P.RT_A] % (4 * rbytes) == 0 and x[P.RT_B] % (4 * rbytes) == 0
-            ra, rb = x[P.RT_A] // rbytes, x[P.RT_B] // rbytes
+            # operands by address, as the kernel reads them: 32 bytes at block bi (bj) of each row
+            # (compact: the offsets have the window's first column taken off)
+            assert x[P.RT_A] % 32 == 0 and x[P.RT_B] % 32 == 0
+            assert geo.compact or (x[P.RT_A] % (4 * rbytes) == 0 and x[P.RT_B] % (4 * rbytes) == 0)
             if rows:
-                assert (x[P.RT_D] - no * 8) % (4 * rbytes) == 0
-                rd = (x[P.RT_D] - no * 8) // rbytes
+                assert (x[P.RT_D] - vd * 8) % (4 * rbytes) == 0
             for g in range(4):
                 bi, bj = (pack[0] >> (8 * g)) & 255, (pack[1] >> (8 * g)) & 255
                 assert bi < nb and bj < nb
                 for k in range(rows):
-                    av = Vrc[ra + k, 4 * bi + four]
+                    ia = int(x[P.RT_A]) // 8 + 4 * bi + k * vldv
+                    assert ia >= 0
+                    av = V[ia + four]
                     if (qmask >> g) & 1:          # B operand of a block of q: d, ones (, junk, junk)
-                        bv = np.array([Vrc[rd + k, no], Vrc[rd + k, no + 1], 0.0, 0.0])
+                        idd = int(x[P.RT_D]) // 8 + k * vldv
+                        bv = np.array([V[idd], V[idd + 1], 0.0, 0.0])
                     else:
-                        bv = Vrc[rb + k, 4 * bj + four]
+                        ib = int(x[P.RT_B]) // 8 + 4 * bj + k * vldv
+                        assert ib >= 0
+                        bv = V[ib + four]
                     S[g] += np.outer(av, bv)
             if (word >> P.RT_TERM_END) & 1:       # the term's sum enters the pack with its weight
                 assert rows
@@ -332,6 +350,7 @@ def run_resident(plan, given, params=None, sources=None):
     Pm[np.isnan(Pm)] = 0.0        # blocks no term reaches: zeroed once per workgroup, never written
     # ---- constraint rows
     rr = _section(it, "OFF_RS_RR", nc * P.RS_RR_WORDS).reshape(nc, P.RS_RR_WORDS)
+    rrwin = _section(it, "OFF_RS_RRWIN", nc if geo.compact else 0).view(np.uint32)
     G, h = np.zeros((nc, no)), np.zeros(nc)
     if it[H["RS_NGDESC"]]:                              # descriptors of the 16-byte pieces of G
         gd = _section(it, "OFF_RS_GDESC", it[H["RS_NGDESC"]] * 2).view(np.uint32).reshape(-1, 2)
@@ -346,7 +365,7 @@ def run_resident(plan, given, params=None, sources=None):
             v0, v1, a0, a1 = rr[R, 0] + 2 * cp, rr[R, 1] + 2 * cp, rr[R, 4], rr[R, 5]
             as_is = gd[e, 0] == v0 | (v1 << 16) and gd[e, 1] == a0 | (a1 << 16)
             swapped = gd[e, 0] == v1 | (v0 << 16) and gd[e, 1] == a1 | (a0 << 16)
-            assert as_is or swapped
+            assert as_is or swapped or geo.compact       # (compact: the piece inside the axis' window)
             # a round marked "one axis": the second of the descriptor is structurally zero here
             u, w = divmod(e // 64, P.RS_GDESC_THREADS // 64)
             if (int(it[H["RS_GSINGLE"]]) >> (u * (P.RS_GDESC_THREADS // 64) + w)) & 1 and e not in fixed:
@@ -380,11 +399,17 @@ def run_resident(plan, given, params=None, sources=None):
         ac = ad = 0.0
         for ax in range(rec[12]):
             arrow = prm[rec[4 + ax]]
-            assert rec[ax] % ldv == 0                        # column 0 of a row
-            vrow = Vrc[rec[ax] // ldv]
-            G[R] += arrow * vrow[:no]
+            assert rec[ax] % vldv == 0                       # the first stored column of a row
+            if geo.compact:                                   # ... which holds its window only
+                c0 = 2 * ((int(rrwin[R]) >> (16 * ax)) & 255)
+                w = min(2 * ((int(rrwin[R]) >> (16 * ax + 8)) & 255), no - c0)
+                row = rec[ax] // vldv - vrow0
+                assert (c0, 2 * ((int(rrwin[R]) >> (16 * ax + 8)) & 255)) == (geo.c0[row], geo.w[row])
+            else:
+                c0, w = 0, no
+            G[R, c0:c0 + w] += arrow * V[rec[ax]:rec[ax] + w]
             ac += arrow * prm[rec[8 + ax]]
-            ad += arrow * vrow[no]
+            ad += arrow * V[rec[ax] + vd]
         for ax in range(rec[12], P.RS_AXMAX):       # the kernel's fast path reads two axes
             assert prm[rec[4 + ax]] == 0.0
         h[R] = (prm[rec[13]] + ac) - ad
@@ -407,8 +432,7 @@ def run_resident(plan, given, params=None, sources=None):
             out["G_data"] = prm[a0] * V[v0]
         else:
             out["G_data"] = prm[a1] * V[v1] + prm[a0] * V[v0]
-    Vrc[:, no + 1] = 0.0                                   # (not part of the row-set program's V)
-    out["V"] = Vrc[:plan.rtot]
+    out["V"] = Vrc
     return out
 
 
@@ -593,7 +617,7 @@ def run_tiled(plan, given, params=None, sources=None, ab=None):
         ac = ad = 0.0
         row_sum = np.zeros(no)
         for ax in range(x[12]):
-            assert x[ax] == grow[R, ax] * ldv
+            assert x[ax] == plan.workspace.rowstart(grow[R, ax])   # (the persistent kernel's index)
             r = grow[R, ax]
             row_sum += prm0[x[4 + ax]] * Vo[r, :no]
             ac += prm0[x[4 + ax]] * prm0[x[8 + ax]]

@@ -1,0 +1,55 @@
+"""The persistent kernel's compact workspace (plan.py Workspace.windows): every row-set keeps only the
+4-column blocks it can be non-zero in.  Same QPs as with the dense workspace and as the oracle's, on the
+per-plan kernel and on the ahead-of-time one, with the descriptor path of G (small problems, incl. the
+34-wide phase with its two-axis pieces) and the row-record path (wide ones)."""
+import numpy as np
+import pytest
+
+from helpers import RTOL_TIGHT, assert_close
+from mpcasm import problems
+from oracle import qp_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def cases(api):
+    for samples, times in ((8, (6, 14)), (8, (7, 15)), (12, (10, 22)), (12, (11, 23))):
+        form = problems.biped(api, problems.BipedConfig(step_samples=samples))
+        form.update(step_times=np.array(times), step_count=0)
+        yield "biped N=%d, %d wide" % (2 * samples, form.optim_len), form
+    yield "lipm3d N=32", problems.lipm3d(api, N=32)
+
+
+@pytest.mark.parametrize("jit", [1, 2], ids=["per-plan kernel", "ahead-of-time kernel"])
+@pytest.mark.parametrize("on_chip", [False, True], ids=["S, U from memory", "S, U on chip"])
+def test_compact_workspace_gives_the_same_qps(gpu_api, jit, on_chip):
+    import torch
+
+    from mpcasm import capi
+    from mpcasm.engine import Assembler
+
+    lib = capi.load()
+    lib.mpcasm_set_option(capi.OPT_JIT, jit)
+    try:
+        batch = 67
+        for name, form in cases(gpu_api):
+            lti = ["LIP"] if on_chip else []
+            dense = Assembler(form, batch=batch, lti=lti, workspace="dense")
+            compact = Assembler(form, batch=batch, lti=lti, workspace="compact")
+            assert dense.plan.workspace.compact == 0 and compact.plan.workspace.compact == 1, name
+            assert compact.plan.workspace.doubles < dense.plan.workspace.doubles
+            given = np.random.default_rng(5).normal(0, 0.1, [batch, form.given_len])
+            g = torch.as_tensor(given, device="cuda")
+            ref = [t.cpu().numpy() for t in dense.assemble(g)]
+            if "persistent" not in dense.last_kernel():
+                continue                       # (C3 with S, U from memory: too big an image, staged)
+            got = [t.cpu().numpy() for t in compact.assemble(g)]
+            assert ("compiled for the plan" if jit == 1 else "ahead of time") in compact.last_kernel(), name
+            for key, a, b in zip("PqGh", got, ref):
+                assert_close(a, b, 1e-13, "%s %s" % (name, key))
+            for b_ in (0, batch - 1):
+                A, hh, Q, qq = orc.assemble(form, given[b_].reshape(-1, 1))
+                for key, a, r in zip("PqGh", got, (Q, qq.ravel(), A, hh.ravel())):
+                    assert_close(a[b_], r, RTOL_TIGHT, "%s %s" % (name, key))
+    finally:
+        lib.mpcasm_set_option(capi.OPT_JIT, 0)

@@ -43,6 +43,13 @@ def check_plan(form, given, tol=1e-12):
         res = plan_emulator.run_resident(plan, given)
         for key, ref in (("P", Q), ("q", q.ravel()), ("G", A), ("h", h.ravel())):
             assert_close(res[key], ref, tol, "resident " + key)
+        # ... and with every row-set keeping only its own columns (where the plan's paths of G allow)
+        small = compile_plan(form, workspace="compact")
+        if small.workspace.compact:
+            assert small.itab[_H["RS_OK"]] and small.workspace.doubles <= plan.workspace.doubles
+            res = plan_emulator.run_resident(small, given)
+            for key, ref in (("P", Q), ("q", q.ravel()), ("G", A), ("h", h.ravel())):
+                assert_close(res[key], ref, tol, "compact " + key)
     return plan
 
 
@@ -210,6 +217,50 @@ def test_lipm3d_and_lti_plans(cpu_api):
     check_plan(form, np.random.default_rng(0).normal(0, 0.05, [form.given_len, 1]))
     form = problems.random_lti(cpu_api, np.random.default_rng(1), nx=5, nu=2, N=6)
     check_plan(form, np.random.default_rng(2).standard_normal([form.given_len, 1]))
+
+
+def test_compact_workspace_plans(cpu_api, monkeypatch):
+    """Wide problems of several axes keep only each row-set's own columns in the persistent kernel's
+    workspace (plan.py Workspace.windows): C3 (three axes, 96 unknowns) with its horizon matrices
+    generated on chip shrinks to a third; the emulated program
+    (operands by address, windows of the rows of G, descriptors where the problem has them) gives the
+    oracle's QP, and the very same plans compiled dense (MPCASM_NO_COMPACT) do too."""
+    form = problems.lipm3d(cpu_api, N=32)
+    given = np.random.default_rng(0).normal(0, 0.05, [form.given_len, 1])
+    A, h, Q, q = orc.assemble(form, given)
+    lip = form.dynamics["LIP"]
+    sizes = {}
+    for dense in (False, True):
+        if dense:
+            monkeypatch.setenv("MPCASM_NO_COMPACT", "1")
+        plan = compile_plan(form, lti=["LIP"])
+        it, ws = plan.itab, plan.workspace
+        assert it[_H["RS_OK"]] == 1 and it[_H["RS_COMPACT"]] == (0 if dense else 1)
+        sizes[dense] = ws.doubles
+        if not dense:
+            assert (ws.ldv, ws.vd) == (34, 32) and set(ws.c0) == {0, 32, 64}
+        g = plan.lti[0]
+        srcs = [s.array for s in plan.sources]
+        srcs[g["ids"][0]] = lip.matrices[-1][0].T.copy()
+        srcs[g["ids"][1]] = lip.matrices[0][0, 0, :].reshape(3, 1).copy()
+        res = plan_emulator.run_resident(plan, given, sources=srcs)
+        for key, ref in (("P", Q), ("q", q.ravel()), ("G", A), ("h", h.ravel())):
+            assert_close(res[key], ref, 1e-12, key)
+    assert 2.8 * sizes[False] < sizes[True]
+    monkeypatch.delenv("MPCASM_NO_COMPACT")
+    # the biped's workspace is small: dense unless asked for (tick by tick, both widths, both
+    # layouts: check_plan in test_biped_plan_over_ticks)
+    for samples in (12, 8):
+        biped = problems.biped(cpu_api, problems.BipedConfig(step_samples=samples))
+        biped.update(step_times=np.array([samples - 2, 2 * samples - 2]), step_count=0)
+        assert compile_plan(biped).itab[_H["RS_COMPACT"]] == 0
+        assert compile_plan(biped, workspace="compact").itab[_H["RS_COMPACT"]] == 1
+    # a CSC plan reads the workspace entry by entry: always dense
+    biped = problems.biped(cpu_api, problems.BipedConfig(step_samples=12))
+    biped.update(step_times=np.array([10, 22]), step_count=0)
+    assert compile_plan(biped, csc="upper", workspace="compact").itab[_H["RS_COMPACT"]] == 0
+    with pytest.raises(ValueError):
+        compile_plan(biped, workspace="tiny")
 
 
 def test_constraint_with_L_and_per_row_fields(cpu_api):

@@ -16,6 +16,12 @@ from mpcasm import engine, problems  # noqa: E402
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 lti = len(sys.argv) > 3 and sys.argv[3] == "lti"
+from mpcasm import capi  # noqa: E402
+
+if os.environ.get("MPCASM_PER_CU"):                      # workgroups per CU of the persistent kernel
+    capi.load().mpcasm_set_option(capi.OPT_RESIDENT_PER_CU, int(os.environ["MPCASM_PER_CU"]))
+if os.environ.get("MPCASM_PHASES"):                      # timing-only ablation (tools/run_variant.py)
+    capi.load().mpcasm_set_option(capi.OPT_PHASE_MASK, int(os.environ["MPCASM_PHASES"], 0))
 api = problems.load_api("mpc_interface")
 form = problems.lipm3d(api, N=32)
 asm = engine.Assembler(form, batch=batch, lti=["LIP"] if lti else ())
