@@ -421,7 +421,12 @@ def c4_record(torch, dev, batch=8192, reps=3):
     stages = asm.plan.tiled["stages"]
     nb = -(-no // 128)
     blocks = nb * (nb + 1) // 2                     # (P symmetric: block pairs bi <= bj)
-    mfma = int(sum(((int(st[3]) >> 16) ** 2) * 4 * 4 for st in stages if (int(st[3]) >> 8) & 1)) * blocks
+    # (Toeplitz form, symmetric P: in a diagonal block the quadrant below the diagonal is a mirror
+    # image -- the wavefronts multiply 2 n^2 + n tile pairs per stage instead of 4 n^2)
+    p_stages = [(int(st[3]) >> 16, (int(st[3]) >> 8) & 0xFF) for st in stages if (int(st[3]) >> 8) & 1]
+    roles = int(asm.plan.tiled["toeplitz"]) and all(fl & 16 for _, fl in p_stages)     # TS_FLAG_SAME
+    mfma = int(sum((n * n) * 4 * 4 * (blocks - nb) + ((2 * n * n + n) * 4 if roles else n * n * 16) * nb
+                   for n, _ in p_stages))
     tflops = mfma * 2048 * batch / (ms * 1e-3) / 1e12
     rec = {"workload": "C4: random LTI nx=12 nu=6 N=64, no=%d nc=%d, per-instance (A,B), weight, given; "
                        "B=%d in one call" % (no, nc, batch),
@@ -434,8 +439,7 @@ def c4_record(torch, dev, batch=8192, reps=3):
                     "unit": "TFLOP/s", "frac": tflops / F64_MFMA_PEAK_TFLOPS,
                     "note": "structurally zero 16-column tiles of the block-lower-triangular horizon "
                             "matrices are not multiplied: %.0f%% of the dense symmetric count"
-                            % (100.0 * mfma / max(1, blocks * sum(1 for st in stages if (int(st[3]) >> 8) & 1)
-                                                  * 16 * 4 * 4))},
+                            % (100.0 * mfma / max(1, blocks * len(p_stages) * 16 * 4 * 4))},
            "workspace_bytes_per_instance": 8 * int(asm.plan.tiled["work"])}
     del asm, given
     torch.cuda.empty_cache()

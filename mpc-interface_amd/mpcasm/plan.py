@@ -1604,7 +1604,7 @@ def compile_plan(form, costs=None, limits=None, lti=(), csc=None, workspace="aut
         in_mixed_rounds = int((~single.reshape(-1, 64).all(axis=1)).sum()) * 64
         owners = both % RS_GDESC_THREADS
         if (both.size and 4 * both.size <= in_mixed_rounds and np.unique(owners).size == both.size
-                and not _os.environ.get('MPCASM_NO_GFIX')):
+                and not _os.environ.get('MPCASM_NO_GFIX')):            # (A/B aid: tools/run_variant.py)
             fix = np.zeros((RS_GDESC_THREADS, 2), dtype=np.int64)
             fix[:, 0], fix[:, 1] = RS_GFIX_NONE << 16, len(b.params)
             fix[owners, 0] = p1[both] | ((both // RS_GDESC_THREADS) << 16)

@@ -22,18 +22,30 @@ get_A, get_B, _ = api.tools.get_system_matrices("J->CCC")
 if which == "c3":
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
     form = problems.lipm3d(api, N=32)
+elif which == "c4":
+    form = None
 else:
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
     form = bench.build_workload(16, 1)["form"]
-taus = np.random.default_rng(1).uniform(0.08, 0.12, B)
-A = torch.as_tensor(np.stack([get_A(tau=t) for t in taus]), device="cuda")
-Bm = torch.as_tensor(np.stack([get_B(tau=t) for t in taus]), device="cuda")
-asm = engine.Assembler(form, batch=B, lti=["LIP"])
-asm.bind_lti("LIP", A, Bm)
+if which == "c4":                                # (random LTI nx=12 nu=6 N=64 on the tiled kernel)
+    B = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+    rng = np.random.default_rng(20262)
+    form = problems.random_lti(api, rng, nx=12, nu=6, N=64)
+    base = [problems.random_lti_matrices(rng, 12, 6) for _ in range(64)]
+    A = torch.as_tensor(np.stack([base[b % 64][0] for b in range(B)]), device="cuda")
+    Bm = torch.as_tensor(np.stack([base[b % 64][1] for b in range(B)]), device="cuda")
+    asm = engine.Assembler(form, batch=B, lti=["plant"])
+    asm.bind_lti("plant", A, Bm)
+else:
+    taus = np.random.default_rng(1).uniform(0.08, 0.12, B)
+    A = torch.as_tensor(np.stack([get_A(tau=t) for t in taus]), device="cuda")
+    Bm = torch.as_tensor(np.stack([get_B(tau=t) for t in taus]), device="cuda")
+    asm = engine.Assembler(form, batch=B, lti=["LIP"])
+    asm.bind_lti("LIP", A, Bm)
 given = torch.as_tensor(np.random.default_rng(0).normal(0, 0.1, [B, form.given_len]), device="cuda")
 no, nc = asm.no, asm.nc
 sizes = [B * no * no * 8, B * no * 8, B * nc * no * 8, B * nc * 8]
-pool = torch.empty(sum(sizes) + (5 << 30), dtype=torch.uint8, device="cuda")
+pool = torch.empty(sum(sizes) + ((5 << 30) if which != "c4" else (64 << 20)), dtype=torch.uint8, device="cuda")
 base = (-pool.data_ptr()) % (2 << 20)           # a 2 MB boundary
 
 
@@ -60,7 +72,7 @@ def timed(out, reps=30):
 cases = {"packed": (0, 0, 0, 0)}
 for g in (256, 1024, 4096, 16384, 65536, 1 << 20, (1 << 20) + 4096, 3 << 20):
     cases["G +%d" % g] = (0, 0, g, 0)
-for g in (8, 16, 32, 64, 128, 256, 512, 1024, 1536, 2048):
+for g in (8, 16, 32, 64, 128, 256, 512, 1024, 1536, 2048) if which != "c4" else ():
     cases["G +%d MB" % g] = (0, 0, g << 20, 0)
     cases["P +%d MB" % g] = (g << 20, 0, 0, 0)
 cases["q, h +8 MB"] = (0, 8 << 20, 0, 8 << 20)

@@ -8,7 +8,7 @@ out=$R/gpurun_out/fill_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 i=0
-for c in "3 1 16 0 8192" "3 1 16 0 65536" "12 6 64 0 1024" "3 1 100 1 2048" "3 1 100 1 16384"; do
+for c in "3 1 16 0 4096" "3 1 16 0 8192" "3 1 16 0 65536" "12 6 64 0 1024" "3 1 100 1 2048" "3 1 100 1 16384"; do
   i=$((i+1))
   echo "$c" > $out/case$i.txt
   rocprofv3 --kernel-trace --stats -d $out/stats$i -o p --output-format csv -- python3 $R/tools/run_fill_only.py $c 30 > $out/stats$i.log 2>&1 || exit 1
