@@ -560,8 +560,11 @@ __device__ __forceinline__ void resident_body(
   // (tools/microbench/store_rate3.hip: +9 % on the C2 output pattern alone).
   const int run_over = (phases >> 10) & 7;  // (bits 10-12, A/B aid: runs of 2^k instances)
   const int run_shift = run_over ? run_over : ((long)batch >= 16L * gridDim.x && !(phases & 256) ? 2 : 0);  // (bit 8: A/B aid)
+  // (bit 13, A/B aid: workgroups of one XCD -- blockIdx.x mod 8 -- take neighbouring instances)
+  const unsigned vblock = (phases & 8192) && gridDim.x % 8 == 0
+                              ? (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8 : blockIdx.x;
   auto instance_at = [&](int n) -> long {
-    return ((((long)(n >> run_shift) * gridDim.x + blockIdx.x)) << run_shift) + (n & ((1 << run_shift) - 1));
+    return ((((long)(n >> run_shift) * gridDim.x + vblock)) << run_shift) + (n & ((1 << run_shift) - 1));
   };
   if (wave < MW) {  // the first instance's inputs start their trip now
     fetch_image(instance_at(0), 0, false);
