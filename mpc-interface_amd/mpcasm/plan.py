@@ -1461,8 +1461,10 @@ def compile_plan(form, costs=None, limits=None, lti=(), csc=None, workspace="aut
     packed_like = csc is None and no % 2 == 0 and nc > 0 and all(rec[2] <= 2 for rec in limit_recs)
     if workspace not in ("auto", "dense", "compact"):
         raise ValueError("workspace: 'auto', 'dense' or 'compact'")
-    if _os.environ.get("MPCASM_NO_COMPACT"):              # (A/B aid: tools/ab_workspace.py)
+    if _os.environ.get("MPCASM_NO_COMPACT"):              # (A/B aids: tools/ab_workspace.py)
         workspace = "dense"
+    elif _os.environ.get("MPCASM_COMPACT") and workspace == "auto":
+        workspace = "compact"
     if packed_like and workspace != "dense" and (workspace == "compact"
                                                  or 8 * ws.doubles > RS_COMPACT_FROM_BYTES):
         cand = Workspace.windows(rtot, no, b.spans, fused["fd_idx"] // ldv, fused["fd_idx"] % ldv)

@@ -41,7 +41,10 @@ def main():
         lib = capi.load()
         for name, off in (("all on", 0), ("no G", 8), ("no trips / P", 2), ("no q / zero blocks", 32),
                           ("no compose", 1), ("no G, P, q", 8 | 2 | 32), ("G only", 1 | 2 | 32),
-                          ("G only, not stored", 1 | 2 | 32 | (512 << 16)), ("G not stored", 512 << 16)):
+                          ("G only, not stored", 1 | 2 | 32 | (512 << 16)), ("G not stored", 512 << 16),
+                          ("runs of 2 instances", (1 << 10) << 16), ("runs of 4", (2 << 10) << 16),
+                          ("runs of 8", (3 << 10) << 16), ("XCD-wise", 8192 << 16),
+                          ("XCD-wise, runs of 8", (8192 | (3 << 10)) << 16), ("all on again", 0)):
             lib.mpcasm_set_option(capi.OPT_PHASE_MASK, (capi.PHASE_DEFAULT & ~(off & 0xFFFF)) | (off >> 16))
             print("  no=%d %-20s %.2f us" % (asm.no, name, bench._event_ms(torch, step, launches) * 1e3))
         lib.mpcasm_set_option(capi.OPT_PHASE_MASK, capi.PHASE_DEFAULT)
