@@ -716,7 +716,14 @@ __device__ __forceinline__ void resident_body(
     }
   }
   // (row, column pair) of this thread's first piece, and the step from piece to piece
-  const int g_first = wt >= 0 && npair > 0 ? ((wt / npair) << 16) | (wt % npair) : 0;
+  // Every workgroup writes its instance's G (row-record path) and P (out of LDS) starting at a place of
+  // its own, whole lines on: workgroups run in step, and with results of 147 KB and 72 KB per instance
+  // (C3) their streams, all at the same offset, would meet on a few memory channels (the write requests
+  // stall for DRAM credits three times as often when the placement is unlucky: profiles/r03_placement.txt)
+  const bool skew = !(phases & 16384);  // (bit 14, A/B aid: off)
+  const int g_rot = skew && gtotal % 8 == 0 && gtotal > 0 ? (int)((blockIdx.x * 53u) % (unsigned)(gtotal / 8)) * 8 : 0;
+  const int g_e0 = wt >= 0 && gtotal > 0 ? (wt + g_rot) % gtotal : 0;
+  const int g_first = wt >= 0 && npair > 0 ? ((g_e0 / npair) << 16) | (g_e0 % npair) : 0;
   const int g_dR = npair > 0 ? WT / npair : 0, g_dcp = npair > 0 ? WT % npair : 0;
 
 
@@ -730,19 +737,21 @@ __device__ __forceinline__ void resident_body(
     int R = first >> 16, cp = first & 0xFFFF;
     for (int e0 = wt; e0 < gtotal; e0 += 3 * WT) {
       int2 ds[3];
-      int c2[3], wn[3];
+      int c2[3], wn[3], at[3];
 #pragma unroll
       for (int u = 0; u < 3; ++u) {
         const int Rr = e0 + u * WT < gtotal ? R : 0;
         ds[u] = *reinterpret_cast<const int2*>(rr + Rr * RR_COMPACT);
         wn[u] = p.rs_compact ? rrwin[Rr] : 0;
         c2[u] = 2 * cp;
+        at[u] = Rr * npair + cp;  // (the piece's place in G: the workgroup starts at g_rot and wraps)
         cp += g_dcp;
         R += g_dR;
         if (cp >= npair) {
           cp -= npair;
           ++R;
         }
+        if (R >= nc) R -= nc;
       }
       double a0[3], a1[3];
       double2 v0[3], v1[3];
@@ -774,7 +783,7 @@ __device__ __forceinline__ void resident_body(
         double2 r;
         r.x = fma(a1[u], v1[u].x, a0[u] * v0[u].x);
         r.y = fma(a1[u], v1[u].y, a0[u] * v0[u].y);
-        if (e < gtotal) store_result(&G2[e], r);
+        if (e < gtotal) store_result(&G2[at[u]], r);
       }
     }
   };
@@ -1215,7 +1224,11 @@ __device__ __forceinline__ void resident_body(
         const int total = no * npair;
         double2* P2 = reinterpret_cast<double2*>(Pb);
         const double2* Pl2 = reinterpret_cast<const double2*>(Pl);
-        for (int e = t_; e < total; e += NT) store_result(&P2[e], Pl2[e]);
+        const int rot = skew && total % 8 == 0 ? (int)((blockIdx.x * 37u) % (unsigned)(total / 8)) * 8 : 0;
+        for (int e = t_; e < total; e += NT) {
+          const int at = e + rot < total ? e + rot : e + rot - total;  // (this workgroup's own starting line)
+          store_result(&P2[at], Pl2[at]);
+        }
       } else {
         for (int e = t_; e < no * no; e += NT) {
           const int row = e / no;

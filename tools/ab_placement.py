@@ -142,7 +142,8 @@ if med[slow] > 1.15 * med[fast]:
     lib = capi.load()
     for label, bits in (("runs of 4 (shipped)", 0), ("single instances", 256), ("runs of 2", 1 << 10), ("runs of 8", 3 << 10),
                         ("runs of 16", 4 << 10), ("runs of 64", 6 << 10), ("XCD-wise, runs of 4", 8192),
-                        ("XCD-wise, runs of 16", 8192 | (4 << 10)), ("XCD-wise, single", 8192 | 256)):
+                        ("XCD-wise, runs of 16", 8192 | (4 << 10)), ("XCD-wise, single", 8192 | 256),
+                        ("streams not skewed", 16384), ("shipped again", 0)):
         lib.mpcasm_set_option(capi.OPT_PHASE_MASK, capi.PHASE_DEFAULT | bits)
         timed(sets[fast], 3)
         tf = min(timed(sets[fast], 10) for _ in range(3))
