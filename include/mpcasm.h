@@ -65,7 +65,11 @@ enum { MPCASM_OPT_PATH = 1, MPCASM_OPT_PHASE_MASK = 2, MPCASM_OPT_RESIDENT_PER_C
  * inputs; bit 6, off by default, makes the persistent kernel also write per-wavefront
  * cycle sums of its phases into d_work, which mpcasm_workspace_bytes sizes for it;
  * default 0xBF).  Results are WRONG with any of bits 0-5 cleared -- never use it
- * outside a profile.
+ * outside a profile.  Bits 8-14 are A/B aids of the persistent kernel that leave the results
+ * right: 8 no runs of four consecutive instances per workgroup, 10-12 runs of 2^k instead,
+ * 13 the workgroups of one XCD take neighbouring instances, 14 every workgroup starts its G and
+ * P streams at their first line (default: at a line of its own); bit 9 computes G without
+ * storing it (results WRONG).
  * MPCASM_OPT_RESIDENT_PER_CU (tuning aid): workgroups of the persistent kernel per CU;
  * 0 (default) = chosen from the batch size, never more than are resident at once.
  * MPCASM_OPT_JIT: the persistent kernel compiled for the very plan by hiprtc (its sizes and
@@ -75,8 +79,9 @@ enum { MPCASM_OPT_PATH = 1, MPCASM_OPT_PHASE_MASK = 2, MPCASM_OPT_RESIDENT_PER_C
  * for the compilation, a second or two); 1 = for every batch; 2 = never.
  * MPCASM_OPT_P_DIRECT (read by mpcasm_plan_create): how the persistent kernel writes P -- 1: its
  * 4x4 blocks go from the matrix core straight to HBM; 2: collected in LDS and copied out with
- * 16-byte stores whenever P fits there beside the workspace; 0 (default): as 1 when P in LDS would
- * cost a workgroup per CU or the launch writes less than ~0.55 GB, else as 2.
+ * 16-byte stores whenever P fits there beside the workspace; 0 (default): as 1 when the launch
+ * writes less than ~0.55 GB, or when P in LDS would cost a workgroup per CU and an instance's
+ * results are small (< 128 KB), else as 2.
  * These options are process-wide test / tuning hooks, not part of a launch's state: set them
  * before other threads start launching. */
 int mpcasm_set_option(int option, int value);
