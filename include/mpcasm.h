@@ -89,6 +89,13 @@ int mpcasm_set_option(int option, int value);
  * -1: back to the process-wide value): part of the plan's state, read by every mpcasm_assemble on
  * it -- what a caller with several plans on several threads uses instead of the hooks above. */
 int mpcasm_plan_set_option(mpcasm_plan* plan, int option, int value);
+/* Needs no device: validates the tables as mpcasm_plan_create does and reports the dynamic LDS
+ * bytes one workgroup of the persistent kernel needs for them -- out[0] with P handed over
+ * directly, out[1] with P collected in LDS (0: the plan does not run on the persistent kernel).
+ * Two workgroups share a CU's 160 KB: a plan compiler uses it to pick the layout of the workspace
+ * that fits two (mpcasm.engine.Assembler, workspace="auto"). */
+int mpcasm_resident_lds_bytes(const int32_t* h_itab, size_t n_itab, const double* h_dtab, size_t n_dtab,
+                              int64_t out[2]);
 /* Diagnostic, needs no device: validates the tables as mpcasm_plan_create does, generates the
  * per-plan constants and compiles the persistent kernel for them with hiprtc (gfx950).
  * MPCASM_OK, MPCASM_ERR_LIMIT (no persistent kernel for this plan, or no libhiprtc.so) or

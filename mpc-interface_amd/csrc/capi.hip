@@ -983,6 +983,21 @@ int mpcasm_plan_create(const int32_t* h_itab, size_t n_itab, const double* h_dta
   return MPCASM_OK;
 }
 
+int mpcasm_resident_lds_bytes(const int32_t* h_itab, size_t n_itab, const double* h_dtab, size_t n_dtab,
+                              int64_t out[2]) {
+  if (!h_itab || (n_dtab && !h_dtab) || !out) return MPCASM_ERR_ARG;
+  const int rc = validate_plan(h_itab, h_dtab, n_itab, n_dtab);
+  if (rc != MPCASM_OK) return rc;
+  PlanDev d;
+  memset(&d, 0, sizeof d);
+  plan_dev_from_tables(h_itab, &d);
+  for (int direct = 0; direct < 2; ++direct) {
+    d.rs_p_direct = 1 - direct;  // out[0]: P direct, out[1]: P in LDS
+    out[direct] = (int64_t)resident_lds_bytes(d);
+  }
+  return MPCASM_OK;
+}
+
 int mpcasm_jit_check(const int32_t* h_itab, size_t n_itab, const double* h_dtab, size_t n_dtab,
                      char* log, size_t log_capacity) {
   if (!h_itab || (n_dtab && !h_dtab)) return MPCASM_ERR_ARG;

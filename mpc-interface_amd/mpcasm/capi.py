@@ -43,6 +43,8 @@ SIGNATURES = {
     "mpcasm_plan_create": (ctypes.c_int, [_void_p, ctypes.c_size_t, _void_p, ctypes.c_size_t,
                                           ctypes.POINTER(_void_p)]),
     "mpcasm_plan_destroy": (ctypes.c_int, [_void_p]),
+    "mpcasm_resident_lds_bytes": (ctypes.c_int, [_void_p, ctypes.c_size_t, _void_p, ctypes.c_size_t,
+                                                 ctypes.POINTER(ctypes.c_int64)]),
     "mpcasm_jit_check": (ctypes.c_int, [_void_p, ctypes.c_size_t, _void_p, ctypes.c_size_t,
                                         ctypes.c_char_p, ctypes.c_size_t]),
     "mpcasm_plan_sizes": (ctypes.c_int, [_void_p, ctypes.POINTER(ctypes.c_int64)]),

@@ -101,6 +101,34 @@ def fill_su_numpy(A, B, N, ltv=False):
 # --------------------------------------------------------------------------
 # K2 + K3 + K4
 # --------------------------------------------------------------------------
+HALF_CU_LDS = 80 * 1024      # two workgroups of the persistent kernel share a CU's 160 KB
+
+
+def resident_lds_bytes(plan):
+    """LDS bytes a workgroup of the persistent kernel needs for ``plan`` -- with ``P`` handed over
+    directly, with ``P`` collected in LDS (``mpcasm_resident_lds_bytes``; 0: not on that kernel)."""
+    out = (ctypes.c_int64 * 2)()
+    itab, dtab = np.ascontiguousarray(plan.itab), np.ascontiguousarray(plan.dtab)
+    capi.check(capi.load().mpcasm_resident_lds_bytes(
+        itab.ctypes.data, itab.size, dtab.ctypes.data if dtab.size else None, dtab.size, out),
+        "mpcasm_resident_lds_bytes")
+    return int(out[0]), int(out[1])
+
+
+def plan_for_device(form, workspace="auto", **kw):
+    """``compile_plan`` plus the one decision that needs the kernel's own LDS layout: with
+    ``workspace="auto"`` a plan whose dense workspace leaves room for ONE workgroup per CU is compiled
+    with the compact workspace when that fits two (same box, one process, `tools/ab_workspace.py`: the
+    biped at N = 24 with S, U read from memory 0.076 -> 0.064 ms at 4 096 instances, 0.276 -> 0.264 at
+    16 384)."""
+    plan = compile_plan(form, workspace=workspace, **kw)
+    if workspace == "auto" and not plan.workspace.compact and resident_lds_bytes(plan)[0] > HALF_CU_LDS:
+        small = compile_plan(form, workspace="compact", **kw)
+        if small.workspace.compact and 0 < resident_lds_bytes(small)[0] <= HALF_CU_LDS:
+            plan = small
+    return plan
+
+
 class Assembler:
     """Batched assembly of one Formulation structure on one device.
 
@@ -130,8 +158,12 @@ class Assembler:
         # pattern of :meth:`csc_pattern` -- written by the assembly kernel itself
         # (biped_mpc_loop.py:57-58 without a second pass).  ValueError / RuntimeError when the
         # problem does not run on the persistent kernel: assemble dense and use export_csc.
-        self.plan = compile_plan(form, costs=costs, limits=limits, lti=tuple(lti), csc=csc,
-                                 workspace=workspace)
+        # workspace = "auto": the persistent kernel's workspace is kept compact (plan.py Workspace)
+        # when it is big (the plan compiler's rule: C3) or when that is what lets a second
+        # workgroup share the CU's LDS (plan_for_device: the biped at N = 24 with S, U read from
+        # memory); "dense" / "compact" force one.
+        self.plan = plan_for_device(form, costs=costs, limits=limits, lti=tuple(lti), csc=csc,
+                                    workspace=workspace)
         self.csc = self.plan.csc
         p = self.plan
         self.ng, self.no, self.nc = p.ng, p.no, p.nc

@@ -263,6 +263,37 @@ def test_compact_workspace_plans(cpu_api, monkeypatch):
         compile_plan(biped, workspace="tiny")
 
 
+def test_workspace_chosen_by_what_fits_two_workgroups(cpu_api):
+    """``engine.plan_for_device`` (no device needed: ``mpcasm_resident_lds_bytes`` lays the tables out
+    as the kernel does): the biped at N = 24 with S, U read from memory needs 95 KB of LDS with the
+    dense workspace -- one workgroup per CU -- and 74 KB with the compact one: compact; with its
+    horizon matrices built on chip the dense one fits two already: dense; C2 dense; C3 compact."""
+    from mpcasm import engine
+
+    def biped(samples):
+        form = problems.biped(cpu_api, problems.BipedConfig(step_samples=samples))
+        form.update(step_times=np.array([samples - 2, 2 * samples - 2]), step_count=0)
+        return form
+
+    n24, c2, c3 = biped(12), biped(8), problems.lipm3d(cpu_api, N=32)
+    for form, lti, compact in ((n24, (), 1), (n24, ("LIP",), 0), (c2, (), 0), (c2, ("LIP",), 0),
+                               (c3, ("LIP",), 1)):
+        plan = engine.plan_for_device(form, lti=lti)
+        assert plan.workspace.compact == compact
+        direct, in_lds = engine.resident_lds_bytes(plan)
+        assert in_lds - direct == 8 * plan.no * (plan.no + plan.no % 2)      # P beside the workspace
+        assert direct <= engine.HALF_CU_LDS
+        if compact:
+            dense = engine.resident_lds_bytes(compile_plan(form, lti=lti, workspace="dense"))
+            saved = 8 * (compile_plan(form, lti=lti, workspace="dense").workspace.doubles
+                         - plan.workspace.doubles)
+            # (what the workspace shrinks by, less the windows of the rows of G: 4 bytes a row)
+            assert dense[0] > engine.HALF_CU_LDS and dense[0] - direct == saved - 4 * plan.nc
+        # asked for by name, the layout is taken as it is
+        assert engine.plan_for_device(form, lti=lti, workspace="dense").workspace.compact == 0
+    assert engine.resident_lds_bytes(compile_plan(c3)) == (0, 0)            # not on the persistent kernel
+
+
 def test_constraint_with_L_and_per_row_fields(cpu_api):
     """Rows from L, per-row arrow / center / extreme, 1-D and 2-D definition
     coefficients, a state-space box."""

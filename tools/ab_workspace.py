@@ -33,15 +33,18 @@ def timed(asm, given, reps):
 def case(name, form, lti_ab):
     given = torch.as_tensor(np.random.default_rng(0).normal(0, 0.1, [B, form.given_len]), device="cuda")
     variants = {}
-    for label, env in (("compact (as shipped)", {}), ("compact, P direct", {"P_DIRECT": "1"}),
-                       ("compact, P via LDS", {"P_DIRECT": "2"}),
-                       ("dense (round 2)", {"MPCASM_NO_COMPACT": "1"})):
+    for label, env in (("as shipped", {}), ("compact, P direct", {"P_DIRECT": "1", "WORKSPACE": "compact"}),
+                       ("compact, P via LDS", {"P_DIRECT": "2", "WORKSPACE": "compact"}),
+                       ("dense, P direct", {"P_DIRECT": "1", "WORKSPACE": "dense"}),
+                       ("dense, P via LDS", {"P_DIRECT": "2", "WORKSPACE": "dense"})):
         os.environ.pop("MPCASM_NO_COMPACT", None)
         env = dict(env)
         capi.load().mpcasm_set_option(capi.OPT_P_DIRECT, int(env.pop("P_DIRECT", "0")))
         os.environ.update(env)
-        asm = engine.Assembler(form, batch=B, lti=["LIP"])
-        asm.bind_lti("LIP", *lti_ab)
+        asm = engine.Assembler(form, batch=B, lti=["LIP"] if lti_ab else [],
+                               workspace=env.pop("WORKSPACE", "auto"))
+        if lti_ab:
+            asm.bind_lti("LIP", *lti_ab)
         asm.assemble(given)
         variants[label] = asm
     os.environ.pop("MPCASM_NO_COMPACT", None)
@@ -69,3 +72,4 @@ case("C3 lipm3d N=32", problems.lipm3d(api, N=32), (A, Bm))
 biped = problems.biped(api, problems.BipedConfig(step_samples=12))
 biped.update(step_times=np.array([10, 22]), step_count=0)
 case("biped N=24", biped, (A, Bm))
+case("biped N=24, S U read", biped, None)
