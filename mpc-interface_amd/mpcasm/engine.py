@@ -115,17 +115,33 @@ def resident_lds_bytes(plan):
     return int(out[0]), int(out[1])
 
 
-def plan_for_device(form, workspace="auto", **kw):
+STREAMING_LAUNCH_BYTES = 560e6    # results per launch from which P is collected in LDS (resident.hip)
+
+
+def plan_for_device(form, workspace="auto", batch=None, **kw):
     """``compile_plan`` plus the one decision that needs the kernel's own LDS layout: with
     ``workspace="auto"`` a plan whose dense workspace leaves room for ONE workgroup per CU is compiled
-    with the compact workspace when that fits two (same box, one process, `tools/ab_workspace.py`: the
-    biped at N = 24 with S, U read from memory 0.076 -> 0.064 ms at 4 096 instances, 0.276 -> 0.264 at
-    16 384)."""
+    with the compact workspace when that fits two -- judged with ``P`` handed over directly, and, for
+    an assembler whose capacity makes its launches streaming ones, first with ``P`` in LDS, which is
+    how such launches run (same box, one process, `tools/ab_workspace.py`: the biped at N = 24 with
+    S, U read from memory 0.076 -> 0.064 ms at 4 096 instances, 0.276 -> 0.264 at 16 384; with its
+    matrices built on chip 0.230 -> 0.219 at 16 384, where the dense plan would be 7 % faster at 4 096)."""
     plan = compile_plan(form, workspace=workspace, **kw)
-    if workspace == "auto" and not plan.workspace.compact and resident_lds_bytes(plan)[0] > HALF_CU_LDS:
-        small = compile_plan(form, workspace="compact", **kw)
-        if small.workspace.compact and 0 < resident_lds_bytes(small)[0] <= HALF_CU_LDS:
-            plan = small
+    if workspace != "auto" or plan.workspace.compact:
+        return plan
+    dense = resident_lds_bytes(plan)
+    if max(dense) <= HALF_CU_LDS:
+        return plan
+    per_instance = 8 * (plan.no * plan.no + plan.no + plan.nc * plan.no + plan.nc)
+    streaming = batch is not None and per_instance * batch >= STREAMING_LAUNCH_BYTES
+    small, lds = None, None
+    for in_lds in ((1, 0) if streaming else (0,)):
+        if dense[in_lds] > HALF_CU_LDS:
+            if small is None:
+                small = compile_plan(form, workspace="compact", **kw)
+                lds = resident_lds_bytes(small)
+            if small.workspace.compact and 0 < lds[in_lds] <= HALF_CU_LDS:
+                return small
     return plan
 
 
@@ -163,7 +179,7 @@ class Assembler:
         # workgroup share the CU's LDS (plan_for_device: the biped at N = 24 with S, U read from
         # memory); "dense" / "compact" force one.
         self.plan = plan_for_device(form, costs=costs, limits=limits, lti=tuple(lti), csc=csc,
-                                    workspace=workspace)
+                                    workspace=workspace, batch=self.batch)
         self.csc = self.plan.csc
         p = self.plan
         self.ng, self.no, self.nc = p.ng, p.no, p.nc

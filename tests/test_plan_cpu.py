@@ -292,6 +292,12 @@ def test_workspace_chosen_by_what_fits_two_workgroups(cpu_api):
         # asked for by name, the layout is taken as it is
         assert engine.plan_for_device(form, lti=lti, workspace="dense").workspace.compact == 0
     assert engine.resident_lds_bytes(compile_plan(c3)) == (0, 0)            # not on the persistent kernel
+    # an assembler for streaming launches (P collected in LDS) is judged with P in LDS first: the biped
+    # at N = 24 with its matrices on chip needs 85 KB dense, 65 KB compact
+    assert engine.plan_for_device(n24, lti=("LIP",), batch=16384).workspace.compact == 1
+    assert engine.plan_for_device(n24, lti=("LIP",), batch=4096).workspace.compact == 0
+    assert engine.plan_for_device(n24, batch=16384).workspace.compact == 1   # (74 KB with P direct)
+    assert engine.plan_for_device(c2, lti=("LIP",), batch=65536).workspace.compact == 0
 
 
 def test_constraint_with_L_and_per_row_fields(cpu_api):
