@@ -1465,7 +1465,7 @@ def compile_plan(form, costs=None, limits=None, lti=(), csc=None, workspace="aut
         workspace = "dense"
     elif _os.environ.get("MPCASM_COMPACT") and workspace == "auto":
         workspace = "compact"
-    if packed_like and workspace != "dense" and (workspace == "compact"
+    if packed_like and rtot > 0 and workspace != "dense" and (workspace == "compact"
                                                  or 8 * ws.doubles > RS_COMPACT_FROM_BYTES):
         cand = Workspace.windows(rtot, no, b.spans, fused["fd_idx"] // ldv, fused["fd_idx"] % ldv)
         if ((workspace == "compact" or 3 * cand.doubles <= 2 * ws.doubles)
