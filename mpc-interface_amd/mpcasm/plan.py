@@ -51,10 +51,15 @@ RS_JC_MAX = 12                            # compose ops a thread can keep in reg
 RS_TRIP_WORDS = 8
 # cost model of the wavefront assignment (rounded cycles of one wavefront), see _resident_program
 TRIP_COST, TRIP_STEP_COST, TERM_COST, TRIP_Q_COST, PACK_COST, G_PIECE_COST = 200, 30, 60, 60, 250, 500
+G_DESC_PIECE_COST = 330     # ... a piece of G by the descriptor table (small problems; stamps: 1 950 cycles for six)
+TABLES_COST, STREAM_WAVE_COST, FETCH_CHUNK_COST = 3300, 500, 350   # horizon tables on chip; h and the rest of a stream wave
 import os as _os
-if _os.environ.get("MPCASM_TRIP_COSTS"):          # tuning aid: "trip,step,term,q,pack,piece"
-    (TRIP_COST, TRIP_STEP_COST, TERM_COST, TRIP_Q_COST, PACK_COST,
-     G_PIECE_COST) = (int(x) for x in _os.environ["MPCASM_TRIP_COSTS"].split(","))
+if _os.environ.get("MPCASM_TRIP_COSTS"):          # tuning aid: "trip,step,term,q,pack,piece[,tables,stream,chunk]"
+    _c = [int(x) for x in _os.environ["MPCASM_TRIP_COSTS"].split(",")]
+    TRIP_COST, TRIP_STEP_COST, TERM_COST, TRIP_Q_COST, PACK_COST, G_PIECE_COST = _c[:6]
+    G_DESC_PIECE_COST = G_PIECE_COST
+    if len(_c) > 6:
+        TABLES_COST, STREAM_WAVE_COST, FETCH_CHUNK_COST = _c[6:9]
 # trip record (csrc/plan_tables.h RT_*): words A, B, D, W, AIM, WORD, BI, BJ;
 # WORD = rows (16 or 4) | short << 5 | half << 6 | nop << 7 | first << 8 | last << 9 | live << 10
 #        | qmask << 14 | last trip of its term in the pack << 18
@@ -988,16 +993,17 @@ def _resident_program(fused, gterms, no, ldv, ws, image, ng, nparams, nc_rows):
     cost = [PACK_COST + sum(trip_cost(trip) for trip in lst) for lst in pack_trips]
     stream_threads = NT - NW * 64
     pieces = nc_rows * max(no // 2, 1)
+    by_descriptor = no % 2 == 0 and pieces <= RS_GDESC_PIECES * RS_GDESC_THREADS   # (compile_plan: rs_gdesc)
 
     loads = []
     for w in range(RS_WAVES):
         if w < NW:
-            gen = 3300 if image["groups"] and w == NW - 1 else 0   # builds the horizon tables
-            loads.append((350 * len(range(w, image["nchunk"], NW)) + gen, w))
+            gen = TABLES_COST if image["groups"] and w == NW - 1 else 0   # builds the horizon tables
+            loads.append((FETCH_CHUNK_COST * len(range(w, image["nchunk"], NW)) + gen, w))
         else:                                      # threads of this wave own pieces e = wt + u WT
             first = (w - NW) * 64
             own = len(range(first, pieces, stream_threads))
-            loads.append((G_PIECE_COST * own + 500, w))
+            loads.append(((G_DESC_PIECE_COST if by_descriptor else G_PIECE_COST) * own + STREAM_WAVE_COST, w))
     heapq.heapify(loads)
     wave_packs = [[] for _ in range(RS_WAVES)]
     for k in sorted(range(len(pack_trips)), key=lambda k: -cost[k]):
