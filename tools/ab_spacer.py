@@ -43,7 +43,10 @@ keep = []
 for spacer_gb in (0, 0, 0, 0, 8, 8, 8, 8, 32, 32, 32, 32, 64, 64):
     P = torch.empty((B, no, no), **f)
     q = torch.empty((B, no), **f)
-    sp = torch.empty(spacer_gb << 27, **f) if spacer_gb else None     # (2^27 doubles = 1 GB)
+    try:
+        sp = torch.empty(spacer_gb << 27, **f) if spacer_gb else None     # (2^27 doubles = 1 GB)
+    except RuntimeError:                                                  # (the device is full)
+        break
     G = torch.empty((B, nc, no), **f)
     h = torch.empty((B, nc), **f)
     keep.append((P, q, G, h, sp))
