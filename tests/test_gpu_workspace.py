@@ -53,3 +53,24 @@ def test_compact_workspace_gives_the_same_qps(gpu_api, jit, on_chip):
                     assert_close(a[b_], r, RTOL_TIGHT, "%s %s" % (name, key))
     finally:
         lib.mpcasm_set_option(capi.OPT_JIT, 0)
+
+
+def test_assembler_picks_the_workspace_that_fits_two_workgroups(gpu_api):
+    """``workspace="auto"`` (engine.plan_for_device): compact when the dense workspace leaves room for one
+    workgroup per CU and the compact one for two -- judged with P in LDS for an assembler sized for
+    streaming launches; results as the oracle's either way."""
+    import torch
+
+    from mpcasm.engine import Assembler
+
+    n24 = problems.biped(gpu_api, problems.BipedConfig(step_samples=12))
+    n24.update(step_times=np.array([10, 22]), step_count=0)
+    for lti, batch, compact in (([], 64, 1), (["LIP"], 64, 0), (["LIP"], 16384, 1)):
+        asm = Assembler(n24, batch=batch, lti=lti)
+        assert asm.plan.workspace.compact == compact, (lti, batch)
+        given = np.random.default_rng(6).normal(0, 0.1, [batch, n24.given_len])
+        got = [t[:3].cpu().numpy() for t in asm.assemble(torch.as_tensor(given, device="cuda"))]
+        A, hh, Q, qq = orc.assemble(n24, given[2].reshape(-1, 1))
+        for key, a, r in zip("PqGh", got, (Q, qq.ravel(), A, hh.ravel())):
+            assert_close(a[2], r, RTOL_TIGHT, key)
+        del asm
