@@ -137,6 +137,29 @@ int validate_tiled(const int32_t* it, const double* h_dtab, int64_t n, int64_t n
   };
   if (!table_ok(it + it[H_OFF_T_CIG], ng) || !table_ok(it + it[H_OFF_T_CIO], nop))
     return MPCASM_ERR_PLAN;
+  if (it[H_T_NP1] >= 0) {  // f2's unrolled tables: every entry inside its stream, every index inside its array
+    const int64_t np1 = it[H_T_NP1], nbrow = (it + it[H_OFF_T_BROW0])[nbase], pment = it[H_PM_NENT];
+    if (!in_range(it[H_OFF_T_P1PTR], nbrow + 1, n, H_WORDS) || !in_range(it[H_OFF_T_P1ENT], np1 * 2, n, H_WORDS) ||
+        it[H_OFF_T_P1ENT] % 2 || !in_range(it[H_OFF_T_P2Y], pment, n, H_WORDS))
+      return MPCASM_ERR_PLAN;
+    const int32_t* pp = it + it[H_OFF_T_P1PTR];
+    if (pp[0] != 0 || pp[nbrow] != np1) return MPCASM_ERR_PLAN;
+    for (int64_t t = 0; t < nbrow; ++t)
+      if (pp[t + 1] < pp[t]) return MPCASM_ERR_PLAN;
+    const int32_t* pe = it + it[H_OFF_T_P1ENT];
+    for (int64_t e = 0; e < np1; ++e) {
+      const int64_t off = (uint32_t)pe[2 * e], sid = (uint32_t)pe[2 * e + 1] >> 24, c = pe[2 * e + 1] & 0xFFFFFF;
+      if (sid > T_SID_CONST || (sid < T_SID_CONST && sid >= it[H_NSRC]) || c >= ng + no) return MPCASM_ERR_PLAN;
+      const int64_t lo = sid == T_SID_CONST ? ddelta : 0;
+      const int64_t hi = sid == T_SID_CONST ? ddelta + ndelta : size[sid];
+      if (off < lo || off >= hi) return MPCASM_ERR_PLAN;
+    }
+    const int32_t* py = it + it[H_OFF_T_P2Y];
+    for (int64_t e = 0; e < pment; ++e)
+      if (py[e] < 0 || py[e] >= nbrow) return MPCASM_ERR_PLAN;
+  } else if (it[H_T_NP1] != -1) {
+    return MPCASM_ERR_PLAN;
+  }
   if (!it[H_T_OK]) return MPCASM_OK;
   // the tiled program
   const int64_t nstage = it[H_T_NSTAGE], rtot = it[H_RTOT];
@@ -812,6 +835,7 @@ void plan_dev_from_tables(const int32_t* it, PlanDev* out) {
   d.rs_ngfix = it[H_RS_NGFIX]; d.off_rs_gfix = it[H_OFF_RS_GFIX];
   d.rs_compact = it[H_RS_COMPACT]; d.rs_ldv = it[H_RS_LDV]; d.rs_vd = it[H_RS_VD];
   d.rs_vrow0 = it[H_RS_VROW0]; d.off_rs_rrwin = it[H_OFF_RS_RRWIN];
+  d.t_np1 = it[H_T_NP1]; d.off_t_p1ptr = it[H_OFF_T_P1PTR]; d.off_t_p1ent = it[H_OFF_T_P1ENT]; d.off_t_p2y = it[H_OFF_T_P2Y];
   d.t_nbrow = d.t_ci_ok ? it[d.off_t_brow0 + d.nbase] : 0;
   d.pm_nfd = it[H_PM_NFD]; d.off_pm_map = it[H_OFF_PM_MAP]; d.off_pm_fdptr = it[H_OFF_PM_FDPTR];
   d.off_pm_op = it[H_OFF_PM_OP]; d.doff_pm_pool = it[H_DOFF_PM_POOL];
@@ -1186,7 +1210,7 @@ int mpcasm_preview_direct(const mpcasm_plan* plan, const double* const* h_src,
                          static_cast<hipStream_t>(stream));
   if (rc != MPCASM_OK) return rc;
   rc = launch_preview_direct(d, eff, d_given, d_optim, d_out, batch, plan->num_cus,
-                             static_cast<hipStream_t>(stream), &err);
+                             static_cast<hipStream_t>(stream), &err, plan->h_itab.data());
   if (rc == MPCASM_ERR_HIP) g_last_hip = (int)err;
   return rc;
 }

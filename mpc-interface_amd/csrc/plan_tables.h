@@ -29,7 +29,7 @@
 namespace mpcasm {
 
 constexpr int32_t PLAN_MAGIC = 0x4D504341;  // 'MPCA'
-constexpr int32_t PLAN_VERSION = 24;
+constexpr int32_t PLAN_VERSION = 25;
 
 enum HeaderWord : int {
   H_MAGIC = 0,
@@ -203,9 +203,16 @@ enum HeaderWord : int {
   H_RS_VROW0,
   H_OFF_RS_RRWIN,   // [NC] (compact) per row of G the windows of its two axes in column pairs:
                     //    first | count << 8, the second axis << 16 (a missing axis: 0)
+  // f2 (preview.hip): the column tables unrolled per base row, and the definitions' row entries by
+  // base row, ready to be copied into LDS once per workgroup
+  H_T_NP1,          // entries of the table below; -1: absent (the column tables do not cover the plan)
+  H_OFF_T_P1PTR,    // [total base rows + 1] a base row's entries, as a range of ...
+  H_OFF_T_P1ENT,    // ... [T_NP1][2]: element offset in its stream (for this very row),
+                    //     column of [given | unknowns] | stream << 24
+  H_OFF_T_P2Y,      // [PM_NENT] per entry of a definition's row: its base row among all base rows
   H_WORDS = 128
 };
-static_assert(H_OFF_RS_RRWIN < H_WORDS, "plan header");
+static_assert(H_OFF_T_P2Y < H_WORDS, "plan header");
 
 constexpr int T_BLOCK = 128;       // columns of a block of P (tiled kernel)
 constexpr int T_SID_CONST = 32;    // the stream that is the plan's own dtab

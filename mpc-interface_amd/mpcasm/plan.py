@@ -17,7 +17,7 @@ import numpy as np
 import scipy.sparse as sp
 
 PLAN_MAGIC = 0x4D504341
-PLAN_VERSION = 24
+PLAN_VERSION = 25
 
 # header words (csrc/plan_tables.h, enum HeaderWord)
 _H = {name: i for i, name in enumerate([
@@ -40,6 +40,7 @@ _H = {name: i for i, name in enumerate([
     "T_OK", "T_NSTAGE", "OFF_T_STAGE", "T_NLTI", "OFF_T_LTI", "OFF_T_LTI_IDS", "T_WORK",
     "OFF_T_GROW", "OFF_T_SROW", "T_DOFF_SCOEF", "OFF_T_PIG", "T_NGREST", "OFF_T_GREST", "OFF_T_BROW0", "OFF_T_BCOLPTR", "OFF_T_BCOLS", "T_TOEPLITZ",
     "RS_NGFIX", "OFF_RS_GFIX", "RS_COMPACT", "RS_LDV", "RS_VD", "RS_VROW0", "OFF_RS_RRWIN",
+    "T_NP1", "OFF_T_P1PTR", "OFF_T_P1ENT", "OFF_T_P2Y",
 ])}
 H_WORDS = 128
 assert len(_H) <= H_WORDS
@@ -1699,6 +1700,30 @@ def compile_plan(form, costs=None, limits=None, lti=(), csc=None, workspace="aut
     bcols = [np.flatnonzero(colseg >= 0) for colseg in b.colseg]
     sections += [("OFF_T_BCOLPTR", np.cumsum([0] + [c.size for c in bcols]).astype(np.int32)),
                  ("OFF_T_BCOLS", (np.concatenate(bcols) if bcols else np.zeros(0)).astype(np.int32))]
+    # f2 (preview.hip): the same column tables unrolled per base row -- entry (element offset in its
+    # stream, column of [given | unknowns] | stream << 24) for every covered column -- and, per entry of
+    # a definition's row, where its base row sits among all base rows: what a workgroup copies into LDS
+    # once and then reads per instance with no table look-up left
+    p1ptr, p1ent = np.zeros(1, dtype=np.int64), []
+    if tiled["ci_ok"]:
+        for bid, cols in enumerate(bcols):
+            k = np.arange(b.base_rows[bid], dtype=np.int64)[:, None]
+            word = ci[bid, cols, 1]
+            step = ((word & 0xFFFFFF) ^ 0x800000) - 0x800000              # (24 bits, signed)
+            offs = ci[bid, cols, 0][None, :] + k * step[None, :]
+            tag = (cols | ((word >> 24) << 24))[None, :].repeat(k.shape[0], axis=0)
+            p1ent.append(np.stack([offs, tag], axis=2).reshape(-1, 2))
+        p1ptr = np.concatenate([[0], np.cumsum([len(bcols[bid]) for bid in range(len(bcols))
+                                                for _ in range(b.base_rows[bid])])]).astype(np.int64)
+    p1ent = np.concatenate(p1ent) if p1ent else np.zeros((0, 2), dtype=np.int64)
+    p1_ok = bool(tiled["ci_ok"]) and (p1ent.size == 0 or (0 <= p1ent[:, 0].min() and p1ent[:, 0].max() < 1 << 31))
+    if not p1_ok:
+        p1ptr, p1ent = np.zeros(1, dtype=np.int64), np.zeros((0, 2), dtype=np.int64)
+    p2y = (np.asarray(b.base_row0, dtype=np.int64)[pm_entbase] + pm_entk) if p1_ok and pm_entbase.size \
+        else np.zeros(0, dtype=np.int64)
+    sections += [("OFF_T_P1PTR", np.asarray(p1ptr, dtype=np.int32)),
+                 ("OFF_T_P1ENT", p1ent.astype(np.uint32).view(np.int32).reshape(-1)),
+                 ("OFF_T_P2Y", p2y.astype(np.int32))]
     sections += [("OFF_RS_DPAR", rs_dpar.reshape(-1)), ("OFF_RS_GDESC", rs_gdesc),
                  ("OFF_RS_GFIX", rs_gfix), ("OFF_RS_RRWIN", rs_rrwin),
                  ("OFF_PM_MAP", pmprog["map"]), ("OFF_PM_FDPTR", pmprog["fd_ptr"]),
@@ -1713,7 +1738,7 @@ def compile_plan(form, costs=None, limits=None, lti=(), csc=None, workspace="aut
             parts.append(np.zeros(1, dtype=np.int32))
             off += 1
         if name in ("OFF_RS_RR", "OFF_RS_INMETA", "OFF_RS_ABMETA", "OFF_RS_DPAR",
-                    "OFF_RS_GDESC", "OFF_RS_GFIX", "OFF_CSC_G", "OFF_T_CIG", "OFF_T_CIO",
+                    "OFF_RS_GDESC", "OFF_RS_GFIX", "OFF_CSC_G", "OFF_T_CIG", "OFF_T_CIO", "OFF_T_P1ENT",
                     "OFF_T_STAGE", "OFF_T_GROW", "OFF_T_SROW", "OFF_T_PIG") and off & 3:   # ... 16-byte quads
             pad = 4 - (off & 3)
             parts.append(np.zeros(pad, dtype=np.int32))
@@ -1750,6 +1775,7 @@ def compile_plan(form, costs=None, limits=None, lti=(), csc=None, workspace="aut
     header[_H["T_OK"]], header[_H["T_NSTAGE"]] = tiled["ok"], tiled["stages"].shape[0]
     header[_H["T_NLTI"]], header[_H["T_WORK"]] = tiled["lti"].shape[0], tiled["work"]
     header[_H["T_TOEPLITZ"]] = tiled["toeplitz"]
+    header[_H["T_NP1"]] = p1ent.shape[0] if p1_ok else -1
     dtab = np.concatenate(dparts).astype(np.float64)
     params = np.asarray(b.params, dtype=np.float64)
     header[_H["MAGIC"]], header[_H["VERSION"]] = PLAN_MAGIC, PLAN_VERSION

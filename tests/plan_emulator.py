@@ -460,6 +460,30 @@ def _tiled_streams(plan, srcs, ab):
     return streams
 
 
+def run_preview_tables(plan, given, optim, sources=None, ab=None):
+    """Rows of every definition, ``Mg @ given + Mo @ optim``, as csrc/preview.hip's staged kernel computes
+    them from the plan's unrolled tables (plan_tables.h H_T_NP1): y[t] = sum over the base row's entries
+    of stream[offset] * [given ; optim][column]; row r = sum of coef * y[base row]."""
+    it, dt = plan.itab, plan.dtab
+    assert it[H["T_NP1"]] >= 0
+    srcs = [s.array for s in plan.sources] if sources is None else sources
+    streams = _tiled_streams(plan, srcs, ab or [])
+    x = np.concatenate([np.asarray(given, dtype=float).ravel(), np.asarray(optim, dtype=float).ravel()])
+    nbrow = int(_section(it, "OFF_T_BROW0", it[H["NBASE"]] + 1)[-1])
+    ptr = _section(it, "OFF_T_P1PTR", nbrow + 1)
+    ent = _section(it, "OFF_T_P1ENT", it[H["T_NP1"]] * 2).view(np.uint32).reshape(-1, 2)
+    assert ptr[0] == 0 and ptr[-1] == len(ent) and (np.diff(ptr) >= 0).all()
+    y = np.zeros(nbrow)
+    for t in range(nbrow):
+        for off, tag in ent[ptr[t]:ptr[t + 1]]:
+            y[t] += streams[int(tag) >> 24][int(off)] * x[int(tag) & 0xFFFFFF]
+    rowptr = _section(it, "OFF_PM_ROWPTR", it[H["PMROWS"]] + 1)
+    p2y = _section(it, "OFF_T_P2Y", it[H["PM_NENT"]])
+    coef = dt[it[H["DOFF_PM_ENTCOEF"]]:it[H["DOFF_PM_ENTCOEF"]] + it[H["PM_NENT"]]]
+    return np.array([np.dot(coef[rowptr[r]:rowptr[r + 1]], y[p2y[rowptr[r]:rowptr[r + 1]]])
+                     for r in range(it[H["PMROWS"]])])
+
+
 def _sext24(x):
     x = np.asarray(x, dtype=np.int64) & 0xFFFFFF
     return np.where(x >= 1 << 23, x - (1 << 24), x)

@@ -35,6 +35,13 @@ def check_plan(form, given, tol=1e-12):
         assert_close(block[:, plan.ng:], PM[var][1], tol, var + " Mo")
     # the column tables / stage list of the tiled kernel (built for every plan)
     assert plan.itab[_H["T_CI_OK"]] == 1
+    # ... unrolled per base row for f2: the rows of every definition from [given ; optim]
+    optim = np.random.default_rng(9).standard_normal(plan.no)
+    rows = plan_emulator.run_preview_tables(plan, given, optim)
+    for var, (r0, nrows) in plan.pm_rows.items():
+        Mg, Mo = PM[var]
+        assert_close(rows[r0:r0 + nrows], (Mg @ np.asarray(given).reshape(-1, 1)).ravel() + Mo @ optim, tol,
+                     var + " preview rows")
     til = plan_emulator.run_tiled(plan, given)
     for key, ref in (("P", Q), ("q", q.ravel()), ("G", A), ("h", h.ravel())):
         assert_close(til[key], ref, tol, "tiled " + key)
