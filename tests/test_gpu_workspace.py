@@ -74,3 +74,26 @@ def test_assembler_picks_the_workspace_that_fits_two_workgroups(gpu_api):
         for key, a, r in zip("PqGh", got, (Q, qq.ravel(), A, hh.ravel())):
             assert_close(a[2], r, RTOL_TIGHT, key)
         del asm
+
+
+def test_compact_workspace_partial_launches_and_halves(gpu_api):
+    """``count`` < batch and the cost-only / constraints-only launches on a compact plan: the same numbers
+    as the whole launch, the rest of the buffers untouched."""
+    import torch
+
+    from mpcasm.engine import Assembler
+
+    form = problems.lipm3d(gpu_api, N=32)
+    batch = 40
+    asm = Assembler(form, batch=batch, lti=["LIP"])
+    assert asm.plan.workspace.compact == 1
+    g = torch.as_tensor(np.random.default_rng(8).normal(0, 0.1, [batch, form.given_len]), device="cuda")
+    ref = [t.clone() for t in asm.assemble(g)]
+    out = tuple(torch.full_like(t, -7.0) for t in ref)
+    asm.assemble(g, out=out, count=13)
+    for a, r in zip(out, ref):
+        assert torch.equal(a[:13], r[:13]) and bool((a[13:] == -7.0).all())
+    P, q, G, h = asm.assemble(g, out=tuple(torch.full_like(t, -7.0) for t in ref), want_constraints=False)
+    assert G is None and h is None and torch.equal(P, ref[0]) and torch.equal(q, ref[1])
+    P, q, G, h = asm.assemble(g, out=tuple(torch.full_like(t, -7.0) for t in ref), want_cost=False)
+    assert P is None and q is None and torch.equal(G, ref[2]) and torch.equal(h, ref[3])
