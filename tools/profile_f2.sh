@@ -14,12 +14,12 @@ out = sys.argv[1]
 for f in glob.glob(out + "/stats/**/*kernel_stats.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         if "preview" in r["Name"] or "lti_tables" in r["Name"]:
-            print("%-28s calls %5s  avg %9.1f us  min %9.1f us" % (re.search(r"(\\w+_kernel)", r["Name"]).group(1), r["Calls"], float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3))
+            print("%-28s calls %5s  avg %9.1f us  min %9.1f us" % (re.search(r"(\w+_kernel)", r["Name"]).group(1), r["Calls"], float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3))
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/lds/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         if "preview" in r["Kernel_Name"]:
-            acc[re.search(r"(\\w+_kernel)", r["Kernel_Name"]).group(1)][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            acc[re.search(r"(\w+_kernel)", r["Kernel_Name"]).group(1)][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for kname, cs in acc.items():
     print(kname + " (65 536 instances per launch):")
     for k, v in sorted(cs.items()):
