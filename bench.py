@@ -384,6 +384,30 @@ def variant_records(torch, dev, batch, seed):
     return out
 
 
+def f2_records(torch, dev, seed, batches=(4096, 65536)):
+    """SURVEY.md 8 row f2, the step after the solve: every row of every definition (body.py:209-219) for a
+    batch of C2 walkers straight from the sources -- no preview matrix in memory (mpcasm_preview_direct)."""
+    from mpcasm import engine
+
+    out = []
+    for batch in batches:
+        work = build_workload(batch, seed)
+        asm = engine.Assembler(work["form"], batch=batch, device=dev)
+        given = torch.as_tensor(work["given"], device=dev)
+        optim = torch.as_tensor(np.random.default_rng(seed).normal(0, 0.5, [batch, asm.no]), device=dev)
+        rows = asm.preview_rows(given, optim)
+        ms = _event_ms(torch, lambda: asm.preview_rows(given, optim, out=rows), 200)
+        nbytes = 8 * (asm.ng + asm.no + asm.plan.pmrows)
+        gbps = nbytes * batch / (ms * 1e-3) / 1e9
+        out.append({"workload": "C2 biped N=16: rows of all definitions from [given; optim], shared S, U",
+                    "batch_per_gpu": batch, "rows": int(asm.plan.pmrows), "avg_launch_ms": ms,
+                    "instances_per_s": batch / (ms * 1e-3), "algorithmic_bytes_per_instance": nbytes,
+                    "achieved": gbps, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS})
+        del asm, rows, given, optim
+    torch.cuda.empty_cache()
+    return out
+
+
 F64_MFMA_PEAK_TFLOPS = 78.6    # dense fp64 matrix peak of gfx950 (v_mfma_f64_16x16x4_f64: 32 flop/clk/SIMD)
 
 
@@ -756,6 +780,11 @@ def run_rank(args):
         record["variants"] = variant_records(torch, dev, B, 20260 + rank)
         # K1 alone on the north-star shapes
         record["fill"] = fill_records(torch, engine, dev, B)
+        # f2: the step after the solve, on the device
+        try:
+            record["f2"] = f2_records(torch, dev, 20260 + rank)
+        except Exception as exc:        # (never at the cost of the main line)
+            record["f2"] = {"error": repr(exc)}
         # C4 on the tiled kernel at its per-GPU batch
         try:
             record["c4"] = c4_record(torch, dev)
