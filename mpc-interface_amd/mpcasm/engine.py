@@ -253,6 +253,10 @@ class Assembler:
         values = self.plan.current_params()
         if values is None:
             return False
+        if self.batch == 1:   # (the drop-in tick: one upload straight into place, no broadcast kernel)
+            self.params.copy_(self._torch.from_numpy(
+                np.ascontiguousarray(values, dtype=np.float64)).reshape(self.params.shape))
+            return True
         base = self._torch.as_tensor(values, dtype=self._torch.float64, device=self.device)
         self.params[:] = base.unsqueeze(0)
         return True
@@ -272,9 +276,23 @@ class Assembler:
                 return False
             fresh.append(np.ascontiguousarray(block, dtype=np.float64))
         generated = {i for g in self.plan.lti for i in g["ids"]}
-        for i, block in enumerate(fresh):
-            if i not in generated:
-                self._src[i], self._src_stride[i] = _as_device(self._torch, block, self.device), 0
+        # all blocks side by side in one device arena, filled by ONE copy from a pinned staging
+        # buffer (a tick of the walking loop is copy-bound: ~20 us per separate upload)
+        torch = self._torch
+        shared = [i for i in range(len(fresh)) if i not in generated]
+        starts = np.cumsum([0] + [fresh[i].size + (fresh[i].size & 1) for i in shared])   # (16-byte aligned)
+        arena = getattr(self, "_src_arena", None)
+        if arena is None or arena[0].numel() != int(starts[-1]):
+            arena = self._src_arena = (
+                torch.empty(int(starts[-1]), dtype=torch.float64, device=self.device),
+                torch.empty(int(starts[-1]), dtype=torch.float64).pin_memory())
+        stage = arena[1].numpy()
+        for a, i in zip(starts, shared):
+            stage[a:a + fresh[i].size] = fresh[i].ravel()
+        arena[0].copy_(arena[1])
+        for a, i in zip(starts, shared):
+            self._src[i] = arena[0][a:a + fresh[i].size].view(fresh[i].shape)
+            self._src_stride[i] = 0
         for g in self.plan.lti:     # S[0][j][i] = A[i][j], U_j[0][0][i] = B[i][j]  (tools.py:14-33)
             ids = g["ids"]
             A = fresh[ids[-1]][0].T

@@ -399,6 +399,15 @@ def structure_fingerprint(costs, limits):
     return tuple(key)
 
 
+_EYES = {}
+
+
+def _eye(n):
+    if n not in _EYES:
+        _EYES[n] = np.eye(n)
+    return _EYES[n]
+
+
 def formulation_key(form):
     """Everything about a Formulation, besides its costs and limits, that a compiled plan
     depends on: the QP domain, the shapes of the horizon matrices, which coefficient blocks of
@@ -417,7 +426,6 @@ def formulation_key(form):
             items = []
             for dep, m in combo.items():
                 m = np.asarray(m, dtype=np.float64)
-                eye = m.ndim == 2 and m.shape[0] == m.shape[1] and np.array_equal(m, np.eye(m.shape[0]))
                 # what add_base decides from the numbers: the coefficient IS the slice of the
                 # dynamics' horizon matrix (a rebindable source) or a block of its own (a constant
                 # source, re-read from the definition) -- a plan compiled for one is wrong for the other
@@ -426,7 +434,10 @@ def formulation_key(form):
                     src = np.asarray(dyn.matrices[domain_ID[dep]])
                     sID = state_ID[var]
                     gather = bool(src.ndim == 3 and sID < src.shape[2] and m.shape == src.shape[:2]
-                                  and np.array_equal(m, src[..., sID]))
+                                  and (m == src[..., sID]).all())
+                # (asked for only where add_base asks: a slice of the horizon matrix is taken as that)
+                eye = (not gather and m.ndim == 2 and m.shape[0] == m.shape[1]
+                       and bool((m == _eye(m.shape[0])).all()))
                 items.append((dep, m.shape, eye, gather))
             key.append((var, form.of[var], tuple(items)))
         else:
