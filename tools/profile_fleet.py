@@ -5,9 +5,9 @@ import torch
 from mpcasm import problems
 from mpcasm.walkers import WalkerFleet
 B=4096
-fleet = WalkerFleet(B, conf=problems.BipedConfig(step_samples=8))
+fleet = WalkerFleet(B, conf=problems.BipedConfig(step_samples=8), graphs="graphs" in sys.argv)
 g = torch.zeros((B, fleet.given_len), dtype=torch.float64, device="cuda")
-for _ in range(20): fleet.tick(g)
+for _ in range(40): fleet.tick(g)
 torch.cuda.synchronize()
 t=time.perf_counter()
 for _ in range(64): fleet.tick(g)
