@@ -116,24 +116,30 @@ __global__ __launch_bounds__(BLOCK) void lti_tables_kernel(PlanDev p, SrcTable s
   }
 }
 
-// The same tables for SMALL systems (n (m + n) <= 64 elements, the LIPM family): a wavefront per system
-// instead of a workgroup -- lane e = (i, c) holds X[i][c], the step's operands cross lanes through LDS (one
+// The same tables for SMALL systems (n (m + n) <= 64 elements, the LIPM family): a wavefront per system -- or
+// per several (the biped's 12 elements: four systems of 16 lanes) -- instead of a workgroup; lane e = (i, c) holds X[i][c], the step's operands cross lanes through LDS (one
 // wavefront's LDS operations complete in order: no barrier), the tables are collected in LDS and leave in
 // whole lines.  Same products in the same order as lti_tables_kernel above, i.e. the same numbers.
 // (That kernel keeps 12 of 256 threads busy on the biped's 3 x 4 elements: 0.29 ms per 65 536 systems.)
 __global__ __launch_bounds__(BLOCK) void lti_tables_small_kernel(PlanDev p, SrcTable src,
                                                                  double* __restrict__ work,
                                                                  long long work_stride, long jobs,
-                                                                 int per_wave) {
+                                                                 int per_system, int lanes, int systems) {
+  // `systems` systems per wavefront, `lanes` (a power of two >= n (m + n)) lanes each
   extern __shared__ __attribute__((aligned(16))) double lti_lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  double* mine = lti_lds + (size_t)wave * per_wave;  // A [64] | X twice [2][64] | TA | TB of this wavefront
+  const int sub = lane / lanes, l = lane - sub * lanes;
+  double* mine = lti_lds + ((size_t)wave * systems + sub) * per_system;  // A [64] | X twice [2][64] | TA | TB
   double* sA = mine;
   double* sX = mine + 64;
   double* tab = mine + 192;
-  for (long job = (long)blockIdx.x * (BLOCK / 64) + wave; job < jobs; job += (long)gridDim.x * (BLOCK / 64)) {
-    const long inst = job / p.t_nlti;
-    const int g = (int)(job - inst * p.t_nlti);
+  const long per_wg = (long)(BLOCK / 64) * systems;
+  for (long first = ((long)blockIdx.x * (BLOCK / 64) + wave) * systems; first < jobs; first += (long)gridDim.x * per_wg) {
+    const long job = first + sub;
+    const bool live = sub < systems && job < jobs;
+    const long jb = live ? job : first;  // (idle lanes follow the wavefront's first system: same loop bounds)
+    const long inst = jb / p.t_nlti;
+    const int g = (int)(jb - inst * p.t_nlti);
     const int32_t* rec = p.itab + p.off_t_lti + g * T_LTI_WORDS;
     const int n = rec[TL_N], m = rec[TL_M], N = rec[TL_HORIZON];
     const int32_t* ids = p.itab + p.off_t_lti_ids + rec[TL_IDS];
@@ -142,31 +148,35 @@ __global__ __launch_bounds__(BLOCK) void lti_tables_small_kernel(PlanDev p, SrcT
     const int w = m + n, elems = n * w, nta = N * n * n, ntb = n * m * 2 * N;
     double* tA = tab;
     double* tB = tab + nta;
-    const int i = lane / w, c = lane - i * w;  // (lanes >= elems idle)
-    if (lane < n * n) sA[lane] = A[lane];
-    if (lane < elems) sX[lane] = c < m ? B[i * m + c] : A[i * n + (c - m)];
-    for (int e = lane; e < ntb; e += 64) tB[e] = 0.0;  // (the zeros in front of every row of TB, and the rest)
+    const int i = l / w, c = l - i * w;  // (lanes >= elems idle)
+    const bool mine_ok = live && l < elems;
+    if (live && l < n * n) sA[l] = A[l];
+    if (mine_ok) sX[l] = c < m ? B[i * m + c] : A[i * n + (c - m)];
+    if (live)
+      for (int e = l; e < ntb; e += lanes) tB[e] = 0.0;  // (the zeros in front of every row of TB, and the rest)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     for (int d = 0; d < N; ++d) {
       const double* X = sX + (d & 1) * 64;
       double* Xn = sX + ((d & 1) ^ 1) * 64;
-      if (lane < elems) {
-        const double v = X[lane];
+      if (mine_ok) {
+        const double v = X[l];
         if (c < m)
           tB[(i * m + c) * 2 * N + N + d] = v;       // (A^d B)[i][c]
         else
           tA[d * n * n + (c - m) * n + i] = v;       // S[k][j][i] = (A^{k+1})[i][j]
         double acc = 0.0;
         for (int t = 0; t < n; ++t) acc = fma(sA[i * n + t], X[t * w + c], acc);
-        Xn[lane] = acc;
+        Xn[l] = acc;
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
-    double* TA = work + inst * work_stride + rec[TL_TA];
-    double* TB = work + inst * work_stride + rec[TL_TB];
-    for (int e = lane; e < nta; e += 64) TA[e] = tA[e];
-    for (int e = lane; e < ntb; e += 64) TB[e] = tB[e];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (read out before the next system overwrites it)
+    if (live) {
+      double* TA = work + inst * work_stride + rec[TL_TA];
+      double* TB = work + inst * work_stride + rec[TL_TB];
+      for (int e = l; e < nta; e += lanes) TA[e] = tA[e];
+      for (int e = l; e < ntb; e += lanes) TB[e] = tB[e];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (read out before the next systems overwrite it)
   }
 }
 
@@ -1076,11 +1086,22 @@ int launch_lti_tables(const PlanDev& p, const SrcTable& src, double* w, int batc
     all_small = all_small && n * (m + n) <= 64 && tables <= 1800;  // (four wavefronts: under 64 KB of LDS)
     small = std::max(small, 192 + tables + (tables & 1));
   }
-  if (all_small) {  // a wavefront per system
+  if (all_small) {  // a wavefront per `systems` systems
+    size_t elems = 0;
+    for (int g = 0; g < p.t_nlti; ++g) {
+      const int32_t* rec = h_itab + p.off_t_lti + g * T_LTI_WORDS;
+      elems = std::max<size_t>(elems, (size_t)rec[TL_N] * (rec[TL_M] + rec[TL_N]));
+    }
+    int lanes = 1;
+    while ((size_t)lanes < elems) lanes *= 2;
+    // (as many systems per wavefront as lanes and 64 KB of LDS per workgroup allow)
+    const int systems = (int)std::max<size_t>(1, std::min<size_t>(64 / lanes, (64 * 1024 / sizeof(double) / (BLOCK / 64)) / small));
     const long jobs = (long)batch * p.t_nlti;
-    const unsigned grid = (unsigned)std::min<long>((jobs + BLOCK / 64 - 1) / (BLOCK / 64), 256L * 8);
-    hipLaunchKernelGGL(lti_tables_small_kernel, dim3(grid), dim3(BLOCK), small * (BLOCK / 64) * sizeof(double),
-                       stream, p, src, w, stride, jobs, (int)small);
+    const long per_wg = (long)(BLOCK / 64) * systems;
+    const unsigned grid = (unsigned)std::min<long>((jobs + per_wg - 1) / per_wg, 256L * 8);
+    hipLaunchKernelGGL(lti_tables_small_kernel, dim3(grid), dim3(BLOCK),
+                       small * systems * (BLOCK / 64) * sizeof(double), stream, p, src, w, stride, jobs, (int)small,
+                       lanes, systems);
     return MPCASM_OK;
   }
   hipLaunchKernelGGL(lti_tables_kernel, dim3((unsigned)batch * p.t_nlti), dim3(BLOCK), lds, stream, p,
