@@ -542,7 +542,11 @@ def run_rank(args):
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_PORT", str(_free_port()))
-        dist.init_process_group(args.backend, rank=rank, world_size=world)
+        kw = {}
+        if args.backend == "nccl":
+            # (the rank's own GPU by name: RCCL otherwise guesses it from the global rank)
+            kw["device_id"] = torch.device("cuda", local_rank)
+        dist.init_process_group(args.backend, rank=rank, world_size=world, **kw)
 
     B = args.batch
     lo, hi = mdist.shard_bounds(world * B, world, rank)   # this rank's slice of the global batch
