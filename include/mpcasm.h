@@ -55,8 +55,10 @@ const char* mpcasm_status_string(int status);
  * the persistent kernel (per-instance fused kernel if it fits), 2 = always the
  * staged K2 -> K3 -> K4 pipeline with the workspace in HBM, 3 = as 1, and a wide problem whose
  * rows are windows of generated horizon tables still composes its tiles (the tiled kernel's
- * general form instead of its Toeplitz form).  The parity tests use it to exercise every path;
- * all paths give the same results. */
+ * general form instead of its Toeplitz form), 4 = as 1, and such a problem multiplies its windows
+ * on the matrix core even where every Hessian term is the full horizon of one state (the tiled
+ * kernel's Toeplitz form instead of its scan form, which sums P along diagonals).  The parity
+ * tests use it to exercise every path; all paths give the same results. */
 enum { MPCASM_OPT_PATH = 1, MPCASM_OPT_PHASE_MASK = 2, MPCASM_OPT_RESIDENT_PER_CU = 3, MPCASM_OPT_JIT = 4,
        MPCASM_OPT_P_DIRECT = 5 };
 /* MPCASM_OPT_PHASE_MASK is a profiling aid (timing-only ablation of the fused
@@ -210,7 +212,8 @@ int mpcasm_assemble(const mpcasm_plan* plan, const double* const* h_src,
  * for the plan, the per-instance fused kernel, the staged K2 -> K3 -> K4 pipeline, the tiled
  * kernel for wide problems. */
 enum { MPCASM_KERNEL_NONE = 0, MPCASM_KERNEL_RESIDENT = 1, MPCASM_KERNEL_RESIDENT_JIT = 2,
-       MPCASM_KERNEL_FUSED = 3, MPCASM_KERNEL_STAGED = 4, MPCASM_KERNEL_TILED = 5 };
+       MPCASM_KERNEL_FUSED = 3, MPCASM_KERNEL_STAGED = 4, MPCASM_KERNEL_TILED = 5,
+       MPCASM_KERNEL_TILED_SCAN = 6 /* the tiled kernel's scan form: P summed along diagonals */ };
 int mpcasm_plan_last_kernel(const mpcasm_plan* plan);
 
 /* K2 alone  preview matrices ------------------------------------------------

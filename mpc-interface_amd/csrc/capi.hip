@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -299,6 +300,65 @@ int validate_tiled(const int32_t* it, const double* h_dtab, int64_t n, int64_t n
             return MPCASM_ERR_PLAN;
         }
       }
+    }
+  }
+  // scan form (toeplitz_scan_kernel): only beside the Toeplitz form; every index the kernel forms
+  // from these tables stays inside TB, d, the parameters and the results
+  {
+    const int64_t K = it[H_T_SCAN], nblk = it[H_T_SCAN_NBLK], nrest = it[H_T_SCAN_NGREST];
+    if (K < 0 || K > T_SCAN_KMAX || (K > 0 && !it[H_T_TOEPLITZ])) return MPCASM_ERR_PLAN;
+    if (K > 0) {
+      const int32_t* g = it + it[H_OFF_T_LTI];
+      const int64_t gn = g[TL_N], gm = g[TL_M], gN = g[TL_HORIZON], per_state = gm * 2 * gN;
+      const int64_t nparams = it[H_NPARAMS];
+      if (gN < 1 || gN > T_SCAN_NMAX || nblk < 1 || nblk > T_SCAN_BLKMAX || nrest < 0 || nrest > nc ||
+          !in_range(it[H_OFF_T_SCAN_BLK], nblk * 2, n, H_WORDS) ||
+          !in_range(it[H_OFF_T_SCAN_GT], K * T_SCAN_GT_WORDS, n, H_WORDS) ||
+          !in_range(it[H_OFF_T_SCAN_GROW], nc * 2, n, H_WORDS) || it[H_OFF_T_SCAN_GROW] % 2 ||
+          !in_range(it[H_OFF_T_SCAN_GREST], nrest, n, H_WORDS) ||
+          !in_range(it[H_OFF_T_SCAN_COLBLK], no, n, H_WORDS) ||
+          !in_range(it[H_T_DOFF_SCAN_GC], K, nd, 0) || !in_range(it[H_T_DOFF_SCAN_GCOEF], nc, nd, 0))
+        return MPCASM_ERR_PLAN;
+      const int32_t* blk = it + it[H_OFF_T_SCAN_BLK];
+      const int32_t* colblk = it + it[H_OFF_T_SCAN_COLBLK];
+      int64_t covered = 0;
+      for (int64_t b = 0; b < nblk; ++b) {
+        const int64_t c0 = blk[2 * b], pbase = blk[2 * b + 1];
+        if (c0 < 0 || c0 + gN > no || pbase < gN || (pbase - gN) % (2 * gN) || (pbase - gN) / (2 * gN) >= gm)
+          return MPCASM_ERR_PLAN;
+        for (int64_t l = 0; l < gN; ++l)
+          if (colblk[c0 + l] != b) return MPCASM_ERR_PLAN;  // (hence disjoint)
+        covered += gN;
+      }
+      int64_t other = 0;
+      for (int64_t c = 0; c < no; ++c) {
+        if (colblk[c] < -1 || colblk[c] >= nblk) return MPCASM_ERR_PLAN;
+        other += colblk[c] < 0;
+      }
+      if (other != it[H_T_SCAN_NOTHER] || covered + other != no) return MPCASM_ERR_PLAN;
+      const int32_t* gt = it + it[H_OFF_T_SCAN_GT];
+      for (int64_t k = 0; k < K; ++k) {
+        const int32_t* x = gt + k * T_SCAN_GT_WORDS;
+        if (x[SG_SBOFF] < 0 || x[SG_SBOFF] % per_state || x[SG_SBOFF] / per_state >= gn ||
+            x[SG_WPARAM] < 0 || x[SG_WPARAM] >= nparams || x[SG_AIMPARAM] < 0 || x[SG_AIMPARAM] >= nparams ||
+            x[SG_DROW] < 0 || x[SG_DROW] + gN > rtot)
+          return MPCASM_ERR_PLAN;
+      }
+      const int32_t* sg = it + it[H_OFF_T_SCAN_GROW];
+      const int32_t* rest = it + it[H_OFF_T_SCAN_GREST];
+      int64_t r = 0;
+      for (int64_t R = 0; R < nc; ++R) {
+        const int64_t u = sg[2 * R], slot = sg[2 * R + 1];
+        if (u == -1) {
+          if (slot != -1 || r >= nrest || rest[r] != R) return MPCASM_ERR_PLAN;
+          ++r;
+          continue;
+        }
+        if (u < 0 || u / per_state >= gn || u % per_state >= gN || slot < 0 || slot >= nparams ||
+            rrw[R * RS_RR_WORDS + RR_NAXES] != 1 || rrw[R * RS_RR_WORDS + RR_ARROW] != slot)
+          return MPCASM_ERR_PLAN;
+      }
+      if (r != nrest) return MPCASM_ERR_PLAN;
     }
   }
   {  // every row of G is written exactly once: riding on a stage or listed in the rest
@@ -836,6 +896,11 @@ void plan_dev_from_tables(const int32_t* it, PlanDev* out) {
   d.rs_compact = it[H_RS_COMPACT]; d.rs_ldv = it[H_RS_LDV]; d.rs_vd = it[H_RS_VD];
   d.rs_vrow0 = it[H_RS_VROW0]; d.off_rs_rrwin = it[H_OFF_RS_RRWIN];
   d.t_np1 = it[H_T_NP1]; d.off_t_p1ptr = it[H_OFF_T_P1PTR]; d.off_t_p1ent = it[H_OFF_T_P1ENT]; d.off_t_p2y = it[H_OFF_T_P2Y];
+  d.t_scan = it[H_T_SCAN]; d.t_scan_nblk = it[H_T_SCAN_NBLK]; d.off_t_scan_blk = it[H_OFF_T_SCAN_BLK];
+  d.off_t_scan_gt = it[H_OFF_T_SCAN_GT]; d.t_doff_scan_gc = it[H_T_DOFF_SCAN_GC];
+  d.off_t_scan_grow = it[H_OFF_T_SCAN_GROW]; d.t_doff_scan_gcoef = it[H_T_DOFF_SCAN_GCOEF];
+  d.t_scan_ngrest = it[H_T_SCAN_NGREST]; d.off_t_scan_grest = it[H_OFF_T_SCAN_GREST];
+  d.off_t_scan_colblk = it[H_OFF_T_SCAN_COLBLK]; d.t_scan_nother = it[H_T_SCAN_NOTHER];
   d.t_nbrow = d.t_ci_ok ? it[d.off_t_brow0 + d.nbase] : 0;
   d.pm_nfd = it[H_PM_NFD]; d.off_pm_map = it[H_OFF_PM_MAP]; d.off_pm_fdptr = it[H_OFF_PM_FDPTR];
   d.off_pm_op = it[H_OFF_PM_OP]; d.doff_pm_pool = it[H_DOFF_PM_POOL];
@@ -894,7 +959,7 @@ int mpcasm_last_hip(void) { return g_last_hip; }
 
 int mpcasm_set_option(int option, int value) {
   if (option == MPCASM_OPT_PATH) {
-    if (value < 0 || value > 3) return MPCASM_ERR_ARG;
+    if (value < 0 || value > 4) return MPCASM_ERR_ARG;
     g_path = value;
     return MPCASM_OK;
   }
@@ -922,7 +987,7 @@ int mpcasm_set_option(int option, int value) {
 
 int mpcasm_plan_set_option(mpcasm_plan* plan, int option, int value) {
   if (!plan) return MPCASM_ERR_ARG;
-  if (option == MPCASM_OPT_PATH && value >= -1 && value <= 3) plan->opt_path = value;
+  if (option == MPCASM_OPT_PATH && value >= -1 && value <= 4) plan->opt_path = value;
   else if (option == MPCASM_OPT_JIT && value >= -1 && value <= 2) plan->opt_jit = value;
   else if (option == MPCASM_OPT_RESIDENT_PER_CU && value >= -1 && value <= 16) plan->opt_per_cu = value;
   else return MPCASM_ERR_ARG;
@@ -1275,6 +1340,20 @@ int mpcasm_gather(const double* d_src, int64_t src_stride, const int32_t* d_inde
 }  // extern "C"
 
 namespace mpcasm {
+
+hipError_t allow_whole_lds(const void* fn) {
+  static std::mutex mutex;
+  static std::vector<std::pair<const void*, int>> done;
+  int device = 0;
+  hipError_t e = hipGetDevice(&device);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> lock(mutex);
+  for (const auto& d : done)
+    if (d.first == fn && d.second == device) return hipSuccess;
+  e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, CU_LDS_BYTES);
+  if (e == hipSuccess) done.emplace_back(fn, device);
+  return e;
+}
 
 int g_path = 0;  // test hook (MPCASM_OPT_PATH): 0 best, 1 no resident kernel, 2 staged only
 int g_resident_per_cu = 0;  // tuning aid (MPCASM_OPT_RESIDENT_PER_CU): 0 = automatic

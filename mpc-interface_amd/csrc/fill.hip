@@ -1032,8 +1032,7 @@ __global__ __launch_bounds__(64) void fill_ltv_row_kernel(const double* __restri
 template <typename K>
 hipError_t allow_lds(K kernel, size_t bytes) {
   if (bytes <= 64 * 1024) return hipSuccess;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  return allow_whole_lds(reinterpret_cast<const void*>(kernel));
 }
 
 }  // namespace

@@ -327,8 +327,7 @@ int launch_assemble_fused(const PlanDev& p, const SrcTable& src, const double* p
   constexpr int NW = 4;
   auto kernel = fused_assemble_kernel<NW>;
   if (lds_bytes > 64 * 1024) {
-    *err = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    *err = allow_whole_lds(reinterpret_cast<const void*>(kernel));
     if (*err != hipSuccess) return MPCASM_ERR_HIP;
   }
   hipLaunchKernelGGL(kernel, dim3(batch), dim3(NW * 64), lds_bytes, stream, p, src, params, given,

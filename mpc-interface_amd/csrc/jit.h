@@ -24,8 +24,9 @@ const void* jit_kernel_for(const PlanDev& d, const int32_t* h_itab, int device, 
                            size_t lds_bytes);
 // the code object of a generated header: from the disk cache ($MPCASM_CACHE_DIR, $XDG_CACHE_HOME/mpcasm
 // or ~/.cache/mpcasm; MPCASM_NO_DISK_CACHE=1: never), else compiled and stored there
+// (distrust_disk: the cached file was read and did not load -- delete it and compile)
 bool jit_code_for(const std::string& header, bool stamps, int phases, std::vector<char>* code,
-                  std::string* log);
+                  std::string* log, bool distrust_disk = false);
 bool jit_available();
 // compilations, code objects read from / written to the disk cache, in this process so far
 void jit_stats(long out[3]);

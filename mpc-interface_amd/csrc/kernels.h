@@ -10,6 +10,13 @@
 
 namespace mpcasm {
 
+// capi.hip: raise a kernel's dynamic-LDS limit to the CU's whole LDS -- ONCE per (function, device),
+// process-wide and under a mutex.  The attribute belongs to the function, not to the calling thread
+// or the plan: a limit that followed each launch's size could be lowered by one host thread under
+// another thread's larger plan (and a replayed graph node of the larger plan would meet it).
+constexpr int CU_LDS_BYTES = 160 * 1024;
+hipError_t allow_whole_lds(const void* fn);
+
 // fill.hip
 int launch_fill_su(const double* A, const double* B, double* S, double* U, int batch, int N, int n,
                    int m, int ltv, hipStream_t stream, hipError_t* err);

@@ -29,7 +29,9 @@ namespace mpcasm {
   X(t_ci_ok) X(t_nop) X(off_t_cig) X(off_t_cio) X(t_doff_delta) X(t_ok) X(t_nstage)                 \
   X(off_t_stage) X(t_nlti) X(off_t_lti) X(off_t_lti_ids) X(t_work) X(off_t_grow)                    \
   X(off_t_srow) X(t_doff_scoef) X(off_t_pig) X(t_ngrest) X(off_t_grest) X(off_t_brow0) X(t_nbrow) X(t_toeplitz) X(rs_diag_table) X(off_t_bcolptr) X(off_t_bcols) \
-  X(rs_ngfix) X(off_rs_gfix) X(rs_compact) X(rs_ldv) X(rs_vd) X(rs_vrow0) X(off_rs_rrwin) X(t_np1) X(off_t_p1ptr) X(off_t_p1ent) X(off_t_p2y)
+  X(rs_ngfix) X(off_rs_gfix) X(rs_compact) X(rs_ldv) X(rs_vd) X(rs_vrow0) X(off_rs_rrwin) X(t_np1) X(off_t_p1ptr) X(off_t_p1ent) X(off_t_p2y) \
+  X(t_scan) X(t_scan_nblk) X(off_t_scan_blk) X(off_t_scan_gt) X(t_doff_scan_gc) X(off_t_scan_grow)      \
+  X(t_doff_scan_gcoef) X(t_scan_ngrest) X(off_t_scan_grest) X(off_t_scan_colblk) X(t_scan_nother)
 
 // device-side view of a plan (pointers into the device copies of the tables).
 //   rs_p_direct: the persistent kernel sends the blocks of P straight to HBM (set by

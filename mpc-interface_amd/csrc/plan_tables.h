@@ -29,7 +29,7 @@
 namespace mpcasm {
 
 constexpr int32_t PLAN_MAGIC = 0x4D504341;  // 'MPCA'
-constexpr int32_t PLAN_VERSION = 25;
+constexpr int32_t PLAN_VERSION = 26;
 
 enum HeaderWord : int {
   H_MAGIC = 0,
@@ -210,9 +210,31 @@ enum HeaderWord : int {
   H_OFF_T_P1ENT,    // ... [T_NP1][2]: element offset in its stream (for this very row),
                     //     column of [given | unknowns] | stream << 24
   H_OFF_T_P2Y,      // [PM_NENT] per entry of a definition's row: its base row among all base rows
-  H_WORDS = 128
+  // ---- scan form of the tiled kernel (toeplitz_scan_kernel).  A Toeplitz plan (H_T_TOEPLITZ) whose
+  // every Hessian term is w (c M_i)^T (c M_i) over ALL N rows of one state i of the generated group:
+  // M_i[k][(j, l)] = T_ij[k - l] (tools.py:27-31), so the block of P on the columns of inputs j, j' is
+  //   P[(j,l)][(j',l')] = C[(j,l)][(j',l')] + P[(j,l+1)][(j',l'+1)]      (nothing behind l = N-1),
+  //   C[r][c] = sum_g w_g c_g^2 M_g[N-1][r] M_g[N-1][c]                    (the states' LAST rows):
+  // a sum along diagonals, O(K) multiply-adds per element instead of the O(K N) of the product.
+  H_T_SCAN,           // K = number of such terms (1 .. T_SCAN_KMAX); 0: the plan has no scan form
+  H_T_SCAN_NBLK,      // inputs of the group that are unknowns (<= T_SCAN_BLKMAX)
+  H_OFF_T_SCAN_BLK,   // [NBLK][2] first column of the input's N unknowns, j 2N + N: the element of TB
+                      //    that row k of state i reads in the input's column l is
+                      //    TB[i m 2N + k + (j 2N + N) - l]
+  H_OFF_T_SCAN_GT,    // [K][T_SCAN_GT_WORDS] i m 2N, weight slot, aim slot, first row of d
+  H_T_DOFF_SCAN_GC,   // [K] dtab: the term's coefficient c
+  H_OFF_T_SCAN_GROW,  // [NC][2] per row of G that is arrow * c * (row k of state i): i m 2N + k, the
+                      //    arrow's parameter slot; else -1, -1
+  H_T_DOFF_SCAN_GCOEF,// [NC] dtab: that row's c
+  H_T_SCAN_NGREST,    // the other rows of G (composed through the column tables)
+  H_OFF_T_SCAN_GREST, // [T_SCAN_NGREST] ascending
+  H_OFF_T_SCAN_COLBLK,// [NO] per unknown the index of its block in SCAN_BLK, or -1
+  H_T_SCAN_NOTHER,    // unknowns in no block (their rows and columns of P hold diagonal terms only)
+  H_WORDS = 160
 };
-static_assert(H_OFF_T_P2Y < H_WORDS, "plan header");
+static_assert(H_T_SCAN_NOTHER < H_WORDS, "plan header");
+constexpr int T_SCAN_KMAX = 16, T_SCAN_BLKMAX = 8, T_SCAN_NMAX = 64, T_SCAN_GT_WORDS = 4;
+enum { SG_SBOFF = 0, SG_WPARAM, SG_AIMPARAM, SG_DROW };
 
 constexpr int T_BLOCK = 128;       // columns of a block of P (tiled kernel)
 constexpr int T_SID_CONST = 32;    // the stream that is the plan's own dtab

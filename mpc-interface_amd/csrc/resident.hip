@@ -1311,7 +1311,6 @@ int launch_jc(const PlanDev& p, const SrcTable& src, const double* params, const
   constexpr int KEPT = 8;
   static thread_local Residency kept[3][KEPT];
   static thread_local int nkept[3] = {0, 0, 0};
-  static thread_local size_t granted[3][16];  // per device (the first 16): attribute in force
   const int slot = (g_phase_mask & 64) ? 2 : (p.rs_nlti != 0 ? 1 : 0);
   int device = 0;
   (void)hipGetDevice(&device);  // (the attribute and the occupancy belong to one device)
@@ -1319,12 +1318,9 @@ int launch_jc(const PlanDev& p, const SrcTable& src, const double* params, const
   for (int i = 0; i < nkept[slot]; ++i)
     if (kept[slot][i].device == device && kept[slot][i].lds == lds_bytes) found = kept[slot][i].per_cu;
   if (found < 0) {
-    size_t& have = granted[slot][device & 15];
-    if (lds_bytes > 64 * 1024 && lds_bytes > have) {
-      *err = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (lds_bytes > 64 * 1024) {
+      *err = allow_whole_lds(reinterpret_cast<const void*>(kernel));
       if (*err != hipSuccess) return MPCASM_ERR_HIP;
-      have = lds_bytes;
     }
     int n = 0;
     *err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, NT, lds_bytes);

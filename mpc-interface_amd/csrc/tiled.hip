@@ -1043,6 +1043,306 @@ __global__ __launch_bounds__(BLOCK, 2) void toeplitz_assemble_kernel(
   }  // (the next block of this instance)
 }
 
+// ---------------------------------------------------------------------------
+// Scan form (plans with H_T_SCAN: every Hessian term is w (c M_i)^T (c M_i) over ALL N rows of one
+// state i of the generated group).  M_i[k][(j, l)] = T_ij[k - l] (T_ij[d] = (A^d B)[i][j], d >= 0,
+// tools.py:27-31) makes the block of P on the columns of two inputs a sum along diagonals:
+//     P[(j,l)][(j',l')] = C[(j,l)][(j',l')] + P[(j,l+1)][(j',l'+1)]     (nothing behind l = N - 1),
+//     C[r][c] = sum_g (w_g c_g^2) M_g[N-1][r] M_g[N-1][c]                 (the LAST row of every state)
+// -- K multiply-adds per element of P instead of the K N of the product (C4: 4 % of the matrix
+// core's work in the Toeplitz form above), which leaves a kernel that only has to WRITE: 5.9 MB per C4
+// instance, 80 % of it rows of G that are windows of the same table.  One workgroup per instance,
+// TB | zeros | d | parameters in LDS, no barrier behind the set-up; the wavefronts draw tickets:
+//   * a row block of P (an input's N rows, from l = N - 1 down): lane = column of an input's block,
+//     its K weighted last-row values for every column block in registers, the row's K values by
+//     broadcast reads, the running sums shifted one lane per row -- 8 bytes per lane, 512-byte runs,
+//     a whole row of P per step;
+//   * four rows of G: 16 bytes per lane straight out of the table times the row's arrow.
+// The gradient (a correlation of the table with s (d - aim): no recurrence) and h come first, out of
+// LDS; rows of G that are no single state row and unknowns outside the input blocks are composed
+// behind the tickets through the column tables (cold paths).
+// ---------------------------------------------------------------------------
+constexpr int SCAN_GROUP = 4;     // rows of G per ticket
+constexpr int SCAN_GCH_MAX = 8;   // 128-column chunks of a row of G: no <= 1024
+
+#ifndef MPCASM_SCAN_DPP
+#define MPCASM_SCAN_DPP 0
+#endif
+// lane i <- lane i + 1, 0 into lane 63
+__device__ __forceinline__ double lane_from_next(double v) {
+#if MPCASM_SCAN_DPP
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x130, 0xF, 0xF, true);  // wave_shl:1
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x130, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+#else
+  const double x = __shfl_down(v, 1, 64);
+  return (threadIdx.x & 63) == 63 ? 0.0 : x;
+#endif
+}
+
+template <int KP, int CB>
+__global__ __launch_bounds__(BLOCK, 2) void toeplitz_scan_kernel(
+    PlanDev p, SrcTable src, const double* __restrict__ params, const double* __restrict__ work,
+    long long work_stride, double* __restrict__ P, double* __restrict__ q, double* __restrict__ G,
+    double* __restrict__ h, int batch, int tbn, int nzero, int dlen, int whole_lines, int phases) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const long inst = blockIdx.x;
+  if (inst >= batch) return;
+  const int no = p.no, nc = p.nc, K = p.t_scan, nblk = p.t_scan_nblk;
+  const double* pb = params + (size_t)inst * p.nparams;
+  const int32_t* grp = p.itab + p.off_t_lti;
+  const int N = grp[TL_HORIZON];
+  const int32_t* ids = p.itab + p.off_t_lti_ids + grp[TL_IDS];
+  const int first_u = ids[0];
+  const int2* blk = reinterpret_cast<const int2*>(p.itab + p.off_t_scan_blk);
+  const int4* gts = reinterpret_cast<const int4*>(p.itab + p.off_t_scan_gt);
+  const double* gcs = p.dtab + p.t_doff_scan_gc;
+  const int32_t* colblk = p.itab + p.off_t_scan_colblk;
+  const unsigned tb_bytes = (unsigned)tbn * 8u;
+  const unsigned zero_off = tb_bytes, d_off = (unsigned)(tbn + nzero) * 8u;
+  const unsigned par_off = d_off + (unsigned)dlen * 8u;
+  const unsigned ticket_off = par_off + (unsigned)((p.nparams + 2) & ~1) * 8u;
+  int* ticket = reinterpret_cast<int*>(lds + ticket_off);
+  // ---- set-up: TB, zeros, d, parameters into LDS ---------------------------------------------
+  {
+    const char* tb = reinterpret_cast<const char*>(src.ptr[first_u] + inst * src.stride[first_u]);
+    const unsigned lds0 = (unsigned)(uintptr_t)lds;
+    for (unsigned c0 = (unsigned)wave * 1024u; c0 < tb_bytes; c0 += WAVES * 1024u) {
+      const unsigned off = c0 + (unsigned)lane * 16u;
+      if (off < tb_bytes) lds_dma16(tb + off, __builtin_amdgcn_readfirstlane(lds0 + c0));
+    }
+    const char* dsrc = reinterpret_cast<const char*>(work + inst * work_stride);
+    const unsigned d_bytes = (unsigned)dlen * 8u, d0 = lds0 + d_off;
+    for (unsigned c0 = (unsigned)wave * 1024u; c0 < d_bytes; c0 += WAVES * 1024u) {
+      const unsigned off = c0 + (unsigned)lane * 16u;
+      if (off < d_bytes) lds_dma16(dsrc + off, __builtin_amdgcn_readfirstlane(d0 + c0));
+    }
+    double* z = reinterpret_cast<double*>(lds + zero_off);
+    for (int e = tid; e < nzero; e += BLOCK) z[e] = 0.0;
+    double* par = reinterpret_cast<double*>(lds + par_off);
+    for (int e = tid; e <= p.nparams; e += BLOCK) par[e] = e < p.nparams ? pb[e] : 0.0;  // ([nparams] reads 0.0)
+    if (tid < 2) ticket[tid] = 0;  // (row blocks of P, groups of rows of G)
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's LDS-DMA loads have landed
+  __syncthreads();
+
+  // ---- h, then the gradient: out of LDS ---------------------------------------------------------
+  if (G != nullptr && (phases & 8)) {
+    const int32_t* grow = p.itab + p.off_t_grow;
+    const int32_t* rrw = p.itab + p.off_rs_rr;
+    for (int R = tid; R < nc; R += BLOCK) {  // h: (extreme + arrow . center) - arrow . d
+      const int32_t* x = rrw + (size_t)R * RS_RR_WORDS;
+      double ac = 0.0, ad = 0.0;
+      for (int ax = 0; ax < x[RR_NAXES]; ++ax) {
+        const double ar = pb[x[RR_ARROW + ax]];
+        ac += ar * pb[x[RR_CENTER + ax]];
+        ad = fma(ar, lds_f64(lds, d_off + (unsigned)grow[R * RS_AXMAX + ax] * 8u), ad);
+      }
+      h[(size_t)inst * nc + R] = (pb[x[RR_EXTREME]] + ac) - ad;
+    }
+  }
+  if (P != nullptr && (phases & 4)) {
+    // q[c] = sum_g (w_g c_g) sum_k (c_g TB[state g, row k, column c]) (d_g[k] - aim_g): d carries its
+    // c_g already; a thread per column, the K terms one after the other (wave-uniform scalars)
+    for (int c = tid; c < no; c += BLOCK) {
+      const int b = colblk[c];
+      double dP, dq;
+      diagonal_of_column(p, pb, c, dP, dq);
+      double acc = 0.0;
+      if (b >= 0) {
+        const unsigned part = (unsigned)(blk[b].y - (c - blk[b].x)) * 8u;
+        for (int g = 0; g < K; ++g) {
+          const int4 x = gts[g];
+          const double cg = gcs[g], aim = pb[x.z];
+          const unsigned tb0 = (unsigned)x.x * 8u + part, d0 = d_off + (unsigned)x.w * 8u;
+          double part_sum = 0.0;
+          for (int k = 0; k < N; ++k)
+            part_sum = fma(lds_f64(lds, d0 + (unsigned)k * 8u) - aim, lds_f64(lds, tb0 + (unsigned)k * 8u),
+                           part_sum);
+          acc = fma((pb[x.y] * cg) * cg, part_sum, acc);
+        }
+      }
+      q[(size_t)inst * no + c] = acc + dq;
+    }
+  }
+
+  // ---- tickets, first round: the row blocks of P -------------------------------------------------
+  double* Pb = P + (size_t)inst * no * no;
+  if (P != nullptr && (phases & 2)) {
+    // where every term's state starts in TB (wave-uniform), and the lane's K weighted last-row values
+    // (w c^2) TB[state, row N - 1, the lane's column] in every column block (0 beyond its N columns)
+    unsigned sb8[KP];
+    double Tl[CB][KP];
+#pragma unroll
+    for (int g = 0; g < KP; ++g) {
+      const int4 x = gts[g < K ? g : 0];
+      const double cg = gcs[g < K ? g : 0];
+      sb8[g] = (unsigned)x.x * 8u;
+      const double wcc = (pb[x.y] * cg) * cg;
+#pragma unroll
+      for (int s = 0; s < CB; ++s) {
+        const bool live = s < nblk && g < K && lane < N;
+        const unsigned a = live ? sb8[g] + (unsigned)(N - 1 + blk[s < nblk ? s : 0].y - lane) * 8u : zero_off;
+        Tl[s][g] = live ? wcc * lds_f64(lds, a) : 0.0;
+      }
+    }
+    for (;;) {
+      int t = 0;
+      if (lane == 0) t = atomicAdd(ticket, 1);
+      t = __builtin_amdgcn_readfirstlane(t);
+      if (t >= nblk) break;
+      const int bi = t;
+      const int r0 = blk[bi].x;
+      // the diagonal terms on this block's own columns (a cost on the input itself)
+      double dP = 0.0, dq = 0.0;
+      if (lane < N) diagonal_of_column(p, pb, r0 + lane, dP, dq);
+      double run[CB];
+#pragma unroll
+      for (int s = 0; s < CB; ++s) run[s] = 0.0;
+      const unsigned rowpart = (unsigned)(N - 1 + blk[bi].y) * 8u;
+      for (int l = N - 1; l >= 0; --l) {
+        double beta[KP];
+#pragma unroll
+        for (int g = 0; g < KP; ++g)
+          beta[g] = g < K ? lds_f64(lds, sb8[g] + rowpart - (unsigned)l * 8u) : 0.0;
+        double* prow = Pb + (size_t)(r0 + l) * no;
+#pragma unroll
+        for (int s = 0; s < CB; ++s) {
+          if (s >= nblk) break;
+          double C = 0.0;
+#pragma unroll
+          for (int g = 0; g < KP; ++g) C = fma(beta[g], Tl[s][g], C);
+          run[s] = C + lane_from_next(run[s]);
+          const double v = (s == bi && lane == l) ? run[s] + dP : run[s];
+          if (lane < N && (phases & 32)) {
+            if (whole_lines)
+              store_result(prow + blk[s].x + lane, v);
+            else
+              prow[blk[s].x + lane] = v;
+          }
+        }
+      }
+    }
+  }
+
+  // ---- tickets, second round: rows of G, SCAN_GROUP at a time ------------------------------------
+  double* Gb = G + (size_t)inst * nc * no;
+  if (G != nullptr && (phases & 8)) {
+    // per lane: its two columns of every 128-column chunk of a row -- byte offset of the columns'
+    // part in TB (the zeros for a column of no input block)
+    const int nch = (no + 127) >> 7;
+    const bool all_blocks = p.t_scan_nother == 0;  // (then no column needs the zeros: no select per read)
+    unsigned gp0[SCAN_GCH_MAX], gp1[SCAN_GCH_MAX];
+#pragma unroll
+    for (int ch = 0; ch < SCAN_GCH_MAX; ++ch) {
+      gp0[ch] = gp1[ch] = all_blocks ? 0u : zero_off;  // (columns behind `no` are read, never stored)
+      if (ch < nch) {
+        const int c = ch * 128 + lane * 2;
+        if (c < no) {
+          const int b = colblk[c];
+          if (b >= 0) gp0[ch] = (unsigned)(blk[b].y - (c - blk[b].x)) * 8u;
+        }
+        if (c + 1 < no) {
+          const int b = colblk[c + 1];
+          if (b >= 0) gp1[ch] = (unsigned)(blk[b].y - (c + 1 - blk[b].x)) * 8u;
+        }
+      }
+    }
+    const int2* sgrow = reinterpret_cast<const int2*>(p.itab + p.off_t_scan_grow);
+    const double* sgcoef = p.dtab + p.t_doff_scan_gcoef;
+    const int ngroups = (nc + SCAN_GROUP - 1) / SCAN_GROUP;
+    for (;;) {
+      int t = 0;
+      if (lane == 0) t = atomicAdd(ticket + 1, 1);
+      t = __builtin_amdgcn_readfirstlane(t);
+      if (t >= ngroups) break;
+      const int R0 = t * SCAN_GROUP;
+      int2 rec[SCAN_GROUP];
+      double cf[SCAN_GROUP];
+#pragma unroll
+      for (int rr = 0; rr < SCAN_GROUP; ++rr) {
+        const int R = R0 + rr < nc ? R0 + rr : nc - 1;
+        rec[rr] = sgrow[R];
+        cf[rr] = sgcoef[R];
+      }
+#pragma unroll
+      for (int rr = 0; rr < SCAN_GROUP; ++rr) {
+        const int R = R0 + rr;
+        if (R >= nc || rec[rr].x < 0) continue;
+        const unsigned u8 = (unsigned)rec[rr].x * 8u;
+        const double ar = lds_f64(lds, par_off + (unsigned)rec[rr].y * 8u);
+        double* grow_out = Gb + (size_t)R * no + lane * 2;
+#pragma unroll
+        for (int ch = 0; ch < SCAN_GCH_MAX; ++ch) {
+          if (ch >= nch) break;
+          const unsigned a0 = all_blocks ? gp0[ch] + u8 : (gp0[ch] < tb_bytes ? gp0[ch] + u8 : zero_off);
+          const unsigned a1 = all_blocks ? gp1[ch] + u8 : (gp1[ch] < tb_bytes ? gp1[ch] + u8 : zero_off);
+          double2 v;
+          v.x = ar * (lds_f64(lds, a0) * cf[rr]);
+          v.y = ar * (lds_f64(lds, a1) * cf[rr]);
+          if (ch * 128 + lane * 2 < no) {
+            if (whole_lines)
+              store_result(reinterpret_cast<double2*>(grow_out + ch * 128), v);
+            else
+              *reinterpret_cast<double2*>(grow_out + ch * 128) = v;
+          }
+        }
+      }
+    }
+  }
+
+  // ---- cold paths --------------------------------------------------------------------------------
+  // rows of G that are no single state row: through the column tables, from the scratch
+  if (G != nullptr && p.t_scan_ngrest > 0 && (phases & 8)) {
+    __shared__ const double* s_base[NSTREAM];
+    stream_bases(p, src, inst, s_base, tid);
+    __syncthreads();
+    RowTables rt;
+    rt.rowptr = p.itab + p.off_rowptr;
+    rt.entbase = p.itab + p.off_entbase;
+    rt.entk = p.itab + p.off_entk;
+    rt.coef = p.dtab + p.doff_entcoef;
+    rt.cio = p.itab + p.off_t_cio;
+    rt.nop = p.t_nop;
+    const int32_t* grow = p.itab + p.off_t_grow;
+    const int32_t* rrw = p.itab + p.off_rs_rr;
+    const int32_t* grest = p.itab + p.off_t_scan_grest;
+    for (int x0 = wave; x0 < p.t_scan_ngrest; x0 += WAVES) {
+      const int R = grest[x0];
+      const int32_t* x = rrw + (size_t)R * RS_RR_WORDS;
+      const int naxes = x[RR_NAXES];
+      for (int c0 = 0; c0 < p.t_nop; c0 += T_BLOCK) {
+        const int colA = c0 + lane * 2;
+        int baseG = -1;
+        ColRef crG;
+        crG.p0 = crG.p1 = p.dtab;
+        crG.rs0 = crG.rs1 = 0;
+        double2 out{0.0, 0.0};
+        for (int ax = 0; ax < naxes; ++ax) {
+          const double ar = pb[x[RR_ARROW + ax]];
+          const double2 v = compose_row2(rt, grow[R * RS_AXMAX + ax], colA, s_base, baseG, crG);
+          out.x = fma(ar, v.x, out.x);
+          out.y = fma(ar, v.y, out.y);
+        }
+        if (colA < no) *reinterpret_cast<double2*>(Gb + (size_t)R * no + colA) = out;
+      }
+    }
+  }
+  // unknowns in no input block: their rows and columns of P hold the diagonal terms only
+  if (P != nullptr && p.t_scan_nother > 0 && (phases & 2))
+    for (int r = wave; r < no; r += WAVES) {
+      const bool row_other = colblk[r] < 0;
+      for (int c = lane; c < no; c += 64)
+        if (row_other || colblk[c] < 0) {
+          double dP = 0.0, dq = 0.0;
+          if (r == c) diagonal_of_column(p, pb, c, dP, dq);
+          Pb[(size_t)r * no + c] = dP;
+        }
+    }
+}
+
 inline unsigned ceil_div(unsigned a, unsigned b) { return (a + b - 1) / b; }
 
 }  // namespace
@@ -1109,6 +1409,53 @@ int launch_lti_tables(const PlanDev& p, const SrcTable& src, double* w, int batc
   return MPCASM_OK;
 }
 
+namespace {
+
+template <int KP, int CB>
+int launch_scan_as(const PlanDev& p, const SrcTable& eff, const double* params, const double* w,
+                   long long stride, double* P, double* q, double* G, double* h, int batch, int tbn,
+                   int dlen, int whole_lines, size_t lds, hipStream_t stream, hipError_t* err) {
+  auto kernel = toeplitz_scan_kernel<KP, CB>;
+  *err = allow_whole_lds(reinterpret_cast<const void*>(kernel));
+  if (*err != hipSuccess) return MPCASM_ERR_HIP;
+  hipLaunchKernelGGL(kernel, dim3((unsigned)batch), dim3(BLOCK), lds, stream, p, eff, params, w, stride,
+                     P, q, G, h, batch, tbn, 2, dlen, whole_lines, g_phase_mask);
+  *err = hipGetLastError();
+  if (*err == hipSuccess) t_last_kernel = MPCASM_KERNEL_TILED_SCAN;
+  return *err == hipSuccess ? MPCASM_OK : MPCASM_ERR_HIP;
+}
+
+// the scan form for this plan, or MPCASM_ERR_LIMIT: no instantiation holds its K terms and column
+// blocks in registers, or an instance does not fit in LDS (the Toeplitz form takes it then)
+int launch_scan(const PlanDev& p, const SrcTable& eff, const double* params, const double* w,
+                long long stride, double* P, double* q, double* G, double* h, int batch, int tbn, int N,
+                const int32_t* h_itab, hipStream_t stream, hipError_t* err) {
+  const int K = p.t_scan, nblk = p.t_scan_nblk;
+  if (p.no > 128 * SCAN_GCH_MAX) return MPCASM_ERR_LIMIT;
+  const int dlen = p.rtot + (p.rtot & 1);
+  const size_t lds = ((size_t)tbn + 2 + dlen + ((p.nparams + 2) & ~1)) * sizeof(double) + 16;
+  if (lds + NSTREAM * sizeof(double*) > (size_t)RESIDENT_LDS_LIMIT) return MPCASM_ERR_LIMIT;
+  // results leave as whole 128-byte lines when every run of a wavefront's store starts and ends on one
+  int whole = p.no % 16 == 0 && N % 16 == 0;
+  const int32_t* blk = h_itab + p.off_t_scan_blk;
+  for (int b = 0; b < nblk; ++b) whole = whole && blk[2 * b] % 16 == 0;
+#define MPCASM_SCAN_CASE(KP, CB)                                                                        \
+  if (K <= KP && nblk <= CB)                                                                           \
+    return launch_scan_as<KP, CB>(p, eff, params, w, stride, P, q, G, h, batch, tbn, dlen, whole, lds, \
+                                  stream, err);
+  MPCASM_SCAN_CASE(4, 4)
+  MPCASM_SCAN_CASE(8, 4)
+  MPCASM_SCAN_CASE(4, 8)
+  MPCASM_SCAN_CASE(8, 8)
+  MPCASM_SCAN_CASE(12, 4)
+  MPCASM_SCAN_CASE(12, 6)
+  MPCASM_SCAN_CASE(16, 4)
+#undef MPCASM_SCAN_CASE
+  return MPCASM_ERR_LIMIT;
+}
+
+}  // namespace
+
 int launch_assemble_tiled(const PlanDev& p, const SrcTable& src, const double* params,
                           const double* given, double* P, double* q, double* G, double* h,
                           void* work, int batch, hipStream_t stream, hipError_t* err,
@@ -1134,18 +1481,19 @@ int launch_assemble_tiled(const PlanDev& p, const SrcTable& src, const double* p
     // every stage is a window of the one generated group's table: operands straight out of LDS
     const int32_t* rec = h_itab + p.off_t_lti;
     const int tbn = rec[TL_N] * rec[TL_M] * 2 * rec[TL_HORIZON];
+    if (p.t_scan > 0 && t_path != 4 && (rec[TL_TB] & 1) == 0 && (stride & 1) == 0) {
+      // scan form: every Hessian term is the full horizon of one state -- P is a sum along diagonals
+      const int rc = launch_scan(p, eff, params, w, stride, P, q, G, h, batch, tbn, rec[TL_HORIZON],
+                                 h_itab, stream, err);
+      if (rc != MPCASM_ERR_LIMIT) return rc;
+    }
     const int nzero = (std::max(rec[TL_HORIZON], 16) + 16 + 1) & ~1;  // (even: what follows stays 16-byte aligned)
     // (behind the table and the zeros: d, and at the end of a diagonal block the gradient's partial
     // sums of four wavefronts + the diagonal gterms of its T_BLOCK columns)
     const size_t lds = ((size_t)tbn + nzero + std::max(p.rtot + (p.rtot & 1), (WAVES + 1) * T_BLOCK)) * sizeof(double);
     if (lds <= (size_t)RESIDENT_LDS_LIMIT && (rec[TL_TB] & 1) == 0 && (stride & 1) == 0) {
-      static thread_local size_t granted = 0;
-      if (lds > granted) {
-        *err = hipFuncSetAttribute(reinterpret_cast<const void*>(toeplitz_assemble_kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, RESIDENT_LDS_LIMIT);
-        if (*err != hipSuccess) return MPCASM_ERR_HIP;
-        granted = RESIDENT_LDS_LIMIT;
-      }
+      *err = allow_whole_lds(reinterpret_cast<const void*>(toeplitz_assemble_kernel));
+      if (*err != hipSuccess) return MPCASM_ERR_HIP;
       hipLaunchKernelGGL(toeplitz_assemble_kernel, dim3((unsigned)batch), dim3(BLOCK), lds,
                          stream, p, eff, params, w, stride, P, q, G, h, nb, npairs, sym, batch, tbn, nzero,
                          g_phase_mask);

@@ -17,7 +17,7 @@ import numpy as np
 import scipy.sparse as sp
 
 PLAN_MAGIC = 0x4D504341
-PLAN_VERSION = 25
+PLAN_VERSION = 26
 
 # header words (csrc/plan_tables.h, enum HeaderWord)
 _H = {name: i for i, name in enumerate([
@@ -41,8 +41,10 @@ _H = {name: i for i, name in enumerate([
     "OFF_T_GROW", "OFF_T_SROW", "T_DOFF_SCOEF", "OFF_T_PIG", "T_NGREST", "OFF_T_GREST", "OFF_T_BROW0", "OFF_T_BCOLPTR", "OFF_T_BCOLS", "T_TOEPLITZ",
     "RS_NGFIX", "OFF_RS_GFIX", "RS_COMPACT", "RS_LDV", "RS_VD", "RS_VROW0", "OFF_RS_RRWIN",
     "T_NP1", "OFF_T_P1PTR", "OFF_T_P1ENT", "OFF_T_P2Y",
+    "T_SCAN", "T_SCAN_NBLK", "OFF_T_SCAN_BLK", "OFF_T_SCAN_GT", "T_DOFF_SCAN_GC", "OFF_T_SCAN_GROW",
+    "T_DOFF_SCAN_GCOEF", "T_SCAN_NGREST", "OFF_T_SCAN_GREST", "OFF_T_SCAN_COLBLK", "T_SCAN_NOTHER",
 ])}
-H_WORDS = 128
+H_WORDS = 160
 assert len(_H) <= H_WORDS
 RS_NW, RS_NT = 4, 512                     # matrix wavefronts (they fetch the inputs), threads per instance
 RS_WAVES = RS_NT // 64
@@ -83,6 +85,8 @@ MAX_SOURCES = 32
 T_BLOCK, T_SID_CONST, T_STAGE_WORDS, T_LTI_WORDS = 128, 32, 16, 8
 TS_FLAG_P, TS_FLAG_HALF, TS_FLAG_SIMPLE_A, TS_FLAG_SIMPLE_B, TS_FLAG_SAME, TS_FLAG_G, TS_FLAG_TOEPLITZ = 1, 2, 4, 8, 16, 32, 64
 T_PIG_MAX = 2
+# scan form of the tiled kernel (csrc/tiled.hip toeplitz_scan_kernel, plan_tables.h T_SCAN*)
+T_SCAN_KMAX, T_SCAN_BLKMAX, T_SCAN_NMAX, T_SCAN_GT_WORDS = 16, 8, 64, 4
 
 
 class Source:
@@ -1270,6 +1274,92 @@ def _tiled_program(b, form, gterms, rowptr, entbase, entk, entcoef, rtot, groups
                 lti_ids=np.asarray(ids, dtype=np.int64), work=work)
 
 
+def _scan_tables(b, gterms, rowptr, entbase, entk, entcoef, groups, g_rows, tiled, nparams):
+    """Tables of the tiled kernel's *scan form* (csrc/tiled.hip ``toeplitz_scan_kernel``,
+    plan_tables.h T_SCAN*).
+
+    When every Hessian term is ``w (c M_i)^T (c M_i)`` over ALL N rows of one state ``i`` of the
+    plan's single generated LTI group, ``M_i[k][(j, l)] = T_ij[k - l]`` (``T_ij[d] = (A^d B)[i][j]``
+    for ``d >= 0``, else 0; tools.py:27-31) and the block of ``P`` on the columns of inputs j, j'
+    obeys ``P[(j,l)][(j',l')] = C[(j,l)][(j',l')] + P[(j,l+1)][(j',l'+1)]`` with the rank-K term
+    ``C[r][c] = sum_g w_g c_g^2 M_g[N-1][r] M_g[N-1][c]`` (the last row of every state) and nothing
+    behind l = N-1: the Hessian is a sum along diagonals, O(K) multiply-adds per element instead
+    of the O(K N) of the product.  The tables: the column blocks ``(first column, j 2N + N)`` of
+    the inputs that are unknowns, the K terms ``(state's offset in TB, weight slot, aim slot, first
+    row of d)`` with their coefficients, and per row of G ``(state's offset in TB + k, arrow slot)``
+    with its coefficient when the row is ``arrow * c * (row k of a state)`` (else -1: the row is
+    composed through the column tables behind the rest)."""
+    nc, no, ng = len(g_rows), b.no, b.ng
+    off = dict(ok=0, K=0, blk=np.zeros((0, 2), np.int64), gt=np.zeros((0, T_SCAN_GT_WORDS), np.int64),
+               gc=np.zeros(0), grow=np.zeros((0, 2), np.int64), gcoef=np.zeros(0),
+               grest=np.zeros(0, np.int64), colblk=np.zeros(0, np.int64), nother=0)
+    if not tiled["toeplitz"] or len(groups) != 1:
+        return off
+    g0 = groups[0]
+    n, m, N = g0["n"], g0["m"], g0["N"]
+    if N > T_SCAN_NMAX or nparams >= 1 << 20:
+        return off
+    state_of = b.lti_state_of(g0)
+    nent_of = np.diff(rowptr)
+
+    def state_row(r):
+        """(state, k, coefficient) when workspace row r is c * (row k of a state of the group)."""
+        if nent_of[r] != 1:
+            return None
+        e = rowptr[r]
+        if int(entbase[e]) not in state_of:
+            return None
+        return state_of[int(entbase[e])], int(entk[e]), float(entcoef[e])
+
+    gt, gc = [], []
+    for g in gterms:
+        aoff, boff, nrows, wparam, doff, aimparam, flags = g[:7]
+        if flags & GT_FLAG_DIAG:
+            continue
+        if flags != GT_FLAG_P or aoff != boff or nrows != N:
+            return off
+        rows = [state_row(r) for r in range(aoff, aoff + N)]
+        if any(x is None for x in rows):
+            return off
+        st, c = rows[0][0], rows[0][2]
+        if any(x != (st, k, c) for k, x in enumerate(rows)):
+            return off
+        gt.append([st * m * 2 * N, wparam, aimparam, doff])
+        gc.append(c)
+    if not 1 <= len(gt) <= T_SCAN_KMAX:
+        return off
+    # the column blocks: input j of the group as an unknown = N consecutive columns
+    colblk = -np.ones(no, dtype=np.int64)
+    blk = []
+    for j, sid in enumerate(g0["ids"][:m]):
+        spans = {(seg[4], seg[5]) for seg in b.segments if seg[6] == SEG_GATHER and seg[0] == sid}
+        if len(spans) != 1:
+            return off
+        dst0, length = spans.pop()
+        if length != N:
+            return off
+        if dst0 < ng:
+            continue                                     # a given input: it enters d only
+        if np.any(colblk[dst0 - ng:dst0 - ng + N] >= 0):
+            return off
+        colblk[dst0 - ng:dst0 - ng + N] = len(blk)
+        blk.append([dst0 - ng, j * 2 * N + N])
+    if not 1 <= len(blk) <= T_SCAN_BLKMAX:
+        return off
+    grow, gcoef, grest = -np.ones((nc, 2), dtype=np.int64), np.zeros(nc), []
+    for R, axes in enumerate(g_rows):
+        x = state_row(axes[0][0]) if len(axes) == 1 else None
+        if x is None:
+            grest.append(R)
+            continue
+        grow[R] = (x[0] * m * 2 * N + x[1], axes[0][1])
+        gcoef[R] = x[2]
+    return dict(ok=1, K=len(gt), blk=np.asarray(blk, dtype=np.int64),
+                gt=np.asarray(gt, dtype=np.int64), gc=np.asarray(gc, dtype=np.float64), grow=grow,
+                gcoef=gcoef, grest=np.asarray(grest, dtype=np.int64), colblk=colblk,
+                nother=int((colblk < 0).sum()))
+
+
 def _structural_patterns(form, b, fused, gterms, limit_recs, lax_recs, rtot, ldv, no, nc):
     """Which entries of P (no x no) and of the stacked G (nc x no) can be non-zero at all:
     from the structurally non-zero elements of the workspace (an element with at least one
@@ -1683,6 +1773,8 @@ def compile_plan(form, costs=None, limits=None, lti=(), csc=None, workspace="aut
                             p_a + (0 if a_rows == 1 else r) * naxes + ax) for ax in range(naxes)])
     tiled = _tiled_program(b, form, gterms, rowptr, entbase, entk, entcoef, rtot, groups, rr_ok,
                            g_rows)
+    scan = _scan_tables(b, gterms, rowptr, entbase, entk, entcoef, groups, g_rows, tiled, len(b.params))
+    tiled["scan"] = scan
     ndt0 = (entcoef.size + pm_entcoef.size + fused["coefpool"].size + resident["coef"].size
             + diag_coefs.size)
     doff_delta = ndt0 + (ndt0 & 1) + 4 + rs_dcoef.size + pmprog["pool"].size
@@ -1735,6 +1827,11 @@ def compile_plan(form, costs=None, limits=None, lti=(), csc=None, workspace="aut
     sections += [("OFF_T_P1PTR", np.asarray(p1ptr, dtype=np.int32)),
                  ("OFF_T_P1ENT", p1ent.astype(np.uint32).view(np.int32).reshape(-1)),
                  ("OFF_T_P2Y", p2y.astype(np.int32))]
+    sections += [("OFF_T_SCAN_BLK", scan["blk"].astype(np.int32).reshape(-1)),
+                 ("OFF_T_SCAN_GT", scan["gt"].astype(np.int32).reshape(-1)),
+                 ("OFF_T_SCAN_GROW", scan["grow"].astype(np.int32).reshape(-1)),
+                 ("OFF_T_SCAN_GREST", scan["grest"].astype(np.int32)),
+                 ("OFF_T_SCAN_COLBLK", scan["colblk"].astype(np.int32))]
     sections += [("OFF_RS_DPAR", rs_dpar.reshape(-1)), ("OFF_RS_GDESC", rs_gdesc),
                  ("OFF_RS_GFIX", rs_gfix), ("OFF_RS_RRWIN", rs_rrwin),
                  ("OFF_PM_MAP", pmprog["map"]), ("OFF_PM_FDPTR", pmprog["fd_ptr"]),
@@ -1750,7 +1847,8 @@ def compile_plan(form, costs=None, limits=None, lti=(), csc=None, workspace="aut
             off += 1
         if name in ("OFF_RS_RR", "OFF_RS_INMETA", "OFF_RS_ABMETA", "OFF_RS_DPAR",
                     "OFF_RS_GDESC", "OFF_RS_GFIX", "OFF_CSC_G", "OFF_T_CIG", "OFF_T_CIO", "OFF_T_P1ENT",
-                    "OFF_T_STAGE", "OFF_T_GROW", "OFF_T_SROW", "OFF_T_PIG") and off & 3:   # ... 16-byte quads
+                    "OFF_T_STAGE", "OFF_T_GROW", "OFF_T_SROW", "OFF_T_PIG", "OFF_T_SCAN_BLK",
+                    "OFF_T_SCAN_GT", "OFF_T_SCAN_GROW") and off & 3:   # ... 16-byte quads
             pad = 4 - (off & 3)
             parts.append(np.zeros(pad, dtype=np.int32))
             off += pad
@@ -1781,6 +1879,13 @@ def compile_plan(form, costs=None, limits=None, lti=(), csc=None, workspace="aut
     header[_H["T_DOFF_DELTA"]], header[_H["T_NDELTA"]] = doff_delta, tiled["delta"].size
     header[_H["T_DOFF_SCOEF"]] = doff_delta + tiled["delta"].size
     dparts.append(tiled["scoef"])
+    header[_H["T_DOFF_SCAN_GC"]] = doff_delta + tiled["delta"].size + tiled["scoef"].size
+    dparts.append(scan["gc"])
+    header[_H["T_DOFF_SCAN_GCOEF"]] = header[_H["T_DOFF_SCAN_GC"]] + scan["gc"].size
+    dparts.append(scan["gcoef"])
+    header[_H["T_SCAN"]] = scan["K"] if scan["ok"] else 0
+    header[_H["T_SCAN_NBLK"]], header[_H["T_SCAN_NGREST"]] = scan["blk"].shape[0], scan["grest"].size
+    header[_H["T_SCAN_NOTHER"]] = scan["nother"]
     header[_H["T_NGREST"]] = tiled["grest"].size
     header[_H["T_CI_OK"]], header[_H["T_NOP"]] = tiled["ci_ok"], tiled["nop"]
     header[_H["T_OK"]], header[_H["T_NSTAGE"]] = tiled["ok"], tiled["stages"].shape[0]

@@ -655,3 +655,80 @@ def run_tiled(plan, given, params=None, sources=None, ab=None):
             assert np.array_equal(G[R], row_sum)              # the riding rows: the same numbers
     assert not np.isnan(G).any()
     return {"P": Pm, "q": q, "G": G, "h": h, "d": d, "Vo": Vo[:, :no]}
+
+
+def run_scan(plan, given, params=None, ab=None):
+    """P, q, G, h of one instance as the tiled kernel's *scan form* computes them (csrc/tiled.hip
+    toeplitz_scan_kernel, plan_tables.h T_SCAN*): the Hessian block of two input column blocks by
+    the recurrence P[(j,l)][(j',l')] = C + P[(j,l+1)][(j',l'+1)] with the rank-K term C from the
+    LAST rows of the states, rows of G straight out of the group's Toeplitz table, the gradient by
+    correlating the table with s (d - aim), everything else (d, h, the diagonal terms, the rows of G
+    that are no single state row) as the other forms do."""
+    it, dt = plan.itab, plan.dtab
+    K = int(it[H["T_SCAN"]])
+    assert K > 0, "the plan has no scan form"
+    ng, no, nc = plan.ng, plan.no, plan.nc
+    params = plan.params if params is None else np.asarray(params, dtype=float)
+    prm0 = np.append(params, 0.0)
+    ref = run_tiled(plan, given, params=params, ab=ab)            # d, and what must come out
+    d = ref["d"]
+    lti = _section(it, "OFF_T_LTI", P.T_LTI_WORDS)
+    n, m, N = int(lti[0]), int(lti[1]), int(lti[2])
+    ids = _section(it, "OFF_T_LTI_IDS", lti[3] + m + 1)[lti[3]:]
+    tb = _tiled_streams(plan, [s.array for s in plan.sources], ab)[ids[0]]
+    assert tb.size == n * m * 2 * N
+    nblk = int(it[H["T_SCAN_NBLK"]])
+    blk = _section(it, "OFF_T_SCAN_BLK", nblk * 2).reshape(nblk, 2)
+    gt = _section(it, "OFF_T_SCAN_GT", K * P.T_SCAN_GT_WORDS).reshape(K, P.T_SCAN_GT_WORDS)
+    gc = dt[it[H["T_DOFF_SCAN_GC"]]:it[H["T_DOFF_SCAN_GC"]] + K]
+    colblk = _section(it, "OFF_T_SCAN_COLBLK", no)
+    assert int((colblk < 0).sum()) == it[H["T_SCAN_NOTHER"]]
+    for bx, (c0, pbase) in enumerate(blk):
+        assert (colblk[c0:c0 + N] == bx).all() and (pbase - N) % (2 * N) == 0
+    lane = np.arange(N)
+
+    def last_row(g, bx):            # M_g[N-1][columns of block bx] / c_g: TB[sboff + N-1 + pbase - l]
+        return tb[gt[g, 0] + N - 1 + blk[bx, 1] - lane]
+
+    Pm = np.zeros((no, no))
+    for bi in range(nblk):
+        for bj in range(nblk):
+            Tl = np.stack([(params[gt[g, 1]] * gc[g]) * gc[g] * last_row(g, bj) for g in range(K)])
+            run = np.zeros(N)
+            for l in range(N - 1, -1, -1):
+                beta = np.array([tb[gt[g, 0] + N - 1 + blk[bi, 1] - l] for g in range(K)])
+                C = np.zeros(N)
+                for g in range(K):                       # (the kernel's order of the K products)
+                    C = C + beta[g] * Tl[g]
+                carry = np.append(run[1:], 0.0)          # lane <- lane + 1, nothing behind the block
+                run = C + carry
+                Pm[blk[bi, 0] + l, blk[bj, 0]:blk[bj, 0] + N] = run
+    q = np.zeros(no)
+    for bx in range(nblk):
+        acc = np.zeros(N)
+        for g in range(K):
+            w, aim, drow = params[gt[g, 1]], params[gt[g, 2]], gt[g, 3]
+            for k in range(N):
+                r = w * (d[drow + k] - aim)                  # (d carries the term's coefficient already)
+                acc += r * (gc[g] * tb[gt[g, 0] + k + blk[bx, 1] - lane])
+        q[blk[bx, 0]:blk[bx, 0] + N] = acc
+    gtab = _section(it, "OFF_GTERM", it[H["NGTERM"]] * P.GT_WORDS).reshape(-1, P.GT_WORDS)
+    for a, b, nn, pw, dd, pa, flags, _ma, _mb, _pad in gtab:
+        if flags & P.GT_FLAG_DIAG:
+            cf = dt[it[H["DOFF_DIAGCOEF"]] + b:it[H["DOFF_DIAGCOEF"]] + b + nn]
+            idx = np.arange(a, a + nn)
+            Pm[idx, idx] += (params[pw] * cf) * cf
+            q[idx] += params[pw] * (cf * (0.0 - params[pa]))
+    grow = _section(it, "OFF_T_SCAN_GROW", nc * 2).reshape(nc, 2)
+    gcoef = dt[it[H["T_DOFF_SCAN_GCOEF"]]:it[H["T_DOFF_SCAN_GCOEF"]] + nc]
+    grest = _section(it, "OFF_T_SCAN_GREST", it[H["T_SCAN_NGREST"]])
+    G = np.zeros((nc, no))
+    for R in range(nc):
+        if grow[R, 0] < 0:
+            assert R in grest
+            G[R] = ref["G"][R]                           # (composed through the column tables)
+            continue
+        assert R not in grest
+        for bx in range(nblk):
+            G[R, blk[bx, 0]:blk[bx, 0] + N] = prm0[grow[R, 1]] * (gcoef[R] * tb[grow[R, 0] + blk[bx, 1] - lane])
+    return {"P": Pm, "q": q, "G": G, "h": ref["h"], "ref": ref}

@@ -4,7 +4,7 @@ HBM -- against the staged pipeline and the oracle; horizon tables generated from
 import numpy as np
 import pytest
 
-from helpers import RTOL, RTOL_TIGHT, assert_close
+from helpers import RTOL, RTOL_TIGHT, assert_close, lti_tracking_problem
 from mpcasm import problems
 from mpcasm.plan import _H
 from oracle import qp_oracle as orc
@@ -73,14 +73,16 @@ def test_tiled_against_staged_and_oracle(gpu_api, torch_gpu, nx, nu, N, B, seed)
     assert torch.equal(G2, Gt) and torch.equal(h2, ht)
 
 
-@pytest.mark.parametrize("path", [0, 3], ids=["toeplitz", "general"])
-@pytest.mark.parametrize("nx,nu,N,B,seed", [(5, 3, 48, 19, 11), (12, 6, 64, 24, 12), (3, 4, 40, 9, 13)])
+@pytest.mark.parametrize("path", [0, 4, 3], ids=["scan", "toeplitz", "general"])
+@pytest.mark.parametrize("nx,nu,N,B,seed", [(5, 3, 48, 19, 11), (12, 6, 64, 24, 12), (3, 4, 40, 9, 13),
+                                            (3, 2, 100, 7, 14)])
 def test_horizon_tables_from_the_systems_own_matrices(gpu_api, torch_gpu, nx, nu, N, B, seed, path):
     """Plans compiled with lti=[...] on the tiled kernel: a pre-pass builds S and the compact
     Toeplitz tables of U from per-instance (A, B) by the reference's recurrence (tools.py:24-29).
-    Both forms of the kernel -- operands read out of the table in LDS (every cost row is a window
-    of it), and the general form that composes tiles (MPCASM_OPT_PATH 3) -- against the staged
-    pipeline fed the K1 fill's S, U of the same systems, and the oracle."""
+    All three forms of the kernel -- P summed along diagonals (every cost is the full horizon of a
+    state: the scan form, horizons up to 64), operands read out of the table in LDS (every cost row is
+    a window of it: MPCASM_OPT_PATH 4), and the general form that composes tiles (MPCASM_OPT_PATH 3)
+    -- against the staged pipeline fed the K1 fill's S, U of the same systems, and the oracle."""
     torch = torch_gpu
     from mpcasm import capi, engine
 
@@ -98,6 +100,7 @@ def test_horizon_tables_from_the_systems_own_matrices(gpu_api, torch_gpu, nx, nu
     Pl, ql, Gl, hl = (t.clone() for t in lti.assemble(given, out=out))
     assert not any(torch.isnan(t).any().item() for t in (Pl, ql, Gl, hl))
     assert "tiled" in lti.last_kernel()
+    assert ("scan" in lti.last_kernel()) == (path == 0 and N <= 64), lti.last_kernel()
     # one half at a time: the same numbers
     P2, q2, _, _ = lti.assemble(given, want_constraints=False)
     assert torch.equal(P2, Pl) and torch.equal(q2, ql)
@@ -125,6 +128,68 @@ def test_horizon_tables_from_the_systems_own_matrices(gpu_api, torch_gpu, nx, nu
     finally:
         dyn.matrices = saved
         dyn.update_definitions()
+
+
+@pytest.mark.parametrize("nx,nu,N,kw", [
+    (4, 6, 40, dict(scaled=True)),                                   # a cost on 2.5 x a state
+    (3, 4, 40, dict(extra_unknown=True, scaled=True)),               # unknowns that are no input of the plant
+    (4, 5, 32, dict(given_input=True, two_axis_limit=True)),         # a GIVEN input; rows of G over two states
+    (6, 8, 16, dict()),                                              # eight column blocks of 16
+    (16, 4, 64, dict()),                                             # sixteen terms
+    (4, 4, 40, dict(scheduled_cost=True)),                           # part of the horizon: NO scan form
+], ids=["scaled", "slack", "given-input", "8-blocks", "16-terms", "scheduled"])
+def test_scan_form_against_the_toeplitz_form_and_the_oracle(gpu_api, torch_gpu, nx, nu, N, kw):
+    """The scan form (P summed along diagonals) on what tells it apart from the matrix-core forms:
+    coefficients, unknowns outside the plant's inputs (their rows and columns of P hold the diagonal
+    terms only), a given input (no column block), rows of G that are no single state row (composed
+    behind the rest), every instantiation's limits -- against the Toeplitz form (MPCASM_OPT_PATH 4)
+    on the same plan and against the oracle with every instance's own system."""
+    torch = torch_gpu
+    from mpcasm import capi, engine
+
+    rng = np.random.default_rng(1000 * nx + N)
+    form, _, _ = lti_tracking_problem(gpu_api, rng, nx, nu, N, **kw)
+    B = 11
+    given = torch.as_tensor(rng.normal(0, 0.3, [B, form.given_len]), device="cuda")
+    As, Bs = zip(*(problems.random_lti_matrices(rng, nx, nu) for _ in range(B)))
+    A, Bm = np.stack(As), np.stack(Bs)
+    results = {}
+    for path in (0, 4):
+        asm = engine.Assembler(form, batch=B, lti=["plant"])
+        asm.set_option(capi.OPT_PATH, path)
+        asm.bind_lti("plant", torch.as_tensor(A, device="cuda"), torch.as_tensor(Bm, device="cuda"))
+        w = rng.uniform(0.1, 1.0, [B, 1, 1]) if path == 0 else w
+        asm.set_param("cost", "track s0", "weight", w)
+        out = tuple(torch.full_like(t, float("nan")) for t in asm.assemble(given))
+        results[path] = tuple(t.clone() for t in asm.assemble(given, out=out))
+        assert not any(torch.isnan(t).any().item() for t in results[path])
+        scan = asm.plan.itab[_H["T_SCAN"]] > 0
+        assert scan == (not kw.get("scheduled_cost"))
+        assert ("scan" in asm.last_kernel()) == (scan and path == 0), asm.last_kernel()
+        if path == 0:
+            P2, q2, _, _ = asm.assemble(given, want_constraints=False)
+            assert torch.equal(P2, results[0][0]) and torch.equal(q2, results[0][1])
+            out = tuple(torch.full_like(t, float("nan")) for t in results[0])
+            _, _, G2, h2 = asm.assemble(given, out=out, want_cost=False)
+            assert torch.equal(G2, results[0][2]) and torch.equal(h2, results[0][3])
+    for mine, theirs in zip(results[0], results[4]):
+        assert _rel(mine, theirs) <= RTOL_TIGHT
+    dyn, goal = form.dynamics["plant"], form.goals["track s0"]
+    saved, w0 = list(dyn.matrices), goal.weight
+    try:
+        for b in (0, 5, B - 1):
+            So, Uo = orc.extend_matrices(N, A[b], Bm[b])
+            dyn.matrices = Uo + [So]
+            dyn.update_definitions()
+            goal.update(weight=float(w[b, 0, 0]))
+            Ao, ho, Qo, qo = orc.assemble(form, given[b].cpu().numpy().reshape(-1, 1))
+            Pl, ql, Gl, hl = (t[b].cpu().numpy() for t in results[0])
+            assert_close(Pl, Qo, RTOL_TIGHT), assert_close(ql, qo.ravel(), RTOL_TIGHT)
+            assert_close(Gl, Ao, RTOL_TIGHT), assert_close(hl, ho.ravel(), RTOL_TIGHT)
+    finally:
+        dyn.matrices = saved
+        dyn.update_definitions()
+        goal.update(weight=w0)
 
 
 def test_crossed_cost_and_two_axis_constraint_on_the_tiled_kernel(gpu_api, torch_gpu):
@@ -211,11 +276,12 @@ def test_c4_at_its_per_gpu_batch_in_one_call(gpu_api, torch_gpu):
     Gv = G.view(B, nx, 2, N, 384)
     for lo in range(0, B, 256):
         assert torch.equal(Gv[lo:lo + 256, :, 0], -Gv[lo:lo + 256, :, 1])
-    # three instances against the oracle (their own systems and weights)
+    # eight instances against the oracle (their own systems and weights)
     dyn, goal = form.dynamics["plant"], form.goals["track s0"]
     saved, w0 = list(dyn.matrices), goal.weight
     try:
-        for b in (0, 4097, B - 1):
+        assert "scan" in asm.last_kernel(), asm.last_kernel()
+        for b in (0, 1, 255, 256, 4097, 6000, B - 2, B - 1):        # (first / last workgroups of a round)
             So, Uo = orc.extend_matrices(N, A[b], Bm[b])
             dyn.matrices = Uo + [So]
             dyn.update_definitions()

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 import plan_emulator
-from helpers import assert_close
+from helpers import assert_close, lti_tracking_problem
 from mpcasm import capi, problems
 from mpcasm.plan import _H, compile_plan, structure_fingerprint
 from oracle import qp_oracle as orc
@@ -534,3 +534,96 @@ def test_compiled_kernels_are_kept_on_disk(cpu_api, tmp_path, monkeypatch):
     assert check() == 0
     s3 = stats()
     assert s3[0] - s2[0] == built and s3[1] == s2[1]
+
+
+@pytest.mark.parametrize("nx,nu,N,kw", [
+    (5, 3, 48, {}),
+    (12, 6, 64, {}),                                       # the C4 shape: K = 12 terms, 6 column blocks
+    (4, 6, 40, dict(scaled=True)),
+    (3, 4, 40, dict(extra_unknown=True, scaled=True)),
+    (4, 5, 32, dict(given_input=True, two_axis_limit=True)),
+])
+def test_scan_form_tables_against_the_oracle(cpu_api, nx, nu, N, kw):
+    """The tiled kernel's scan form (P summed along diagonals, plan_tables.h T_SCAN*), emulated from
+    the plan's tables for a system of its own per instance, against the oracle on the reference's
+    dense matrices of that system."""
+    rng = np.random.default_rng(nx * 100 + N)
+    form, _, _ = lti_tracking_problem(cpu_api, rng, nx, nu, N, **kw) if kw else (
+        problems.random_lti(cpu_api, rng, nx=nx, nu=nu, N=N), None, None)
+    plan = compile_plan(form, lti=["plant"])
+    it = plan.itab
+    assert it[_H["T_OK"]] == 1 and it[_H["T_TOEPLITZ"]] == 1 and it[_H["T_SCAN"]] == nx
+    assert it[_H["T_SCAN_NBLK"]] == nu - (1 if kw.get("given_input") else 0)
+    assert it[_H["T_SCAN_NOTHER"]] == (N if kw.get("extra_unknown") else 0)
+    assert it[_H["T_SCAN_NGREST"]] == (N if kw.get("two_axis_limit") else 0)
+    A, B = problems.random_lti_matrices(rng, nx, nu)
+    given = rng.normal(0, 0.3, form.given_len)
+    out = plan_emulator.run_scan(plan, given, ab=[(A, B)])
+    dyn = form.dynamics["plant"]
+    saved = list(dyn.matrices)
+    try:
+        So, Uo = orc.extend_matrices(N, A, B)
+        dyn.matrices = Uo + [So]
+        dyn.update_definitions()
+        Ao, ho, Qo, qo = orc.assemble(form, given.reshape(-1, 1))
+    finally:
+        dyn.matrices = saved
+        dyn.update_definitions()
+    for key, ref in (("P", Qo), ("q", qo.ravel()), ("G", Ao), ("h", ho.ravel())):
+        assert_close(out[key], ref, 1e-12, "scan " + key)
+
+
+def test_scan_form_only_where_it_holds(cpu_api):
+    """No scan form: a cost on part of the horizon (the diagonal sums would need the missing rows), a
+    horizon beyond the kernel's lanes, sources read from memory (no generated group)."""
+    rng = np.random.default_rng(3)
+    form, _, _ = lti_tracking_problem(cpu_api, rng, 4, 4, 40, scheduled_cost=True)
+    plan = compile_plan(form, lti=["plant"])
+    assert plan.itab[_H["T_TOEPLITZ"]] == 1 and plan.itab[_H["T_SCAN"]] == 0
+    form = problems.random_lti(cpu_api, rng, nx=3, nu=2, N=100)
+    assert compile_plan(form, lti=["plant"]).itab[_H["T_SCAN"]] == 0
+    form = problems.random_lti(cpu_api, rng, nx=4, nu=4, N=40)
+    assert compile_plan(form).itab[_H["T_SCAN"]] == 0
+
+
+def test_scan_form_tables_are_validated(cpu_api):
+    """One corrupted word of the scan tables each: MPCASM_ERR_PLAN before anything reaches a device."""
+    import mpcasm.plan as P
+
+    lib = capi.load()
+    rng = np.random.default_rng(4)
+    form, _, _ = lti_tracking_problem(cpu_api, rng, 4, 5, 32, given_input=True, two_axis_limit=True)
+    plan = compile_plan(form, lti=["plant"])
+    it = plan.itab
+    handle = ctypes.c_void_p()
+
+    def create(itab):
+        return lib.mpcasm_plan_create(itab.ctypes.data, itab.size, plan.dtab.ctypes.data,
+                                      plan.dtab.size, ctypes.byref(handle))
+
+    rc = create(it)
+    assert rc in (0, -4), rc
+    if rc == 0:
+        assert lib.mpcasm_plan_destroy(handle) == 0
+    nparams = int(it[_H["NPARAMS"]])
+    blk, gt, grow = it[_H["OFF_T_SCAN_BLK"]], it[_H["OFF_T_SCAN_GT"]], it[_H["OFF_T_SCAN_GROW"]]
+    simple = next(R for R in range(plan.nc) if it[grow + 2 * R] >= 0)
+    corruptions = {
+        "terms": (_H["T_SCAN"], P.T_SCAN_KMAX + 1),
+        "blocks": (_H["T_SCAN_NBLK"], 0),
+        "block: first column": (blk, plan.no),
+        "block: input offset": (blk + 1, it[blk + 1] + 1),
+        "term: state offset": (gt, it[gt] + 1),
+        "term: weight slot": (gt + 1, nparams),
+        "term: rows of d": (gt + 3, plan.rtot),
+        "row of G: table row": (grow + 2 * simple, it[grow + 2 * simple] + 32),
+        "row of G: arrow": (grow + 2 * simple + 1, it[grow + 2 * simple + 1] + 1),
+        "rows of G by the tables: count": (_H["T_SCAN_NGREST"], it[_H["T_SCAN_NGREST"]] - 1),
+        "unknowns outside the blocks": (_H["T_SCAN_NOTHER"], 1),
+        "column -> block": (it[_H["OFF_T_SCAN_COLBLK"]], 1),
+    }
+    for what, (word, value) in corruptions.items():
+        bad = it.copy()
+        assert bad[word] != value, what
+        bad[word] = value
+        assert create(bad) == -2, what
