@@ -1350,8 +1350,17 @@ hipError_t allow_whole_lds(const void* fn) {
   std::lock_guard<std::mutex> lock(mutex);
   for (const auto& d : done)
     if (d.first == fn && d.second == device) return hipSuccess;
-  e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, CU_LDS_BYTES);
-  if (e == hipSuccess) done.emplace_back(fn, device);
+  // (the runtime of this image refuses the CU's full 160 KiB -- hipErrorInvalidValue -- and grants
+  // 156 KiB, what the kernels' own limit RESIDENT_LDS_LIMIT asks for: the larger one first, for a
+  // runtime that gives it)
+  for (int bytes : {CU_LDS_BYTES, RESIDENT_LDS_LIMIT}) {
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) {
+      done.emplace_back(fn, device);
+      return e;
+    }
+    (void)hipGetLastError();
+  }
   return e;
 }
 

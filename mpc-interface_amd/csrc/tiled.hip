@@ -1066,7 +1066,7 @@ constexpr int SCAN_GROUP = 4;     // rows of G per ticket
 constexpr int SCAN_GCH_MAX = 8;   // 128-column chunks of a row of G: no <= 1024
 
 #ifndef MPCASM_SCAN_DPP
-#define MPCASM_SCAN_DPP 0
+#define MPCASM_SCAN_DPP 1   // (tools/microbench/dpp_wave_shift.hip: wave_shl:1 is lane i <- lane i + 1, 0 into lane 63)
 #endif
 // lane i <- lane i + 1, 0 into lane 63
 __device__ __forceinline__ double lane_from_next(double v) {

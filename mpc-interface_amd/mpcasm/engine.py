@@ -16,7 +16,7 @@ import ctypes
 import numpy as np
 
 from . import capi
-from .plan import compile_plan
+from .plan import compile_plan, is_causal
 
 
 def _torch():
@@ -275,6 +275,10 @@ class Assembler:
             if block is None:
                 return False
             fresh.append(np.ascontiguousarray(block, dtype=np.float64))
+        # a U_j the plan's tile masks / CSC patterns took as causal (zeros above the diagonal,
+        # tools.py:27-31) no longer is: the tables do not hold for it
+        if any(not is_causal(fresh[i]) for i in self.plan.causal_assumed):
+            return False
         generated = {i for g in self.plan.lti for i in g["ids"]}
         # all blocks side by side in one device arena, filled by ONE copy from a pinned staging
         # buffer (a tick of the walking loop is copy-bound: ~20 us per separate upload)
@@ -300,15 +304,28 @@ class Assembler:
             self.bind_lti(g["name"], A, Bm)
         return True
 
-    def bind_source(self, key, tensor):
+    def bind_source(self, key, tensor, check=True):
         """Use ``tensor`` for the horizon matrix ``key = (dynamics name, k)``:
-        shape ``(N, p, n)`` (shared) or ``(B, N, p, n)`` (one per instance)."""
+        shape ``(N, p, n)`` (shared) or ``(B, N, p, n)`` (one per instance).
+
+        Where the plan's tables rely on the matrix being causal -- ``U_j[k][l] = 0`` for ``l > k``,
+        as ``tools.extend_matrices`` / :func:`fill_su` produce it: the tile masks of the tiled kernel
+        (wide problems) and the CSC patterns -- a tensor that is not raises ``ValueError`` (one
+        reduction on the device per call; ``check=False`` for a caller that guarantees it)."""
         torch = self._torch
         i = self._src_index[key]
         if key[0] in self._lti:
             raise ValueError("the horizon matrices of %r are generated on chip: bind_lti" % key[0])
         shape = tuple(self.plan.sources[i].array.shape)
         t = _as_device(torch, tensor, self.device)
+        if check and i in self.plan.causal_assumed and tuple(t.shape)[-3:] == shape:
+            N = shape[0]
+            above = torch.triu(torch.ones(N, N, dtype=torch.bool, device=self.device), diagonal=1)
+            if bool((t[..., above, :] != 0).any().item()):
+                raise ValueError(
+                    "source %r: the plan was compiled for a causal horizon matrix (zeros above the "
+                    "diagonal, as tools.extend_matrices produces it); compile a plan from a "
+                    "formulation that holds such a matrix to bind this one" % (key,))
         if tuple(t.shape) == shape:
             self._src[i], self._src_stride[i] = t, 0
         elif tuple(t.shape) == (self.batch,) + shape:

@@ -121,6 +121,7 @@ class Plan:
         self.given_ID = {}
         self.param_getters = []    # (start, size, callable) -> current numbers of the objects
         self.fingerprint = None    # structure of the costs / limits this plan was built from
+        self.causal_assumed = []   # ids of the sources whose zeros above the diagonal the tables rely on
 
     def current_params(self):
         """Parameter vector re-read from the Cost / Constraint objects, or ``None``
@@ -1052,6 +1053,15 @@ def _resident_program(fused, gterms, no, ldv, ws, image, ng, nparams, nc_rows):
     return out
 
 
+def is_causal(U):
+    """Whether a ``(..., N, N, n)`` array holds exact zeros above the diagonal: ``U[.., k, l, :] == 0``
+    for ``l > k`` -- what ``tools.extend_matrices`` (tools.py:27-31) and ``mpcasm_fill_su`` produce."""
+    U = np.asarray(U)
+    N = U.shape[-3]
+    kk, ll = np.meshgrid(np.arange(N), np.arange(N), indexing="ij")
+    return not np.any(U[..., ll > kk, :])
+
+
 def causal_sources(form, sources, groups=()):
     """Ids of the sources that are the ``U_j`` of an ExtendedSystem and hold exact zeros above
     the diagonal: ``U_j[k][l] = A^(k-l) B`` for ``l <= k``, else 0 (tools.py:27-31).  The tables
@@ -1065,10 +1075,8 @@ def causal_sources(form, sources, groups=()):
             continue
         m = len(getattr(form.dynamics[key[0]], "matrices", [])) - 1
         N = src.array.shape[0]
-        if key[1] < m and src.array.shape[1] == N:
-            kk, ll = np.meshgrid(np.arange(N), np.arange(N), indexing="ij")
-            if not np.any(src.array[ll > kk]):
-                out.add(sid)
+        if key[1] < m and src.array.shape[1] == N and is_causal(src.array):
+            out.add(sid)
     return out
 
 
@@ -1266,6 +1274,7 @@ def _tiled_program(b, form, gterms, rowptr, entbase, entk, entcoef, rtot, groups
              and len(b.sources) <= MAX_SOURCES and rtot < (1 << 24))
     toeplitz = int(bool(ok and stages and all((st[3] >> 8) & TS_FLAG_TOEPLITZ for st in stages)))
     return dict(ok=ok, toeplitz=toeplitz, ci_ok=int(ci_ok), nop=nop, ci=ci, delta=delta, masks=masks,
+                causal=causal,
                 srow=np.asarray(srow, dtype=np.int64).reshape(-1),
                 scoef=np.asarray(scoef, dtype=np.float64).reshape(-1),
                 pig=np.asarray(pig, dtype=np.int64).reshape(-1), grest=grest,
@@ -1360,27 +1369,25 @@ def _scan_tables(b, gterms, rowptr, entbase, entk, entcoef, groups, g_rows, tile
                 nother=int((colblk < 0).sum()))
 
 
-def _structural_patterns(form, b, fused, gterms, limit_recs, lax_recs, rtot, ldv, no, nc):
+def _structural_patterns(form, b, fused, gterms, limit_recs, lax_recs, rtot, ldv, no, nc, groups=()):
     """Which entries of P (no x no) and of the stacked G (nc x no) can be non-zero at all:
     from the structurally non-zero elements of the workspace (an element with at least one
     op whose source is not a known zero -- ``U_j[k][l]`` above the diagonal l > k is zero
-    for every system, tools.py:27-31).  None when the op lists were not built (huge plans)."""
+    for every system, tools.py:27-31; a source compiled as causal must stay so: ``Plan.causal_assumed``).
+    None when the op lists were not built (huge plans)."""
     if rtot and fused["fd_idx"].size == 0:
         return None, None
     ops = fused["ops"].view(np.uint32).reshape(-1, 2)
     arena = fused["arena"].reshape(-1, 2)
     zero_src = np.zeros(int(fused["arena_total"]) + 1, dtype=bool)
+    causal = causal_sources(form, b.sources, groups)
     for sid, src in enumerate(b.sources):
-        key = src.key
-        if len(key) == 2 and key[0] in form.dynamics and src.array.ndim == 3:
-            dyn = form.dynamics[key[0]]
-            m = len(getattr(dyn, "matrices", [])) - 1
+        if sid in causal:                                        # a U_j: (N, N, n), zeros above the diagonal
             N = src.array.shape[0]
-            if key[1] < m and src.array.shape[1] == N:          # a U_j: (N, N, n)
-                kk, ll = np.meshgrid(np.arange(N), np.arange(N), indexing="ij")
-                above = np.repeat((ll > kk).reshape(-1), src.array.shape[2])
-                off = int(arena[sid, 0])
-                zero_src[off:off + above.size] = above
+            kk, ll = np.meshgrid(np.arange(N), np.arange(N), indexing="ij")
+            above = np.repeat((ll > kk).reshape(-1), src.array.shape[2])
+            off = int(arena[sid, 0])
+            zero_src[off:off + above.size] = above
     live = ~zero_src[ops[:, 0].astype(np.int64)] if ops.size else np.zeros(0, dtype=bool)
     Vnz = np.zeros(max(rtot, 1) * ldv, dtype=bool)
     fd_idx, fd_ptr = fused["fd_idx"], fused["fd_ptr"]
@@ -1729,7 +1736,7 @@ def compile_plan(form, costs=None, limits=None, lti=(), csc=None, workspace="aut
     # dimension no rounded up to even) and, per stored entry (R, c) of G, what a 16-byte piece
     # has for two columns: Workspace.index(row0, c) | Workspace.index(row1, c) << 16, arrow0 | arrow1 << 16
     P_pattern, G_pattern = _structural_patterns(
-        form, b, fused, gterms, limit_recs, lax_recs, rtot, ldv, no, nc)
+        form, b, fused, gterms, limit_recs, lax_recs, rtot, ldv, no, nc, groups)
     csc_p = csc_g = np.zeros(0, dtype=np.int32)
     csc_info, csc_gsingle = None, 0
     if csc is not None:
@@ -1951,4 +1958,10 @@ def compile_plan(form, costs=None, limits=None, lti=(), csc=None, workspace="aut
     plan.csc = csc_info
     plan.lti = [dict(name=g["name"], n=g["n"], m=g["m"], N=g["N"], ids=list(g["ids"])) for g in groups]
     plan.tiled = tiled
+    # Sources (U_j read from memory) whose zeros above the diagonal some table of this plan relies
+    # on -- the tile masks and stage classes of the tiled kernel, the CSC patterns: whatever is
+    # bound in their place must be causal too (Assembler.bind_source / rebind_sources check it).
+    generated = {i for g in groups for i in g["ids"]}
+    plan.causal_assumed = sorted(i for i in tiled["causal"] if i not in generated) \
+        if (tiled["ok"] or csc is not None) else []
     return plan

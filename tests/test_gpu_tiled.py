@@ -388,3 +388,27 @@ def test_odd_width_falls_back_to_the_staged_pipeline(gpu_api, torch_gpu):
     assert_close(G[2], Ao, RTOL_TIGHT), assert_close(h[2], ho.ravel(), RTOL_TIGHT)
     with pytest.raises(Exception):
         engine.Assembler(form, batch=5, lti=["plant"]).assemble(given)   # nowhere to generate the tables
+
+
+def test_a_non_causal_matrix_is_refused_where_the_masks_assume_causality(gpu_api, torch_gpu):
+    """the tiled kernel skips the tiles of U_j above the diagonal.  A tensor with entries
+    there is refused by bind_source (ValueError) and by rebind_sources (False: recompile), instead of
+    silently giving a wrong P."""
+    torch = torch_gpu
+    from mpcasm import engine
+
+    rng = np.random.default_rng(8)
+    form = problems.random_lti(gpu_api, rng, nx=4, nu=4, N=32)
+    asm = engine.Assembler(form, batch=3)
+    assert asm.plan.causal_assumed
+    dyn = form.dynamics["plant"]
+    U1 = np.array(dyn.matrices[1])
+    bad = np.broadcast_to(U1, (3,) + U1.shape).copy()
+    bad[1, 3, 20, 0] = 0.25
+    with pytest.raises(ValueError):
+        asm.bind_source(("plant", 1), torch.as_tensor(bad, device="cuda"))
+    asm.bind_source(("plant", 1), torch.as_tensor(np.broadcast_to(U1, (3,) + U1.shape).copy(), device="cuda"))
+    frozen = {("plant", k): np.array(M) for k, M in enumerate(dyn.matrices)}
+    assert asm.rebind_sources(form, frozen)
+    frozen[("plant", 1)][3, 20, 0] = 0.25
+    assert not asm.rebind_sources(form, frozen)

@@ -627,3 +627,38 @@ def test_scan_form_tables_are_validated(cpu_api):
         assert bad[word] != value, what
         bad[word] = value
         assert create(bad) == -2, what
+
+
+def test_causality_of_bound_horizon_matrices_is_part_of_the_contract(cpu_api):
+    """The tile masks of the tiled kernel (and the CSC patterns) skip U_j[k][l > k]: a plan records the
+    sources it took as causal (``Plan.causal_assumed``), and a formulation whose U_j holds entries above
+    the diagonal compiles to a plan that assumes nothing of them."""
+    from mpcasm.plan import is_causal
+
+    rng = np.random.default_rng(8)
+    form = problems.random_lti(cpu_api, rng, nx=4, nu=4, N=32)            # no = 128: the tiled kernel
+    plan = compile_plan(form)
+    dyn = form.dynamics["plant"]
+    u_ids = [i for i, s in enumerate(plan.sources) if s.key[0] == "plant" and s.key[1] < 4]
+    assert plan.itab[_H["T_OK"]] == 1 and plan.causal_assumed == u_ids
+    assert all(is_causal(plan.sources[i].array) for i in u_ids)
+    assert compile_plan(form, lti=["plant"]).causal_assumed == []         # generated on chip: causal by construction
+    small = problems.random_lti(cpu_api, rng, nx=3, nu=2, N=8)            # the persistent kernel: structural masks only
+    assert compile_plan(small).causal_assumed == []
+    # entries above the diagonal: every tile of that source counts as non-zero
+    saved = [np.array(M) for M in dyn.matrices]
+    try:
+        dyn.matrices[1][3, 20, 0] = 0.25
+        dyn.update_definitions()
+        form.make_preview_matrices()
+        dense = compile_plan(form)
+        assert u_ids[1] not in dense.causal_assumed and not is_causal(dense.sources[u_ids[1]].array)
+        given = rng.normal(0, 0.3, [form.given_len, 1])
+        out = plan_emulator.run_tiled(dense, given)                       # (asserts: nothing outside the multiplied tiles)
+        A, h, Q, q = orc.assemble(form, given)
+        assert_close(out["P"], Q, 1e-12, "P"), assert_close(out["G"], A, 1e-12, "G")
+    finally:
+        for M, old in zip(dyn.matrices, saved):
+            M[...] = old
+        dyn.update_definitions()
+        form.make_preview_matrices()
