@@ -309,7 +309,7 @@ int validate_tiled(const int32_t* it, const double* h_dtab, int64_t n, int64_t n
     if (K < 0 || K > T_SCAN_KMAX || (K > 0 && !it[H_T_TOEPLITZ])) return MPCASM_ERR_PLAN;
     if (K > 0) {
       const int32_t* g = it + it[H_OFF_T_LTI];
-      const int64_t gn = g[TL_N], gm = g[TL_M], gN = g[TL_HORIZON], per_state = gm * 2 * gN;
+      const int64_t gn = g[TL_N], gm = g[TL_M], gN = g[TL_HORIZON], per_state = gm * gN;
       const int64_t nparams = it[H_NPARAMS];
       if (gN < 1 || gN > T_SCAN_NMAX || nblk < 1 || nblk > T_SCAN_BLKMAX || nrest < 0 || nrest > nc ||
           !in_range(it[H_OFF_T_SCAN_BLK], nblk * 2, n, H_WORDS) ||
@@ -324,7 +324,7 @@ int validate_tiled(const int32_t* it, const double* h_dtab, int64_t n, int64_t n
       int64_t covered = 0;
       for (int64_t b = 0; b < nblk; ++b) {
         const int64_t c0 = blk[2 * b], pbase = blk[2 * b + 1];
-        if (c0 < 0 || c0 + gN > no || pbase < gN || (pbase - gN) % (2 * gN) || (pbase - gN) / (2 * gN) >= gm)
+        if (c0 < 0 || c0 + gN > no || pbase < 0 || pbase % gN || pbase / gN >= gm)
           return MPCASM_ERR_PLAN;
         for (int64_t l = 0; l < gN; ++l)
           if (colblk[c0 + l] != b) return MPCASM_ERR_PLAN;  // (hence disjoint)
@@ -901,6 +901,11 @@ void plan_dev_from_tables(const int32_t* it, PlanDev* out) {
   d.off_t_scan_grow = it[H_OFF_T_SCAN_GROW]; d.t_doff_scan_gcoef = it[H_T_DOFF_SCAN_GCOEF];
   d.t_scan_ngrest = it[H_T_SCAN_NGREST]; d.off_t_scan_grest = it[H_OFF_T_SCAN_GREST];
   d.off_t_scan_colblk = it[H_OFF_T_SCAN_COLBLK]; d.t_scan_nother = it[H_T_SCAN_NOTHER];
+  d.sw_ok = it[H_SW_OK]; d.sw_n = it[H_SW_N]; d.sw_m = it[H_SW_M]; d.sw_horizon = it[H_SW_HORIZON];
+  d.sw_src_a = it[H_SW_SRC_A]; d.sw_src_b = it[H_SW_SRC_B]; d.sw_naxes = it[H_SW_NAXES];
+  d.off_sw_axis = it[H_OFF_SW_AXIS]; d.sw_nterm = it[H_SW_NTERM]; d.off_sw_term = it[H_OFF_SW_TERM];
+  d.sw_nlim = it[H_SW_NLIM]; d.off_sw_lim = it[H_OFF_SW_LIM]; d.off_sw_col = it[H_OFF_SW_COL];
+  d.sw_doff_cvec = it[H_SW_DOFF_CVEC]; d.sw_ncvec = it[H_SW_NCVEC];
   d.t_nbrow = d.t_ci_ok ? it[d.off_t_brow0 + d.nbase] : 0;
   d.pm_nfd = it[H_PM_NFD]; d.off_pm_map = it[H_OFF_PM_MAP]; d.off_pm_fdptr = it[H_OFF_PM_FDPTR];
   d.off_pm_op = it[H_OFF_PM_OP]; d.doff_pm_pool = it[H_DOFF_PM_POOL];

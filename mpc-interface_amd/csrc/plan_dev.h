@@ -31,7 +31,9 @@ namespace mpcasm {
   X(off_t_srow) X(t_doff_scoef) X(off_t_pig) X(t_ngrest) X(off_t_grest) X(off_t_brow0) X(t_nbrow) X(t_toeplitz) X(rs_diag_table) X(off_t_bcolptr) X(off_t_bcols) \
   X(rs_ngfix) X(off_rs_gfix) X(rs_compact) X(rs_ldv) X(rs_vd) X(rs_vrow0) X(off_rs_rrwin) X(t_np1) X(off_t_p1ptr) X(off_t_p1ent) X(off_t_p2y) \
   X(t_scan) X(t_scan_nblk) X(off_t_scan_blk) X(off_t_scan_gt) X(t_doff_scan_gc) X(off_t_scan_grow)      \
-  X(t_doff_scan_gcoef) X(t_scan_ngrest) X(off_t_scan_grest) X(off_t_scan_colblk) X(t_scan_nother)
+  X(t_doff_scan_gcoef) X(t_scan_ngrest) X(off_t_scan_grest) X(off_t_scan_colblk) X(t_scan_nother) \
+  X(sw_ok) X(sw_n) X(sw_m) X(sw_horizon) X(sw_src_a) X(sw_src_b) X(sw_naxes) X(off_sw_axis) X(sw_nterm)  \
+  X(off_sw_term) X(sw_nlim) X(off_sw_lim) X(off_sw_col) X(sw_doff_cvec) X(sw_ncvec)
 
 // device-side view of a plan (pointers into the device copies of the tables).
 //   rs_p_direct: the persistent kernel sends the blocks of P straight to HBM (set by

@@ -29,7 +29,7 @@
 namespace mpcasm {
 
 constexpr int32_t PLAN_MAGIC = 0x4D504341;  // 'MPCA'
-constexpr int32_t PLAN_VERSION = 26;
+constexpr int32_t PLAN_VERSION = 27;
 
 enum HeaderWord : int {
   H_MAGIC = 0,
@@ -218,21 +218,52 @@ enum HeaderWord : int {
   // a sum along diagonals, O(K) multiply-adds per element instead of the O(K N) of the product.
   H_T_SCAN,           // K = number of such terms (1 .. T_SCAN_KMAX); 0: the plan has no scan form
   H_T_SCAN_NBLK,      // inputs of the group that are unknowns (<= T_SCAN_BLKMAX)
-  H_OFF_T_SCAN_BLK,   // [NBLK][2] first column of the input's N unknowns, j 2N + N: the element of TB
-                      //    that row k of state i reads in the input's column l is
-                      //    TB[i m 2N + k + (j 2N + N) - l]
-  H_OFF_T_SCAN_GT,    // [K][T_SCAN_GT_WORDS] i m 2N, weight slot, aim slot, first row of d
+  // The kernel keeps the group's table without the zero halves of TB: Tc[(i m + j) N + d] = T_ij[d].
+  H_OFF_T_SCAN_BLK,   // [NBLK][2] first column of the input's N unknowns, j N: what row k of state i
+                      //    holds in the input's column l is Tc[i m N + k + j N - l] for l <= k, else 0
+  H_OFF_T_SCAN_GT,    // [K][T_SCAN_GT_WORDS] i m N, weight slot, aim slot, first row of d
   H_T_DOFF_SCAN_GC,   // [K] dtab: the term's coefficient c
-  H_OFF_T_SCAN_GROW,  // [NC][2] per row of G that is arrow * c * (row k of state i): i m 2N + k, the
+  H_OFF_T_SCAN_GROW,  // [NC][2] per row of G that is arrow * c * (row k of state i): i m N + k, the
                       //    arrow's parameter slot; else -1, -1
   H_T_DOFF_SCAN_GCOEF,// [NC] dtab: that row's c
   H_T_SCAN_NGREST,    // the other rows of G (composed through the column tables)
   H_OFF_T_SCAN_GREST, // [T_SCAN_NGREST] ascending
   H_OFF_T_SCAN_COLBLK,// [NO] per unknown the index of its block in SCAN_BLK, or -1
   H_T_SCAN_NOTHER,    // unknowns in no block (their rows and columns of P hold diagonal terms only)
+  // ---- sweep kernel (sweep.hip): a dynamics compiled as `ltv`, x+ = A_k x + B_k u with its own
+  // (A_k, B_k) per step and instance (BASELINE config C5).  No horizon matrix is ever formed: with
+  // Phi(k, l) = A_k ... A_l, row k of an output c . x holds c^T Phi(k, l+1) B_l in the columns of step
+  // l <= k (tools.py:27-31 with per-step matrices), and
+  //   P[(j,l)][(j',l')] = (Psi_l B_l[:,j]) . U[l][l'][:,j'] (l' <= l),  Psi_l = W_l + A_{l+1}^T Psi_{l+1} A_{l+1}
+  //   q[(j,l)] = B_l[:,j] . lam_l,   lam_l = rho_l + A_{l+1}^T lam_{l+1}
+  // with W_l = sum w c c^T and rho_l = sum w (d - aim) c over the cost rows of step l.
+  H_SW_OK,            // 1: the plan runs on the sweep kernel (and on nothing else)
+  H_SW_N,             // states (<= SW_NMAX)
+  H_SW_M,             // inputs (<= SW_MMAX)
+  H_SW_HORIZON,
+  H_SW_SRC_A,         // source slots that carry A [N][n][n] and B [N][n][m] of every instance
+  H_SW_SRC_B,
+  H_SW_NAXES,         // axes sharing the system (<= SW_AXMAX): each has its own initial state and inputs
+  H_OFF_SW_AXIS,      // [NAXES][SW_AXIS_WORDS] given column of the initial state, first unknown of input j
+  H_SW_NTERM,
+  H_OFF_SW_TERM,      // [NTERM][SW_TERM_WORDS] a cost's rows on one axis, see ST_* below
+  H_SW_NLIM,
+  H_OFF_SW_LIM,       // [NLIM][SW_LIM_WORDS + SW_AXMAX * SW_LAX_WORDS] a limit, see SL_* / SX_* below
+  H_OFF_SW_COL,       // [NO] per unknown: axis | input << 8 | step << 16
+  H_SW_DOFF_CVEC,     // [NCVEC][SW_NMAX] dtab: the combinations c of the states (0 beyond n)
+  H_SW_NCVEC,
   H_WORDS = 160
 };
-static_assert(H_T_SCAN_NOTHER < H_WORDS, "plan header");
+static_assert(H_SW_NCVEC < H_WORDS, "plan header");
+constexpr int SW_NMAX = 4, SW_MMAX = 4, SW_AXMAX = 4, SW_AXIS_WORDS = 8, SW_TERM_WORDS = 8, SW_LIM_WORDS = 8,
+              SW_LAX_WORDS = 8;
+// a cost term on one axis: rows i = 0 .. ST_COUNT-1 are c . x of step ST_K0 + i ST_KSTEP
+enum { ST_AXIS = 0, ST_K0, ST_KSTEP, ST_COUNT, ST_WPARAM, ST_AIMPARAM, ST_CVEC, ST_PAD };
+// a limit: rows SL_OUT0 .. + SL_COUNT - 1 of G, h; per axis (SL_NAXES records of SW_LAX_WORDS behind
+// the head): line i is arrow[i] * (c . x of step SX_K0 + i SX_KSTEP) on axis SX_AXIS; the arrow of
+// line i in parameter SX_ARROW + i SX_ARROW_STEP, the centre likewise, the extreme in SL_EXTREME (+ i)
+enum { SL_OUT0 = 0, SL_COUNT, SL_NAXES, SL_EXTREME, SL_EXTREME_STEP, SL_PAD0, SL_PAD1, SL_PAD2 };
+enum { SX_AXIS = 0, SX_K0, SX_KSTEP, SX_CVEC, SX_ARROW, SX_ARROW_STEP, SX_CENTER, SX_CENTER_STEP };
 constexpr int T_SCAN_KMAX = 16, T_SCAN_BLKMAX = 8, T_SCAN_NMAX = 64, T_SCAN_GT_WORDS = 4;
 enum { SG_SBOFF = 0, SG_WPARAM, SG_AIMPARAM, SG_DROW };
 

@@ -1050,20 +1050,25 @@ __global__ __launch_bounds__(BLOCK, 2) void toeplitz_assemble_kernel(
 //     P[(j,l)][(j',l')] = C[(j,l)][(j',l')] + P[(j,l+1)][(j',l'+1)]     (nothing behind l = N - 1),
 //     C[r][c] = sum_g (w_g c_g^2) M_g[N-1][r] M_g[N-1][c]                 (the LAST row of every state)
 // -- K multiply-adds per element of P instead of the K N of the product (C4: 4 % of the matrix
-// core's work in the Toeplitz form above), which leaves a kernel that only has to WRITE: 5.9 MB per C4
-// instance, 80 % of it rows of G that are windows of the same table.  One workgroup per instance,
-// TB | zeros | d | parameters in LDS, no barrier behind the set-up; the wavefronts draw tickets:
+// core's work in the Toeplitz form above) -- and the gradient an adjoint recursion,
+//     q[(j,l)] = B[:,j] . lam_l,   lam_l = rho_l + A^T lam_{l+1},   rho_l[i] = sum_g (w_g c_g)(d_g[l] - aim_g)
+// (O(N n^2) instead of a correlation of the table with d - aim), which leaves a kernel that only has to
+// WRITE: 5.9 MB per C4 instance, 80 % of it rows of G that are windows of the same table.  One workgroup
+// per instance; LDS: d | parameters | lam | tickets | Tc, the table WITHOUT the zero halves of TB
+// (Tc[(i m + j) N + d] = T_ij[d]: 37 KB for C4 instead of 74; a column l > k of row k is masked by a
+// compare instead of read as a zero); no barrier behind the set-up.  Wavefront 0 runs the recursion
+// and writes q; then all draw tickets:
 //   * a row block of P (an input's N rows, from l = N - 1 down): lane = column of an input's block,
 //     its K weighted last-row values for every column block in registers, the row's K values by
-//     broadcast reads, the running sums shifted one lane per row -- 8 bytes per lane, 512-byte runs,
-//     a whole row of P per step;
+//     broadcast reads, the running sums shifted one lane per row (DPP) -- 8 bytes per lane, 512-byte
+//     runs, a whole row of P per step;
 //   * four rows of G: 16 bytes per lane straight out of the table times the row's arrow.
-// The gradient (a correlation of the table with s (d - aim): no recurrence) and h come first, out of
-// LDS; rows of G that are no single state row and unknowns outside the input blocks are composed
-// behind the tickets through the column tables (cold paths).
+// h comes first, out of LDS; rows of G that are no single state row and unknowns outside the input
+// blocks are composed behind the tickets through the column tables (cold paths).
 // ---------------------------------------------------------------------------
 constexpr int SCAN_GROUP = 4;     // rows of G per ticket
 constexpr int SCAN_GCH_MAX = 8;   // 128-column chunks of a row of G: no <= 1024
+constexpr int SCAN_AREG = 16;     // states up to which wavefront 0 keeps its column of A in registers
 
 #ifndef MPCASM_SCAN_DPP
 #define MPCASM_SCAN_DPP 1   // (tools/microbench/dpp_wave_shift.hip: wave_shl:1 is lane i <- lane i + 1, 0 into lane 63)
@@ -1080,11 +1085,30 @@ __device__ __forceinline__ double lane_from_next(double v) {
 #endif
 }
 
+// where things sit in the scan kernel's dynamic LDS (bytes); the table last, at least N doubles in:
+// a window that starts before its row's first step reads what lies in front (and is masked)
+struct ScanLds {
+  unsigned d, par, lam, ticket, tb, total;
+};
+__host__ __device__ inline ScanLds scan_lds(int dlen, int nparams, int n, int m, int N) {
+  ScanLds x;
+  x.d = 0;
+  x.par = x.d + (unsigned)dlen * 8u;
+  x.lam = x.par + (unsigned)((nparams + 2) & ~1) * 8u;
+  x.ticket = x.lam + (unsigned)((n * N + 1) & ~1) * 8u;
+  x.tb = x.ticket + 16u;
+  if (x.tb < (unsigned)N * 8u) x.tb = (unsigned)((N + 1) & ~1) * 8u;
+  x.total = x.tb + (unsigned)(n * m * N) * 8u;
+  return x;
+}
+
 template <int KP, int CB>
 __global__ __launch_bounds__(BLOCK, 2) void toeplitz_scan_kernel(
-    PlanDev p, SrcTable src, const double* __restrict__ params, const double* __restrict__ work,
-    long long work_stride, double* __restrict__ P, double* __restrict__ q, double* __restrict__ G,
-    double* __restrict__ h, int batch, int tbn, int nzero, int dlen, int whole_lines, int phases) {
+    PlanDev p, SrcTable src, const double* __restrict__ sysA, long long strideA,
+    const double* __restrict__ sysB, long long strideB, const double* __restrict__ params,
+    const double* __restrict__ work, long long work_stride, double* __restrict__ P,
+    double* __restrict__ q, double* __restrict__ G, double* __restrict__ h, int batch, int dlen,
+    int whole_lines, int phases) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1093,76 +1117,94 @@ __global__ __launch_bounds__(BLOCK, 2) void toeplitz_scan_kernel(
   const int no = p.no, nc = p.nc, K = p.t_scan, nblk = p.t_scan_nblk;
   const double* pb = params + (size_t)inst * p.nparams;
   const int32_t* grp = p.itab + p.off_t_lti;
-  const int N = grp[TL_HORIZON];
+  const int n = grp[TL_N], m = grp[TL_M], N = grp[TL_HORIZON];
   const int32_t* ids = p.itab + p.off_t_lti_ids + grp[TL_IDS];
   const int first_u = ids[0];
   const int2* blk = reinterpret_cast<const int2*>(p.itab + p.off_t_scan_blk);
   const int4* gts = reinterpret_cast<const int4*>(p.itab + p.off_t_scan_gt);
   const double* gcs = p.dtab + p.t_doff_scan_gc;
   const int32_t* colblk = p.itab + p.off_t_scan_colblk;
-  const unsigned tb_bytes = (unsigned)tbn * 8u;
-  const unsigned zero_off = tb_bytes, d_off = (unsigned)(tbn + nzero) * 8u;
-  const unsigned par_off = d_off + (unsigned)dlen * 8u;
-  const unsigned ticket_off = par_off + (unsigned)((p.nparams + 2) & ~1) * 8u;
-  int* ticket = reinterpret_cast<int*>(lds + ticket_off);
-  // ---- set-up: TB, zeros, d, parameters into LDS ---------------------------------------------
+  const ScanLds L = scan_lds(dlen, p.nparams, n, m, N);
+  int* ticket = reinterpret_cast<int*>(lds + L.ticket);
+  // ---- set-up: the table (the value halves of TB's rows), d, the parameters into LDS -------------
   {
     const char* tb = reinterpret_cast<const char*>(src.ptr[first_u] + inst * src.stride[first_u]);
     const unsigned lds0 = (unsigned)(uintptr_t)lds;
-    for (unsigned c0 = (unsigned)wave * 1024u; c0 < tb_bytes; c0 += WAVES * 1024u) {
-      const unsigned off = c0 + (unsigned)lane * 16u;
-      if (off < tb_bytes) lds_dma16(tb + off, __builtin_amdgcn_readfirstlane(lds0 + c0));
+    const unsigned half = (unsigned)N >> 1;                    // 16-byte pieces of a row (N is even)
+    const unsigned pieces = (unsigned)(n * m) * half;
+    for (unsigned e0 = (unsigned)wave * 64u; e0 < pieces; e0 += WAVES * 64u) {
+      const unsigned e = e0 + (unsigned)lane;
+      if (e < pieces) {
+        const unsigned r = e / half, x = e - r * half;
+        lds_dma16(tb + ((size_t)r * 2 * N + N) * 8 + x * 16u, __builtin_amdgcn_readfirstlane(lds0 + L.tb + e0 * 16u));
+      }
     }
     const char* dsrc = reinterpret_cast<const char*>(work + inst * work_stride);
-    const unsigned d_bytes = (unsigned)dlen * 8u, d0 = lds0 + d_off;
+    const unsigned d_bytes = (unsigned)dlen * 8u;
     for (unsigned c0 = (unsigned)wave * 1024u; c0 < d_bytes; c0 += WAVES * 1024u) {
       const unsigned off = c0 + (unsigned)lane * 16u;
-      if (off < d_bytes) lds_dma16(dsrc + off, __builtin_amdgcn_readfirstlane(d0 + c0));
+      if (off < d_bytes) lds_dma16(dsrc + off, __builtin_amdgcn_readfirstlane(lds0 + L.d + c0));
     }
-    double* z = reinterpret_cast<double*>(lds + zero_off);
-    for (int e = tid; e < nzero; e += BLOCK) z[e] = 0.0;
-    double* par = reinterpret_cast<double*>(lds + par_off);
+    double* par = reinterpret_cast<double*>(lds + L.par);
     for (int e = tid; e <= p.nparams; e += BLOCK) par[e] = e < p.nparams ? pb[e] : 0.0;  // ([nparams] reads 0.0)
     if (tid < 2) ticket[tid] = 0;  // (row blocks of P, groups of rows of G)
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's LDS-DMA loads have landed
   __syncthreads();
 
-  // ---- h, then the gradient: out of LDS ---------------------------------------------------------
+  // ---- h: (extreme + arrow . center) - arrow . d ---------------------------------------------------
   if (G != nullptr && (phases & 8)) {
     const int32_t* grow = p.itab + p.off_t_grow;
     const int32_t* rrw = p.itab + p.off_rs_rr;
-    for (int R = tid; R < nc; R += BLOCK) {  // h: (extreme + arrow . center) - arrow . d
+    for (int R = tid; R < nc; R += BLOCK) {
       const int32_t* x = rrw + (size_t)R * RS_RR_WORDS;
       double ac = 0.0, ad = 0.0;
       for (int ax = 0; ax < x[RR_NAXES]; ++ax) {
         const double ar = pb[x[RR_ARROW + ax]];
         ac += ar * pb[x[RR_CENTER + ax]];
-        ad = fma(ar, lds_f64(lds, d_off + (unsigned)grow[R * RS_AXMAX + ax] * 8u), ad);
+        ad = fma(ar, lds_f64(lds, L.d + (unsigned)grow[R * RS_AXMAX + ax] * 8u), ad);
       }
       h[(size_t)inst * nc + R] = (pb[x[RR_EXTREME]] + ac) - ad;
     }
   }
-  if (P != nullptr && (phases & 4)) {
-    // q[c] = sum_g (w_g c_g) sum_k (c_g TB[state g, row k, column c]) (d_g[k] - aim_g): d carries its
-    // c_g already; a thread per column, the K terms one after the other (wave-uniform scalars)
-    for (int c = tid; c < no; c += BLOCK) {
+  // ---- the gradient, by wavefront 0 while the others already draw tickets --------------------------
+  if (P != nullptr && (phases & 4) && wave == 0) {
+    const double* A = sysA + inst * strideA;
+    const double* Bm = sysB + inst * strideB;
+    // lane i < n: lam_l[i] = rho_l[i] + sum_t A[t][i] lam_{l+1}[t]; the table lam[i][l] in LDS
+    double acol[SCAN_AREG];
+    const bool in_regs = n <= SCAN_AREG;
+#pragma unroll
+    for (int t = 0; t < SCAN_AREG; ++t) acol[t] = (in_regs && t < n && lane < n) ? A[t * n + lane] : 0.0;
+    const unsigned per_state = (unsigned)(m * N);
+    for (int l = N - 1; l >= 0; --l) {
+      double acc = 0.0;
+      for (int g = 0; g < K; ++g) {   // rho_l: the terms on this lane's state
+        const int4 x = gts[g];
+        const double r = (pb[x.y] * gcs[g]) * (lds_f64(lds, L.d + (unsigned)(x.w + l) * 8u) - pb[x.z]);
+        acc += ((unsigned)x.x / per_state == (unsigned)lane) ? r : 0.0;
+      }
+      if (l + 1 < N) {
+        if (in_regs) {
+#pragma unroll
+          for (int t = 0; t < SCAN_AREG; ++t)
+            if (t < n) acc = fma(acol[t], lds_f64(lds, L.lam + (unsigned)(t * N + l + 1) * 8u), acc);
+        } else {
+          for (int t = 0; t < n; ++t)
+            acc = fma(lane < n ? A[t * n + lane] : 0.0, lds_f64(lds, L.lam + (unsigned)(t * N + l + 1) * 8u), acc);
+        }
+      }
+      if (lane < n) *reinterpret_cast<double*>(lds + L.lam + (unsigned)(lane * N + l) * 8u) = acc;
+      asm volatile("" ::: "memory");  // (a wavefront's LDS operations complete in order: the next step reads these)
+    }
+    for (int c = lane; c < no; c += 64) {   // q[(j, l)] = B[:, j] . lam_l + the diagonal terms
       const int b = colblk[c];
       double dP, dq;
       diagonal_of_column(p, pb, c, dP, dq);
       double acc = 0.0;
       if (b >= 0) {
-        const unsigned part = (unsigned)(blk[b].y - (c - blk[b].x)) * 8u;
-        for (int g = 0; g < K; ++g) {
-          const int4 x = gts[g];
-          const double cg = gcs[g], aim = pb[x.z];
-          const unsigned tb0 = (unsigned)x.x * 8u + part, d0 = d_off + (unsigned)x.w * 8u;
-          double part_sum = 0.0;
-          for (int k = 0; k < N; ++k)
-            part_sum = fma(lds_f64(lds, d0 + (unsigned)k * 8u) - aim, lds_f64(lds, tb0 + (unsigned)k * 8u),
-                           part_sum);
-          acc = fma((pb[x.y] * cg) * cg, part_sum, acc);
-        }
+        const int j = blk[b].y / N, l = c - blk[b].x;
+        for (int i = 0; i < n; ++i) acc = fma(Bm[i * m + j], lds_f64(lds, L.lam + (unsigned)(i * N + l) * 8u), acc);
       }
       q[(size_t)inst * no + c] = acc + dq;
     }
@@ -1171,20 +1213,20 @@ __global__ __launch_bounds__(BLOCK, 2) void toeplitz_scan_kernel(
   // ---- tickets, first round: the row blocks of P -------------------------------------------------
   double* Pb = P + (size_t)inst * no * no;
   if (P != nullptr && (phases & 2)) {
-    // where every term's state starts in TB (wave-uniform), and the lane's K weighted last-row values
-    // (w c^2) TB[state, row N - 1, the lane's column] in every column block (0 beyond its N columns)
+    // where every term's state starts in Tc (wave-uniform), and the lane's K weighted last-row values
+    // (w c^2) Tc[state, column block, N - 1 - lane] in every column block (0 beyond its N columns)
     unsigned sb8[KP];
     double Tl[CB][KP];
 #pragma unroll
     for (int g = 0; g < KP; ++g) {
       const int4 x = gts[g < K ? g : 0];
       const double cg = gcs[g < K ? g : 0];
-      sb8[g] = (unsigned)x.x * 8u;
+      sb8[g] = L.tb + (unsigned)x.x * 8u;
       const double wcc = (pb[x.y] * cg) * cg;
 #pragma unroll
       for (int s = 0; s < CB; ++s) {
         const bool live = s < nblk && g < K && lane < N;
-        const unsigned a = live ? sb8[g] + (unsigned)(N - 1 + blk[s < nblk ? s : 0].y - lane) * 8u : zero_off;
+        const unsigned a = live ? sb8[g] + (unsigned)(blk[s < nblk ? s : 0].y + N - 1 - lane) * 8u : L.tb;
         Tl[s][g] = live ? wcc * lds_f64(lds, a) : 0.0;
       }
     }
@@ -1201,7 +1243,7 @@ __global__ __launch_bounds__(BLOCK, 2) void toeplitz_scan_kernel(
       double run[CB];
 #pragma unroll
       for (int s = 0; s < CB; ++s) run[s] = 0.0;
-      const unsigned rowpart = (unsigned)(N - 1 + blk[bi].y) * 8u;
+      const unsigned rowpart = (unsigned)(blk[bi].y + N - 1) * 8u;
       for (int l = N - 1; l >= 0; --l) {
         double beta[KP];
 #pragma unroll
@@ -1230,23 +1272,29 @@ __global__ __launch_bounds__(BLOCK, 2) void toeplitz_scan_kernel(
   // ---- tickets, second round: rows of G, SCAN_GROUP at a time ------------------------------------
   double* Gb = G + (size_t)inst * nc * no;
   if (G != nullptr && (phases & 8)) {
-    // per lane: its two columns of every 128-column chunk of a row -- byte offset of the columns'
-    // part in TB (the zeros for a column of no input block)
+    // per lane: its two columns of every 128-column chunk of a row -- (j N - l) 8 + where Tc starts, and
+    // the column's step l (a row of step k holds zeros in l > k; a column of no input block: always)
     const int nch = (no + 127) >> 7;
-    const bool all_blocks = p.t_scan_nother == 0;  // (then no column needs the zeros: no select per read)
-    unsigned gp0[SCAN_GCH_MAX], gp1[SCAN_GCH_MAX];
+    int gp0[SCAN_GCH_MAX], gp1[SCAN_GCH_MAX], gl0[SCAN_GCH_MAX], gl1[SCAN_GCH_MAX];
 #pragma unroll
     for (int ch = 0; ch < SCAN_GCH_MAX; ++ch) {
-      gp0[ch] = gp1[ch] = all_blocks ? 0u : zero_off;  // (columns behind `no` are read, never stored)
+      gp0[ch] = gp1[ch] = (int)L.tb;
+      gl0[ch] = gl1[ch] = 0x7FFFFFFF;
       if (ch < nch) {
         const int c = ch * 128 + lane * 2;
         if (c < no) {
           const int b = colblk[c];
-          if (b >= 0) gp0[ch] = (unsigned)(blk[b].y - (c - blk[b].x)) * 8u;
+          if (b >= 0) {
+            gl0[ch] = c - blk[b].x;
+            gp0[ch] = (int)L.tb + (blk[b].y - gl0[ch]) * 8;
+          }
         }
         if (c + 1 < no) {
           const int b = colblk[c + 1];
-          if (b >= 0) gp1[ch] = (unsigned)(blk[b].y - (c + 1 - blk[b].x)) * 8u;
+          if (b >= 0) {
+            gl1[ch] = c + 1 - blk[b].x;
+            gp1[ch] = (int)L.tb + (blk[b].y - gl1[ch]) * 8;
+          }
         }
       }
     }
@@ -1271,17 +1319,17 @@ __global__ __launch_bounds__(BLOCK, 2) void toeplitz_scan_kernel(
       for (int rr = 0; rr < SCAN_GROUP; ++rr) {
         const int R = R0 + rr;
         if (R >= nc || rec[rr].x < 0) continue;
-        const unsigned u8 = (unsigned)rec[rr].x * 8u;
-        const double ar = lds_f64(lds, par_off + (unsigned)rec[rr].y * 8u);
+        const int u8 = rec[rr].x * 8;
+        const int k = rec[rr].x % N;   // (the row's step: i m N + k)
+        const double ar = lds_f64(lds, L.par + (unsigned)rec[rr].y * 8u) * cf[rr];
         double* grow_out = Gb + (size_t)R * no + lane * 2;
 #pragma unroll
         for (int ch = 0; ch < SCAN_GCH_MAX; ++ch) {
           if (ch >= nch) break;
-          const unsigned a0 = all_blocks ? gp0[ch] + u8 : (gp0[ch] < tb_bytes ? gp0[ch] + u8 : zero_off);
-          const unsigned a1 = all_blocks ? gp1[ch] + u8 : (gp1[ch] < tb_bytes ? gp1[ch] + u8 : zero_off);
+          const double t0 = lds_f64(lds, (unsigned)(gp0[ch] + u8)), t1 = lds_f64(lds, (unsigned)(gp1[ch] + u8));
           double2 v;
-          v.x = ar * (lds_f64(lds, a0) * cf[rr]);
-          v.y = ar * (lds_f64(lds, a1) * cf[rr]);
+          v.x = gl0[ch] <= k ? ar * t0 : 0.0;
+          v.y = gl1[ch] <= k ? ar * t1 : 0.0;
           if (ch * 128 + lane * 2 < no) {
             if (whole_lines)
               store_result(reinterpret_cast<double2*>(grow_out + ch * 128), v);
@@ -1412,37 +1460,46 @@ int launch_lti_tables(const PlanDev& p, const SrcTable& src, double* w, int batc
 namespace {
 
 template <int KP, int CB>
-int launch_scan_as(const PlanDev& p, const SrcTable& eff, const double* params, const double* w,
-                   long long stride, double* P, double* q, double* G, double* h, int batch, int tbn,
-                   int dlen, int whole_lines, size_t lds, hipStream_t stream, hipError_t* err) {
+int launch_scan_as(const PlanDev& p, const SrcTable& eff, const double* A, long long strideA,
+                   const double* Bm, long long strideB, const double* params, const double* w,
+                   long long stride, double* P, double* q, double* G, double* h, int batch, int dlen,
+                   int whole_lines, size_t lds, hipStream_t stream, hipError_t* err) {
   auto kernel = toeplitz_scan_kernel<KP, CB>;
-  *err = allow_whole_lds(reinterpret_cast<const void*>(kernel));
-  if (*err != hipSuccess) return MPCASM_ERR_HIP;
-  hipLaunchKernelGGL(kernel, dim3((unsigned)batch), dim3(BLOCK), lds, stream, p, eff, params, w, stride,
-                     P, q, G, h, batch, tbn, 2, dlen, whole_lines, g_phase_mask);
+  if (lds > 64 * 1024) {
+    *err = allow_whole_lds(reinterpret_cast<const void*>(kernel));
+    if (*err != hipSuccess) return MPCASM_ERR_HIP;
+  }
+  hipLaunchKernelGGL(kernel, dim3((unsigned)batch), dim3(BLOCK), lds, stream, p, eff, A, strideA, Bm, strideB,
+                     params, w, stride, P, q, G, h, batch, dlen, whole_lines, g_phase_mask);
   *err = hipGetLastError();
   if (*err == hipSuccess) t_last_kernel = MPCASM_KERNEL_TILED_SCAN;
   return *err == hipSuccess ? MPCASM_OK : MPCASM_ERR_HIP;
 }
 
 // the scan form for this plan, or MPCASM_ERR_LIMIT: no instantiation holds its K terms and column
-// blocks in registers, or an instance does not fit in LDS (the Toeplitz form takes it then)
-int launch_scan(const PlanDev& p, const SrcTable& eff, const double* params, const double* w,
-                long long stride, double* P, double* q, double* G, double* h, int batch, int tbn, int N,
+// blocks in registers, or an instance does not fit in LDS (the Toeplitz form takes it then).
+// `src`: the launch's own sources (the group's (A, B) in the slots of its first two), `eff`: with the
+// generated tables in the places of the group's U_j and S.
+int launch_scan(const PlanDev& p, const SrcTable& src, const SrcTable& eff, const double* params,
+                const double* w, long long stride, double* P, double* q, double* G, double* h, int batch,
                 const int32_t* h_itab, hipStream_t stream, hipError_t* err) {
   const int K = p.t_scan, nblk = p.t_scan_nblk;
-  if (p.no > 128 * SCAN_GCH_MAX) return MPCASM_ERR_LIMIT;
+  const int32_t* rec = h_itab + p.off_t_lti;
+  const int n = rec[TL_N], m = rec[TL_M], N = rec[TL_HORIZON];
+  if (p.no > 128 * SCAN_GCH_MAX || n > 64 || (N & 1)) return MPCASM_ERR_LIMIT;
   const int dlen = p.rtot + (p.rtot & 1);
-  const size_t lds = ((size_t)tbn + 2 + dlen + ((p.nparams + 2) & ~1)) * sizeof(double) + 16;
+  const size_t lds = scan_lds(dlen, p.nparams, n, m, N).total;
   if (lds + NSTREAM * sizeof(double*) > (size_t)RESIDENT_LDS_LIMIT) return MPCASM_ERR_LIMIT;
+  const int32_t* ids = h_itab + p.off_t_lti_ids + rec[TL_IDS];
   // results leave as whole 128-byte lines when every run of a wavefront's store starts and ends on one
   int whole = p.no % 16 == 0 && N % 16 == 0;
   const int32_t* blk = h_itab + p.off_t_scan_blk;
   for (int b = 0; b < nblk; ++b) whole = whole && blk[2 * b] % 16 == 0;
-#define MPCASM_SCAN_CASE(KP, CB)                                                                        \
-  if (K <= KP && nblk <= CB)                                                                           \
-    return launch_scan_as<KP, CB>(p, eff, params, w, stride, P, q, G, h, batch, tbn, dlen, whole, lds, \
-                                  stream, err);
+#define MPCASM_SCAN_CASE(KP, CB)                                                                          \
+  if (K <= KP && nblk <= CB)                                                                             \
+    return launch_scan_as<KP, CB>(p, eff, src.ptr[ids[0]], src.stride[ids[0]], src.ptr[ids[1]],           \
+                                  src.stride[ids[1]], params, w, stride, P, q, G, h, batch, dlen, whole, \
+                                  lds, stream, err);
   MPCASM_SCAN_CASE(4, 4)
   MPCASM_SCAN_CASE(8, 4)
   MPCASM_SCAN_CASE(4, 8)
@@ -1483,8 +1540,7 @@ int launch_assemble_tiled(const PlanDev& p, const SrcTable& src, const double* p
     const int tbn = rec[TL_N] * rec[TL_M] * 2 * rec[TL_HORIZON];
     if (p.t_scan > 0 && t_path != 4 && (rec[TL_TB] & 1) == 0 && (stride & 1) == 0) {
       // scan form: every Hessian term is the full horizon of one state -- P is a sum along diagonals
-      const int rc = launch_scan(p, eff, params, w, stride, P, q, G, h, batch, tbn, rec[TL_HORIZON],
-                                 h_itab, stream, err);
+      const int rc = launch_scan(p, src, eff, params, w, stride, P, q, G, h, batch, h_itab, stream, err);
       if (rc != MPCASM_ERR_LIMIT) return rc;
     }
     const int nzero = (std::max(rec[TL_HORIZON], 16) + 16 + 1) & ~1;  // (even: what follows stays 16-byte aligned)

@@ -17,7 +17,7 @@ import numpy as np
 import scipy.sparse as sp
 
 PLAN_MAGIC = 0x4D504341
-PLAN_VERSION = 26
+PLAN_VERSION = 27
 
 # header words (csrc/plan_tables.h, enum HeaderWord)
 _H = {name: i for i, name in enumerate([
@@ -43,6 +43,8 @@ _H = {name: i for i, name in enumerate([
     "T_NP1", "OFF_T_P1PTR", "OFF_T_P1ENT", "OFF_T_P2Y",
     "T_SCAN", "T_SCAN_NBLK", "OFF_T_SCAN_BLK", "OFF_T_SCAN_GT", "T_DOFF_SCAN_GC", "OFF_T_SCAN_GROW",
     "T_DOFF_SCAN_GCOEF", "T_SCAN_NGREST", "OFF_T_SCAN_GREST", "OFF_T_SCAN_COLBLK", "T_SCAN_NOTHER",
+    "SW_OK", "SW_N", "SW_M", "SW_HORIZON", "SW_SRC_A", "SW_SRC_B", "SW_NAXES", "OFF_SW_AXIS", "SW_NTERM",
+    "OFF_SW_TERM", "SW_NLIM", "OFF_SW_LIM", "OFF_SW_COL", "SW_DOFF_CVEC", "SW_NCVEC",
 ])}
 H_WORDS = 160
 assert len(_H) <= H_WORDS
@@ -87,6 +89,8 @@ TS_FLAG_P, TS_FLAG_HALF, TS_FLAG_SIMPLE_A, TS_FLAG_SIMPLE_B, TS_FLAG_SAME, TS_FL
 T_PIG_MAX = 2
 # scan form of the tiled kernel (csrc/tiled.hip toeplitz_scan_kernel, plan_tables.h T_SCAN*)
 T_SCAN_KMAX, T_SCAN_BLKMAX, T_SCAN_NMAX, T_SCAN_GT_WORDS = 16, 8, 64, 4
+# sweep kernel (csrc/sweep.hip, plan_tables.h SW_*): per-step dynamics, the Hessian by two recursions
+SW_NMAX, SW_MMAX, SW_AXMAX, SW_AXIS_WORDS, SW_TERM_WORDS, SW_LIM_WORDS, SW_LAX_WORDS = 4, 4, 4, 8, 8, 8, 8
 
 
 class Source:
@@ -1293,11 +1297,12 @@ def _scan_tables(b, gterms, rowptr, entbase, entk, entcoef, groups, g_rows, tile
     obeys ``P[(j,l)][(j',l')] = C[(j,l)][(j',l')] + P[(j,l+1)][(j',l'+1)]`` with the rank-K term
     ``C[r][c] = sum_g w_g c_g^2 M_g[N-1][r] M_g[N-1][c]`` (the last row of every state) and nothing
     behind l = N-1: the Hessian is a sum along diagonals, O(K) multiply-adds per element instead
-    of the O(K N) of the product.  The tables: the column blocks ``(first column, j 2N + N)`` of
-    the inputs that are unknowns, the K terms ``(state's offset in TB, weight slot, aim slot, first
-    row of d)`` with their coefficients, and per row of G ``(state's offset in TB + k, arrow slot)``
-    with its coefficient when the row is ``arrow * c * (row k of a state)`` (else -1: the row is
-    composed through the column tables behind the rest)."""
+    of the O(K N) of the product.  The kernel keeps the table without its zero halves,
+    ``Tc[(i m + j) N + d] = T_ij[d]``.  The tables: the column blocks ``(first column, j N)`` of the
+    inputs that are unknowns, the K terms ``(i m N, weight slot, aim slot, first row of d)`` with their
+    coefficients, and per row of G ``(i m N + k, arrow slot)`` with its coefficient when the row is
+    ``arrow * c * (row k of state i)`` (else -1: the row is composed through the column tables behind
+    the rest)."""
     nc, no, ng = len(g_rows), b.no, b.ng
     off = dict(ok=0, K=0, blk=np.zeros((0, 2), np.int64), gt=np.zeros((0, T_SCAN_GT_WORDS), np.int64),
                gc=np.zeros(0), grow=np.zeros((0, 2), np.int64), gcoef=np.zeros(0),
@@ -1333,7 +1338,7 @@ def _scan_tables(b, gterms, rowptr, entbase, entk, entcoef, groups, g_rows, tile
         st, c = rows[0][0], rows[0][2]
         if any(x != (st, k, c) for k, x in enumerate(rows)):
             return off
-        gt.append([st * m * 2 * N, wparam, aimparam, doff])
+        gt.append([st * m * N, wparam, aimparam, doff])
         gc.append(c)
     if not 1 <= len(gt) <= T_SCAN_KMAX:
         return off
@@ -1352,7 +1357,7 @@ def _scan_tables(b, gterms, rowptr, entbase, entk, entcoef, groups, g_rows, tile
         if np.any(colblk[dst0 - ng:dst0 - ng + N] >= 0):
             return off
         colblk[dst0 - ng:dst0 - ng + N] = len(blk)
-        blk.append([dst0 - ng, j * 2 * N + N])
+        blk.append([dst0 - ng, j * N])
     if not 1 <= len(blk) <= T_SCAN_BLKMAX:
         return off
     grow, gcoef, grest = -np.ones((nc, 2), dtype=np.int64), np.zeros(nc), []
@@ -1361,12 +1366,134 @@ def _scan_tables(b, gterms, rowptr, entbase, entk, entcoef, groups, g_rows, tile
         if x is None:
             grest.append(R)
             continue
-        grow[R] = (x[0] * m * 2 * N + x[1], axes[0][1])
+        grow[R] = (x[0] * m * N + x[1], axes[0][1])
         gcoef[R] = x[2]
     return dict(ok=1, K=len(gt), blk=np.asarray(blk, dtype=np.int64),
                 gt=np.asarray(gt, dtype=np.int64), gc=np.asarray(gc, dtype=np.float64), grow=grow,
                 gcoef=gcoef, grest=np.asarray(grest, dtype=np.int64), colblk=colblk,
                 nother=int((colblk < 0).sum()))
+
+
+def _sweep_tables(b, gterms, limit_recs, lax_recs, rowptr, entbase, entk, entcoef, group, nparams):
+    """Tables of the sweep kernel (csrc/sweep.hip, plan_tables.h SW_*) for a dynamics compiled as
+    ``ltv``: ``x+ = A_k x + B_k u`` with its own ``(A_k, B_k)`` per step and instance.  The kernel never
+    forms a horizon matrix; with ``Phi(k, l) = A_k ... A_l`` (identity for ``l > k``) row k of an
+    output ``c . x`` is ``c^T Phi(k, l+1) B_l`` in the columns of step l <= k (tools.py:27-31 with
+    per-step matrices), and
+
+        P[(j,l)][(j',l')] = B_l[:,j]^T Psi_l U[l][l'][:,j']            (l' <= l; the mirror image above)
+        Psi_l = W_l + A_{l+1}^T Psi_{l+1} A_{l+1},   W_l = sum of w c c^T over the cost rows of step l
+        q[(j,l)] = B_l[:,j]^T lam_l,   lam_l = rho_l + A_{l+1}^T lam_{l+1},   rho_l = sum w (d - aim) c
+
+    -- O(n) multiply-adds per element of P and G, every row written once.  What the plan has to be
+    for that: one such system (any number of axes sharing it), every unknown an input of it, every
+    given value an initial state of it, every row of a cost or limit a fixed combination ``c`` of
+    the states of ONE step and one axis, the steps of a row-set an arithmetic progression, no
+    crossed cost.  Returns ``(tables, None)`` or ``(None, why not)``."""
+    ng, no = b.ng, b.no
+    n, m, N = group["n"], group["m"], group["N"]
+    if n > SW_NMAX or m > SW_MMAX:
+        return None, "more than %d states or %d inputs" % (SW_NMAX, SW_MMAX)
+    state_of = b.lti_state_of(group)
+    u_ids, s_id = group["ids"][:m], group["ids"][m]
+    # axes: the bases of the group by the given columns of their initial state
+    axis_of_x0, axes, base_axis = {}, [], {}
+    for var, bid in b.base_ids.items():
+        if bid not in state_of:
+            continue
+        segs = [b.segments[sg] for sg in sorted(set(int(x) for x in b.colseg[bid] if x >= 0))]
+        x0 = [sg for sg in segs if sg[0] == s_id]
+        ins = {sg[0]: sg for sg in segs if sg[0] in u_ids}
+        if len(x0) != 1 or len(ins) != m or len(segs) != m + 1:
+            return None, "a state of the system reads something else than its S and U_j"
+        x0c, blocks = x0[0][4], [ins[sid][4] for sid in u_ids]
+        if x0c >= ng or x0[0][5] != n or any(c < ng or ins[sid][5] != N for c, sid in zip(blocks, u_ids)):
+            return None, "the initial state must be given and every input an unknown of N steps"
+        rec = [x0c] + [c - ng for c in blocks]
+        if x0c not in axis_of_x0:
+            axis_of_x0[x0c] = len(axes)
+            axes.append(rec)
+        elif axes[axis_of_x0[x0c]] != rec:
+            return None, "states of one axis with different columns"
+        base_axis[bid] = axis_of_x0[x0c]
+    if not 1 <= len(axes) <= SW_AXMAX:
+        return None, "no axis, or more than %d" % SW_AXMAX
+    col = -np.ones(no, dtype=np.int64)
+    for a, rec in enumerate(axes):
+        for j, c0 in enumerate(rec[1:]):
+            if np.any(col[c0:c0 + N] >= 0):
+                return None, "overlapping input columns"
+            col[c0:c0 + N] = a | (j << 8) | (np.arange(N) << 16)
+    if np.any(col < 0) or ng != n * len(axes) or sorted(r[0] for r in axes) != list(range(0, ng, n)):
+        return None, "unknowns that are no input of the system, or given values that are no initial state"
+    cvecs = []
+
+    def rowset(row0, count, rs):
+        """(axis, k0, kstep, cvec offset) of workspace rows row0 .. (one row for every line when rs == 1)."""
+        rows = [row0] if rs == 1 else list(range(row0, row0 + count))
+        info = []
+        for r in rows:
+            e0, e1 = rowptr[r], rowptr[r + 1]
+            if e1 == e0:
+                return None
+            bids, ks = entbase[e0:e1], entk[e0:e1]
+            if any(int(x) not in state_of for x in bids) or len(set(int(k) for k in ks)) != 1:
+                return None
+            ax = {base_axis[int(x)] for x in bids}
+            if len(ax) != 1:
+                return None
+            c = np.zeros(n)
+            for x, cf in zip(bids, entcoef[e0:e1]):
+                c[state_of[int(x)]] += cf
+            info.append((ax.pop(), int(ks[0]), c))
+        a, k0, c = info[0]
+        kstep = info[1][1] - k0 if len(info) > 1 else 0
+        for i, (ai, ki, ci) in enumerate(info):
+            if ai != a or ki != k0 + i * kstep or not np.array_equal(ci, c):
+                return None
+        if not (0 <= k0 < N and 0 <= k0 + (len(info) - 1) * kstep < N):
+            return None
+        cvecs.append(c)
+        return a, k0, (0 if rs == 1 else kstep), (len(cvecs) - 1) * SW_NMAX
+
+    terms = []
+    for g in gterms:
+        aoff, boff, nrows, wparam, doff, aimparam, flags = g[:7]
+        if flags & GT_FLAG_DIAG:
+            continue
+        if flags != GT_FLAG_P or aoff != boff or doff != aoff:
+            return None, "a crossed cost"
+        info = rowset(aoff, nrows, nrows)
+        if info is None:
+            return None, "a cost whose rows are no fixed combination of one step's states"
+        terms.append([info[0], info[1], info[2], nrows, wparam, aimparam, info[3], 0])
+    lims = []
+    for out0, nrows, naxes, lax0, p_a, a_rows, p_c, c_rows, p_e, e_rows, *_ in limit_recs:
+        if naxes > SW_AXMAX:
+            return None, "a limit over more than %d axes" % SW_AXMAX
+        rec = [out0, nrows, naxes, p_e, int(e_rows != 1), 0, 0, 0]
+        for ax in range(SW_AXMAX):
+            if ax >= naxes:
+                rec += [0] * SW_LAX_WORDS
+                continue
+            off, rs = lax_recs[lax0 + ax]
+            info = rowset(off, nrows, rs)
+            if info is None:
+                return None, "a limit whose rows are no fixed combination of one step's states"
+            rec += [info[0], info[1], info[2], info[3], p_a + ax, (0 if a_rows == 1 else naxes),
+                    p_c + ax, (0 if c_rows == 1 else naxes)]
+        lims.append(rec)
+    cv = np.zeros((len(cvecs), SW_NMAX))
+    for i, c in enumerate(cvecs):
+        cv[i, :n] = c
+    axis_tab = np.zeros((len(axes), SW_AXIS_WORDS), dtype=np.int64)
+    for a, rec in enumerate(axes):
+        axis_tab[a, 0] = rec[0]
+        axis_tab[a, 1:1 + m] = rec[1:]
+    return dict(n=n, m=m, N=N, src_a=group["ids"][0], src_b=group["ids"][1], axes=axis_tab,
+                terms=np.asarray(terms, dtype=np.int64).reshape(-1, SW_TERM_WORDS),
+                lims=np.asarray(lims, dtype=np.int64).reshape(-1, SW_LIM_WORDS + SW_AXMAX * SW_LAX_WORDS),
+                col=col, cvec=cv.reshape(-1)), None
 
 
 def _structural_patterns(form, b, fused, gterms, limit_recs, lax_recs, rtot, ldv, no, nc, groups=()):
@@ -1426,7 +1553,7 @@ def csc_pattern(mask, upper=False):
     return indptr, rows_sorted.astype(np.int32), flat
 
 
-def compile_plan(form, costs=None, limits=None, lti=(), csc=None, workspace="auto"):
+def compile_plan(form, costs=None, limits=None, lti=(), csc=None, workspace="auto", ltv=()):
     """Compile ``form`` (an up-to-date Formulation: sizes and IDs current).
 
     ``costs``: dict name -> Cost to include (default ``form.goals``);
@@ -1435,6 +1562,12 @@ def compile_plan(form, costs=None, limits=None, lti=(), csc=None, workspace="aut
     ``lti``: names of ExtendedSystem dynamics whose horizon matrices the assembly kernel
     generates on chip from per-instance ``(A, B)`` instead of reading ``S, U`` (K1 fused into
     the assembly; only the persistent kernel can run such a plan);
+    ``ltv``: ONE name of an ExtendedSystem whose dynamics differ from step to step and instance to
+    instance, ``x+ = A_k x + B_k u`` (BASELINE config C5): the sweep kernel (csrc/sweep.hip) takes
+    ``A (N, n, n)``, ``B (N, n, m)`` per instance and assembles without forming a horizon matrix
+    (:func:`_sweep_tables` states what the formulation has to be for that; ValueError otherwise).
+    The reference has no such path (``dynamics.py:222-231`` re-extends ONE pair per tick): pinned to
+    it where all steps share one pair;
     ``csc``: ``"upper"`` or ``"full"`` -- the plan's assembly writes, instead of dense P and G,
     the ``data`` arrays of their CSC forms on the structural pattern (P: its upper triangle /
     all of it), what ``scipy.sparse.csc_matrix(Q)``, ``csc_matrix(A)`` hand the solver in
@@ -1568,6 +1701,14 @@ def compile_plan(form, costs=None, limits=None, lti=(), csc=None, workspace="aut
         rec[7] = mask(rec[0], rec[2])
         rec[8] = mask(rec[1], rec[2]) if rec[1] >= 0 else 0
     groups = _lti_groups(form, b.sources, lti)
+    sweep = None
+    if ltv:
+        if len(tuple(ltv)) != 1 or lti or csc is not None:
+            raise ValueError("ltv: one dynamics name, without lti= or csc=")
+        sweep, why = _sweep_tables(b, gterms, limit_recs, lax_recs, rowptr, entbase, entk, entcoef,
+                                   _lti_groups(form, b.sources, ltv)[0], len(b.params))
+        if sweep is None:
+            raise ValueError("dynamics %r cannot be assembled step by step: %s" % (tuple(ltv)[0], why))
     image = _resident_image(b.sources, b.ng, len(b.params), groups)
     # The persistent kernel's workspace: dense, or -- a wide problem whose row-sets each live in a
     # part of the columns -- compact, when that is what lets a second workgroup share the CU's LDS.
@@ -1834,6 +1975,12 @@ def compile_plan(form, costs=None, limits=None, lti=(), csc=None, workspace="aut
     sections += [("OFF_T_P1PTR", np.asarray(p1ptr, dtype=np.int32)),
                  ("OFF_T_P1ENT", p1ent.astype(np.uint32).view(np.int32).reshape(-1)),
                  ("OFF_T_P2Y", p2y.astype(np.int32))]
+    sw_empty = dict(axes=np.zeros(0), terms=np.zeros(0), lims=np.zeros(0), col=np.zeros(0), cvec=np.zeros(0))
+    sw = sweep or sw_empty
+    sections += [("OFF_SW_AXIS", np.asarray(sw["axes"]).astype(np.int32).reshape(-1)),
+                 ("OFF_SW_TERM", np.asarray(sw["terms"]).astype(np.int32).reshape(-1)),
+                 ("OFF_SW_LIM", np.asarray(sw["lims"]).astype(np.int32).reshape(-1)),
+                 ("OFF_SW_COL", np.asarray(sw["col"]).astype(np.int32).reshape(-1))]
     sections += [("OFF_T_SCAN_BLK", scan["blk"].astype(np.int32).reshape(-1)),
                  ("OFF_T_SCAN_GT", scan["gt"].astype(np.int32).reshape(-1)),
                  ("OFF_T_SCAN_GROW", scan["grow"].astype(np.int32).reshape(-1)),
@@ -1855,7 +2002,7 @@ def compile_plan(form, costs=None, limits=None, lti=(), csc=None, workspace="aut
         if name in ("OFF_RS_RR", "OFF_RS_INMETA", "OFF_RS_ABMETA", "OFF_RS_DPAR",
                     "OFF_RS_GDESC", "OFF_RS_GFIX", "OFF_CSC_G", "OFF_T_CIG", "OFF_T_CIO", "OFF_T_P1ENT",
                     "OFF_T_STAGE", "OFF_T_GROW", "OFF_T_SROW", "OFF_T_PIG", "OFF_T_SCAN_BLK",
-                    "OFF_T_SCAN_GT", "OFF_T_SCAN_GROW") and off & 3:   # ... 16-byte quads
+                    "OFF_T_SCAN_GT", "OFF_T_SCAN_GROW", "OFF_SW_AXIS", "OFF_SW_TERM", "OFF_SW_LIM") and off & 3:   # ... 16-byte quads
             pad = 4 - (off & 3)
             parts.append(np.zeros(pad, dtype=np.int32))
             off += pad
@@ -1890,6 +2037,16 @@ def compile_plan(form, costs=None, limits=None, lti=(), csc=None, workspace="aut
     dparts.append(scan["gc"])
     header[_H["T_DOFF_SCAN_GCOEF"]] = header[_H["T_DOFF_SCAN_GC"]] + scan["gc"].size
     dparts.append(scan["gcoef"])
+    header[_H["SW_DOFF_CVEC"]] = header[_H["T_DOFF_SCAN_GCOEF"]] + scan["gcoef"].size
+    header[_H["SW_DOFF_CVEC"]] += header[_H["SW_DOFF_CVEC"]] & 1          # (read as 16-byte pairs)
+    dparts.append(np.zeros(int(header[_H["SW_DOFF_CVEC"]]) - sum(part.size for part in dparts)))
+    dparts.append(np.asarray(sw["cvec"], dtype=np.float64))
+    header[_H["SW_NCVEC"]] = np.asarray(sw["cvec"]).size // SW_NMAX
+    if sweep is not None:
+        header[_H["SW_OK"]], header[_H["SW_N"]], header[_H["SW_M"]] = 1, sweep["n"], sweep["m"]
+        header[_H["SW_HORIZON"]], header[_H["SW_NAXES"]] = sweep["N"], sweep["axes"].shape[0]
+        header[_H["SW_SRC_A"]], header[_H["SW_SRC_B"]] = sweep["src_a"], sweep["src_b"]
+        header[_H["SW_NTERM"]], header[_H["SW_NLIM"]] = sweep["terms"].shape[0], sweep["lims"].shape[0]
     header[_H["T_SCAN"]] = scan["K"] if scan["ok"] else 0
     header[_H["T_SCAN_NBLK"]], header[_H["T_SCAN_NGREST"]] = scan["blk"].shape[0], scan["grest"].size
     header[_H["T_SCAN_NOTHER"]] = scan["nother"]
@@ -1957,6 +2114,9 @@ def compile_plan(form, costs=None, limits=None, lti=(), csc=None, workspace="aut
     plan.P_pattern, plan.G_pattern = P_pattern, G_pattern
     plan.csc = csc_info
     plan.lti = [dict(name=g["name"], n=g["n"], m=g["m"], N=g["N"], ids=list(g["ids"])) for g in groups]
+    plan.ltv = ([dict(name=tuple(ltv)[0], n=sweep["n"], m=sweep["m"], N=sweep["N"],
+                      ids=[sweep["src_a"], sweep["src_b"]])] if sweep is not None else [])
+    plan.sweep = sweep
     plan.tiled = tiled
     # Sources (U_j read from memory) whose zeros above the diagonal some table of this plan relies
     # on -- the tile masks and stage classes of the tiled kernel, the CSC patterns: whatever is

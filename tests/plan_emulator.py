@@ -677,6 +677,10 @@ def run_scan(plan, given, params=None, ab=None):
     ids = _section(it, "OFF_T_LTI_IDS", lti[3] + m + 1)[lti[3]:]
     tb = _tiled_streams(plan, [s.array for s in plan.sources], ab)[ids[0]]
     assert tb.size == n * m * 2 * N
+    tb = np.ascontiguousarray(tb.reshape(n * m, 2 * N)[:, N:]).ravel()     # Tc: without the zero halves
+
+    def at(i):                       # Tc[i], 0 where the window leaves the row towards negative steps
+        return tb[np.maximum(i, 0)]
     nblk = int(it[H["T_SCAN_NBLK"]])
     blk = _section(it, "OFF_T_SCAN_BLK", nblk * 2).reshape(nblk, 2)
     gt = _section(it, "OFF_T_SCAN_GT", K * P.T_SCAN_GT_WORDS).reshape(K, P.T_SCAN_GT_WORDS)
@@ -684,7 +688,7 @@ def run_scan(plan, given, params=None, ab=None):
     colblk = _section(it, "OFF_T_SCAN_COLBLK", no)
     assert int((colblk < 0).sum()) == it[H["T_SCAN_NOTHER"]]
     for bx, (c0, pbase) in enumerate(blk):
-        assert (colblk[c0:c0 + N] == bx).all() and (pbase - N) % (2 * N) == 0
+        assert (colblk[c0:c0 + N] == bx).all() and pbase % N == 0
     lane = np.arange(N)
 
     def last_row(g, bx):            # M_g[N-1][columns of block bx] / c_g: TB[sboff + N-1 + pbase - l]
@@ -710,8 +714,21 @@ def run_scan(plan, given, params=None, ab=None):
             w, aim, drow = params[gt[g, 1]], params[gt[g, 2]], gt[g, 3]
             for k in range(N):
                 r = w * (d[drow + k] - aim)                  # (d carries the term's coefficient already)
-                acc += r * (gc[g] * tb[gt[g, 0] + k + blk[bx, 1] - lane])
+                acc += r * (gc[g] * np.where(lane <= k, at(gt[g, 0] + k + blk[bx, 1] - lane), 0.0))
         q[blk[bx, 0]:blk[bx, 0] + N] = acc
+    # ... and as the kernel does it: lam_l = rho_l + A^T lam_{l+1}, rho_l[i] = sum over the terms on
+    # state i of (w c)(d[l] - aim), q[(j, l)] = B[:, j] . lam_l -- O(N n^2) instead of a correlation
+    Am, Bm = (np.asarray(x, dtype=float) for x in ab[0])
+    lam, q_rec = np.zeros(n), np.zeros(no)
+    for l in range(N - 1, -1, -1):
+        rho = np.zeros(n)
+        for g in range(K):
+            rho[gt[g, 0] // (m * N)] += (params[gt[g, 1]] * gc[g]) * (d[gt[g, 3] + l] - params[gt[g, 2]])
+        lam = rho + Am.T @ lam
+        for bx in range(nblk):
+            q_rec[blk[bx, 0] + l] = Bm[:, blk[bx, 1] // N] @ lam
+    assert np.abs(q_rec - q).max() <= 1e-12 * max(np.abs(q).max(), 1e-300), "gradient by the adjoint recursion"
+    q = q_rec
     gtab = _section(it, "OFF_GTERM", it[H["NGTERM"]] * P.GT_WORDS).reshape(-1, P.GT_WORDS)
     for a, b, nn, pw, dd, pa, flags, _ma, _mb, _pad in gtab:
         if flags & P.GT_FLAG_DIAG:
@@ -730,5 +747,7 @@ def run_scan(plan, given, params=None, ab=None):
             continue
         assert R not in grest
         for bx in range(nblk):
-            G[R, blk[bx, 0]:blk[bx, 0] + N] = prm0[grow[R, 1]] * (gcoef[R] * tb[grow[R, 0] + blk[bx, 1] - lane])
+            k = grow[R, 0] % N                           # (the row's step: columns l > k hold zeros)
+            G[R, blk[bx, 0]:blk[bx, 0] + N] = prm0[grow[R, 1]] * (
+                gcoef[R] * np.where(lane <= k, at(grow[R, 0] + blk[bx, 1] - lane), 0.0))
     return {"P": Pm, "q": q, "G": G, "h": ref["h"], "ref": ref}
