@@ -99,6 +99,18 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def _rendezvous_port(world):
+    """A port of its own only for a world of ONE rank (--dist-at-world-1): with several ranks every
+    rank must be told the same one by the launcher -- a default picked per rank would make
+    init_process_group hang until it times out instead of failing at once."""
+    if "MASTER_PORT" in os.environ:
+        return
+    if world > 1:
+        raise SystemExit("bench.py: %d ranks but no MASTER_PORT in the environment (start the ranks with "
+                         "torch.distributed.run, or let `bench.py --gpus N` start them)" % world)
+    os.environ["MASTER_PORT"] = str(_free_port())
+
+
 def launch_ranks(args, argv):
     """Start ``args.gpus`` ranks of this script as child processes (one per GPU) and wait.
     The parent never initialises the GPU -- it counts devices from the kernel driver's topology,
@@ -488,7 +500,7 @@ def run_stub(args, world, rank):
         sys.exit(3)
     use_dist = world > 1 or args.dist_at_world_1
     if use_dist:
-        os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        _rendezvous_port(world)
         dist.init_process_group(args.backend, rank=rank, world_size=world)
     B, no, nc = args.batch, 36, 76
     lo, hi = mdist.shard_bounds(world * B, world, rank)
@@ -541,7 +553,7 @@ def run_rank(args):
     if world > 1 or args.dist_at_world_1:
         import torch.distributed as dist
 
-        os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        _rendezvous_port(world)
         kw = {}
         if args.backend == "nccl":
             # (the rank's own GPU by name: RCCL otherwise guesses it from the global rank)

@@ -50,6 +50,81 @@ bool in_range(int64_t off, int64_t len, int64_t n, int64_t lo) {
   return off >= lo && len >= 0 && off + len <= n;
 }
 
+// the sweep kernel's tables (H_SW_OK): every column, parameter slot, step and combination it reads
+int validate_sweep(const int32_t* it, int64_t n, int64_t nd) {
+  if (it[H_SW_OK] & ~1) return MPCASM_ERR_PLAN;
+  if (!it[H_SW_OK]) return MPCASM_OK;
+  const int64_t sn = it[H_SW_N], sm = it[H_SW_M], N = it[H_SW_HORIZON], naxes = it[H_SW_NAXES];
+  const int64_t ng = it[H_NG], no = it[H_NO], nc = it[H_NC], nparams = it[H_NPARAMS], nsrc = it[H_NSRC];
+  const int64_t nterm = it[H_SW_NTERM], nlim = it[H_SW_NLIM], ncv = it[H_SW_NCVEC];
+  constexpr int64_t LIMW = SW_LIM_WORDS + SW_AXMAX * SW_LAX_WORDS;
+  if (sn < 1 || sn > SW_NMAX || sm < 1 || sm > SW_MMAX || N < 1 || N > 32767 || naxes < 1 || naxes > SW_AXMAX ||
+      it[H_SW_SRC_A] < 0 || it[H_SW_SRC_A] >= nsrc || it[H_SW_SRC_B] < 0 || it[H_SW_SRC_B] >= nsrc ||
+      it[H_SW_SRC_A] == it[H_SW_SRC_B] || nterm < 0 || nlim < 0 || ncv < 0 ||
+      !in_range(it[H_OFF_SW_AXIS], naxes * SW_AXIS_WORDS, n, H_WORDS) ||
+      !in_range(it[H_OFF_SW_TERM], nterm * SW_TERM_WORDS, n, H_WORDS) ||
+      !in_range(it[H_OFF_SW_LIM], nlim * LIMW, n, H_WORDS) || !in_range(it[H_OFF_SW_COL], no, n, H_WORDS) ||
+      !in_range(it[H_SW_DOFF_CVEC], ncv * SW_NMAX, nd, 0) ||
+      !in_range(it[H_OFF_RS_DPAR], no * 2 * RS_DIAG_MAX, n, H_WORDS) || it[H_OFF_RS_DPAR] % 4 ||
+      !in_range(it[H_DOFF_RS_DCOEF], no * RS_DIAG_MAX, nd, 0) || it[H_DOFF_RS_DCOEF] % 2)
+    return MPCASM_ERR_PLAN;
+  const int32_t* ax = it + it[H_OFF_SW_AXIS];
+  const int32_t* col = it + it[H_OFF_SW_COL];
+  std::vector<char> seen(std::max<int64_t>(no, 1), 0);
+  for (int64_t a = 0; a < naxes; ++a) {
+    if (ax[a * SW_AXIS_WORDS] < 0 || ax[a * SW_AXIS_WORDS] + sn > ng) return MPCASM_ERR_PLAN;
+    for (int64_t j = 0; j < sm; ++j) {
+      const int64_t c0 = ax[a * SW_AXIS_WORDS + 1 + j];
+      if (c0 < 0 || c0 + N > no) return MPCASM_ERR_PLAN;
+      for (int64_t l = 0; l < N; ++l) {
+        if (seen[c0 + l] || col[c0 + l] != (int32_t)(a | (j << 8) | (l << 16))) return MPCASM_ERR_PLAN;
+        seen[c0 + l] = 1;
+      }
+    }
+  }
+  for (int64_t c = 0; c < no; ++c)
+    if (!seen[c]) return MPCASM_ERR_PLAN;  // every unknown is an input of the system
+  auto steps_ok = [&](int64_t k0, int64_t ks, int64_t cnt) {
+    return cnt >= 1 && k0 >= 0 && k0 < N && k0 + (cnt - 1) * ks >= 0 && k0 + (cnt - 1) * ks < N;
+  };
+  auto slot_ok = [&](int64_t slot, int64_t step, int64_t cnt) {
+    return slot >= 0 && step >= 0 && slot + (cnt - 1) * step < nparams;
+  };
+  const int32_t* tr = it + it[H_OFF_SW_TERM];
+  for (int64_t t = 0; t < nterm; ++t, tr += SW_TERM_WORDS)
+    if (tr[ST_AXIS] < 0 || tr[ST_AXIS] >= naxes || !steps_ok(tr[ST_K0], tr[ST_KSTEP], tr[ST_COUNT]) ||
+        tr[ST_WPARAM] < 0 || tr[ST_WPARAM] >= nparams || tr[ST_AIMPARAM] < 0 || tr[ST_AIMPARAM] >= nparams ||
+        tr[ST_CVEC] < 0 || tr[ST_CVEC] % SW_NMAX || tr[ST_CVEC] / SW_NMAX >= ncv)
+      return MPCASM_ERR_PLAN;
+  std::vector<char> line(std::max<int64_t>(nc, 1), 0);
+  const int32_t* lm = it + it[H_OFF_SW_LIM];
+  for (int64_t t = 0; t < nlim; ++t, lm += LIMW) {
+    const int64_t out0 = lm[SL_OUT0], cnt = lm[SL_COUNT], nax = lm[SL_NAXES];
+    if (out0 < 0 || cnt < 1 || out0 + cnt > nc || nax < 1 || nax > SW_AXMAX ||
+        !slot_ok(lm[SL_EXTREME], lm[SL_EXTREME_STEP], cnt))
+      return MPCASM_ERR_PLAN;
+    for (int64_t i = 0; i < cnt; ++i) {
+      if (line[out0 + i]) return MPCASM_ERR_PLAN;
+      line[out0 + i] = 1;
+    }
+    for (int64_t a = 0; a < nax; ++a) {
+      const int32_t* x = lm + SW_LIM_WORDS + a * SW_LAX_WORDS;
+      const int32_t* x0 = lm + SW_LIM_WORDS;
+      if (x[SX_AXIS] < 0 || x[SX_AXIS] >= naxes || !steps_ok(x[SX_K0], x[SX_KSTEP], cnt) ||
+          x[SX_K0] != x0[SX_K0] || x[SX_KSTEP] != x0[SX_KSTEP] ||       // (a line's axes: one step)
+          x[SX_CVEC] < 0 || x[SX_CVEC] % SW_NMAX || x[SX_CVEC] / SW_NMAX >= ncv ||
+          !slot_ok(x[SX_ARROW], x[SX_ARROW_STEP], cnt) || !slot_ok(x[SX_CENTER], x[SX_CENTER_STEP], cnt))
+        return MPCASM_ERR_PLAN;
+    }
+  }
+  for (int64_t R = 0; R < nc; ++R)
+    if (!line[R]) return MPCASM_ERR_PLAN;  // every line of G, h is written
+  const int32_t* dp = it + it[H_OFF_RS_DPAR];
+  for (int64_t i = 0; i < no * 2 * RS_DIAG_MAX; ++i)
+    if (dp[i] < 0 || dp[i] > nparams) return MPCASM_ERR_PLAN;
+  return MPCASM_OK;
+}
+
 // the column tables (H_T_CI_OK) and the tiled program (H_T_OK): every stream, offset and row a
 // kernel of tiled.hip derives from them stays inside its table
 int validate_tiled(const int32_t* it, const double* h_dtab, int64_t n, int64_t nd) {
@@ -763,6 +838,8 @@ int validate_plan(const int32_t* it, const double* h_dtab, size_t n_itab, size_t
   {
     const int vrc = validate_tiled(it, h_dtab, n, nd);
     if (vrc != MPCASM_OK) return vrc;
+    const int src = validate_sweep(it, n, nd);
+    if (src != MPCASM_OK) return src;
   }
   // content checks: every index a kernel dereferences stays inside its table
   const int32_t* seg = it + it[H_OFF_SEG];
@@ -1141,7 +1218,7 @@ int mpcasm_plan_prepare(const mpcasm_plan* plan, int batch) {
   int current = -1;
   if (hipGetDevice(&current) != hipSuccess || current != plan->device) return MPCASM_ERR_ARG;
   PlanDev p = plan->dev;
-  if (!p.rs_ok) return MPCASM_OK;  // (nothing is compiled per plan for the other kernels)
+  if (!p.rs_ok || p.sw_ok) return MPCASM_OK;  // (nothing is compiled per plan for the other kernels)
   p.rs_p_direct = resident_p_direct_for(plan->dev, batch);
   const size_t rs = resident_lds_bytes(p);
   if (rs == 0 || rs > RESIDENT_LDS_LIMIT) return MPCASM_OK;
@@ -1188,6 +1265,10 @@ int mpcasm_workspace_bytes(const mpcasm_plan* plan, int batch, size_t* out_bytes
   // a wide problem on the tiled kernel needs d and the generated horizon tables only -- unless the
   // options in force send it down the staged pipeline (a test hook): ask again after changing them
   const int path = plan->opt_path >= 0 ? plan->opt_path : g_path;
+  if (sweep_eligible(plan->dev)) {  // (everything in LDS)
+    *out_bytes = stamps;
+    return MPCASM_OK;
+  }
   if (tiled_eligible(plan->dev) && path != 2) {
     *out_bytes = std::max(tiled_workspace_bytes(plan->dev, batch), stamps);
     return MPCASM_OK;
@@ -1209,7 +1290,7 @@ int mpcasm_assemble(const mpcasm_plan* plan, const double* const* h_src,
     return MPCASM_ERR_ARG;
   if ((d_P == nullptr) != (d_q == nullptr) || (d_G == nullptr) != (d_h == nullptr))
     return MPCASM_ERR_ARG;
-  if (d.rtot && !d_work) return MPCASM_ERR_ARG;
+  if (d.rtot && !d_work && !d.sw_ok) return MPCASM_ERR_ARG;
   {  // the plan's tables (and its compiled kernel) live on the device it was created on
     int current = -1;
     if (hipGetDevice(&current) != hipSuccess || current != plan->device) return MPCASM_ERR_ARG;
@@ -1240,7 +1321,7 @@ int mpcasm_preview_matrices(const mpcasm_plan* plan, const double* const* h_src,
                             const int64_t* h_src_stride, double* d_PM, int batch, void* stream) {
   if (!plan || !d_PM || batch < 0) return MPCASM_ERR_ARG;
   if (plan->dev.nsrc && (!h_src || !h_src_stride)) return MPCASM_ERR_ARG;
-  if (plan->dev.rs_nlti != 0) return MPCASM_ERR_LIMIT;  // the plan has no S, U to read
+  if (plan->dev.rs_nlti != 0 || plan->dev.sw_ok) return MPCASM_ERR_LIMIT;  // the plan has no S, U to read
   if (batch == 0) return MPCASM_OK;
   SrcTable src;
   int rc = make_src_table(plan, h_src, h_src_stride, &src);
@@ -1271,7 +1352,12 @@ int mpcasm_preview_direct(const mpcasm_plan* plan, const double* const* h_src,
   if ((d.nsrc && (!h_src || !h_src_stride)) || (d.ng && !d_given) || (d.no && !d_optim))
     return MPCASM_ERR_ARG;
   if (batch == 0 || d.pmrows == 0) return MPCASM_OK;
+  if (d.sw_ok) return MPCASM_ERR_LIMIT;  // (per-step dynamics: no horizon tables to preview from)
   if (d.t_nlti != 0 && !d_work) return MPCASM_ERR_ARG;
+  {  // the plan's tables live on the device it was created on
+    int current = -1;
+    if (hipGetDevice(&current) != hipSuccess || current != plan->device) return MPCASM_ERR_ARG;
+  }
   SrcTable src, eff;
   int rc = make_src_table(plan, h_src, h_src_stride, &src);
   if (rc != MPCASM_OK) return rc;
@@ -1380,6 +1466,12 @@ int launch_assemble(const PlanDev& plan, const SrcTable& src, const double* para
                     const double* given, double* P, double* q, double* G, double* h, void* work,
                     int batch, int num_cus, hipStream_t stream, hipError_t* err,
                     const int32_t* h_itab, int device) {
+  // a dynamics compiled as ltv: the sweep kernel and nothing else (the other kernels' tables describe
+  // the formulation's own horizon matrices, the source slots carry (A_k, B_k))
+  if (sweep_eligible(plan)) {
+    t_last_kernel = MPCASM_KERNEL_SWEEP;
+    return launch_assemble_sweep(plan, src, params, given, P, q, G, h, batch, stream, err);
+  }
   PlanDev p = plan;
   p.rs_p_direct = p.rs_ok ? resident_p_direct_for(plan, batch) : 0;  // (the launch's size decides)
   // the persistent kernel may take a whole CU's LDS (one workgroup of 8 wavefronts per

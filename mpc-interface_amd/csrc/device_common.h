@@ -30,6 +30,24 @@ __device__ __forceinline__ void diagonal_terms(const PlanDev& p, const double* p
   }
 }
 
+// P[c][c] and q[c] of the diagonal gterms on column c (a cost on a free variable itself): from
+// the plan's per-column table when no column carries more than RS_DIAG_MAX of them
+// (H_OFF_RS_DPAR: weight, aim slots; H_DOFF_RS_DCOEF), else by walking the gterm list
+__device__ __forceinline__ void diagonal_of_column(const PlanDev& p, const double* pb, int c,
+                                                   double& dP, double& dq) {
+  if (p.rs_diag_table) {
+    const int4 sl = *reinterpret_cast<const int4*>(p.itab + p.off_rs_dpar + 4 * c);
+    const double* cf = p.dtab + p.doff_rs_dcoef + 2 * c;
+    // (a free slot points at the parameter behind the last: read as 0 weight through its 0 coefficient)
+    const double w0 = sl.x < p.nparams ? pb[sl.x] : 0.0, a0 = sl.y < p.nparams ? pb[sl.y] : 0.0;
+    const double w1 = sl.z < p.nparams ? pb[sl.z] : 0.0, a1 = sl.w < p.nparams ? pb[sl.w] : 0.0;
+    dP = (w0 * cf[0]) * cf[0] + (w1 * cf[1]) * cf[1];
+    dq = w0 * (cf[0] * (0.0 - a0)) + w1 * (cf[1] * (0.0 - a1));
+  } else {
+    diagonal_terms(p, pb, c, dP, dq);
+  }
+}
+
 // One element of a composed row: sum_e coef[e] * base_row(entbase[e], entk[e])[c]
 // (flattened definition graph, body.py:158-193).  Column c belongs to at most
 // one segment of each base variable (colseg); a segment is either an identity

@@ -35,6 +35,11 @@ int launch_assemble_tiled(const PlanDev& p, const SrcTable& src, const double* p
                           const int32_t* h_itab);
 int launch_lti_tables(const PlanDev& p, const SrcTable& src, double* work, int batch,
                       const int32_t* h_itab, SrcTable* eff, hipStream_t stream);
+// sweep.hip: a dynamics compiled as ltv -- per-step, per-instance (A_k, B_k), no horizon matrix
+bool sweep_eligible(const PlanDev& p);
+int launch_assemble_sweep(const PlanDev& p, const SrcTable& src, const double* params,
+                          const double* given, double* P, double* q, double* G, double* h, int batch,
+                          hipStream_t stream, hipError_t* err);
 // preview.hip
 int launch_preview_direct(const PlanDev& p, const SrcTable& eff, const double* given,
                           const double* optim, double* out, int batch, int num_cus,

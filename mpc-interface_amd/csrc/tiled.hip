@@ -23,6 +23,7 @@
 // horizon matrices of an LTI system that is 34 of 64.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <algorithm>
 #include <type_traits>
@@ -301,24 +302,6 @@ __device__ __forceinline__ void mfma_tiles(f64x4 (&acc)[4][4], const double* at,
     for (int ta = 0; ta < NA; ++ta)
 #pragma unroll
       for (int tb = 0; tb < NB; ++tb) acc[ta][tb] = mfma_f64_16x16x4(a[ta], b[tb], acc[ta][tb]);
-  }
-}
-
-// P[c][c] and q[c] of the diagonal gterms on column c (a cost on a free variable itself): from
-// the plan's per-column table when no column carries more than RS_DIAG_MAX of them
-// (H_OFF_RS_DPAR: weight, aim slots; H_DOFF_RS_DCOEF), else by walking the gterm list
-__device__ __forceinline__ void diagonal_of_column(const PlanDev& p, const double* pb, int c,
-                                                   double& dP, double& dq) {
-  if (p.rs_diag_table) {
-    const int4 sl = *reinterpret_cast<const int4*>(p.itab + p.off_rs_dpar + 4 * c);
-    const double* cf = p.dtab + p.doff_rs_dcoef + 2 * c;
-    // (a free slot points at the parameter behind the last: read as 0 weight through its 0 coefficient)
-    const double w0 = sl.x < p.nparams ? pb[sl.x] : 0.0, a0 = sl.y < p.nparams ? pb[sl.y] : 0.0;
-    const double w1 = sl.z < p.nparams ? pb[sl.z] : 0.0, a1 = sl.w < p.nparams ? pb[sl.w] : 0.0;
-    dP = (w0 * cf[0]) * cf[0] + (w1 * cf[1]) * cf[1];
-    dq = w0 * (cf[0] * (0.0 - a0)) + w1 * (cf[1] * (0.0 - a1));
-  } else {
-    diagonal_terms(p, pb, c, dP, dq);
   }
 }
 
@@ -1066,7 +1049,7 @@ __global__ __launch_bounds__(BLOCK, 2) void toeplitz_assemble_kernel(
 // h comes first, out of LDS; rows of G that are no single state row and unknowns outside the input
 // blocks are composed behind the tickets through the column tables (cold paths).
 // ---------------------------------------------------------------------------
-constexpr int SCAN_GROUP = 4;     // rows of G per ticket
+constexpr int SCAN_GROUP = 4;     // rows of G per ticket, at most (MPCASM_SCAN_GROUP: 1 .. 4)
 constexpr int SCAN_GCH_MAX = 8;   // 128-column chunks of a row of G: no <= 1024
 constexpr int SCAN_AREG = 16;     // states up to which wavefront 0 keeps its column of A in registers
 
@@ -1108,7 +1091,7 @@ __global__ __launch_bounds__(BLOCK, 2) void toeplitz_scan_kernel(
     const double* __restrict__ sysB, long long strideB, const double* __restrict__ params,
     const double* __restrict__ work, long long work_stride, double* __restrict__ P,
     double* __restrict__ q, double* __restrict__ G, double* __restrict__ h, int batch, int dlen,
-    int whole_lines, int phases) {
+    int whole_lines, int group, int phases) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1171,30 +1154,34 @@ __global__ __launch_bounds__(BLOCK, 2) void toeplitz_scan_kernel(
   if (P != nullptr && (phases & 4) && wave == 0) {
     const double* A = sysA + inst * strideA;
     const double* Bm = sysB + inst * strideB;
-    // lane i < n: lam_l[i] = rho_l[i] + sum_t A[t][i] lam_{l+1}[t]; the table lam[i][l] in LDS
+    // lam[i][l] in LDS: first rho_l[i] = sum over the terms on state i of (w c)(d[l] - aim) -- lanes over
+    // the steps, the terms one after the other (their constants are wave-uniform) --, then, step by
+    // step from the last, lam_l[i] += sum_t A[t][i] lam_{l+1}[t] on lane i < n
+    double* lam = reinterpret_cast<double*>(lds + L.lam);
+    for (int e = lane; e < n * N; e += 64) lam[e] = 0.0;
+    const unsigned per_state = (unsigned)(m * N);
+    for (int g = 0; g < K; ++g) {
+      const int4 x = gts[g];
+      const double wc = pb[x.y] * gcs[g], aim = pb[x.z];
+      const unsigned st = (unsigned)x.x / per_state;
+      for (int l = lane; l < N; l += 64)
+        lam[st * N + l] += wc * (lds_f64(lds, L.d + (unsigned)(x.w + l) * 8u) - aim);
+    }
     double acol[SCAN_AREG];
     const bool in_regs = n <= SCAN_AREG;
 #pragma unroll
     for (int t = 0; t < SCAN_AREG; ++t) acol[t] = (in_regs && t < n && lane < n) ? A[t * n + lane] : 0.0;
-    const unsigned per_state = (unsigned)(m * N);
-    for (int l = N - 1; l >= 0; --l) {
-      double acc = 0.0;
-      for (int g = 0; g < K; ++g) {   // rho_l: the terms on this lane's state
-        const int4 x = gts[g];
-        const double r = (pb[x.y] * gcs[g]) * (lds_f64(lds, L.d + (unsigned)(x.w + l) * 8u) - pb[x.z]);
-        acc += ((unsigned)x.x / per_state == (unsigned)lane) ? r : 0.0;
-      }
-      if (l + 1 < N) {
-        if (in_regs) {
+    asm volatile("" ::: "memory");
+    for (int l = N - 2; l >= 0; --l) {
+      double acc = lane < n ? lam[lane * N + l] : 0.0;
+      if (in_regs) {
 #pragma unroll
-          for (int t = 0; t < SCAN_AREG; ++t)
-            if (t < n) acc = fma(acol[t], lds_f64(lds, L.lam + (unsigned)(t * N + l + 1) * 8u), acc);
-        } else {
-          for (int t = 0; t < n; ++t)
-            acc = fma(lane < n ? A[t * n + lane] : 0.0, lds_f64(lds, L.lam + (unsigned)(t * N + l + 1) * 8u), acc);
-        }
+        for (int t = 0; t < SCAN_AREG; ++t)
+          if (t < n) acc = fma(acol[t], lam[t * N + l + 1], acc);
+      } else {
+        for (int t = 0; t < n; ++t) acc = fma(lane < n ? A[t * n + lane] : 0.0, lam[t * N + l + 1], acc);
       }
-      if (lane < n) *reinterpret_cast<double*>(lds + L.lam + (unsigned)(lane * N + l) * 8u) = acc;
+      if (lane < n) lam[lane * N + l] = acc;
       asm volatile("" ::: "memory");  // (a wavefront's LDS operations complete in order: the next step reads these)
     }
     for (int c = lane; c < no; c += 64) {   // q[(j, l)] = B[:, j] . lam_l + the diagonal terms
@@ -1300,13 +1287,13 @@ __global__ __launch_bounds__(BLOCK, 2) void toeplitz_scan_kernel(
     }
     const int2* sgrow = reinterpret_cast<const int2*>(p.itab + p.off_t_scan_grow);
     const double* sgcoef = p.dtab + p.t_doff_scan_gcoef;
-    const int ngroups = (nc + SCAN_GROUP - 1) / SCAN_GROUP;
+    const int ngroups = (nc + group - 1) / group;
     for (;;) {
       int t = 0;
       if (lane == 0) t = atomicAdd(ticket + 1, 1);
       t = __builtin_amdgcn_readfirstlane(t);
       if (t >= ngroups) break;
-      const int R0 = t * SCAN_GROUP;
+      const int R0 = t * group;
       int2 rec[SCAN_GROUP];
       double cf[SCAN_GROUP];
 #pragma unroll
@@ -1318,7 +1305,7 @@ __global__ __launch_bounds__(BLOCK, 2) void toeplitz_scan_kernel(
 #pragma unroll
       for (int rr = 0; rr < SCAN_GROUP; ++rr) {
         const int R = R0 + rr;
-        if (R >= nc || rec[rr].x < 0) continue;
+        if (rr >= group || R >= nc || rec[rr].x < 0) continue;
         const int u8 = rec[rr].x * 8;
         const int k = rec[rr].x % N;   // (the row's step: i m N + k)
         const double ar = lds_f64(lds, L.par + (unsigned)rec[rr].y * 8u) * cf[rr];
@@ -1469,8 +1456,15 @@ int launch_scan_as(const PlanDev& p, const SrcTable& eff, const double* A, long 
     *err = allow_whole_lds(reinterpret_cast<const void*>(kernel));
     if (*err != hipSuccess) return MPCASM_ERR_HIP;
   }
+  // rows of G per ticket (tuning aid MPCASM_SCAN_GROUP; tools/ab_scan.sh): fewer = the wavefronts of a
+  // workgroup write closer together, more = fewer tickets
+  static const int group = [] {
+    const char* e = getenv("MPCASM_SCAN_GROUP");
+    const int v = e ? atoi(e) : SCAN_GROUP;
+    return v < 1 ? 1 : (v > SCAN_GROUP ? SCAN_GROUP : v);
+  }();
   hipLaunchKernelGGL(kernel, dim3((unsigned)batch), dim3(BLOCK), lds, stream, p, eff, A, strideA, Bm, strideB,
-                     params, w, stride, P, q, G, h, batch, dlen, whole_lines, g_phase_mask);
+                     params, w, stride, P, q, G, h, batch, dlen, whole_lines, group, g_phase_mask);
   *err = hipGetLastError();
   if (*err == hipSuccess) t_last_kernel = MPCASM_KERNEL_TILED_SCAN;
   return *err == hipSuccess ? MPCASM_OK : MPCASM_ERR_HIP;

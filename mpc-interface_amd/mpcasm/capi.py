@@ -82,7 +82,8 @@ KERNEL_NAMES = {0: "none", 1: "resident_assemble_kernel (persistent, ahead of ti
                 2: "resident_spec_kernel (persistent, compiled for the plan by hiprtc)",
                 3: "fused_assemble_kernel", 4: "staged pipeline (compose_rowsets / hessian / constraints)",
                 5: "tiled_assemble_kernel",
-                6: "toeplitz_scan_kernel (tiled, scan form: P summed along diagonals)"}
+                6: "toeplitz_scan_kernel (tiled, scan form: P summed along diagonals)",
+                7: "ltv_sweep_kernel (per-step dynamics, no horizon matrix)"}
 BOX_RECENTER, BOX_TRANSLATE, BOX_ROTATE, BOX_SCALE, BOX_MARGIN = range(5)
 
 

@@ -145,6 +145,16 @@ def plan_for_device(form, workspace="auto", batch=None, **kw):
     return plan
 
 
+def _checked_out(torch, out, shape, device, what):
+    """A caller's result buffer: float64, contiguous, on the assembler's device, at least ``shape``."""
+    if (not torch.is_tensor(out) or out.dtype != torch.float64 or not out.is_contiguous()
+            or out.device != device or out.dim() != len(shape) or out.shape[1:] != tuple(shape[1:])
+            or out.shape[0] < shape[0]):
+        raise ValueError("%s: out must be a contiguous float64 tensor on %s of shape (>= %d, %s)"
+                         % (what, device, shape[0], ", ".join(str(x) for x in shape[1:])))
+    return out
+
+
 class Assembler:
     """Batched assembly of one Formulation structure on one device.
 
@@ -163,7 +173,7 @@ class Assembler:
     """
 
     def __init__(self, form, batch=1, device=None, costs=None, limits=None, lti=(), csc=None,
-                 workspace="auto"):
+                 workspace="auto", ltv=()):
         torch = require_device()
         self._torch = torch
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None \
@@ -178,8 +188,10 @@ class Assembler:
         # when it is big (the plan compiler's rule: C3) or when that is what lets a second
         # workgroup share the CU's LDS (plan_for_device: the biped at N = 24 with S, U read from
         # memory); "dense" / "compact" force one.
+        # ltv = [name]: the dynamics ``name`` has its own (A_k, B_k) at every step, per instance
+        # (:meth:`bind_ltv`; BASELINE config C5): the sweep kernel assembles without horizon matrices
         self.plan = plan_for_device(form, costs=costs, limits=limits, lti=tuple(lti), csc=csc,
-                                    workspace=workspace, batch=self.batch)
+                                    workspace=workspace, batch=self.batch, ltv=tuple(ltv))
         self.csc = self.plan.csc
         p = self.plan
         self.ng, self.no, self.nc = p.ng, p.no, p.nc
@@ -204,6 +216,9 @@ class Assembler:
             A = p.sources[ids[-1]].array[0].T
             Bm = np.stack([p.sources[ids[j]].array[0, 0, :] for j in range(g["m"])], axis=1)
             self.bind_lti(g["name"], A, Bm)
+
+        self._ltv = {g["name"]: g for g in p.ltv}
+        self._bind_ltv_nominal([s.array for s in p.sources])
 
         base = torch.as_tensor(p.params, dtype=torch.float64, device=self.device)
         self.params = base.unsqueeze(0).repeat(self.batch, 1).contiguous()
@@ -279,7 +294,7 @@ class Assembler:
         # tools.py:27-31) no longer is: the tables do not hold for it
         if any(not is_causal(fresh[i]) for i in self.plan.causal_assumed):
             return False
-        generated = {i for g in self.plan.lti for i in g["ids"]}
+        generated = {i for g in self.plan.lti + self.plan.ltv for i in g["ids"]}
         # all blocks side by side in one device arena, filled by ONE copy from a pinned staging
         # buffer (a tick of the walking loop is copy-bound: ~20 us per separate upload)
         torch = self._torch
@@ -302,6 +317,7 @@ class Assembler:
             A = fresh[ids[-1]][0].T
             Bm = np.stack([fresh[ids[j]][0, 0, :] for j in range(g["m"])], axis=1)
             self.bind_lti(g["name"], A, Bm)
+        self._bind_ltv_nominal(fresh)
         return True
 
     def bind_source(self, key, tensor, check=True):
@@ -314,8 +330,8 @@ class Assembler:
         reduction on the device per call; ``check=False`` for a caller that guarantees it)."""
         torch = self._torch
         i = self._src_index[key]
-        if key[0] in self._lti:
-            raise ValueError("the horizon matrices of %r are generated on chip: bind_lti" % key[0])
+        if key[0] in self._lti or key[0] in self._ltv:
+            raise ValueError("the horizon matrices of %r are generated on chip: bind_lti / bind_ltv" % key[0])
         shape = tuple(self.plan.sources[i].array.shape)
         t = _as_device(torch, tensor, self.device)
         if check and i in self.plan.causal_assumed and tuple(t.shape)[-3:] == shape:
@@ -333,6 +349,35 @@ class Assembler:
         else:
             raise ValueError("source %r expects %s or %s, got %s"
                              % (key, shape, (self.batch,) + shape, tuple(t.shape)))
+
+    def _bind_ltv_nominal(self, arrays):
+        """Until :meth:`bind_ltv` says otherwise: at every step the pair the horizon matrices in
+        ``arrays`` were extended from, S[0][j][i] = A[i][j], U_j[0][0][i] = B[i][j] (tools.py:14-33)."""
+        keys = [s.key for s in self.plan.sources]
+        for g in self.plan.ltv:
+            m = g["m"]
+            A = arrays[keys.index((g["name"], m))][0].T
+            Bm = np.stack([arrays[keys.index((g["name"], j))][0, 0, :] for j in range(m)], axis=1)
+            self.bind_ltv(g["name"], np.broadcast_to(A, (g["N"],) + A.shape).copy(),
+                          np.broadcast_to(Bm, (g["N"],) + Bm.shape).copy())
+
+    def bind_ltv(self, name, A, B):
+        """Per-step system matrices of a dynamics compiled as ``ltv``: ``A`` ``(N, n, n)`` /
+        ``(B, N, n, n)`` and ``B`` ``(N, n, m)`` / ``(B, N, n, m)``, ``x_{k+1} = A_k x_k + B_k u_k``.
+        They travel in the slots of the dynamics' first two horizon matrices (include/mpcasm.h)."""
+        torch = self._torch
+        g = self._ltv[name]
+        n, m, N = g["n"], g["m"], g["N"]
+        for slot, (t, shape) in enumerate(((A, (N, n, n)), (B, (N, n, m)))):
+            t = _as_device(torch, t, self.device)
+            i = g["ids"][slot]
+            if tuple(t.shape) == shape:
+                self._src[i], self._src_stride[i] = t, 0
+            elif tuple(t.shape) == (self.batch,) + shape:
+                self._src[i], self._src_stride[i] = t, int(np.prod(shape))
+            else:
+                raise ValueError("%s of %r expects %s or %s, got %s"
+                                 % ("AB"[slot], name, shape, (self.batch,) + shape, tuple(t.shape)))
 
     def bind_lti(self, name, A, B):
         """System matrices of a dynamics compiled as ``lti``: ``A`` ``(n, n)`` / ``(B, n, n)``
@@ -489,6 +534,8 @@ class Assembler:
         ``(B, no)`` (the solver's answer)."""
         torch = self._torch
         n = self.batch if count is None else int(count)
+        if not 0 <= n <= self.batch:         # (the scratch and the result are sized for the batch)
+            raise ValueError("count must lie in 0 .. %d, got %d" % (self.batch, n))
         g = _as_device(torch, given, self.device).reshape(-1, self.ng) if self.ng else None
         x = _as_device(torch, optim, self.device).reshape(-1, self.no) if self.no else None
         for t, name in ((g, "given"), (x, "optim")):
@@ -496,6 +543,8 @@ class Assembler:
                 raise ValueError("%s must have %d rows, got %d" % (name, n, t.shape[0]))
         if out is None:
             out = torch.empty((self.batch, self.plan.pmrows), dtype=torch.float64, device=self.device)
+        else:
+            _checked_out(torch, out, (n, self.plan.pmrows), self.device, "preview_rows")
         ptrs, strides = self._src_args()
         work = self._workspace()
         with torch.cuda.device(self.device):
@@ -530,8 +579,13 @@ class Assembler:
         torch = self._torch
         table, names = self.goal_terms(form)
         n = self.batch if count is None else int(count)
+        if not 0 <= n <= self.batch or rows.shape[0] < n:
+            raise ValueError("count must lie in 0 .. %d and within the %d rows given, got %d"
+                             % (self.batch, rows.shape[0], n))
         if out is None:
             out = torch.empty((self.batch, len(names)), dtype=torch.float64, device=self.device)
+        else:
+            _checked_out(torch, out, (n, len(names)), self.device, "goal_distance")
         with torch.cuda.device(self.device):
             rc = capi.load().mpcasm_goal_distance(
                 rows.data_ptr(), rows.shape[1], self.params.data_ptr(), self.params.shape[1],

@@ -1482,6 +1482,8 @@ def _sweep_tables(b, gterms, limit_recs, lax_recs, rowptr, entbase, entk, entcoe
                 return None, "a limit whose rows are no fixed combination of one step's states"
             rec += [info[0], info[1], info[2], info[3], p_a + ax, (0 if a_rows == 1 else naxes),
                     p_c + ax, (0 if c_rows == 1 else naxes)]
+        if any(rec[SW_LIM_WORDS + ax * SW_LAX_WORDS + 1:][:2] != rec[SW_LIM_WORDS + 1:][:2] for ax in range(naxes)):
+            return None, "a limit whose axes take their lines from different steps"
         lims.append(rec)
     cv = np.zeros((len(cvecs), SW_NMAX))
     for i, c in enumerate(cvecs):

@@ -322,8 +322,34 @@ def random_lti(api, rng, nx=12, nu=6, N=64, bound=5.0):
 
 
 # --------------------------------------------------------------------------
-# C5: per-step dynamics for the fill kernel
+# C5: per-step dynamics -- for the fill kernel, and as an assembly
 # --------------------------------------------------------------------------
+def lipm_ltv(api, N=100, tau=0.1, omega=3.3445, foot_corner=(0.1, 0.05), target_vel=(0.3, 0.0)):
+    """The C5-shaped assembly: the ``dP->CCC`` pendulum (input: the CoP's velocity) on two axes over
+    N steps with the biped's kinds of costs and boxes -- input effort, velocity tracking, CoP
+    centring; the CoP inside the foot at every step, the DCM inside it at the last -- ``2 N``
+    unknowns, ``4 N + 4`` inequality rows.  Built on the nominal ``(A, B)``; an assembler compiled
+    with ``ltv=["LIP"]`` takes per-step, per-instance ``(A_k, B_k)`` (:func:`ltv_lipm_steps`)."""
+    t = api.tools
+    axes = ["_x", "_y"]
+    pendulum = api.ControlSystem.from_name("dP->CCC", axes, tau=tau, omega=omega)
+    lip = api.ExtendedSystem.from_cotrol_system(pendulum, "x", N)
+    lip.define_output("b", {"CoM": 1, "CoM_ddot": -1 / omega**2})
+    lip.define_output("DCM", {"CoM": 1, "CoM_dot": 1 / omega})
+    foot = t.make_simetric_vertices(np.array(foot_corner))
+    form = api.Formulation()
+    form.incorporate_dynamics("LIP", lip)
+    form.incorporate_goal("effort", api.Cost("cCoP_dot", 1e-3, aim=[0, 0], axes=axes))
+    form.incorporate_goal("velocity", api.Cost("CoM_dot", 1e-2, aim=list(target_vel), axes=axes))
+    form.incorporate_goal("centre CoP", api.Cost("b", 1.0, aim=[0, 0], axes=axes))
+    form.incorporate_box("CoP", api.Box.task_space("b", foot, axes))
+    form.incorporate_box("terminal", api.Box.task_space("DCM", foot, axes, schedule=range(N - 1, N)))
+    form.identify_qp_domain(["cCoP_dot_x", "cCoP_dot_y"])
+    form.make_preview_matrices()
+    return form
+
+
+
 def ltv_lipm_steps(api, N=100, tau=0.1, omega=3.3445, theta=0.0):
     """``(A_k, B_k)`` of the ``dP->CCC`` pendulum with a slowly varying natural
     frequency ``omega_k = omega (1 + 0.05 sin(2 pi k / N + theta))``."""

@@ -751,3 +751,124 @@ def run_scan(plan, given, params=None, ab=None):
             G[R, blk[bx, 0]:blk[bx, 0] + N] = prm0[grow[R, 1]] * (
                 gcoef[R] * np.where(lane <= k, at(grow[R, 0] + blk[bx, 1] - lane), 0.0))
     return {"P": Pm, "q": q, "G": G, "h": ref["h"], "ref": ref}
+
+
+def run_sweep(plan, given, A_steps, B_steps, params=None):
+    """P, q, G, h of one instance as the sweep kernel computes them (csrc/sweep.hip, plan_tables.h SW_*)
+    from per-step ``A_steps (N, n, n)``, ``B_steps (N, n, m)``: the free response of every axis, the
+    backward recursions Psi_l = W_l + A_{l+1}^T Psi_{l+1} A_{l+1} and lam_l = rho_l + A_{l+1}^T lam_{l+1},
+    the forward sweep of u = Phi(l, l'+1) B_l' per column (the rows of G of step l and P at and below the
+    diagonal), the backward sweep of z = Phi(l', l+1)^T Psi_l' B_l' (P above the diagonal).  No horizon
+    matrix is formed."""
+    it, dt = plan.itab, plan.dtab
+    assert it[H["SW_OK"]] == 1
+    n, m, N, naxes = (int(it[H[k]]) for k in ("SW_N", "SW_M", "SW_HORIZON", "SW_NAXES"))
+    ng, no, nc = plan.ng, plan.no, plan.nc
+    params = plan.params if params is None else np.asarray(params, dtype=float)
+    prm = np.append(params, 0.0)
+    A, B = np.asarray(A_steps, dtype=float), np.asarray(B_steps, dtype=float)
+    assert A.shape == (N, n, n) and B.shape == (N, n, m)
+    g = np.asarray(given, dtype=float).ravel()
+    axis = _section(it, "OFF_SW_AXIS", naxes * P.SW_AXIS_WORDS).reshape(naxes, P.SW_AXIS_WORDS)
+    terms = _section(it, "OFF_SW_TERM", it[H["SW_NTERM"]] * P.SW_TERM_WORDS).reshape(-1, P.SW_TERM_WORDS)
+    lw = P.SW_LIM_WORDS + P.SW_AXMAX * P.SW_LAX_WORDS
+    lims = _section(it, "OFF_SW_LIM", it[H["SW_NLIM"]] * lw).reshape(-1, lw)
+    col = _section(it, "OFF_SW_COL", no)
+    cvec = dt[it[H["SW_DOFF_CVEC"]]:it[H["SW_DOFF_CVEC"]] + it[H["SW_NCVEC"]] * P.SW_NMAX].reshape(-1, P.SW_NMAX)
+
+    def cv(off):
+        return cvec[off // P.SW_NMAX, :n]
+
+    # the free response x_k = A_k x_{k-1}, x_{-1} = the axis' initial state
+    xbar = np.zeros((naxes, N, n))
+    for a in range(naxes):
+        x = g[axis[a, 0]:axis[a, 0] + n]
+        for k in range(N):
+            x = A[k] @ x
+            xbar[a, k] = x
+    # backward: Psi, lam -> gv[a][j][l] = Psi_l B_l[:, j], q
+    W, rho = np.zeros((naxes, N, n, n)), np.zeros((naxes, N, n))
+    for a, k0, ks, cnt, pw, pa, co, _ in terms:
+        c = cv(co)
+        for i in range(cnt):
+            k = k0 + i * ks
+            W[a, k] += prm[pw] * np.outer(c, c)
+            rho[a, k] += (prm[pw] * (c @ xbar[a, k] - prm[pa])) * c
+    gv, q = np.zeros((naxes, m, N, n)), np.zeros(no)
+    for a in range(naxes):
+        Psi, lam = np.zeros((n, n)), np.zeros(n)
+        for l in range(N - 1, -1, -1):
+            if l + 1 < N:
+                Psi, lam = A[l + 1].T @ Psi @ A[l + 1], A[l + 1].T @ lam
+            Psi, lam = Psi + W[a, l], lam + rho[a, l]
+            for j in range(m):
+                gv[a, j, l] = Psi @ B[l][:, j]
+                q[axis[a, 1 + j] + l] = B[l][:, j] @ lam
+    ca, cj, cl = col & 255, (col >> 8) & 255, col >> 16
+    for c in range(no):
+        assert axis[ca[c], 1 + cj[c]] + cl[c] == c
+    Pm, G, h = np.full((no, no), np.nan), np.full((nc, no), np.nan), np.zeros(nc)
+    # forward sweep
+    u = np.zeros((no, n))
+    for l in range(N):
+        for c in range(no):
+            if cl[c] == l:
+                u[c] = B[l][:, cj[c]]
+            elif cl[c] < l:
+                u[c] = A[l] @ u[c]
+        for a in range(naxes):
+            for j in range(m):
+                r = axis[a, 1 + j] + l
+                for c in range(no):
+                    if ca[c] != a:
+                        Pm[r, c] = 0.0
+                    elif cl[c] <= l:
+                        Pm[r, c] = gv[a, j, l] @ u[c]
+        for rec in lims:
+            out0, cnt, nax, pe, pes = rec[:5]
+            for i in range(cnt):
+                row = np.zeros(no)
+                hit = False
+                for ax in range(nax):
+                    a, k0, ks, co, parr, pas, pcen, pcs = rec[P.SW_LIM_WORDS + ax * P.SW_LAX_WORDS:][:8]
+                    if k0 + i * ks != l:
+                        continue
+                    hit = True
+                    row += np.where(ca == a, prm[parr + i * pas] * (u @ cv(co)), 0.0)
+                if hit:
+                    assert np.isnan(G[out0 + i]).all()             # (every axis of a line at the same step)
+                    G[out0 + i] = row
+    # backward sweep: above the diagonal
+    z = np.zeros((no, n))
+    for l in range(N - 1, -1, -1):
+        for c in range(no):
+            if cl[c] == l:
+                z[c] = gv[ca[c], cj[c], l]
+            elif cl[c] > l:
+                z[c] = A[l + 1].T @ z[c]
+        for a in range(naxes):
+            for j in range(m):
+                r = axis[a, 1 + j] + l
+                for c in range(no):
+                    if ca[c] == a and cl[c] > l:
+                        assert np.isnan(Pm[r, c])
+                        Pm[r, c] = B[l][:, j] @ z[c]
+    assert not np.isnan(Pm).any() and not np.isnan(G).any()
+    for rec in lims:
+        out0, cnt, nax, pe, pes = rec[:5]
+        for i in range(cnt):
+            ac = ad = 0.0
+            for ax in range(nax):
+                a, k0, ks, co, parr, pas, pcen, pcs = rec[P.SW_LIM_WORDS + ax * P.SW_LAX_WORDS:][:8]
+                ar = prm[parr + i * pas]
+                ac += ar * prm[pcen + i * pcs]
+                ad += ar * (cv(co) @ xbar[a, k0 + i * ks])
+            h[out0 + i] = (prm[pe + i * pes] + ac) - ad
+    gtab = _section(it, "OFF_GTERM", it[H["NGTERM"]] * P.GT_WORDS).reshape(-1, P.GT_WORDS)
+    for a, b, nn, pw, dd, pa, flags, _ma, _mb, _pad in gtab:
+        if flags & P.GT_FLAG_DIAG:
+            cf = dt[it[H["DOFF_DIAGCOEF"]] + b:it[H["DOFF_DIAGCOEF"]] + b + nn]
+            idx = np.arange(a, a + nn)
+            Pm[idx, idx] += (params[pw] * cf) * cf
+            q[idx] += params[pw] * (cf * (0.0 - params[pa]))
+    return {"P": Pm, "q": q, "G": G, "h": h}

@@ -662,3 +662,94 @@ def test_causality_of_bound_horizon_matrices_is_part_of_the_contract(cpu_api):
             M[...] = old
         dyn.update_definitions()
         form.make_preview_matrices()
+
+
+@pytest.mark.parametrize("N", [12, 100])
+def test_sweep_tables_against_the_oracle(cpu_api, N):
+    """A dynamics compiled as ``ltv`` (per-step A_k, B_k; BASELINE config C5): the sweep kernel's
+    recursions, emulated from the plan's tables, against the oracle on the dense S, U of
+    ``extend_matrices_ltv`` for the same per-step system -- and, pinned to the reference, with every
+    step the formulation's own pair against the oracle on the reference's ``extend_matrices``."""
+    form = problems.lipm_ltv(cpu_api, N=N)
+    plan = compile_plan(form, ltv=["LIP"])
+    assert plan.itab[_H["SW_OK"]] == 1 and plan.no == 2 * N and plan.nc == 4 * N + 4
+    rng = np.random.default_rng(N)
+    given = rng.normal(0, 0.05, form.given_len)
+    dyn = form.dynamics["LIP"]
+    saved = list(dyn.matrices)
+    A, B = problems.ltv_lipm_steps(cpu_api, N=N, theta=0.4)
+    A0 = np.broadcast_to(saved[-1][0].T, A.shape)
+    B0 = np.broadcast_to(saved[0][0, 0, :].reshape(-1, 1), B.shape)
+    try:
+        for Ak, Bk, extend in ((A, B, lambda: orc.extend_matrices_ltv(N, A, B)),
+                               (A0, B0, lambda: orc.extend_matrices(N, A0[0], B0[0]))):
+            out = plan_emulator.run_sweep(plan, given, Ak, Bk)
+            So, Uo = extend()
+            dyn.matrices = list(Uo) + [So]
+            dyn.update_definitions()
+            Ao, ho, Qo, qo = orc.assemble(form, given.reshape(-1, 1))
+            for key, ref in (("P", Qo), ("q", qo.ravel()), ("G", Ao), ("h", ho.ravel())):
+                assert_close(out[key], ref, 1e-12, "sweep " + key)
+    finally:
+        dyn.matrices = saved
+        dyn.update_definitions()
+
+
+def test_what_cannot_be_assembled_step_by_step_is_refused(cpu_api):
+    """``ltv=`` needs every row of a cost or limit to be one step's states: a crossed cost, an L that
+    mixes steps, an unknown that is no input of the system -- ValueError at compile time."""
+    api = cpu_api
+    N = 12
+    form = problems.lipm_ltv(api, N=N)
+    form.incorporate_goal("crossed", api.Cost("CoM", 0.1, aim=[0, 0], axes=["_x", "_y"], cross="CoM_dot",
+                                              cross_aim=[0, 0]))
+    with pytest.raises(ValueError, match="crossed"):
+        compile_plan(form, ltv=["LIP"])
+    form = problems.lipm_ltv(api, N=N)
+    form.incorporate_goal("mixed", api.Cost("CoM", 0.1, aim=[0, 0], axes=["_x", "_y"],
+                                            L=[np.tril(np.ones((N, N)))] * 2))
+    with pytest.raises(ValueError, match="one step"):
+        compile_plan(form, ltv=["LIP"])
+    form = problems.biped(api, problems.BipedConfig(step_samples=8))
+    form.update(step_times=np.array([6, 14]), step_count=0)
+    with pytest.raises(ValueError):
+        compile_plan(form, ltv=["LIP"])
+
+
+def test_sweep_tables_are_validated(cpu_api):
+    import mpcasm.plan as P
+
+    lib = capi.load()
+    form = problems.lipm_ltv(cpu_api, N=12)
+    plan = compile_plan(form, ltv=["LIP"])
+    it = plan.itab
+    handle = ctypes.c_void_p()
+
+    def create(itab):
+        return lib.mpcasm_plan_create(itab.ctypes.data, itab.size, plan.dtab.ctypes.data,
+                                      plan.dtab.size, ctypes.byref(handle))
+
+    rc = create(it)
+    assert rc in (0, -4), rc
+    if rc == 0:
+        assert lib.mpcasm_plan_destroy(handle) == 0
+    ax, tr, lm, col = (it[_H[k]] for k in ("OFF_SW_AXIS", "OFF_SW_TERM", "OFF_SW_LIM", "OFF_SW_COL"))
+    corruptions = {
+        "states": (_H["SW_N"], P.SW_NMAX + 1),
+        "source slot": (_H["SW_SRC_A"], int(it[_H["NSRC"]])),
+        "axis: initial state": (ax, plan.ng),
+        "axis: first unknown": (ax + 1, plan.no - 3),
+        "column word": (col + 5, it[col + 5] + (1 << 16)),
+        "term: step": (tr + 1, 12),
+        "term: weight": (tr + 4, int(it[_H["NPARAMS"]])),
+        "term: combination": (tr + 6, 4 * int(it[_H["SW_NCVEC"]])),
+        "limit: first line": (lm, plan.nc),
+        "limit: axis": (lm + P.SW_LIM_WORDS, 4),
+        "limit: arrow": (lm + P.SW_LIM_WORDS + 4, int(it[_H["NPARAMS"]])),
+        "limit: steps of its axes": (lm + P.SW_LIM_WORDS + P.SW_LAX_WORDS + 1, 3),
+    }
+    for what, (word, value) in corruptions.items():
+        bad = it.copy()
+        assert bad[word] != value, what
+        bad[word] = value
+        assert create(bad) == -2, what
