@@ -119,6 +119,42 @@ int validate_sweep(const int32_t* it, int64_t n, int64_t nd) {
   }
   for (int64_t R = 0; R < nc; ++R)
     if (!line[R]) return MPCASM_ERR_PLAN;  // every line of G, h is written
+  {  // the per-step lists say what the records say: every cost row and every line once, at its step
+    const int64_t ncent = it[H_SW_NCENT], ngent = it[H_SW_NGENT];
+    if (ncent < 0 || ngent != nc || !in_range(it[H_OFF_SW_CPTR], N + 1, n, H_WORDS) ||
+        !in_range(it[H_OFF_SW_CENT], ncent, n, H_WORDS) || !in_range(it[H_OFF_SW_GPTR], N + 1, n, H_WORDS) ||
+        !in_range(it[H_OFF_SW_GENT], ngent * 2, n, H_WORDS))
+      return MPCASM_ERR_PLAN;
+    const int32_t* cptr = it + it[H_OFF_SW_CPTR];
+    const int32_t* cent = it + it[H_OFF_SW_CENT];
+    const int32_t* gptr = it + it[H_OFF_SW_GPTR];
+    const int32_t* gent = it + it[H_OFF_SW_GENT];
+    if (cptr[0] != 0 || cptr[N] != ncent || gptr[0] != 0 || gptr[N] != ngent) return MPCASM_ERR_PLAN;
+    std::vector<int64_t> rows(std::max<int64_t>(nterm, 1), 0);
+    std::fill(line.begin(), line.end(), 0);
+    for (int64_t l = 0; l < N; ++l) {
+      if (cptr[l + 1] < cptr[l] || gptr[l + 1] < gptr[l]) return MPCASM_ERR_PLAN;
+      for (int64_t e = cptr[l]; e < cptr[l + 1]; ++e) {
+        const int64_t ti = cent[e];
+        if (ti < 0 || ti >= nterm) return MPCASM_ERR_PLAN;
+        const int32_t* x = it + it[H_OFF_SW_TERM] + ti * SW_TERM_WORDS;
+        const int64_t ks = x[ST_KSTEP], dk = l - x[ST_K0];
+        ++rows[ti];
+        if (ks == 0 ? dk != 0 : (dk % ks != 0 || dk / ks < 0 || dk / ks >= x[ST_COUNT])) return MPCASM_ERR_PLAN;
+      }
+      for (int64_t e = gptr[l]; e < gptr[l + 1]; ++e) {
+        const int64_t li = gent[2 * e], i = gent[2 * e + 1];
+        if (li < 0 || li >= nlim) return MPCASM_ERR_PLAN;
+        const int32_t* x = it + it[H_OFF_SW_LIM] + li * LIMW;
+        if (i < 0 || i >= x[SL_COUNT] || x[SW_LIM_WORDS + SX_K0] + i * x[SW_LIM_WORDS + SX_KSTEP] != l ||
+            line[x[SL_OUT0] + i])
+          return MPCASM_ERR_PLAN;
+        line[x[SL_OUT0] + i] = 1;
+      }
+    }
+    for (int64_t t = 0; t < nterm; ++t)
+      if (rows[t] != (it + it[H_OFF_SW_TERM] + t * SW_TERM_WORDS)[ST_COUNT]) return MPCASM_ERR_PLAN;
+  }
   const int32_t* dp = it + it[H_OFF_RS_DPAR];
   for (int64_t i = 0; i < no * 2 * RS_DIAG_MAX; ++i)
     if (dp[i] < 0 || dp[i] > nparams) return MPCASM_ERR_PLAN;
@@ -983,6 +1019,8 @@ void plan_dev_from_tables(const int32_t* it, PlanDev* out) {
   d.off_sw_axis = it[H_OFF_SW_AXIS]; d.sw_nterm = it[H_SW_NTERM]; d.off_sw_term = it[H_OFF_SW_TERM];
   d.sw_nlim = it[H_SW_NLIM]; d.off_sw_lim = it[H_OFF_SW_LIM]; d.off_sw_col = it[H_OFF_SW_COL];
   d.sw_doff_cvec = it[H_SW_DOFF_CVEC]; d.sw_ncvec = it[H_SW_NCVEC];
+  d.off_sw_cptr = it[H_OFF_SW_CPTR]; d.off_sw_cent = it[H_OFF_SW_CENT]; d.sw_ncent = it[H_SW_NCENT];
+  d.off_sw_gptr = it[H_OFF_SW_GPTR]; d.off_sw_gent = it[H_OFF_SW_GENT]; d.sw_ngent = it[H_SW_NGENT];
   d.t_nbrow = d.t_ci_ok ? it[d.off_t_brow0 + d.nbase] : 0;
   d.pm_nfd = it[H_PM_NFD]; d.off_pm_map = it[H_OFF_PM_MAP]; d.off_pm_fdptr = it[H_OFF_PM_FDPTR];
   d.off_pm_op = it[H_OFF_PM_OP]; d.doff_pm_pool = it[H_DOFF_PM_POOL];

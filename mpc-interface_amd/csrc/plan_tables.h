@@ -29,7 +29,7 @@
 namespace mpcasm {
 
 constexpr int32_t PLAN_MAGIC = 0x4D504341;  // 'MPCA'
-constexpr int32_t PLAN_VERSION = 27;
+constexpr int32_t PLAN_VERSION = 28;
 
 enum HeaderWord : int {
   H_MAGIC = 0,
@@ -252,9 +252,17 @@ enum HeaderWord : int {
   H_OFF_SW_COL,       // [NO] per unknown: axis | input << 8 | step << 16
   H_SW_DOFF_CVEC,     // [NCVEC][SW_NMAX] dtab: the combinations c of the states (0 beyond n)
   H_SW_NCVEC,
+  // what happens at every step, as lists the kernel walks: the cost rows of step l are the terms
+  // CENT[CPTR[l] .. CPTR[l+1]), the lines of G of step l are GENT[GPTR[l] .. GPTR[l+1]) = (limit, line)
+  H_OFF_SW_CPTR,      // [HORIZON + 1]
+  H_OFF_SW_CENT,      // [NCENT]
+  H_SW_NCENT,
+  H_OFF_SW_GPTR,      // [HORIZON + 1]
+  H_OFF_SW_GENT,      // [NGENT][2]
+  H_SW_NGENT,
   H_WORDS = 160
 };
-static_assert(H_SW_NCVEC < H_WORDS, "plan header");
+static_assert(H_SW_NGENT < H_WORDS, "plan header");
 constexpr int SW_NMAX = 4, SW_MMAX = 4, SW_AXMAX = 4, SW_AXIS_WORDS = 8, SW_TERM_WORDS = 8, SW_LIM_WORDS = 8,
               SW_LAX_WORDS = 8;
 // a cost term on one axis: rows i = 0 .. ST_COUNT-1 are c . x of step ST_K0 + i ST_KSTEP

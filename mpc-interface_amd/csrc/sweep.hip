@@ -42,19 +42,35 @@ constexpr int SW_WAVES = SW_BLOCK / 64;
 __device__ __forceinline__ double ldsd(const double* base, int i) { return base[i]; }
 
 // LDS of one workgroup (doubles): all steps' [A_k | B_k], the free responses, Psi_l B_l[:, j], q, the
-// parameters, a scratch for the recursions' exchanges
+// parameters, a scratch for the recursions' exchanges, the combinations c, then the plan's small
+// integer tables (terms, limits, the per-step lists, the axes)
 struct SweepLds {
-  int ab, xbar, gv, qs, par, scratch, total;
+  int ab, xbar, gv, qs, par, scratch, cvec, ints, total;
+  int i_term, i_lim, i_cptr, i_cent, i_gptr, i_gent, i_axis, nints;
 };
-__host__ __device__ inline SweepLds sweep_lds(int n, int m, int N, int naxes, int no, int nparams) {
+constexpr int LIMW = SW_LIM_WORDS + SW_AXMAX * SW_LAX_WORDS;
+__host__ __device__ inline SweepLds sweep_lds(const PlanDev& p) {
+  const int n = p.sw_n, m = p.sw_m, N = p.sw_horizon, naxes = p.sw_naxes;
   SweepLds x;
   x.ab = 0;
   x.xbar = x.ab + N * (n * n + n * m);
   x.gv = x.xbar + naxes * N * n;
   x.qs = x.gv + naxes * m * N * n;
-  x.par = x.qs + no;
-  x.scratch = x.par + nparams + 1;
-  x.total = x.scratch + 2 * SW_AXMAX * SW_NMAX * SW_NMAX + SW_AXMAX * SW_NMAX;
+  x.par = x.qs + p.no;
+  x.scratch = x.par + p.nparams + 1;
+  x.cvec = x.scratch + 2 * SW_AXMAX * SW_NMAX * SW_NMAX + SW_AXMAX * SW_NMAX;
+  x.cvec += x.cvec & 1;
+  x.ints = x.cvec + p.sw_ncvec * SW_NMAX;
+  x.i_term = 0;
+  x.i_lim = x.i_term + p.sw_nterm * SW_TERM_WORDS;
+  x.i_cptr = x.i_lim + p.sw_nlim * LIMW;
+  x.i_cent = x.i_cptr + N + 1;
+  x.i_gptr = x.i_cent + p.sw_ncent;
+  x.i_gent = x.i_gptr + N + 1;
+  x.i_gent += x.i_gent & 1;
+  x.i_axis = x.i_gent + 2 * p.sw_ngent;
+  x.nints = x.i_axis + naxes * SW_AXIS_WORDS;
+  x.total = x.ints + (x.nints + 1) / 2;
   x.total += x.total & 1;
   return x;
 }
@@ -73,32 +89,47 @@ __global__ __launch_bounds__(SW_BLOCK) void ltv_sweep_kernel(
   if (inst >= batch) return;
   const int n = p.sw_n, m = p.sw_m, N = p.sw_horizon, naxes = p.sw_naxes, no = p.no, nc = p.nc;
   const int nn = n * n, nm = n * m, abw = nn + nm;
-  const SweepLds L = sweep_lds(n, m, N, naxes, no, p.nparams);
+  const SweepLds L = sweep_lds(p);
   double* AB = sw + L.ab;       // [N][n n + n m]: A_k row major, then B_k
   double* xbar = sw + L.xbar;   // [naxes][N][n]
   double* gv = sw + L.gv;       // [naxes][m][N][n]
   double* qs = sw + L.qs;       // [no]
   double* par = sw + L.par;     // [nparams + 1], the last 0.0
   double* scr = sw + L.scratch;
+  double* cvec = sw + L.cvec;   // [ncvec][SW_NMAX]
+  int* itb = reinterpret_cast<int*>(sw + L.ints);
+  const int* terms = itb + L.i_term;
+  const int* lims = itb + L.i_lim;
+  const int* cptr = itb + L.i_cptr;
+  const int* cent = itb + L.i_cent;
+  const int* gptr = itb + L.i_gptr;
+  const int2* gent = reinterpret_cast<const int2*>(itb + L.i_gent);
+  const int* axis = itb + L.i_axis;
   const double* pb = params + (size_t)inst * p.nparams;
-  const int32_t* axis = p.itab + p.off_sw_axis;
-  const int32_t* terms = p.itab + p.off_sw_term;
-  const int32_t* lims = p.itab + p.off_sw_lim;
-  const int32_t* colw = p.itab + p.off_sw_col;
-  const double* cvec = p.dtab + p.sw_doff_cvec;
-  constexpr int LIMW = SW_LIM_WORDS + SW_AXMAX * SW_LAX_WORDS;
 
-  // ---- set-up: every step's (A_k, B_k), the parameters --------------------------------------------
+  // ---- set-up: every step's (A_k, B_k), the parameters, the plan's tables -----------------------------
   {
     const double* A = sysA + inst * strideA;
     const double* Bm = sysB + inst * strideB;
     for (int e = tid; e < N * nn; e += SW_BLOCK) AB[(e / nn) * abw + e % nn] = A[e];
     for (int e = tid; e < N * nm; e += SW_BLOCK) AB[(e / nm) * abw + nn + e % nm] = Bm[e];
     for (int e = tid; e <= p.nparams; e += SW_BLOCK) par[e] = e < p.nparams ? pb[e] : 0.0;
+    for (int e = tid; e < p.sw_ncvec * SW_NMAX; e += SW_BLOCK) cvec[e] = (p.dtab + p.sw_doff_cvec)[e];
+    auto copy = [&](int dst, int src_off, int count) {
+      for (int e = tid; e < count; e += SW_BLOCK) itb[dst + e] = (p.itab + src_off)[e];
+    };
+    copy(L.i_term, p.off_sw_term, p.sw_nterm * SW_TERM_WORDS);
+    copy(L.i_lim, p.off_sw_lim, p.sw_nlim * LIMW);
+    copy(L.i_cptr, p.off_sw_cptr, N + 1);
+    copy(L.i_cent, p.off_sw_cent, p.sw_ncent);
+    copy(L.i_gptr, p.off_sw_gptr, N + 1);
+    copy(L.i_gent, p.off_sw_gent, 2 * p.sw_ngent);
+    copy(L.i_axis, p.off_sw_axis, naxes * SW_AXIS_WORDS);
   }
   // this thread's columns: axis, input, step; the diagonal terms on them (a cost on the input itself)
   int ca[CPT], cj[CPT], cl[CPT];
   double dPc[CPT], dqc[CPT];
+  const int32_t* colw = p.itab + p.off_sw_col;
 #pragma unroll
   for (int t = 0; t < CPT; ++t) {
     const int c = tid + t * SW_BLOCK;
@@ -143,23 +174,22 @@ __global__ __launch_bounds__(SW_BLOCK) void ltv_sweep_kernel(
 
   // ---- h: (extreme + arrow . center) - arrow . (c . x of the line's step) ---------------------------
   if (G != nullptr)
-    for (int li = 0; li < p.sw_nlim; ++li) {
-      const int32_t* rec = lims + li * LIMW;
-      const int out0 = rec[SL_OUT0], cnt = rec[SL_COUNT], nax = rec[SL_NAXES];
-      for (int i = tid; i < cnt; i += SW_BLOCK) {
-        double ac = 0.0, ad = 0.0;
-        for (int ax = 0; ax < nax; ++ax) {
-          const int32_t* xr = rec + SW_LIM_WORDS + ax * SW_LAX_WORDS;
-          const double ar = par[xr[SX_ARROW] + i * xr[SX_ARROW_STEP]];
-          ac += ar * par[xr[SX_CENTER] + i * xr[SX_CENTER_STEP]];
-          const double* xb = xbar + (xr[SX_AXIS] * N + xr[SX_K0] + i * xr[SX_KSTEP]) * n;
-          const double* cv = cvec + xr[SX_CVEC];
-          double d = 0.0;
-          for (int s = 0; s < n; ++s) d = fma(cv[s], xb[s], d);
-          ad = fma(ar, d, ad);
-        }
-        h[(size_t)inst * nc + out0 + i] = (par[rec[SL_EXTREME] + i * rec[SL_EXTREME_STEP]] + ac) - ad;
+    for (int e = tid; e < p.sw_ngent; e += SW_BLOCK) {
+      const int2 ge = gent[e];
+      const int* rec = lims + ge.x * LIMW;
+      const int i = ge.y, nax = rec[SL_NAXES];
+      double ac = 0.0, ad = 0.0;
+      for (int ax = 0; ax < nax; ++ax) {
+        const int* xr = rec + SW_LIM_WORDS + ax * SW_LAX_WORDS;
+        const double ar = par[xr[SX_ARROW] + i * xr[SX_ARROW_STEP]];
+        ac += ar * par[xr[SX_CENTER] + i * xr[SX_CENTER_STEP]];
+        const double* xb = xbar + (xr[SX_AXIS] * N + xr[SX_K0] + i * xr[SX_KSTEP]) * n;
+        const double* cv = cvec + xr[SX_CVEC];
+        double d = 0.0;
+        for (int s = 0; s < n; ++s) d = fma(cv[s], xb[s], d);
+        ad = fma(ar, d, ad);
       }
+      h[(size_t)inst * nc + rec[SL_OUT0] + i] = (par[rec[SL_EXTREME] + i * rec[SL_EXTREME_STEP]] + ac) - ad;
     }
 
   // ---- backward: Psi_l, lam_l -> gv[a][j][l] = Psi_l B_l[:, j], qs[(a, j, l)] = B_l[:, j] . lam_l --------
@@ -193,19 +223,13 @@ __global__ __launch_bounds__(SW_BLOCK) void ltv_sweep_kernel(
           for (int s = 0; s < n; ++s) psi = fma(An[s * n + i], sT[s * n + jj], psi);
         lam = lnew;
       }
-      // + W_l, rho_l: the cost rows of step l on this axis
-      for (int ti = 0; ti < p.sw_nterm; ++ti) {
-        const int32_t* tr = terms + ti * SW_TERM_WORDS;
-        const int k0 = tr[ST_K0], ks = tr[ST_KSTEP], cnt = tr[ST_COUNT];
-        // (lines at the same step, ks == 0: every one of them counts)
-        int times = 0;
-        if (ks == 0)
-          times = l == k0 ? cnt : 0;
-        else if ((l - k0) % ks == 0 && (l - k0) / ks >= 0 && (l - k0) / ks < cnt)
-          times = 1;
-        if (times == 0 || !live || tr[ST_AXIS] != a) continue;
+      // + W_l, rho_l: the cost rows of step l on this lane's axis
+      const int e1 = cptr[l + 1];
+      for (int ce = cptr[l]; ce < e1; ++ce) {
+        const int* tr = terms + cent[ce] * SW_TERM_WORDS;
+        if (!live || tr[ST_AXIS] != a) continue;
         const double* cv = cvec + tr[ST_CVEC];
-        const double w = par[tr[ST_WPARAM]] * (double)times;
+        const double w = par[tr[ST_WPARAM]];
         psi = fma(w * cv[i], cv[jj], psi);
         if (jj == 0) {
           const double* xb = xbar + (a * N + l) * n;
@@ -296,43 +320,35 @@ __global__ __launch_bounds__(SW_BLOCK) void ltv_sweep_kernel(
             }
           }
         }
-    if (G != nullptr)
-      for (int li = 0; li < p.sw_nlim; ++li) {
-        const int32_t* rec = lims + li * LIMW;
-        const int cnt = rec[SL_COUNT], nax = rec[SL_NAXES];
-        const int32_t* x0 = rec + SW_LIM_WORDS;   // (every axis of a limit shares k0, kstep: plan.py)
-        const int k0 = x0[SX_K0], ks = x0[SX_KSTEP];
-        int i0 = 0, i1 = 0;                       // the lines of this step: [i0, i1)
-        if (ks == 0) {
-          if (l == k0) i1 = cnt;
-        } else if ((l - k0) % ks == 0 && (l - k0) / ks >= 0 && (l - k0) / ks < cnt) {
-          i0 = (l - k0) / ks;
-          i1 = i0 + 1;
-        }
-        for (int i = i0; i < i1; ++i) {
-          double val[CPT];
+    if (G != nullptr) {
+      const int e1 = gptr[l + 1];
+      for (int ge = gptr[l]; ge < e1; ++ge) {
+        const int2 line = gent[ge];
+        const int* rec = lims + line.x * LIMW;
+        const int i = line.y, nax = rec[SL_NAXES];
+        double val[CPT];
 #pragma unroll
-          for (int t = 0; t < CPT; ++t) val[t] = 0.0;
-          for (int ax = 0; ax < nax; ++ax) {
-            const int32_t* xr = rec + SW_LIM_WORDS + ax * SW_LAX_WORDS;
-            const double ar = par[xr[SX_ARROW] + i * xr[SX_ARROW_STEP]];
-            const double* cv = cvec + xr[SX_CVEC];
-#pragma unroll
-            for (int t = 0; t < CPT; ++t) {
-              double d = 0.0;
-#pragma unroll
-              for (int s = 0; s < SW_NMAX; ++s)
-                if (s < n) d = fma(cv[s], u[t][s], d);
-              val[t] += ca[t] == xr[SX_AXIS] ? ar * d : 0.0;
-            }
-          }
+        for (int t = 0; t < CPT; ++t) val[t] = 0.0;
+        for (int ax = 0; ax < nax; ++ax) {
+          const int* xr = rec + SW_LIM_WORDS + ax * SW_LAX_WORDS;
+          const double ar = par[xr[SX_ARROW] + i * xr[SX_ARROW_STEP]];
+          const double* cv = cvec + xr[SX_CVEC];
 #pragma unroll
           for (int t = 0; t < CPT; ++t) {
-            const int c = tid + t * SW_BLOCK;
-            if (c < no) Gb[(size_t)(rec[SL_OUT0] + i) * no + c] = val[t];
+            double d = 0.0;
+#pragma unroll
+            for (int s = 0; s < SW_NMAX; ++s)
+              if (s < n) d = fma(cv[s], u[t][s], d);
+            val[t] += ca[t] == xr[SX_AXIS] ? ar * d : 0.0;
           }
         }
+#pragma unroll
+        for (int t = 0; t < CPT; ++t) {
+          const int c = tid + t * SW_BLOCK;
+          if (c < no) Gb[(size_t)(rec[SL_OUT0] + i) * no + c] = val[t];
+        }
       }
+    }
   }
   if (P == nullptr) return;
 
@@ -391,11 +407,11 @@ bool sweep_eligible(const PlanDev& p) { return p.sw_ok != 0; }
 int launch_assemble_sweep(const PlanDev& p, const SrcTable& src, const double* params,
                           const double* given, double* P, double* q, double* G, double* h, int batch,
                           hipStream_t stream, hipError_t* err) {
-  const int n = p.sw_n, m = p.sw_m, N = p.sw_horizon, naxes = p.sw_naxes;
+  const int n = p.sw_n, m = p.sw_m, naxes = p.sw_naxes;
   if (n < 1 || n > SW_NMAX || m < 1 || m > SW_MMAX || naxes < 1 || naxes > SW_AXMAX ||
       naxes * n * n > 64 || p.no > SW_BLOCK * 4)
     return MPCASM_ERR_LIMIT;
-  const size_t lds = (size_t)sweep_lds(n, m, N, naxes, p.no, p.nparams).total * sizeof(double);
+  const size_t lds = (size_t)sweep_lds(p).total * sizeof(double);
   if (lds > (size_t)RESIDENT_LDS_LIMIT) return MPCASM_ERR_LIMIT;
   const double* A = src.ptr[p.sw_src_a];
   const double* Bm = src.ptr[p.sw_src_b];

@@ -1049,7 +1049,7 @@ __global__ __launch_bounds__(BLOCK, 2) void toeplitz_assemble_kernel(
 // h comes first, out of LDS; rows of G that are no single state row and unknowns outside the input
 // blocks are composed behind the tickets through the column tables (cold paths).
 // ---------------------------------------------------------------------------
-constexpr int SCAN_GROUP = 4;     // rows of G per ticket, at most (MPCASM_SCAN_GROUP: 1 .. 4)
+constexpr int SCAN_GROUP = 8;     // rows of G per ticket, at most (MPCASM_SCAN_GROUP: 1 .. 8)
 constexpr int SCAN_GCH_MAX = 8;   // 128-column chunks of a row of G: no <= 1024
 constexpr int SCAN_AREG = 16;     // states up to which wavefront 0 keeps its column of A in registers
 
@@ -1288,27 +1288,41 @@ __global__ __launch_bounds__(BLOCK, 2) void toeplitz_scan_kernel(
     const int2* sgrow = reinterpret_cast<const int2*>(p.itab + p.off_t_scan_grow);
     const double* sgcoef = p.dtab + p.t_doff_scan_gcoef;
     const int ngroups = (nc + group - 1) / group;
-    for (;;) {
-      int t = 0;
-      if (lane == 0) t = atomicAdd(ticket + 1, 1);
-      t = __builtin_amdgcn_readfirstlane(t);
-      if (t >= ngroups) break;
-      const int R0 = t * group;
+    // a ticket = `group` consecutive rows; the next ticket is drawn, and its rows' records requested,
+    // before this one's rows are stored (the records' trip through the scalar cache -- and the
+    // ticket's through LDS -- hides behind a dozen stores instead of standing in front of them)
+    struct Rows {
       int2 rec[SCAN_GROUP];
       double cf[SCAN_GROUP];
+    };
+    auto take = [&]() -> int {
+      int t = 0;
+      if (lane == 0) t = atomicAdd(ticket + 1, 1);
+      return __builtin_amdgcn_readfirstlane(t);
+    };
+    auto request = [&](int t, Rows& r) __attribute__((always_inline)) {
 #pragma unroll
       for (int rr = 0; rr < SCAN_GROUP; ++rr) {
-        const int R = R0 + rr < nc ? R0 + rr : nc - 1;
-        rec[rr] = sgrow[R];
-        cf[rr] = sgcoef[R];
+        const int R = t * group + rr;
+        const int Rc = (rr < group && R < nc) ? R : nc - 1;
+        r.rec[rr] = sgrow[Rc];
+        r.cf[rr] = sgcoef[Rc];
       }
+    };
+    Rows cur, nxt;
+    int t = take();
+    if (t < ngroups) request(t, cur);
+    while (t < ngroups) {
+      const int tn = take();
+      if (tn < ngroups) request(tn, nxt);
+      const int R0 = t * group;
 #pragma unroll
       for (int rr = 0; rr < SCAN_GROUP; ++rr) {
         const int R = R0 + rr;
-        if (rr >= group || R >= nc || rec[rr].x < 0) continue;
-        const int u8 = rec[rr].x * 8;
-        const int k = rec[rr].x % N;   // (the row's step: i m N + k)
-        const double ar = lds_f64(lds, L.par + (unsigned)rec[rr].y * 8u) * cf[rr];
+        if (rr >= group || R >= nc || cur.rec[rr].x < 0) continue;
+        const int u8 = cur.rec[rr].x * 8;
+        const int k = cur.rec[rr].x % N;   // (the row's step: i m N + k)
+        const double ar = lds_f64(lds, L.par + (unsigned)cur.rec[rr].y * 8u) * cur.cf[rr];
         double* grow_out = Gb + (size_t)R * no + lane * 2;
 #pragma unroll
         for (int ch = 0; ch < SCAN_GCH_MAX; ++ch) {
@@ -1325,6 +1339,8 @@ __global__ __launch_bounds__(BLOCK, 2) void toeplitz_scan_kernel(
           }
         }
       }
+      cur = nxt;
+      t = tn;
     }
   }
 
@@ -1460,7 +1476,7 @@ int launch_scan_as(const PlanDev& p, const SrcTable& eff, const double* A, long 
   // workgroup write closer together, more = fewer tickets
   static const int group = [] {
     const char* e = getenv("MPCASM_SCAN_GROUP");
-    const int v = e ? atoi(e) : SCAN_GROUP;
+    const int v = e ? atoi(e) : 4;
     return v < 1 ? 1 : (v > SCAN_GROUP ? SCAN_GROUP : v);
   }();
   hipLaunchKernelGGL(kernel, dim3((unsigned)batch), dim3(BLOCK), lds, stream, p, eff, A, strideA, Bm, strideB,

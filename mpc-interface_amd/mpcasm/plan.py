@@ -17,7 +17,7 @@ import numpy as np
 import scipy.sparse as sp
 
 PLAN_MAGIC = 0x4D504341
-PLAN_VERSION = 27
+PLAN_VERSION = 28
 
 # header words (csrc/plan_tables.h, enum HeaderWord)
 _H = {name: i for i, name in enumerate([
@@ -45,6 +45,7 @@ _H = {name: i for i, name in enumerate([
     "T_DOFF_SCAN_GCOEF", "T_SCAN_NGREST", "OFF_T_SCAN_GREST", "OFF_T_SCAN_COLBLK", "T_SCAN_NOTHER",
     "SW_OK", "SW_N", "SW_M", "SW_HORIZON", "SW_SRC_A", "SW_SRC_B", "SW_NAXES", "OFF_SW_AXIS", "SW_NTERM",
     "OFF_SW_TERM", "SW_NLIM", "OFF_SW_LIM", "OFF_SW_COL", "SW_DOFF_CVEC", "SW_NCVEC",
+    "OFF_SW_CPTR", "OFF_SW_CENT", "SW_NCENT", "OFF_SW_GPTR", "OFF_SW_GENT", "SW_NGENT",
 ])}
 H_WORDS = 160
 assert len(_H) <= H_WORDS
@@ -1453,8 +1454,13 @@ def _sweep_tables(b, gterms, limit_recs, lax_recs, rowptr, entbase, entk, entcoe
                 return None
         if not (0 <= k0 < N and 0 <= k0 + (len(info) - 1) * kstep < N):
             return None
-        cvecs.append(c)
-        return a, k0, (0 if rs == 1 else kstep), (len(cvecs) - 1) * SW_NMAX
+        for at, have in enumerate(cvecs):            # (the same combination: one entry)
+            if np.array_equal(have, c):
+                break
+        else:
+            at = len(cvecs)
+            cvecs.append(c)
+        return a, k0, (0 if rs == 1 else kstep), at * SW_NMAX
 
     terms = []
     for g in gterms:
@@ -1492,7 +1498,24 @@ def _sweep_tables(b, gterms, limit_recs, lax_recs, rowptr, entbase, entk, entcoe
     for a, rec in enumerate(axes):
         axis_tab[a, 0] = rec[0]
         axis_tab[a, 1:1 + m] = rec[1:]
+    # what happens at every step, in lists the kernel walks (no search, no division per step):
+    # the cost rows of step l, CENT[CPTR[l] .. CPTR[l+1]) = term; the lines of G of step l,
+    # GENT[GPTR[l] .. GPTR[l+1]) = (limit, line i)
+    cent = [[] for _ in range(N)]
+    for ti, (a, k0, ks, cnt, *_rest) in enumerate(terms):
+        for i in range(cnt):
+            cent[k0 + i * ks].append(ti)
+    gent = [[] for _ in range(N)]
+    for li, rec in enumerate(lims):
+        k0, ks = rec[SW_LIM_WORDS + 1], rec[SW_LIM_WORDS + 2]
+        for i in range(rec[1]):
+            gent[k0 + i * ks].append((li, i))
+    cptr = np.cumsum([0] + [len(x) for x in cent])
+    gptr = np.cumsum([0] + [len(x) for x in gent])
+    cent = np.asarray([t for x in cent for t in x], dtype=np.int64)
+    gent = np.asarray([t for x in gent for t in x], dtype=np.int64).reshape(-1, 2)
     return dict(n=n, m=m, N=N, src_a=group["ids"][0], src_b=group["ids"][1], axes=axis_tab,
+                cptr=cptr, cent=cent, gptr=gptr, gent=gent,
                 terms=np.asarray(terms, dtype=np.int64).reshape(-1, SW_TERM_WORDS),
                 lims=np.asarray(lims, dtype=np.int64).reshape(-1, SW_LIM_WORDS + SW_AXMAX * SW_LAX_WORDS),
                 col=col, cvec=cv.reshape(-1)), None
@@ -1977,12 +2000,17 @@ def compile_plan(form, costs=None, limits=None, lti=(), csc=None, workspace="aut
     sections += [("OFF_T_P1PTR", np.asarray(p1ptr, dtype=np.int32)),
                  ("OFF_T_P1ENT", p1ent.astype(np.uint32).view(np.int32).reshape(-1)),
                  ("OFF_T_P2Y", p2y.astype(np.int32))]
-    sw_empty = dict(axes=np.zeros(0), terms=np.zeros(0), lims=np.zeros(0), col=np.zeros(0), cvec=np.zeros(0))
+    sw_empty = dict(axes=np.zeros(0), terms=np.zeros(0), lims=np.zeros(0), col=np.zeros(0), cvec=np.zeros(0),
+                    cptr=np.zeros(0), cent=np.zeros(0), gptr=np.zeros(0), gent=np.zeros(0))
     sw = sweep or sw_empty
     sections += [("OFF_SW_AXIS", np.asarray(sw["axes"]).astype(np.int32).reshape(-1)),
                  ("OFF_SW_TERM", np.asarray(sw["terms"]).astype(np.int32).reshape(-1)),
                  ("OFF_SW_LIM", np.asarray(sw["lims"]).astype(np.int32).reshape(-1)),
-                 ("OFF_SW_COL", np.asarray(sw["col"]).astype(np.int32).reshape(-1))]
+                 ("OFF_SW_COL", np.asarray(sw["col"]).astype(np.int32).reshape(-1)),
+                 ("OFF_SW_CPTR", np.asarray(sw["cptr"]).astype(np.int32).reshape(-1)),
+                 ("OFF_SW_CENT", np.asarray(sw["cent"]).astype(np.int32).reshape(-1)),
+                 ("OFF_SW_GPTR", np.asarray(sw["gptr"]).astype(np.int32).reshape(-1)),
+                 ("OFF_SW_GENT", np.asarray(sw["gent"]).astype(np.int32).reshape(-1))]
     sections += [("OFF_T_SCAN_BLK", scan["blk"].astype(np.int32).reshape(-1)),
                  ("OFF_T_SCAN_GT", scan["gt"].astype(np.int32).reshape(-1)),
                  ("OFF_T_SCAN_GROW", scan["grow"].astype(np.int32).reshape(-1)),
@@ -2049,6 +2077,7 @@ def compile_plan(form, costs=None, limits=None, lti=(), csc=None, workspace="aut
         header[_H["SW_HORIZON"]], header[_H["SW_NAXES"]] = sweep["N"], sweep["axes"].shape[0]
         header[_H["SW_SRC_A"]], header[_H["SW_SRC_B"]] = sweep["src_a"], sweep["src_b"]
         header[_H["SW_NTERM"]], header[_H["SW_NLIM"]] = sweep["terms"].shape[0], sweep["lims"].shape[0]
+        header[_H["SW_NCENT"]], header[_H["SW_NGENT"]] = sweep["cent"].size, sweep["gent"].shape[0]
     header[_H["T_SCAN"]] = scan["K"] if scan["ok"] else 0
     header[_H["T_SCAN_NBLK"]], header[_H["T_SCAN_NGREST"]] = scan["blk"].shape[0], scan["grest"].size
     header[_H["T_SCAN_NOTHER"]] = scan["nother"]
