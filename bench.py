@@ -426,9 +426,10 @@ F64_MFMA_PEAK_TFLOPS = 78.6    # dense fp64 matrix peak of gfx950 (v_mfma_f64_16
 def c4_record(torch, dev, batch=8192, reps=3):
     """BASELINE config C4 (random LTI nx=12 nu=6 N=64: no=384, nc=1536) at its per-GPU batch in ONE
     call on the tiled kernel, a different system in every instance (horizon tables generated from
-    (A, B): no S, U in memory, no workspace).  Bound: the fp64 matrix core for the Hessian, HBM for
-    the results; both fractions are reported."""
-    from mpcasm import engine, problems
+    (A, B): no S, U in memory, no workspace).  Every cost is the full horizon of one state: the kernel
+    sums P along diagonals (scan form) and only has to write -- bound: HBM.  The Toeplitz form of the
+    same plan (windows of the table multiplied on the fp64 matrix core) is timed beside it."""
+    from mpcasm import capi, engine, problems
 
     nx, nu, N = 12, 6, 64
     need = 8 * batch * (384 * 384 + 384 + 1536 * 384 + 1536) * 1.05
@@ -448,38 +449,198 @@ def c4_record(torch, dev, batch=8192, reps=3):
     asm.set_param("cost", "track s0", "weight", rng.uniform(0.1, 1.0, [batch, 1, 1]))
     given = torch.as_tensor(rng.normal(0, 0.3, [batch, form.given_len]), device=dev)
     ms = _event_ms(torch, lambda: asm.assemble(given), reps, warm=1, settle_ms=0.0)
+    kernel = asm.last_kernel()
     no, nc = asm.no, asm.nc
     out_bytes = 8 * (no * no + no + nc * no + nc)
     in_bytes = 8 * (asm.ng + int(asm.params.shape[1]) + nx * nx + nx * nu)
     gbps = (out_bytes + in_bytes) * batch / (ms * 1e-3) / 1e9
-    # executed matrix-core work, from the plan: a stage of class n multiplies n x n tiles per
-    # wavefront, 4 wavefronts per block of P, 4 k-steps of v_mfma_f64_16x16x4_f64 (2048 flop) each
+    rec = {"workload": "C4: random LTI nx=12 nu=6 N=64, no=%d nc=%d, per-instance (A,B), weight, given; "
+                       "B=%d in one call" % (no, nc, batch),
+           "kernel": kernel, "batch_per_gpu": batch, "ms_per_call": ms, "assemblies_per_s": batch / (ms * 1e-3),
+           "algorithmic_bytes_per_assembly": out_bytes + in_bytes, "bound": "hbm",
+           "hbm": {"achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS},
+           "workspace_bytes_per_instance": 8 * int(asm.plan.tiled["work"])}
+    # the same plan with its windows multiplied on the matrix core (MPCASM_OPT_PATH 4)
+    asm.set_option(capi.OPT_PATH, 4)
+    ms4 = _event_ms(torch, lambda: asm.assemble(given), 2, warm=1, settle_ms=0.0)
     stages = asm.plan.tiled["stages"]
     nb = -(-no // 128)
     blocks = nb * (nb + 1) // 2                     # (P symmetric: block pairs bi <= bj)
-    # (Toeplitz form, symmetric P: in a diagonal block the quadrant below the diagonal is a mirror
-    # image -- the wavefronts multiply 2 n^2 + n tile pairs per stage instead of 4 n^2)
     p_stages = [(int(st[3]) >> 16, (int(st[3]) >> 8) & 0xFF) for st in stages if (int(st[3]) >> 8) & 1]
     roles = int(asm.plan.tiled["toeplitz"]) and all(fl & 16 for _, fl in p_stages)     # TS_FLAG_SAME
     mfma = int(sum((n * n) * 4 * 4 * (blocks - nb) + ((2 * n * n + n) * 4 if roles else n * n * 16) * nb
                    for n, _ in p_stages))
-    tflops = mfma * 2048 * batch / (ms * 1e-3) / 1e12
-    rec = {"workload": "C4: random LTI nx=12 nu=6 N=64, no=%d nc=%d, per-instance (A,B), weight, given; "
-                       "B=%d in one call" % (no, nc, batch),
-           "kernel": asm.last_kernel() + (" (Toeplitz form: operands out of the TB table in LDS)"
-                                          if int(asm.plan.tiled["toeplitz"]) else ""),
-           "batch_per_gpu": batch, "ms_per_call": ms, "assemblies_per_s": batch / (ms * 1e-3),
-           "algorithmic_bytes_per_assembly": out_bytes + in_bytes,
-           "hbm": {"achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS},
-           "mfma": {"executed_mfma_per_assembly": mfma, "achieved": tflops, "peak": F64_MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": tflops / F64_MFMA_PEAK_TFLOPS,
-                    "note": "structurally zero 16-column tiles of the block-lower-triangular horizon "
-                            "matrices are not multiplied: %.0f%% of the dense symmetric count"
-                            % (100.0 * mfma / max(1, blocks * len(p_stages) * 16 * 4 * 4))},
-           "workspace_bytes_per_instance": 8 * int(asm.plan.tiled["work"])}
+    tflops = mfma * 2048 * batch / (ms4 * 1e-3) / 1e12
+    rec["toeplitz_form"] = {"kernel": asm.last_kernel(), "ms_per_call": ms4, "assemblies_per_s": batch / (ms4 * 1e-3),
+                            "hbm_frac": (out_bytes + in_bytes) * batch / (ms4 * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                            "executed_mfma_per_assembly": mfma, "mfma_TFLOPs": tflops,
+                            "mfma_frac": tflops / F64_MFMA_PEAK_TFLOPS}
     del asm, given
     torch.cuda.empty_cache()
     return rec
+
+
+def c5_record(torch, dev, batch=2048, reps=10):
+    """BASELINE config C5 as an ASSEMBLY (problems.lipm_ltv: LTV LIPM, N=100, two axes: no=200, nc=404) at
+    its per-GPU batch, per-step per-instance (A_k, B_k), on the sweep kernel -- no horizon matrix is
+    formed; algorithmic bytes: the results + 8 N (n^2 + n m) of (A_k, B_k) + given + parameters."""
+    from mpcasm import engine, problems
+
+    N = 100
+    api = problems.load_api("mpc_interface")
+    rng = np.random.default_rng(20263)
+    form = problems.lipm_ltv(api, N=N)
+    first = [problems.ltv_lipm_steps(api, N=N, theta=float(t)) for t in rng.uniform(0, 2 * np.pi, 8)]
+    A = torch.as_tensor(np.stack([first[i % 8][0] * (1.0 - 1e-3 * (i // 8) / max(batch // 8, 1))
+                                  for i in range(batch)]), device=dev)
+    Bm = torch.as_tensor(np.stack([first[i % 8][1] * (1.0 + 1e-3 * (i // 8) / max(batch // 8, 1))
+                                   for i in range(batch)]), device=dev)
+    asm = engine.Assembler(form, batch=batch, device=dev, ltv=["LIP"])
+    asm.bind_ltv("LIP", A, Bm)
+    given = torch.as_tensor(rng.normal(0, 0.05, [batch, form.given_len]), device=dev)
+    ms = _event_ms(torch, lambda: asm.assemble(given), reps)
+    no, nc = asm.no, asm.nc
+    nbytes = 8 * (no * no + no + nc * no + nc) + 8 * (N * 12 + asm.ng + int(asm.params.shape[1]))
+    gbps = nbytes * batch / (ms * 1e-3) / 1e9
+    rec = {"workload": "C5: LTV LIPM (dP->CCC) N=100, 2 axes, no=%d nc=%d, per-step per-instance (A_k,B_k); B=%d"
+                       % (no, nc, batch),
+           "kernel": asm.last_kernel(), "batch_per_gpu": batch, "ms_per_call": ms,
+           "assemblies_per_s": batch / (ms * 1e-3), "algorithmic_bytes_per_assembly": nbytes, "bound": "hbm",
+           "hbm": {"achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS}}
+    del asm, given, A, Bm
+    torch.cuda.empty_cache()
+    return rec
+
+
+def c3_record(torch, dev, batch=16384, sets=8, reps=10):
+    """BASELINE config C3 (3-D LIPM N=32: no=96, nc=196) at B=16384, horizon matrices built on chip, into
+    `sets` separately allocated sets of result buffers, all held at once (where P and G lie in memory moves
+    this configuration: min / median / max over the sets)."""
+    from mpcasm import engine, problems
+
+    api = problems.load_api("mpc_interface")
+    form = problems.lipm3d(api, N=32)
+    rng = np.random.default_rng(20261)
+    asm = engine.Assembler(form, batch=batch, device=dev, lti=["LIP"])
+    given = torch.as_tensor(rng.normal(0, 0.05, [batch, form.given_len]), device=dev)
+    f = dict(dtype=torch.float64, device=dev)
+    no, nc = asm.no, asm.nc
+    held = [(torch.empty((batch, no, no), **f), torch.empty((batch, no), **f),
+             torch.empty((batch, nc, no), **f), torch.empty((batch, nc), **f)) for _ in range(sets)]
+    times = [_event_ms(torch, lambda o=o: asm.assemble(given, out=o), reps, settle_ms=10.0) for o in held]
+    nbytes = 8 * (no * no + no + nc * no + nc) + 8 * (asm.ng + int(asm.params.shape[1]) + 12)
+    med = float(np.median(times))
+    rec = {"workload": "C3: 3-D LIPM N=32, no=%d nc=%d, horizon matrices on chip; B=%d" % (no, nc, batch),
+           "kernel": asm.last_kernel(), "batch_per_gpu": batch, "result_buffer_sets": sets,
+           "ms_per_call": {"min": min(times), "median": med, "max": max(times)},
+           "assemblies_per_s": batch / (med * 1e-3), "algorithmic_bytes_per_assembly": nbytes, "bound": "hbm",
+           "hbm_frac": {"best": nbytes * batch / (min(times) * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                        "median": nbytes * batch / (med * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                        "worst": nbytes * batch / (max(times) * 1e-3) / 1e9 / HBM_PEAK_GBPS}}
+    del asm, held, given
+    torch.cuda.empty_cache()
+    return rec
+
+
+def c1_record(ticks=64):
+    """BASELINE config C1: the walking loop's tick for ONE instance through the drop-in API -- update(),
+    generate_all_qp_matrices(given), results on the host (biped_mpc_loop.py:50-56) -- beside the same tick
+    with the oracle (numpy on one host core) in place of the kernels."""
+    from mpcasm import problems
+    from oracle import qp_oracle as orc
+
+    api = problems.load_api("mpc_interface")
+    conf = problems.BipedConfig(step_samples=8)
+    form = problems.biped(api, conf)
+    n = conf.step_samples
+    rng = np.random.default_rng(0)
+
+    def tick(k, solve):
+        phi = k % n
+        form.update(step_times=np.array([(i + 1) * n - 1 - phi for i in range(conf.num_steps)]), step_count=k // n)
+        return solve(rng.normal(0, 0.1, [form.given_len, 1]))
+
+    out = {}
+    for name, solve in (("tick_ms", form.generate_all_qp_matrices),
+                        ("oracle_tick_ms", lambda given: orc.assemble(form, given))):
+        for k in range(2 * n):
+            tick(k, solve)
+        t0 = time.perf_counter()
+        for k in range(ticks):
+            tick(k, solve)
+        out[name] = (time.perf_counter() - t0) / ticks * 1e3
+    out["workload"] = "C1: biped N=16, one instance, update() + generate_all_qp_matrices(), results on the host"
+    return out
+
+
+def _sig(x, digits=4):
+    """Numbers of the one-line record: a few significant digits."""
+    if isinstance(x, float):
+        return float("%.*g" % (digits, x))
+    if isinstance(x, dict):
+        return {k: _sig(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, digits) for v in x]
+    return x
+
+
+def compact_line(rec):
+    """The ONE line of the contract, short enough to survive a 2000-character tail: every key of the
+    contract with its full meaning, the sub-records as numbers under short keys; the long form of the
+    same record (workload descriptions, clocks, byte counts) goes to bench_full.json and stderr."""
+    def short_kernel(name):
+        return str(name).split(" ")[0]
+
+    r = rec["roofline"]
+    out = {k: rec[k] for k in ("metric", "value", "unit", "n_gpus", "n_ranks_seen", "steps", "warmup",
+                               "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    c = rec["config"]
+    out["config"] = {"workload": "C2 biped LIPM N=16 2 axes no=%d nc=%d, per-instance (A,B)/given/aim, %s"
+                                 % (c["no"], c["nc"], "K1 on chip" if c["fused"] else "fill+assemble"),
+                     "batch_per_gpu": c["batch_per_gpu"], "global_batch": c["global_batch"],
+                     "streams": c["launch_streams"]}
+    out["roofline"] = {"kernel": short_kernel(r["kernel_name"]), "bound": r["bound"], "achieved": r["achieved"],
+                       "peak": r["peak"], "unit": r["unit"], "frac": r["frac"], "traffic": r["traffic"],
+                       "bytes": r["algorithmic_bytes_per_launch"], "avg_launch_ms": r["avg_launch_ms"]}
+    if "cpu_baseline" in rec:
+        b = rec["cpu_baseline"]
+        out["cpu_baseline"] = {"value": b["value"], "unit": b["unit"], "cores": b["cores"], "kind": b["kind"],
+                               "sample": b["sample_short"], "one_core": b["single_core_value"]}
+    out["devices"] = rec["devices"]
+    if "gather" in rec:
+        g = rec["gather"]
+        out["gather"] = {"backend": g["backend"], "ms": g["ms"], "GBps": g["GBps_received_per_gpu"],
+                         "instances_per_gpu_after": g["instances_per_gpu_after"]}
+    if "fill" in rec:        # K1 alone: fraction of HBM at (shape @ systems)
+        out["fill"] = {"%s@%d" % (f["shape"].split(" ")[0], f["systems"]): f["frac"] for f in rec["fill"]}
+    if "variants" in rec:    # the other C2 shapes: fraction of HBM
+        out["variants"] = {("w%d%s" % (v["no"], "r" if "reduced" in v["workload"] else "")): v["frac"]
+                           for v in rec["variants"]}
+    for key in ("c1", "c3", "c4", "c5", "f2", "extra"):
+        v = rec.get(key)
+        if v is None:
+            continue
+        if isinstance(v, dict) and "error" in v:
+            out[key] = {"error": v["error"][:60]}
+        elif key == "c1":
+            out[key] = {"tick_ms": v["tick_ms"], "oracle_tick_ms": v["oracle_tick_ms"]}
+        elif key == "c3":
+            out[key] = {"B": v["batch_per_gpu"], "ms": [v["ms_per_call"][k] for k in ("min", "median", "max")],
+                        "per_s": v["assemblies_per_s"], "frac": v["hbm_frac"]["median"]}
+        elif key == "c4":
+            out[key] = {"B": v["batch_per_gpu"], "kernel": short_kernel(v["kernel"]), "ms": v["ms_per_call"],
+                        "per_s": v["assemblies_per_s"], "frac": v["hbm"]["frac"],
+                        "mfma_form": {"ms": v["toeplitz_form"]["ms_per_call"],
+                                      "mfma_frac": v["toeplitz_form"]["mfma_frac"]}}
+        elif key == "c5":
+            out[key] = {"B": v["batch_per_gpu"], "kernel": short_kernel(v["kernel"]), "ms": v["ms_per_call"],
+                        "per_s": v["assemblies_per_s"], "frac": v["hbm"]["frac"]}
+        elif key == "f2":
+            out[key] = {"B%d" % f["batch_per_gpu"]: {"ms": f["avg_launch_ms"], "frac": f["frac"]} for f in v}
+        elif key == "extra":
+            out["B65536"] = {"ms": v["ms_per_step"], "per_s": v["assemblies_per_s"], "frac": v["frac"]}
+    out["full"] = rec.get("full_record", None)
+    return _sig(out)
 
 
 def tiled(x, times):
@@ -695,10 +856,10 @@ def run_rank(args):
     kernel_name = "mpcasm_assemble -> %s: %sK2 compose + K3 hessian_mfma + K4 constraint_stack in one " \
                   "launch" % (asm.last_kernel(), "K1 horizon tables + " if fused else "")
     ranks_seen = dist.get_world_size() if dist is not None else 1
-    devices = [torch.cuda.get_device_name(local_rank)]
+    devices = ["r%d cuda:%d %s" % (rank, local_rank, torch.cuda.get_device_name(local_rank).replace("AMD Instinct ", ""))]
     if dist is not None:
         names = [None] * ranks_seen
-        dist.all_gather_object(names, "rank %d: %s (cuda:%d)" % (rank, devices[0], local_rank))
+        dist.all_gather_object(names, devices[0])
         devices = names
     timed_ms = elapsed * 1e3
     if timed_ms < 5.0 and rank == 0:
@@ -728,6 +889,7 @@ def run_rank(args):
                         "per-instance (A,B), given, velocity aim; B=%d per GPU" % (no, nc, ng, B),
             "batch_per_gpu": B,
             "global_batch": B * world,
+            "no": no, "nc": nc, "fused": bool(fused),
             "horizon": N,
             "output_buffer_sets": len(outs),
             "launch_streams": nstreams,
@@ -736,6 +898,7 @@ def run_rank(args):
         },
         "roofline": {
             "kernel": kernel_name,
+            "kernel_name": asm.last_kernel(),
             "bound": "hbm",
             "achieved": achieved,
             "peak": HBM_PEAK_GBPS,
@@ -801,11 +964,16 @@ def run_rank(args):
             record["f2"] = f2_records(torch, dev, 20260 + rank)
         except Exception as exc:        # (never at the cost of the main line)
             record["f2"] = {"error": repr(exc)}
-        # C4 on the tiled kernel at its per-GPU batch
-        try:
-            record["c4"] = c4_record(torch, dev)
-        except Exception as exc:        # (never at the cost of the main line)
-            record["c4"] = {"error": repr(exc)}
+        # the other BASELINE configurations: C1 (the drop-in tick of one instance), C3, C4, C5 at their
+        # per-GPU batches (never at the cost of the main line)
+        for key, make in (("c1", lambda: c1_record()), ("c3", lambda: c3_record(torch, dev)),
+                          ("c4", lambda: c4_record(torch, dev)), ("c5", lambda: c5_record(torch, dev))):
+            if rank != 0 and key == "c1":
+                continue
+            try:
+                record[key] = make()
+            except Exception as exc:
+                record[key] = {"error": repr(exc)}
         # the same step at B=65536: 2.2 GB of outputs per step, no cache can hold it
         big = 65536
         times = (big + B - 1) // B
@@ -845,6 +1013,8 @@ def run_rank(args):
             "cores": procs,
             "kind": "port",
             "single_core_value": rate1,
+            "sample_short": "oracle (numpy port of the path), %d assemblies in 10 s on %d procs; 1 proc: %d in %.0f s"
+                            % (count, procs, count1, secs1),
             "compiled_fill_single_thread": compiled,
             "sample": "%d assemblies of the same workload in 10 s on %d processes (one formulation "
                       "each): oracle/qp_oracle.py (extend_matrices + preview matrices + all QP "
@@ -853,7 +1023,18 @@ def run_rank(args):
                       % (count, procs, count1, secs1, os.cpu_count() or 0),
         }
     if rank == 0:
-        print(json.dumps(record), flush=True)
+        # the long form beside the line: a file (gpurun_out/ travels back from a GPU box) and stderr
+        full_dir = os.path.join(ROOT, "gpurun_out")
+        try:
+            os.makedirs(full_dir, exist_ok=True)
+            full_path = os.path.join(full_dir, "bench_full.json")
+            with open(full_path, "w") as f:
+                json.dump(record, f, indent=1)
+            record["full_record"] = "gpurun_out/bench_full.json"
+        except OSError:
+            record["full_record"] = "stderr"
+        print(json.dumps(record), file=sys.stderr, flush=True)
+        print(json.dumps(compact_line(record)), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -1071,19 +1071,25 @@ __device__ __forceinline__ double lane_from_next(double v) {
 // where things sit in the scan kernel's dynamic LDS (bytes); the table last, at least N doubles in:
 // a window that starts before its row's first step reads what lies in front (and is masked)
 struct ScanLds {
-  unsigned d, par, lam, ticket, tb, total;
+  unsigned d, par, lam, ticket, rows, tb, total;
 };
-__host__ __device__ inline ScanLds scan_lds(int dlen, int nparams, int n, int m, int N) {
+// `rows_in_lds`: the records of the rows of G (16 bytes each: table row, arrow slot, coefficient) ride
+// along -- read per row out of LDS, in order with the table's own reads, instead of through the scalar
+// cache (whose returns every LDS wait would have to include)
+__host__ __device__ inline ScanLds scan_lds(int dlen, int nparams, int n, int m, int N, int nc, bool rows_in_lds) {
   ScanLds x;
   x.d = 0;
   x.par = x.d + (unsigned)dlen * 8u;
   x.lam = x.par + (unsigned)((nparams + 2) & ~1) * 8u;
   x.ticket = x.lam + (unsigned)((n * N + 1) & ~1) * 8u;
-  x.tb = x.ticket + 16u;
+  x.rows = x.ticket + 16u;
+  x.tb = x.rows + (rows_in_lds ? (unsigned)nc * 16u : 0u);
   if (x.tb < (unsigned)N * 8u) x.tb = (unsigned)((N + 1) & ~1) * 8u;
   x.total = x.tb + (unsigned)(n * m * N) * 8u;
   return x;
 }
+// two workgroups per CU as long as an instance stays below this
+constexpr unsigned SCAN_HALF_CU = 80 * 1024;
 
 template <int KP, int CB>
 __global__ __launch_bounds__(BLOCK, 2) void toeplitz_scan_kernel(
@@ -1091,7 +1097,7 @@ __global__ __launch_bounds__(BLOCK, 2) void toeplitz_scan_kernel(
     const double* __restrict__ sysB, long long strideB, const double* __restrict__ params,
     const double* __restrict__ work, long long work_stride, double* __restrict__ P,
     double* __restrict__ q, double* __restrict__ G, double* __restrict__ h, int batch, int dlen,
-    int whole_lines, int group, int phases) {
+    int whole_lines, int group, int rows_in_lds, int phases) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1107,7 +1113,7 @@ __global__ __launch_bounds__(BLOCK, 2) void toeplitz_scan_kernel(
   const int4* gts = reinterpret_cast<const int4*>(p.itab + p.off_t_scan_gt);
   const double* gcs = p.dtab + p.t_doff_scan_gc;
   const int32_t* colblk = p.itab + p.off_t_scan_colblk;
-  const ScanLds L = scan_lds(dlen, p.nparams, n, m, N);
+  const ScanLds L = scan_lds(dlen, p.nparams, n, m, N, nc, rows_in_lds != 0);
   int* ticket = reinterpret_cast<int*>(lds + L.ticket);
   // ---- set-up: the table (the value halves of TB's rows), d, the parameters into LDS -------------
   {
@@ -1131,6 +1137,15 @@ __global__ __launch_bounds__(BLOCK, 2) void toeplitz_scan_kernel(
     double* par = reinterpret_cast<double*>(lds + L.par);
     for (int e = tid; e <= p.nparams; e += BLOCK) par[e] = e < p.nparams ? pb[e] : 0.0;  // ([nparams] reads 0.0)
     if (tid < 2) ticket[tid] = 0;  // (row blocks of P, groups of rows of G)
+    if (rows_in_lds && G != nullptr) {
+      const int2* sg = reinterpret_cast<const int2*>(p.itab + p.off_t_scan_grow);
+      const double* sc = p.dtab + p.t_doff_scan_gcoef;
+      for (int R = tid; R < nc; R += BLOCK) {
+        const int2 r = sg[R];
+        *reinterpret_cast<int2*>(lds + L.rows + (unsigned)R * 16u) = r;
+        *reinterpret_cast<double*>(lds + L.rows + (unsigned)R * 16u + 8u) = sc[R];
+      }
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's LDS-DMA loads have landed
   __syncthreads();
@@ -1288,41 +1303,34 @@ __global__ __launch_bounds__(BLOCK, 2) void toeplitz_scan_kernel(
     const int2* sgrow = reinterpret_cast<const int2*>(p.itab + p.off_t_scan_grow);
     const double* sgcoef = p.dtab + p.t_doff_scan_gcoef;
     const int ngroups = (nc + group - 1) / group;
-    // a ticket = `group` consecutive rows; the next ticket is drawn, and its rows' records requested,
-    // before this one's rows are stored (the records' trip through the scalar cache -- and the
-    // ticket's through LDS -- hides behind a dozen stores instead of standing in front of them)
-    struct Rows {
-      int2 rec[SCAN_GROUP];
-      double cf[SCAN_GROUP];
-    };
-    auto take = [&]() -> int {
+    for (;;) {
       int t = 0;
       if (lane == 0) t = atomicAdd(ticket + 1, 1);
-      return __builtin_amdgcn_readfirstlane(t);
-    };
-    auto request = [&](int t, Rows& r) __attribute__((always_inline)) {
+      t = __builtin_amdgcn_readfirstlane(t);
+      if (t >= ngroups) break;
+      const int R0 = t * group;
+      int2 rec[SCAN_GROUP];
+      double cf[SCAN_GROUP];
 #pragma unroll
       for (int rr = 0; rr < SCAN_GROUP; ++rr) {
-        const int R = t * group + rr;
-        const int Rc = (rr < group && R < nc) ? R : nc - 1;
-        r.rec[rr] = sgrow[Rc];
-        r.cf[rr] = sgcoef[Rc];
+        const int R = (rr < group && R0 + rr < nc) ? R0 + rr : nc - 1;
+        if (rows_in_lds) {
+          rec[rr] = *reinterpret_cast<const int2*>(lds + L.rows + (unsigned)R * 16u);
+          cf[rr] = lds_f64(lds, L.rows + (unsigned)R * 16u + 8u);
+        } else {
+          rec[rr] = sgrow[R];
+          cf[rr] = sgcoef[R];
+        }
       }
-    };
-    Rows cur, nxt;
-    int t = take();
-    if (t < ngroups) request(t, cur);
-    while (t < ngroups) {
-      const int tn = take();
-      if (tn < ngroups) request(tn, nxt);
-      const int R0 = t * group;
 #pragma unroll
       for (int rr = 0; rr < SCAN_GROUP; ++rr) {
         const int R = R0 + rr;
-        if (rr >= group || R >= nc || cur.rec[rr].x < 0) continue;
-        const int u8 = cur.rec[rr].x * 8;
-        const int k = cur.rec[rr].x % N;   // (the row's step: i m N + k)
-        const double ar = lds_f64(lds, L.par + (unsigned)cur.rec[rr].y * 8u) * cur.cf[rr];
+        if (rr >= group || R >= nc) break;
+        const int ux = __builtin_amdgcn_readfirstlane(rec[rr].x), slot = __builtin_amdgcn_readfirstlane(rec[rr].y);
+        if (ux < 0) continue;
+        const int u8 = ux * 8;
+        const int k = ux % N;   // (the row's step: i m N + k)
+        const double ar = lds_f64(lds, L.par + (unsigned)slot * 8u) * cf[rr];
         double* grow_out = Gb + (size_t)R * no + lane * 2;
 #pragma unroll
         for (int ch = 0; ch < SCAN_GCH_MAX; ++ch) {
@@ -1339,8 +1347,6 @@ __global__ __launch_bounds__(BLOCK, 2) void toeplitz_scan_kernel(
           }
         }
       }
-      cur = nxt;
-      t = tn;
     }
   }
 
@@ -1466,7 +1472,7 @@ template <int KP, int CB>
 int launch_scan_as(const PlanDev& p, const SrcTable& eff, const double* A, long long strideA,
                    const double* Bm, long long strideB, const double* params, const double* w,
                    long long stride, double* P, double* q, double* G, double* h, int batch, int dlen,
-                   int whole_lines, size_t lds, hipStream_t stream, hipError_t* err) {
+                   int whole_lines, int rows_in_lds, size_t lds, hipStream_t stream, hipError_t* err) {
   auto kernel = toeplitz_scan_kernel<KP, CB>;
   if (lds > 64 * 1024) {
     *err = allow_whole_lds(reinterpret_cast<const void*>(kernel));
@@ -1480,7 +1486,7 @@ int launch_scan_as(const PlanDev& p, const SrcTable& eff, const double* A, long 
     return v < 1 ? 1 : (v > SCAN_GROUP ? SCAN_GROUP : v);
   }();
   hipLaunchKernelGGL(kernel, dim3((unsigned)batch), dim3(BLOCK), lds, stream, p, eff, A, strideA, Bm, strideB,
-                     params, w, stride, P, q, G, h, batch, dlen, whole_lines, group, g_phase_mask);
+                     params, w, stride, P, q, G, h, batch, dlen, whole_lines, group, rows_in_lds, g_phase_mask);
   *err = hipGetLastError();
   if (*err == hipSuccess) t_last_kernel = MPCASM_KERNEL_TILED_SCAN;
   return *err == hipSuccess ? MPCASM_OK : MPCASM_ERR_HIP;
@@ -1498,7 +1504,9 @@ int launch_scan(const PlanDev& p, const SrcTable& src, const SrcTable& eff, cons
   const int n = rec[TL_N], m = rec[TL_M], N = rec[TL_HORIZON];
   if (p.no > 128 * SCAN_GCH_MAX || n > 64 || (N & 1)) return MPCASM_ERR_LIMIT;
   const int dlen = p.rtot + (p.rtot & 1);
-  const size_t lds = scan_lds(dlen, p.nparams, n, m, N).total;
+  // the records of G's rows in LDS while that leaves room for two workgroups per CU
+  const int rows_in_lds = scan_lds(dlen, p.nparams, n, m, N, p.nc, true).total + NSTREAM * sizeof(double*) <= SCAN_HALF_CU;
+  const size_t lds = scan_lds(dlen, p.nparams, n, m, N, p.nc, rows_in_lds != 0).total;
   if (lds + NSTREAM * sizeof(double*) > (size_t)RESIDENT_LDS_LIMIT) return MPCASM_ERR_LIMIT;
   const int32_t* ids = h_itab + p.off_t_lti_ids + rec[TL_IDS];
   // results leave as whole 128-byte lines when every run of a wavefront's store starts and ends on one
@@ -1509,7 +1517,7 @@ int launch_scan(const PlanDev& p, const SrcTable& src, const SrcTable& eff, cons
   if (K <= KP && nblk <= CB)                                                                             \
     return launch_scan_as<KP, CB>(p, eff, src.ptr[ids[0]], src.stride[ids[0]], src.ptr[ids[1]],           \
                                   src.stride[ids[1]], params, w, stride, P, q, G, h, batch, dlen, whole, \
-                                  lds, stream, err);
+                                  rows_in_lds, lds, stream, err);
   MPCASM_SCAN_CASE(4, 4)
   MPCASM_SCAN_CASE(8, 4)
   MPCASM_SCAN_CASE(4, 8)

@@ -27,10 +27,16 @@ def test_rccl_with_one_rank():
     assert proc.returncode == 0, proc.stderr[-3000:]
     rec = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith("{")][0])
     assert rec["n_gpus"] == 1 and rec["n_ranks_seen"] == 1 and len(rec["devices"]) == 1
-    assert rec["devices"][0].startswith("rank 0:")
+    assert rec["devices"][0].startswith("r0 cuda:0")
     g = rec["gather"]
     assert g["backend"] == "nccl" and g["instances_per_gpu_after"] == 1024 and g["ms"] > 0
     assert rec["value"] > 0 and "resident" in rec["roofline"]["kernel"]
+    # the ONE line of the contract survives a 2000-character tail, sub-records included
+    line = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")][0]
+    assert len(line) < 2000, len(line)
+    for key in ("roofline", "fill", "variants", "c3", "c4", "c5", "f2", "B65536"):
+        assert key in rec, key
+    assert rec["roofline"]["bound"] == "hbm" and 0 < rec["roofline"]["frac"] < 1
 
 
 def test_gather_batch_over_rccl_in_process():
