@@ -41,39 +41,44 @@ constexpr int SW_WAVES = SW_BLOCK / 64;
 
 __device__ __forceinline__ double ldsd(const double* base, int i) { return base[i]; }
 
-// LDS of one workgroup (doubles): all steps' [A_k | B_k], the free responses, Psi_l B_l[:, j], q, the
-// parameters, a scratch for the recursions' exchanges, the combinations c, then the plan's small
-// integer tables (terms, limits, the per-step lists, the axes)
+// LDS of one workgroup (doubles): all steps' [A_k | B_k], the free responses, Psi_l B_l[:, j], lam_l, the
+// parameters, the combinations c, per line of G and axis the weights arrow * c (0: the line has nothing
+// on that axis), then the plan's small integer tables (terms, limits, the per-step lists, the axes) and
+// per line its row of G
 struct SweepLds {
-  int ab, xbar, gv, qs, par, scratch, cvec, ints, total;
-  int i_term, i_lim, i_cptr, i_cent, i_gptr, i_gent, i_axis, nints;
+  int ab, xbar, gv, lam, par, cvec, lw, ints, total;
+  int i_term, i_lim, i_gptr, i_gent, i_axis, i_lrow, nints;
 };
 constexpr int LIMW = SW_LIM_WORDS + SW_AXMAX * SW_LAX_WORDS;
+constexpr int SW_TERMS_REG = 8;   // cost terms the recursion waves keep in registers
 __host__ __device__ inline SweepLds sweep_lds(const PlanDev& p) {
   const int n = p.sw_n, m = p.sw_m, N = p.sw_horizon, naxes = p.sw_naxes;
   SweepLds x;
   x.ab = 0;
   x.xbar = x.ab + N * (n * n + n * m);
   x.gv = x.xbar + naxes * N * n;
-  x.qs = x.gv + naxes * m * N * n;
-  x.par = x.qs + p.no;
-  x.scratch = x.par + p.nparams + 1;
-  x.cvec = x.scratch + 2 * SW_AXMAX * SW_NMAX * SW_NMAX + SW_AXMAX * SW_NMAX;
+  x.lam = x.gv + naxes * m * N * n;
+  x.par = x.lam + naxes * N * n;
+  x.cvec = x.par + p.nparams + 1;
   x.cvec += x.cvec & 1;
-  x.ints = x.cvec + p.sw_ncvec * SW_NMAX;
+  x.lw = x.cvec + p.sw_ncvec * SW_NMAX;
+  x.ints = x.lw + p.sw_ngent * naxes * n;
+  x.ints += x.ints & 1;
   x.i_term = 0;
   x.i_lim = x.i_term + p.sw_nterm * SW_TERM_WORDS;
-  x.i_cptr = x.i_lim + p.sw_nlim * LIMW;
-  x.i_cent = x.i_cptr + N + 1;
-  x.i_gptr = x.i_cent + p.sw_ncent;
+  x.i_gptr = x.i_lim + p.sw_nlim * LIMW;
   x.i_gent = x.i_gptr + N + 1;
   x.i_gent += x.i_gent & 1;
   x.i_axis = x.i_gent + 2 * p.sw_ngent;
-  x.nints = x.i_axis + naxes * SW_AXIS_WORDS;
+  x.i_lrow = x.i_axis + naxes * SW_AXIS_WORDS;
+  x.nints = x.i_lrow + p.sw_ngent;
   x.total = x.ints + (x.nints + 1) / 2;
   x.total += x.total & 1;
   return x;
 }
+
+// value of lane `src` (same for a double's two halves)
+__device__ __forceinline__ double lane_value(double v, int src) { return __shfl(v, src, 64); }
 
 // CPT: columns per thread (no <= SW_BLOCK * CPT)
 template <int CPT>
@@ -93,19 +98,19 @@ __global__ __launch_bounds__(SW_BLOCK) void ltv_sweep_kernel(
   double* AB = sw + L.ab;       // [N][n n + n m]: A_k row major, then B_k
   double* xbar = sw + L.xbar;   // [naxes][N][n]
   double* gv = sw + L.gv;       // [naxes][m][N][n]
-  double* qs = sw + L.qs;       // [no]
+  double* lamT = sw + L.lam;    // [naxes][N][n]
   double* par = sw + L.par;     // [nparams + 1], the last 0.0
-  double* scr = sw + L.scratch;
   double* cvec = sw + L.cvec;   // [ncvec][SW_NMAX]
+  double* lw = sw + L.lw;       // [lines][naxes][n]
   int* itb = reinterpret_cast<int*>(sw + L.ints);
   const int* terms = itb + L.i_term;
   const int* lims = itb + L.i_lim;
-  const int* cptr = itb + L.i_cptr;
-  const int* cent = itb + L.i_cent;
   const int* gptr = itb + L.i_gptr;
   const int2* gent = reinterpret_cast<const int2*>(itb + L.i_gent);
   const int* axis = itb + L.i_axis;
+  int* lrow = itb + L.i_lrow;
   const double* pb = params + (size_t)inst * p.nparams;
+  const int nlines = p.sw_ngent;
 
   // ---- set-up: every step's (A_k, B_k), the parameters, the plan's tables -----------------------------
   {
@@ -120,10 +125,8 @@ __global__ __launch_bounds__(SW_BLOCK) void ltv_sweep_kernel(
     };
     copy(L.i_term, p.off_sw_term, p.sw_nterm * SW_TERM_WORDS);
     copy(L.i_lim, p.off_sw_lim, p.sw_nlim * LIMW);
-    copy(L.i_cptr, p.off_sw_cptr, N + 1);
-    copy(L.i_cent, p.off_sw_cent, p.sw_ncent);
     copy(L.i_gptr, p.off_sw_gptr, N + 1);
-    copy(L.i_gent, p.off_sw_gent, 2 * p.sw_ngent);
+    copy(L.i_gent, p.off_sw_gent, 2 * nlines);
     copy(L.i_axis, p.off_sw_axis, naxes * SW_AXIS_WORDS);
   }
   // this thread's columns: axis, input, step; the diagonal terms on them (a cost on the input itself)
@@ -146,35 +149,156 @@ __global__ __launch_bounds__(SW_BLOCK) void ltv_sweep_kernel(
   }
   __syncthreads();
 
-  // ---- the free response of every axis: x_k = A_k x_{k-1} (a thread per axis) ---------------------
-  if (tid < naxes) {
-    double x[SW_NMAX];
+  // ---- the recursions, side by side on two wavefronts; the others lay out the lines of G -------------
+  // Lane (a, i, jj) = a 16 + i 4 + jj: a quad holds a row i of an n x n matrix of axis a, so "row i times
+  // a column" is four quad broadcasts (DPP) and "column i of A^T times ..." four lane reads -- no trip
+  // through LDS in the dependent chain; the step's A comes out of LDS a step ahead.
+  const int ra = lane >> 4, ri = (lane >> 2) & 3, rj = lane & 3;
+  const bool rlive = ra < naxes && ri < n && rj < n;
+  if (wave == 0 && P != nullptr) {
+    // Psi_l = W_l + A_{l+1}^T Psi_{l+1} A_{l+1};  gv[a][j][l] = Psi_l B_l[:, j]
+    double wcc[SW_TERMS_REG];   // w c[i] c[jj] of the terms on this lane's axis (0: another axis)
+    int tk0[SW_TERMS_REG], tks[SW_TERMS_REG], tcnt[SW_TERMS_REG];
+    const bool in_regs = p.sw_nterm <= SW_TERMS_REG;
 #pragma unroll
-    for (int i = 0; i < SW_NMAX; ++i) x[i] = i < n ? given[(size_t)inst * p.ng + axis[tid * SW_AXIS_WORDS] + i] : 0.0;
-    for (int k = 0; k < N; ++k) {
-      const double* Ak = AB + k * abw;
-      double y[SW_NMAX];
+    for (int t = 0; t < SW_TERMS_REG; ++t) {
+      const int* tr = terms + (t < p.sw_nterm ? t : 0) * SW_TERM_WORDS;
+      const bool mine = in_regs && t < p.sw_nterm && rlive && tr[ST_AXIS] == ra;
+      const double* cv = cvec + tr[ST_CVEC];
+      wcc[t] = mine ? (par[tr[ST_WPARAM]] * cv[ri]) * cv[rj] : 0.0;
+      tk0[t] = tr[ST_K0];
+      tks[t] = tr[ST_KSTEP];
+      tcnt[t] = t < p.sw_nterm ? tr[ST_COUNT] : 0;
+    }
+    double psi = 0.0;
+    for (int l = N - 1; l >= 0; --l) {
+      if (l + 1 < N) {
+        const double* An = AB + (l + 1) * abw;
+        double acol[SW_NMAX], arow[SW_NMAX];   // A[s][jj], A[s][i]
 #pragma unroll
-      for (int i = 0; i < SW_NMAX; ++i) {
-        y[i] = 0.0;
-        if (i < n) {
+        for (int s_ = 0; s_ < SW_NMAX; ++s_) {
+          acol[s_] = (rlive && s_ < n) ? An[s_ * n + rj] : 0.0;
+          arow[s_] = (rlive && s_ < n) ? An[s_ * n + ri] : 0.0;
+        }
+        // T[i][jj] = sum_s Psi[i][s] A[s][jj]
+        double t_ = quad_broadcast<0>(psi) * acol[0];
+        t_ = fma(quad_broadcast<1>(psi), acol[1], t_);
+        t_ = fma(quad_broadcast<2>(psi), acol[2], t_);
+        t_ = fma(quad_broadcast<3>(psi), acol[3], t_);
+        // Psi'[i][jj] = sum_s A[s][i] T[s][jj]
+        const int base = (lane & ~15) | rj;
+        double nw = arow[0] * lane_value(t_, base);
+        nw = fma(arow[1], lane_value(t_, base + 4), nw);
+        nw = fma(arow[2], lane_value(t_, base + 8), nw);
+        nw = fma(arow[3], lane_value(t_, base + 12), nw);
+        psi = rlive ? nw : 0.0;
+      }
+      if (in_regs) {
 #pragma unroll
-          for (int t = 0; t < SW_NMAX; ++t)
-            if (t < n) y[i] = fma(Ak[i * n + t], x[t], y[i]);
+        for (int t = 0; t < SW_TERMS_REG; ++t) {
+          const int dk = l - tk0[t];
+          const bool on = tks[t] == 1 ? (dk >= 0 && dk < tcnt[t])
+                          : (tks[t] == 0 ? dk == 0 : (dk % tks[t] == 0 && dk / tks[t] >= 0 && dk / tks[t] < tcnt[t]));
+          const double times = (tks[t] == 0 && on) ? (double)tcnt[t] : 1.0;   // (lines at one step: all of them)
+          psi += on ? wcc[t] * times : 0.0;
+        }
+      } else {
+        for (int t = 0; t < p.sw_nterm; ++t) {
+          const int* tr = terms + t * SW_TERM_WORDS;
+          const int dk = l - tr[ST_K0], ks = tr[ST_KSTEP], cnt = tr[ST_COUNT];
+          const bool on = ks == 0 ? dk == 0 : (dk % ks == 0 && dk / ks >= 0 && dk / ks < cnt);
+          if (!on || !rlive || tr[ST_AXIS] != ra) continue;
+          const double* cv = cvec + tr[ST_CVEC];
+          psi = fma((par[tr[ST_WPARAM]] * cv[ri]) * cv[rj], ks == 0 ? (double)cnt : 1.0, psi);
         }
       }
+      // gv[a][j][l][i] = sum_s Psi[i][s] B_l[s][j]: lane (a, i, jj) takes the inputs j = jj, jj + n, ...
+      const double* Bl = AB + l * abw + nn;
+      const double p0 = quad_broadcast<0>(psi), p1 = quad_broadcast<1>(psi), p2 = quad_broadcast<2>(psi),
+                   p3 = quad_broadcast<3>(psi);
+      if (rlive)
+        for (int j = rj; j < m; j += n) {
+          double gsum = p0 * Bl[j];
+          if (n > 1) gsum = fma(p1, Bl[m + j], gsum);
+          if (n > 2) gsum = fma(p2, Bl[2 * m + j], gsum);
+          if (n > 3) gsum = fma(p3, Bl[3 * m + j], gsum);
+          gv[((ra * m + j) * N + l) * n + ri] = gsum;
+        }
+    }
+  } else if (wave == 1) {
+    // lane (a, i, 0): the free response x_k = A_k x_{k-1}, then lam_l = rho_l + A_{l+1}^T lam_{l+1}
+    const bool xl = rlive && rj == 0;
+    double x = xl ? given[(size_t)inst * p.ng + axis[ra * SW_AXIS_WORDS] + ri] : 0.0;
+    for (int k = 0; k < N; ++k) {
+      const double* Ak = AB + k * abw;
+      double arow[SW_NMAX];   // A[i][s]
 #pragma unroll
-      for (int i = 0; i < SW_NMAX; ++i) {
-        x[i] = y[i];
-        if (i < n) xbar[(tid * N + k) * n + i] = y[i];
+      for (int s_ = 0; s_ < SW_NMAX; ++s_) arow[s_] = (xl && s_ < n) ? Ak[ri * n + s_] : 0.0;
+      const int base = lane & ~15;   // x[s] lives in lane (a, s, 0)
+      double y = arow[0] * lane_value(x, base);
+      y = fma(arow[1], lane_value(x, base + 4), y);
+      y = fma(arow[2], lane_value(x, base + 8), y);
+      y = fma(arow[3], lane_value(x, base + 12), y);
+      x = xl ? y : 0.0;
+      if (xl) xbar[(ra * N + k) * n + ri] = x;
+    }
+    if (P != nullptr) {
+      double lam = 0.0;
+      for (int l = N - 1; l >= 0; --l) {
+        const int base = lane & ~15;
+        if (l + 1 < N) {
+          const double* An = AB + (l + 1) * abw;
+          double acl[SW_NMAX];   // A[s][i]
+#pragma unroll
+          for (int s_ = 0; s_ < SW_NMAX; ++s_) acl[s_] = (xl && s_ < n) ? An[s_ * n + ri] : 0.0;
+          double y = acl[0] * lane_value(lam, base);
+          y = fma(acl[1], lane_value(lam, base + 4), y);
+          y = fma(acl[2], lane_value(lam, base + 8), y);
+          y = fma(acl[3], lane_value(lam, base + 12), y);
+          lam = xl ? y : 0.0;
+        }
+        // rho_l[i] = sum over the cost rows of step l on this axis of w (c . x_l - aim) c[i]
+        const double x0 = lane_value(x, base);   // (x of the last step is not what is needed: read x_l back)
+        (void)x0;
+        const double* xb = xbar + ((xl ? ra : 0) * N + l) * n;
+        for (int t = 0; t < p.sw_nterm; ++t) {
+          const int* tr = terms + t * SW_TERM_WORDS;
+          const int dk = l - tr[ST_K0], ks = tr[ST_KSTEP], cnt = tr[ST_COUNT];
+          const bool on = ks == 1 ? (dk >= 0 && dk < cnt)
+                                  : (ks == 0 ? dk == 0 : (dk % ks == 0 && dk / ks >= 0 && dk / ks < cnt));
+          if (!on) continue;
+          const double* cv = cvec + tr[ST_CVEC];
+          double d = 0.0;
+          for (int s_ = 0; s_ < n; ++s_) d = fma(cv[s_], xb[s_], d);
+          const double wr = par[tr[ST_WPARAM]] * (ks == 0 ? (double)cnt : 1.0) * (d - par[tr[ST_AIMPARAM]]);
+          lam += (xl && tr[ST_AXIS] == ra) ? wr * cv[ri] : 0.0;
+        }
+        if (xl) lamT[(ra * N + l) * n + ri] = lam;
+      }
+    }
+  }
+  if (G != nullptr && wave >= 2) {
+    // lines of G, in the order of the steps: their rows, and per axis the weights arrow * c
+    const int wt = tid - 128, WT = SW_BLOCK - 128;
+    for (int e = wt; e < nlines; e += WT) {
+      const int2 ge = gent[e];
+      const int* rec = lims + ge.x * LIMW;
+      lrow[e] = rec[SL_OUT0] + ge.y;
+      for (int a = 0; a < naxes; ++a)
+        for (int s_ = 0; s_ < n; ++s_) lw[(e * naxes + a) * n + s_] = 0.0;
+      for (int ax = 0; ax < rec[SL_NAXES]; ++ax) {
+        const int* xr = rec + SW_LIM_WORDS + ax * SW_LAX_WORDS;
+        const double ar = par[xr[SX_ARROW] + ge.y * xr[SX_ARROW_STEP]];
+        const double* cv = cvec + xr[SX_CVEC];
+        for (int s_ = 0; s_ < n; ++s_) lw[(e * naxes + xr[SX_AXIS]) * n + s_] += ar * cv[s_];
       }
     }
   }
   __syncthreads();
 
-  // ---- h: (extreme + arrow . center) - arrow . (c . x of the line's step) ---------------------------
+  // ---- h: (extreme + arrow . center) - arrow . (c . x of the line's step);  q = B_l[:, j] . lam_l ---------
   if (G != nullptr)
-    for (int e = tid; e < p.sw_ngent; e += SW_BLOCK) {
+    for (int e = tid; e < nlines; e += SW_BLOCK) {
       const int2 ge = gent[e];
       const int* rec = lims + ge.x * LIMW;
       const int i = ge.y, nax = rec[SL_NAXES];
@@ -186,90 +310,33 @@ __global__ __launch_bounds__(SW_BLOCK) void ltv_sweep_kernel(
         const double* xb = xbar + (xr[SX_AXIS] * N + xr[SX_K0] + i * xr[SX_KSTEP]) * n;
         const double* cv = cvec + xr[SX_CVEC];
         double d = 0.0;
-        for (int s = 0; s < n; ++s) d = fma(cv[s], xb[s], d);
+        for (int s_ = 0; s_ < n; ++s_) d = fma(cv[s_], xb[s_], d);
         ad = fma(ar, d, ad);
       }
       h[(size_t)inst * nc + rec[SL_OUT0] + i] = (par[rec[SL_EXTREME] + i * rec[SL_EXTREME_STEP]] + ac) - ad;
     }
-
-  // ---- backward: Psi_l, lam_l -> gv[a][j][l] = Psi_l B_l[:, j], qs[(a, j, l)] = B_l[:, j] . lam_l --------
-  // wavefront 0: lane (a, i, jj) holds Psi[i][jj] of axis a; the lanes jj == 0 also lam[i]; products
-  // through the scratch (a wavefront's LDS operations complete in order: no barrier)
-  if (wave == 0 && P != nullptr) {
-    const int a = lane / nn, e = lane - a * nn, i = e / n, jj = e - i * n;
-    const bool live = a < naxes;
-    double* sP = scr + (live ? a : 0) * 2 * SW_NMAX * SW_NMAX;   // Psi of this axis, then T = Psi A
-    double* sT = sP + SW_NMAX * SW_NMAX;
-    double* sL = scr + 2 * SW_AXMAX * SW_NMAX * SW_NMAX + (live ? a : 0) * SW_NMAX;
-    double psi = 0.0, lam = 0.0;
-    for (int l = N - 1; l >= 0; --l) {
-      if (l + 1 < N) {  // Psi <- A_{l+1}^T Psi A_{l+1}, lam <- A_{l+1}^T lam
-        const double* An = AB + (l + 1) * abw;
-        if (live) {
-          sP[i * n + jj] = psi;
-          if (jj == 0) sL[i] = lam;
-        }
-        asm volatile("" ::: "memory");
-        double t = 0.0, lnew = 0.0;
-        if (live) {
-          for (int s = 0; s < n; ++s) t = fma(sP[i * n + s], An[s * n + jj], t);
-          sT[i * n + jj] = t;
-          if (jj == 0)
-            for (int s = 0; s < n; ++s) lnew = fma(An[s * n + i], sL[s], lnew);
-        }
-        asm volatile("" ::: "memory");
-        psi = 0.0;
-        if (live)
-          for (int s = 0; s < n; ++s) psi = fma(An[s * n + i], sT[s * n + jj], psi);
-        lam = lnew;
-      }
-      // + W_l, rho_l: the cost rows of step l on this lane's axis
-      const int e1 = cptr[l + 1];
-      for (int ce = cptr[l]; ce < e1; ++ce) {
-        const int* tr = terms + cent[ce] * SW_TERM_WORDS;
-        if (!live || tr[ST_AXIS] != a) continue;
-        const double* cv = cvec + tr[ST_CVEC];
-        const double w = par[tr[ST_WPARAM]];
-        psi = fma(w * cv[i], cv[jj], psi);
-        if (jj == 0) {
-          const double* xb = xbar + (a * N + l) * n;
-          double d = 0.0;
-          for (int s = 0; s < n; ++s) d = fma(cv[s], xb[s], d);
-          lam = fma(w * (d - par[tr[ST_AIMPARAM]]), cv[i], lam);
-        }
-      }
-      // gv, qs of this step
-      const double* Bl = AB + l * abw + nn;
-      if (live) {
-        sP[i * n + jj] = psi;
-        if (jj == 0) sL[i] = lam;
-      }
-      asm volatile("" ::: "memory");
-      if (live)
-        for (int j = jj; j < m; j += n) {  // lane (a, i, j): (Psi B_l[:, j])[i]; the lanes i == 0 also q
-          double gsum = 0.0;
-          for (int s = 0; s < n; ++s) gsum = fma(sP[i * n + s], Bl[s * m + j], gsum);
-          gv[((a * m + j) * N + l) * n + i] = gsum;
-          if (i == 0) {
-            double qsum = 0.0;
-            for (int s = 0; s < n; ++s) qsum = fma(Bl[s * m + j], sL[s], qsum);
-            qs[axis[a * SW_AXIS_WORDS + 1 + j] + l] = qsum;
-          }
-        }
-      asm volatile("" ::: "memory");
-    }
-  }
-  __syncthreads();
   if (P != nullptr)
 #pragma unroll
     for (int t = 0; t < CPT; ++t) {
       const int c = tid + t * SW_BLOCK;
-      if (c < no) q[(size_t)inst * no + c] = qs[c] + dqc[t];
+      if (c < no) {
+        const double* Bl = AB + cl[t] * abw + nn;
+        const double* lm = lamT + (ca[t] * N + cl[t]) * n;
+        double acc = dqc[t];
+        for (int s_ = 0; s_ < n; ++s_) acc = fma(Bl[s_ * m + cj[t]], lm[s_], acc);
+        q[(size_t)inst * no + c] = acc;
+      }
     }
 
   // ---- forward sweep: u = Phi(l, l'+1) B_l' per column; rows of G of step l, P at and below the diagonal ----
   double* Pb = P + (size_t)inst * no * no;
   double* Gb = G + (size_t)inst * nc * no;
+  // first unknown of every (axis, input): wave-uniform, kept in registers
+  int c0[SW_AXMAX][SW_MMAX];
+#pragma unroll
+  for (int a = 0; a < SW_AXMAX; ++a)
+#pragma unroll
+    for (int j = 0; j < SW_MMAX; ++j) c0[a][j] = (a < naxes && j < m) ? axis[a * SW_AXIS_WORDS + 1 + j] : 0;
   double u[CPT][SW_NMAX];
 #pragma unroll
   for (int t = 0; t < CPT; ++t)
@@ -278,6 +345,7 @@ __global__ __launch_bounds__(SW_BLOCK) void ltv_sweep_kernel(
   for (int l = 0; l < N; ++l) {
     const double* Al = AB + l * abw;
     const double* Bl = Al + nn;
+    const int e0 = gptr[l], e1 = gptr[l + 1];   // (requested with the step's A: one trip)
 #pragma unroll
     for (int t = 0; t < CPT; ++t) {
       if (ca[t] < 0) continue;
@@ -291,19 +359,23 @@ __global__ __launch_bounds__(SW_BLOCK) void ltv_sweep_kernel(
           y[i] = 0.0;
           if (i < n) {
 #pragma unroll
-            for (int s = 0; s < SW_NMAX; ++s)
-              if (s < n) y[i] = fma(Al[i * n + s], u[t][s], y[i]);
+            for (int s_ = 0; s_ < SW_NMAX; ++s_)
+              if (s_ < n) y[i] = fma(Al[i * n + s_], u[t][s_], y[i]);
           }
         }
 #pragma unroll
         for (int i = 0; i < SW_NMAX; ++i) u[t][i] = y[i];
       }
     }
-    if (P != nullptr)
-      for (int a = 0; a < naxes; ++a)
-        for (int j = 0; j < m; ++j) {
+    if (P != nullptr) {
+#pragma unroll
+      for (int a = 0; a < SW_AXMAX; ++a) {
+        if (a >= naxes) break;
+#pragma unroll
+        for (int j = 0; j < SW_MMAX; ++j) {
+          if (j >= m) break;
           const double* g = gv + ((a * m + j) * N + l) * n;
-          const int r = axis[a * SW_AXIS_WORDS + 1 + j] + l;
+          const int r = c0[a][j] + l;
 #pragma unroll
           for (int t = 0; t < CPT; ++t) {
             const int c = tid + t * SW_BLOCK;
@@ -313,39 +385,43 @@ __global__ __launch_bounds__(SW_BLOCK) void ltv_sweep_kernel(
             } else if (cl[t] <= l) {
               double v = 0.0;
 #pragma unroll
-              for (int s = 0; s < SW_NMAX; ++s)
-                if (s < n) v = fma(g[s], u[t][s], v);
+              for (int s_ = 0; s_ < SW_NMAX; ++s_)
+                if (s_ < n) v = fma(g[s_], u[t][s_], v);
               if (c == r) v += dPc[t];
               Pb[(size_t)r * no + c] = v;
             }
           }
         }
+      }
+    }
     if (G != nullptr) {
-      const int e1 = gptr[l + 1];
-      for (int ge = gptr[l]; ge < e1; ++ge) {
-        const int2 line = gent[ge];
-        const int* rec = lims + line.x * LIMW;
-        const int i = line.y, nax = rec[SL_NAXES];
-        double val[CPT];
+      // four lines at a time: their rows and this thread's weights requested together, then used
+      for (int e = e0; e < e1; e += 4) {
+        int row[4];
+        double w4[4][CPT][SW_NMAX];
 #pragma unroll
-        for (int t = 0; t < CPT; ++t) val[t] = 0.0;
-        for (int ax = 0; ax < nax; ++ax) {
-          const int* xr = rec + SW_LIM_WORDS + ax * SW_LAX_WORDS;
-          const double ar = par[xr[SX_ARROW] + i * xr[SX_ARROW_STEP]];
-          const double* cv = cvec + xr[SX_CVEC];
+        for (int x = 0; x < 4; ++x) {
+          const int ee = e + x < e1 ? e + x : e1 - 1;
+          row[x] = lrow[ee];
 #pragma unroll
           for (int t = 0; t < CPT; ++t) {
-            double d = 0.0;
+            const double* wv = lw + (ee * naxes + (ca[t] < 0 ? 0 : ca[t])) * n;
 #pragma unroll
-            for (int s = 0; s < SW_NMAX; ++s)
-              if (s < n) d = fma(cv[s], u[t][s], d);
-            val[t] += ca[t] == xr[SX_AXIS] ? ar * d : 0.0;
+            for (int s_ = 0; s_ < SW_NMAX; ++s_) w4[x][t][s_] = s_ < n ? wv[s_] : 0.0;
           }
         }
 #pragma unroll
-        for (int t = 0; t < CPT; ++t) {
-          const int c = tid + t * SW_BLOCK;
-          if (c < no) Gb[(size_t)(rec[SL_OUT0] + i) * no + c] = val[t];
+        for (int x = 0; x < 4; ++x) {
+          if (e + x >= e1) break;
+#pragma unroll
+          for (int t = 0; t < CPT; ++t) {
+            const int c = tid + t * SW_BLOCK;
+            if (c >= no) continue;
+            double v = 0.0;
+#pragma unroll
+            for (int s_ = 0; s_ < SW_NMAX; ++s_) v = fma(w4[x][t][s_], u[t][s_], v);
+            Gb[(size_t)row[x] * no + c] = v;
+          }
         }
       }
     }
@@ -375,28 +451,33 @@ __global__ __launch_bounds__(SW_BLOCK) void ltv_sweep_kernel(
           y[i] = 0.0;
           if (i < n) {
 #pragma unroll
-            for (int s = 0; s < SW_NMAX; ++s)
-              if (s < n) y[i] = fma(An[s * n + i], z[t][s], y[i]);
+            for (int s_ = 0; s_ < SW_NMAX; ++s_)
+              if (s_ < n) y[i] = fma(An[s_ * n + i], z[t][s_], y[i]);
           }
         }
 #pragma unroll
         for (int i = 0; i < SW_NMAX; ++i) z[t][i] = y[i];
       }
     }
-    for (int a = 0; a < naxes; ++a)
-      for (int j = 0; j < m; ++j) {
-        const int r = axis[a * SW_AXIS_WORDS + 1 + j] + l;
+#pragma unroll
+    for (int a = 0; a < SW_AXMAX; ++a) {
+      if (a >= naxes) break;
+#pragma unroll
+      for (int j = 0; j < SW_MMAX; ++j) {
+        if (j >= m) break;
+        const int r = c0[a][j] + l;
 #pragma unroll
         for (int t = 0; t < CPT; ++t) {
           const int c = tid + t * SW_BLOCK;
           if (ca[t] != a || cl[t] <= l) continue;
           double v = 0.0;
 #pragma unroll
-          for (int s = 0; s < SW_NMAX; ++s)
-            if (s < n) v = fma(Bl[s * m + j], z[t][s], v);
+          for (int s_ = 0; s_ < SW_NMAX; ++s_)
+            if (s_ < n) v = fma(Bl[s_ * m + j], z[t][s_], v);
           Pb[(size_t)r * no + c] = v;
         }
       }
+    }
   }
 }
 

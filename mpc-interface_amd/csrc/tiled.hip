@@ -1482,7 +1482,7 @@ int launch_scan_as(const PlanDev& p, const SrcTable& eff, const double* A, long 
   // workgroup write closer together, more = fewer tickets
   static const int group = [] {
     const char* e = getenv("MPCASM_SCAN_GROUP");
-    const int v = e ? atoi(e) : 4;
+    const int v = e ? atoi(e) : SCAN_GROUP;   // (r04: 8 rows per ticket 8.6 ms per 8192 C4 instances, 4: 9.3, 1: 9.7)
     return v < 1 ? 1 : (v > SCAN_GROUP ? SCAN_GROUP : v);
   }();
   hipLaunchKernelGGL(kernel, dim3((unsigned)batch), dim3(BLOCK), lds, stream, p, eff, A, strideA, Bm, strideB,

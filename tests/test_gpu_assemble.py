@@ -185,7 +185,11 @@ def test_biped_batch_c2(gpu_api):
 
     asm, given, (aims, centers), (P, q, G, h) = batched_case(form, batch, 20260, vary)
     assert G.shape == (batch, 76, 36)
-    for b in (0, 1, 1777, batch - 1):
+    # 64 instances against the oracle: the ends, the instances around the boundaries of the workgroups'
+    # runs of four, random ones (four were thin where the oracle costs a millisecond each)
+    picks = sorted({0, 1, 3, 4, 2047, 2048, 1777, batch - 2, batch - 1}
+                   | set(int(x) for x in np.random.default_rng(4).integers(0, batch, 55)))
+    for b in picks:
         form.goals["track vel_x"].update(aim=aims[b, 0])
         for k in range(4):
             limits[k].update(center=centers[k][b])
