@@ -93,6 +93,7 @@ int validate_sweep(const int32_t* it, int64_t n, int64_t nd) {
   const int32_t* tr = it + it[H_OFF_SW_TERM];
   for (int64_t t = 0; t < nterm; ++t, tr += SW_TERM_WORDS)
     if (tr[ST_AXIS] < 0 || tr[ST_AXIS] >= naxes || !steps_ok(tr[ST_K0], tr[ST_KSTEP], tr[ST_COUNT]) ||
+        tr[ST_KSTEP] < 0 ||  // (the kernel walks a term's steps downwards from its last)
         tr[ST_WPARAM] < 0 || tr[ST_WPARAM] >= nparams || tr[ST_AIMPARAM] < 0 || tr[ST_AIMPARAM] >= nparams ||
         tr[ST_CVEC] < 0 || tr[ST_CVEC] % SW_NMAX || tr[ST_CVEC] / SW_NMAX >= ncv)
       return MPCASM_ERR_PLAN;

@@ -157,8 +157,10 @@ __global__ __launch_bounds__(SW_BLOCK) void ltv_sweep_kernel(
   const bool rlive = ra < naxes && ri < n && rj < n;
   if (wave == 0 && P != nullptr) {
     // Psi_l = W_l + A_{l+1}^T Psi_{l+1} A_{l+1};  gv[a][j][l] = Psi_l B_l[:, j]
+    // A term's steps are k0, k0 + ks, ... (ks >= 0, cnt of them): walked downwards with a counter --
+    // `tnext` the next step that has a row, `tleft` how many are left (no division per step).
     double wcc[SW_TERMS_REG];   // w c[i] c[jj] of the terms on this lane's axis (0: another axis)
-    int tk0[SW_TERMS_REG], tks[SW_TERMS_REG], tcnt[SW_TERMS_REG];
+    int tnext[SW_TERMS_REG], tks[SW_TERMS_REG], tleft[SW_TERMS_REG];
     const bool in_regs = p.sw_nterm <= SW_TERMS_REG;
 #pragma unroll
     for (int t = 0; t < SW_TERMS_REG; ++t) {
@@ -166,9 +168,9 @@ __global__ __launch_bounds__(SW_BLOCK) void ltv_sweep_kernel(
       const bool mine = in_regs && t < p.sw_nterm && rlive && tr[ST_AXIS] == ra;
       const double* cv = cvec + tr[ST_CVEC];
       wcc[t] = mine ? (par[tr[ST_WPARAM]] * cv[ri]) * cv[rj] : 0.0;
-      tk0[t] = tr[ST_K0];
       tks[t] = tr[ST_KSTEP];
-      tcnt[t] = t < p.sw_nterm ? tr[ST_COUNT] : 0;
+      tleft[t] = t < p.sw_nterm ? tr[ST_COUNT] : 0;
+      tnext[t] = tr[ST_K0] + (tr[ST_COUNT] - 1) * tr[ST_KSTEP];
     }
     double psi = 0.0;
     for (int l = N - 1; l >= 0; --l) {
@@ -196,17 +198,21 @@ __global__ __launch_bounds__(SW_BLOCK) void ltv_sweep_kernel(
       if (in_regs) {
 #pragma unroll
         for (int t = 0; t < SW_TERMS_REG; ++t) {
-          const int dk = l - tk0[t];
-          const bool on = tks[t] == 1 ? (dk >= 0 && dk < tcnt[t])
-                          : (tks[t] == 0 ? dk == 0 : (dk % tks[t] == 0 && dk / tks[t] >= 0 && dk / tks[t] < tcnt[t]));
-          const double times = (tks[t] == 0 && on) ? (double)tcnt[t] : 1.0;   // (lines at one step: all of them)
-          psi += on ? wcc[t] * times : 0.0;
+          const bool on = tleft[t] > 0 && l == tnext[t];
+          const int take = !on ? 0 : (tks[t] == 0 ? tleft[t] : 1);   // (rows at one step: all of them)
+          psi = fma(wcc[t], (double)take, psi);
+          tleft[t] -= take;
+          tnext[t] -= on ? tks[t] : 0;
         }
       } else {
         for (int t = 0; t < p.sw_nterm; ++t) {
           const int* tr = terms + t * SW_TERM_WORDS;
           const int dk = l - tr[ST_K0], ks = tr[ST_KSTEP], cnt = tr[ST_COUNT];
-          const bool on = ks == 0 ? dk == 0 : (dk % ks == 0 && dk / ks >= 0 && dk / ks < cnt);
+          bool on;
+          if (ks <= 1)
+            on = ks == 1 ? (dk >= 0 && dk < cnt) : dk == 0;
+          else
+            on = dk >= 0 && dk % ks == 0 && dk / ks < cnt;
           if (!on || !rlive || tr[ST_AXIS] != ra) continue;
           const double* cv = cvec + tr[ST_CVEC];
           psi = fma((par[tr[ST_WPARAM]] * cv[ri]) * cv[rj], ks == 0 ? (double)cnt : 1.0, psi);
@@ -258,14 +264,15 @@ __global__ __launch_bounds__(SW_BLOCK) void ltv_sweep_kernel(
           lam = xl ? y : 0.0;
         }
         // rho_l[i] = sum over the cost rows of step l on this axis of w (c . x_l - aim) c[i]
-        const double x0 = lane_value(x, base);   // (x of the last step is not what is needed: read x_l back)
-        (void)x0;
         const double* xb = xbar + ((xl ? ra : 0) * N + l) * n;
         for (int t = 0; t < p.sw_nterm; ++t) {
           const int* tr = terms + t * SW_TERM_WORDS;
           const int dk = l - tr[ST_K0], ks = tr[ST_KSTEP], cnt = tr[ST_COUNT];
-          const bool on = ks == 1 ? (dk >= 0 && dk < cnt)
-                                  : (ks == 0 ? dk == 0 : (dk % ks == 0 && dk / ks >= 0 && dk / ks < cnt));
+          bool on;
+          if (ks <= 1)                      // (the usual schedules: no division)
+            on = ks == 1 ? (dk >= 0 && dk < cnt) : dk == 0;
+          else
+            on = dk >= 0 && dk % ks == 0 && dk / ks < cnt;
           if (!on) continue;
           const double* cv = cvec + tr[ST_CVEC];
           double d = 0.0;

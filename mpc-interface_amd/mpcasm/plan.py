@@ -1472,7 +1472,10 @@ def _sweep_tables(b, gterms, limit_recs, lax_recs, rowptr, entbase, entk, entcoe
         info = rowset(aoff, nrows, nrows)
         if info is None:
             return None, "a cost whose rows are no fixed combination of one step's states"
-        terms.append([info[0], info[1], info[2], nrows, wparam, aimparam, info[3], 0])
+        a, k0, ks, co = info
+        if ks < 0:                 # (the rows of a cost in any order: steps ascending for the kernel)
+            k0, ks = k0 + (nrows - 1) * ks, -ks
+        terms.append([a, k0, ks, nrows, wparam, aimparam, co, 0])
     lims = []
     for out0, nrows, naxes, lax0, p_a, a_rows, p_c, c_rows, p_e, e_rows, *_ in limit_recs:
         if naxes > SW_AXMAX:
