@@ -80,8 +80,10 @@ __host__ __device__ inline SweepLds sweep_lds(const PlanDev& p) {
 // value of lane `src` (same for a double's two halves)
 __device__ __forceinline__ double lane_value(double v, int src) { return __shfl(v, src, 64); }
 
-// CPT: columns per thread (no <= SW_BLOCK * CPT)
-template <int CPT>
+// CPT: columns per thread (no <= SW_BLOCK * CPT); NS, MS, AS: the system's states, inputs and the axes
+// as constants (0: read from the plan) -- the loops over them unroll without guards, which is a
+// third of the instructions of a step for the LIPM family (n = 3, m = 1, two axes: C5)
+template <int CPT, int NS, int MS, int AS>
 __global__ __launch_bounds__(SW_BLOCK) void ltv_sweep_kernel(
     PlanDev p, const double* __restrict__ sysA, long long strideA, const double* __restrict__ sysB,
     long long strideB, const double* __restrict__ params, const double* __restrict__ given,
@@ -92,7 +94,8 @@ __global__ __launch_bounds__(SW_BLOCK) void ltv_sweep_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const long inst = blockIdx.x;
   if (inst >= batch) return;
-  const int n = p.sw_n, m = p.sw_m, N = p.sw_horizon, naxes = p.sw_naxes, no = p.no, nc = p.nc;
+  const int n = NS ? NS : p.sw_n, m = MS ? MS : p.sw_m, naxes = AS ? AS : p.sw_naxes;
+  const int N = p.sw_horizon, no = p.no, nc = p.nc;
   const int nn = n * n, nm = n * m, abw = nn + nm;
   const SweepLds L = sweep_lds(p);
   double* AB = sw + L.ab;       // [N][n n + n m]: A_k row major, then B_k
@@ -157,21 +160,39 @@ __global__ __launch_bounds__(SW_BLOCK) void ltv_sweep_kernel(
   const bool rlive = ra < naxes && ri < n && rj < n;
   if (wave == 0 && P != nullptr) {
     // Psi_l = W_l + A_{l+1}^T Psi_{l+1} A_{l+1};  gv[a][j][l] = Psi_l B_l[:, j]
-    // A term's steps are k0, k0 + ks, ... (ks >= 0, cnt of them): walked downwards with a counter --
-    // `tnext` the next step that has a row, `tleft` how many are left (no division per step).
-    double wcc[SW_TERMS_REG];   // w c[i] c[jj] of the terms on this lane's axis (0: another axis)
+    // W_l: the terms that cover the whole horizon are one constant per lane (w c[i] c[jj] summed); the
+    // others (a schedule) are walked downwards with a counter -- `tnext` the next step that has a row,
+    // `tleft` how many are left: no search and no division per step.
+    double wall = 0.0, wcc[SW_TERMS_REG];
     int tnext[SW_TERMS_REG], tks[SW_TERMS_REG], tleft[SW_TERMS_REG];
-    const bool in_regs = p.sw_nterm <= SW_TERMS_REG;
-#pragma unroll
-    for (int t = 0; t < SW_TERMS_REG; ++t) {
-      const int* tr = terms + (t < p.sw_nterm ? t : 0) * SW_TERM_WORDS;
-      const bool mine = in_regs && t < p.sw_nterm && rlive && tr[ST_AXIS] == ra;
+    int npart = 0;
+    for (int t = 0; t < p.sw_nterm; ++t) {
+      const int* tr = terms + t * SW_TERM_WORDS;
+      const bool mine = rlive && tr[ST_AXIS] == ra;
       const double* cv = cvec + tr[ST_CVEC];
-      wcc[t] = mine ? (par[tr[ST_WPARAM]] * cv[ri]) * cv[rj] : 0.0;
-      tks[t] = tr[ST_KSTEP];
-      tleft[t] = t < p.sw_nterm ? tr[ST_COUNT] : 0;
-      tnext[t] = tr[ST_K0] + (tr[ST_COUNT] - 1) * tr[ST_KSTEP];
+      const double v = mine ? (par[tr[ST_WPARAM]] * cv[ri]) * cv[rj] : 0.0;
+      const bool whole = tr[ST_K0] == 0 && tr[ST_KSTEP] == 1 && tr[ST_COUNT] == N;   // (wave-uniform)
+      if (whole) {
+        wall += v;
+      } else {
+#pragma unroll
+        for (int k = 0; k < SW_TERMS_REG; ++k)
+          if (k == npart) {
+            wcc[k] = v;
+            tks[k] = tr[ST_KSTEP];
+            tleft[k] = tr[ST_COUNT];
+            tnext[k] = tr[ST_K0] + (tr[ST_COUNT] - 1) * tr[ST_KSTEP];
+          }
+        ++npart;
+      }
     }
+    const bool in_regs = npart <= SW_TERMS_REG;
+#pragma unroll
+    for (int k = 0; k < SW_TERMS_REG; ++k)
+      if (k >= npart) {
+        wcc[k] = 0.0;
+        tks[k] = tleft[k] = tnext[k] = 0;
+      }
     double psi = 0.0;
     for (int l = N - 1; l >= 0; --l) {
       if (l + 1 < N) {
@@ -195,9 +216,11 @@ __global__ __launch_bounds__(SW_BLOCK) void ltv_sweep_kernel(
         nw = fma(arow[3], lane_value(t_, base + 12), nw);
         psi = rlive ? nw : 0.0;
       }
+      psi += wall;
       if (in_regs) {
 #pragma unroll
         for (int t = 0; t < SW_TERMS_REG; ++t) {
+          if (t >= npart) break;
           const bool on = tleft[t] > 0 && l == tnext[t];
           const int take = !on ? 0 : (tks[t] == 0 ? tleft[t] : 1);   // (rows at one step: all of them)
           psi = fma(wcc[t], (double)take, psi);
@@ -208,6 +231,7 @@ __global__ __launch_bounds__(SW_BLOCK) void ltv_sweep_kernel(
         for (int t = 0; t < p.sw_nterm; ++t) {
           const int* tr = terms + t * SW_TERM_WORDS;
           const int dk = l - tr[ST_K0], ks = tr[ST_KSTEP], cnt = tr[ST_COUNT];
+          if (tr[ST_K0] == 0 && ks == 1 && cnt == N) continue;       // (in `wall`)
           bool on;
           if (ks <= 1)
             on = ks == 1 ? (dk >= 0 && dk < cnt) : dk == 0;
@@ -232,15 +256,16 @@ __global__ __launch_bounds__(SW_BLOCK) void ltv_sweep_kernel(
         }
     }
   } else if (wave == 1) {
-    // lane (a, i, 0): the free response x_k = A_k x_{k-1}, then lam_l = rho_l + A_{l+1}^T lam_{l+1}
+    // lane (a, i, 0): the free response x_k = A_k x_{k-1}; then rho_l for every step at once (lanes over
+    // (axis, step)); then lam_l = rho_l + A_{l+1}^T lam_{l+1}, step by step on lane (a, i, 0)
     const bool xl = rlive && rj == 0;
+    const int base = lane & ~15;   // x[s], lam[s] live in lane (a, s, 0)
     double x = xl ? given[(size_t)inst * p.ng + axis[ra * SW_AXIS_WORDS] + ri] : 0.0;
     for (int k = 0; k < N; ++k) {
       const double* Ak = AB + k * abw;
       double arow[SW_NMAX];   // A[i][s]
 #pragma unroll
       for (int s_ = 0; s_ < SW_NMAX; ++s_) arow[s_] = (xl && s_ < n) ? Ak[ri * n + s_] : 0.0;
-      const int base = lane & ~15;   // x[s] lives in lane (a, s, 0)
       double y = arow[0] * lane_value(x, base);
       y = fma(arow[1], lane_value(x, base + 4), y);
       y = fma(arow[2], lane_value(x, base + 8), y);
@@ -249,22 +274,14 @@ __global__ __launch_bounds__(SW_BLOCK) void ltv_sweep_kernel(
       if (xl) xbar[(ra * N + k) * n + ri] = x;
     }
     if (P != nullptr) {
-      double lam = 0.0;
-      for (int l = N - 1; l >= 0; --l) {
-        const int base = lane & ~15;
-        if (l + 1 < N) {
-          const double* An = AB + (l + 1) * abw;
-          double acl[SW_NMAX];   // A[s][i]
+      asm volatile("" ::: "memory");   // (a wavefront's LDS operations complete in order: xbar is there)
+      // rho_l[i] = sum over the cost rows of step l on the axis of w (c . x_l - aim) c[i] -> lamT
+      for (int e = lane; e < naxes * N; e += 64) {
+        const int a = e / N, l = e - a * N;
+        const double* xb = xbar + e * n;
+        double rho[SW_NMAX];
 #pragma unroll
-          for (int s_ = 0; s_ < SW_NMAX; ++s_) acl[s_] = (xl && s_ < n) ? An[s_ * n + ri] : 0.0;
-          double y = acl[0] * lane_value(lam, base);
-          y = fma(acl[1], lane_value(lam, base + 4), y);
-          y = fma(acl[2], lane_value(lam, base + 8), y);
-          y = fma(acl[3], lane_value(lam, base + 12), y);
-          lam = xl ? y : 0.0;
-        }
-        // rho_l[i] = sum over the cost rows of step l on this axis of w (c . x_l - aim) c[i]
-        const double* xb = xbar + ((xl ? ra : 0) * N + l) * n;
+        for (int i = 0; i < SW_NMAX; ++i) rho[i] = 0.0;
         for (int t = 0; t < p.sw_nterm; ++t) {
           const int* tr = terms + t * SW_TERM_WORDS;
           const int dk = l - tr[ST_K0], ks = tr[ST_KSTEP], cnt = tr[ST_COUNT];
@@ -273,13 +290,34 @@ __global__ __launch_bounds__(SW_BLOCK) void ltv_sweep_kernel(
             on = ks == 1 ? (dk >= 0 && dk < cnt) : dk == 0;
           else
             on = dk >= 0 && dk % ks == 0 && dk / ks < cnt;
-          if (!on) continue;
+          if (!on || tr[ST_AXIS] != a) continue;
           const double* cv = cvec + tr[ST_CVEC];
           double d = 0.0;
           for (int s_ = 0; s_ < n; ++s_) d = fma(cv[s_], xb[s_], d);
           const double wr = par[tr[ST_WPARAM]] * (ks == 0 ? (double)cnt : 1.0) * (d - par[tr[ST_AIMPARAM]]);
-          lam += (xl && tr[ST_AXIS] == ra) ? wr * cv[ri] : 0.0;
+#pragma unroll
+          for (int i = 0; i < SW_NMAX; ++i)
+            if (i < n) rho[i] = fma(wr, cv[i], rho[i]);
         }
+#pragma unroll
+        for (int i = 0; i < SW_NMAX; ++i)
+          if (i < n) lamT[e * n + i] = rho[i];
+      }
+      asm volatile("" ::: "memory");
+      double lam = 0.0;
+      for (int l = N - 1; l >= 0; --l) {
+        double acc = xl ? lamT[(ra * N + l) * n + ri] : 0.0;
+        if (l + 1 < N) {
+          const double* An = AB + (l + 1) * abw;
+          double acl[SW_NMAX];   // A[s][i]
+#pragma unroll
+          for (int s_ = 0; s_ < SW_NMAX; ++s_) acl[s_] = (xl && s_ < n) ? An[s_ * n + ri] : 0.0;
+          acc = fma(acl[0], lane_value(lam, base), acc);
+          acc = fma(acl[1], lane_value(lam, base + 4), acc);
+          acc = fma(acl[2], lane_value(lam, base + 8), acc);
+          acc = fma(acl[3], lane_value(lam, base + 12), acc);
+        }
+        lam = xl ? acc : 0.0;
         if (xl) lamT[(ra * N + l) * n + ri] = lam;
       }
     }
@@ -336,6 +374,9 @@ __global__ __launch_bounds__(SW_BLOCK) void ltv_sweep_kernel(
     }
 
   // ---- forward sweep: u = Phi(l, l'+1) B_l' per column; rows of G of step l, P at and below the diagonal ----
+  // (branch-free per step: a thread's column is "not yet" (u = 0), "now" (u = B_l[:, j]) or "running"
+  // (u = A_l u) by selects; threads without a column leave here)
+  if (CPT == 1 && tid >= no) return;
   double* Pb = P + (size_t)inst * no * no;
   double* Gb = G + (size_t)inst * nc * no;
   // first unknown of every (axis, input): wave-uniform, kept in registers
@@ -355,24 +396,20 @@ __global__ __launch_bounds__(SW_BLOCK) void ltv_sweep_kernel(
     const int e0 = gptr[l], e1 = gptr[l + 1];   // (requested with the step's A: one trip)
 #pragma unroll
     for (int t = 0; t < CPT; ++t) {
-      if (ca[t] < 0) continue;
-      if (cl[t] == l) {
+      double y[SW_NMAX];
 #pragma unroll
-        for (int i = 0; i < SW_NMAX; ++i) u[t][i] = i < n ? Bl[i * m + cj[t]] : 0.0;
-      } else if (cl[t] < l) {
-        double y[SW_NMAX];
+      for (int i = 0; i < SW_NMAX; ++i) {
+        y[i] = 0.0;
+        if (i < n) {
 #pragma unroll
-        for (int i = 0; i < SW_NMAX; ++i) {
-          y[i] = 0.0;
-          if (i < n) {
-#pragma unroll
-            for (int s_ = 0; s_ < SW_NMAX; ++s_)
-              if (s_ < n) y[i] = fma(Al[i * n + s_], u[t][s_], y[i]);
-          }
+          for (int s_ = 0; s_ < SW_NMAX; ++s_)
+            if (s_ < n) y[i] = fma(Al[i * n + s_], u[t][s_], y[i]);
+          const double bnow = Bl[i * m + cj[t]];
+          y[i] = cl[t] == l ? bnow : y[i];       // (u is 0 before its step: A_l 0 = 0)
         }
-#pragma unroll
-        for (int i = 0; i < SW_NMAX; ++i) u[t][i] = y[i];
       }
+#pragma unroll
+      for (int i = 0; i < SW_NMAX; ++i) u[t][i] = y[i];
     }
     if (P != nullptr) {
 #pragma unroll
@@ -383,20 +420,17 @@ __global__ __launch_bounds__(SW_BLOCK) void ltv_sweep_kernel(
           if (j >= m) break;
           const double* g = gv + ((a * m + j) * N + l) * n;
           const int r = c0[a][j] + l;
+          double* prow = Pb + (size_t)r * no;
 #pragma unroll
           for (int t = 0; t < CPT; ++t) {
             const int c = tid + t * SW_BLOCK;
-            if (ca[t] < 0) continue;
-            if (ca[t] != a) {
-              Pb[(size_t)r * no + c] = 0.0;
-            } else if (cl[t] <= l) {
-              double v = 0.0;
+            double v = c == r ? dPc[t] : 0.0;
 #pragma unroll
-              for (int s_ = 0; s_ < SW_NMAX; ++s_)
-                if (s_ < n) v = fma(g[s_], u[t][s_], v);
-              if (c == r) v += dPc[t];
-              Pb[(size_t)r * no + c] = v;
-            }
+            for (int s_ = 0; s_ < SW_NMAX; ++s_)
+              if (s_ < n) v = fma(g[s_], u[t][s_], v);
+            // another axis: a zero; this axis: at and below the diagonal now, above it in the backward sweep
+            const bool other = ca[t] != a;
+            if ((CPT == 1 || c < no) && (other || cl[t] <= l)) prow[c] = other ? 0.0 : v;
           }
         }
       }
@@ -420,14 +454,15 @@ __global__ __launch_bounds__(SW_BLOCK) void ltv_sweep_kernel(
 #pragma unroll
         for (int x = 0; x < 4; ++x) {
           if (e + x >= e1) break;
+          double* grow = Gb + (size_t)row[x] * no;
 #pragma unroll
           for (int t = 0; t < CPT; ++t) {
             const int c = tid + t * SW_BLOCK;
-            if (c >= no) continue;
             double v = 0.0;
 #pragma unroll
-            for (int s_ = 0; s_ < SW_NMAX; ++s_) v = fma(w4[x][t][s_], u[t][s_], v);
-            Gb[(size_t)row[x] * no + c] = v;
+            for (int s_ = 0; s_ < SW_NMAX; ++s_)
+              if (s_ < n) v = fma(w4[x][t][s_], u[t][s_], v);
+            if (CPT == 1 || c < no) grow[c] = v;
           }
         }
       }
@@ -446,25 +481,21 @@ __global__ __launch_bounds__(SW_BLOCK) void ltv_sweep_kernel(
     const double* Bl = AB + l * abw + nn;
 #pragma unroll
     for (int t = 0; t < CPT; ++t) {
-      if (ca[t] < 0) continue;
-      if (cl[t] == l) {
-        const double* g = gv + ((ca[t] * m + cj[t]) * N + l) * n;
+      const int cat = ca[t] < 0 ? 0 : ca[t];
+      const double* g = gv + ((cat * m + cj[t]) * N + l) * n;
+      double y[SW_NMAX];
 #pragma unroll
-        for (int i = 0; i < SW_NMAX; ++i) z[t][i] = i < n ? g[i] : 0.0;
-      } else if (cl[t] > l) {
-        double y[SW_NMAX];
+      for (int i = 0; i < SW_NMAX; ++i) {
+        y[i] = 0.0;
+        if (i < n) {
 #pragma unroll
-        for (int i = 0; i < SW_NMAX; ++i) {
-          y[i] = 0.0;
-          if (i < n) {
-#pragma unroll
-            for (int s_ = 0; s_ < SW_NMAX; ++s_)
-              if (s_ < n) y[i] = fma(An[s_ * n + i], z[t][s_], y[i]);
-          }
+          for (int s_ = 0; s_ < SW_NMAX; ++s_)
+            if (s_ < n) y[i] = fma(An[s_ * n + i], z[t][s_], y[i]);
+          y[i] = cl[t] == l ? g[i] : y[i];       // (z is 0 behind its step: A^T 0 = 0)
         }
-#pragma unroll
-        for (int i = 0; i < SW_NMAX; ++i) z[t][i] = y[i];
       }
+#pragma unroll
+      for (int i = 0; i < SW_NMAX; ++i) z[t][i] = y[i];
     }
 #pragma unroll
     for (int a = 0; a < SW_AXMAX; ++a) {
@@ -472,16 +503,15 @@ __global__ __launch_bounds__(SW_BLOCK) void ltv_sweep_kernel(
 #pragma unroll
       for (int j = 0; j < SW_MMAX; ++j) {
         if (j >= m) break;
-        const int r = c0[a][j] + l;
+        double* prow = Pb + (size_t)(c0[a][j] + l) * no;
 #pragma unroll
         for (int t = 0; t < CPT; ++t) {
           const int c = tid + t * SW_BLOCK;
-          if (ca[t] != a || cl[t] <= l) continue;
           double v = 0.0;
 #pragma unroll
           for (int s_ = 0; s_ < SW_NMAX; ++s_)
             if (s_ < n) v = fma(Bl[s_ * m + j], z[t][s_], v);
-          Pb[(size_t)r * no + c] = v;
+          if (ca[t] == a && cl[t] > l) prow[c] = v;
         }
       }
     }
@@ -504,9 +534,9 @@ int launch_assemble_sweep(const PlanDev& p, const SrcTable& src, const double* p
   const double* A = src.ptr[p.sw_src_a];
   const double* Bm = src.ptr[p.sw_src_b];
   const long long sa = src.stride[p.sw_src_a], sb = src.stride[p.sw_src_b];
-#define MPCASM_SWEEP_CASE(CPT)                                                                         \
-  if (p.no <= SW_BLOCK * CPT) {                                                                        \
-    auto kernel = ltv_sweep_kernel<CPT>;                                                               \
+#define MPCASM_SWEEP_CASE(CPT, NS, MS, AS)                                                             \
+  if (p.no <= SW_BLOCK * CPT && (NS == 0 || (n == NS && m == MS && naxes == AS))) {                    \
+    auto kernel = ltv_sweep_kernel<CPT, NS, MS, AS>;                                                   \
     if (lds > 64 * 1024) {                                                                             \
       *err = allow_whole_lds(reinterpret_cast<const void*>(kernel));                                   \
       if (*err != hipSuccess) return MPCASM_ERR_HIP;                                                   \
@@ -516,9 +546,10 @@ int launch_assemble_sweep(const PlanDev& p, const SrcTable& src, const double* p
     *err = hipGetLastError();                                                                          \
     return *err == hipSuccess ? MPCASM_OK : MPCASM_ERR_HIP;                                            \
   }
-  MPCASM_SWEEP_CASE(1)
-  MPCASM_SWEEP_CASE(2)
-  MPCASM_SWEEP_CASE(4)
+  MPCASM_SWEEP_CASE(1, 3, 1, 2)
+  MPCASM_SWEEP_CASE(1, 0, 0, 0)
+  MPCASM_SWEEP_CASE(2, 0, 0, 0)
+  MPCASM_SWEEP_CASE(4, 0, 0, 0)
 #undef MPCASM_SWEEP_CASE
   return MPCASM_ERR_LIMIT;
 }
