@@ -257,6 +257,18 @@ int mpcasm_goal_distance(const double* d_preview, int64_t preview_stride, const 
                          int64_t n_params, const int32_t* d_terms, int nterms, int ngoals,
                          double* d_out, int batch, void* stream);
 
+/* ... and the same distances straight from the sources, without the rows ever leaving the chip:
+ * what full_goal_distance needs after a solve (body.py:230-234) -- 8 bytes per goal and instance
+ * instead of 8 bytes per row of every definition.  Arguments as mpcasm_preview_direct + the goal
+ * table of mpcasm_goal_distance; d_out[batch][ngoals].  MPCASM_ERR_LIMIT when the plan does not run
+ * on the kernel that does this (sources of an instance's own, more than 16 terms, rows of one
+ * instance beyond LDS): take the rows with mpcasm_preview_direct and call mpcasm_goal_distance. */
+int mpcasm_preview_goal_distance(const mpcasm_plan* plan, const double* const* h_src,
+                                 const int64_t* h_src_stride, const double* d_given,
+                                 const double* d_optim, const double* d_params, const int32_t* d_terms,
+                                 int nterms, int ngoals, double* d_out, void* d_work, int batch,
+                                 void* stream);
+
 /* f3  sparse hand-off -----------------------------------------------------------
  * Replaces the dense -> CSC conversion in front of the solver call of the walking loop
  *   Q = scipy.sparse.csc_matrix(Q); A = scipy.sparse.csc_matrix(A)

@@ -1410,6 +1410,36 @@ int mpcasm_preview_direct(const mpcasm_plan* plan, const double* const* h_src,
   return rc;
 }
 
+int mpcasm_preview_goal_distance(const mpcasm_plan* plan, const double* const* h_src,
+                                 const int64_t* h_src_stride, const double* d_given,
+                                 const double* d_optim, const double* d_params, const int32_t* d_terms,
+                                 int nterms, int ngoals, double* d_out, void* d_work, int batch,
+                                 void* stream) {
+  if (!plan || batch < 0 || nterms < 0 || ngoals < 0) return MPCASM_ERR_ARG;
+  const PlanDev& d = plan->dev;
+  if (batch == 0 || ngoals == 0) return MPCASM_OK;
+  if (!d_out || (d.nsrc && (!h_src || !h_src_stride)) || (d.ng && !d_given) || (d.no && !d_optim) ||
+      (nterms && (!d_terms || !d_params)))
+    return MPCASM_ERR_ARG;
+  if (d.sw_ok) return MPCASM_ERR_LIMIT;
+  if (d.t_nlti != 0 && !d_work) return MPCASM_ERR_ARG;
+  {
+    int current = -1;
+    if (hipGetDevice(&current) != hipSuccess || current != plan->device) return MPCASM_ERR_ARG;
+  }
+  SrcTable src, eff;
+  int rc = make_src_table(plan, h_src, h_src_stride, &src);
+  if (rc != MPCASM_OK) return rc;
+  hipError_t err;
+  rc = launch_lti_tables(d, src, static_cast<double*>(d_work), batch, plan->h_itab.data(), &eff,
+                         static_cast<hipStream_t>(stream));
+  if (rc != MPCASM_OK) return rc;
+  rc = launch_preview_goals(d, eff, d_given, d_optim, d_params, d.nparams, d_terms, nterms, ngoals, d_out,
+                            batch, plan->num_cus, static_cast<hipStream_t>(stream), &err, plan->h_itab.data());
+  if (rc == MPCASM_ERR_HIP) g_last_hip = (int)err;
+  return rc;
+}
+
 int mpcasm_goal_distance(const double* d_preview, int64_t preview_stride, const double* d_params,
                          int64_t n_params, const int32_t* d_terms, int nterms, int ngoals,
                          double* d_out, int batch, void* stream) {
@@ -1509,7 +1539,7 @@ int launch_assemble(const PlanDev& plan, const SrcTable& src, const double* para
   // the formulation's own horizon matrices, the source slots carry (A_k, B_k))
   if (sweep_eligible(plan)) {
     t_last_kernel = MPCASM_KERNEL_SWEEP;
-    return launch_assemble_sweep(plan, src, params, given, P, q, G, h, batch, stream, err);
+    return launch_assemble_sweep(plan, src, params, given, P, q, G, h, batch, stream, err, h_itab);
   }
   PlanDev p = plan;
   p.rs_p_direct = p.rs_ok ? resident_p_direct_for(plan, batch) : 0;  // (the launch's size decides)

@@ -39,11 +39,15 @@ int launch_lti_tables(const PlanDev& p, const SrcTable& src, double* work, int b
 bool sweep_eligible(const PlanDev& p);
 int launch_assemble_sweep(const PlanDev& p, const SrcTable& src, const double* params,
                           const double* given, double* P, double* q, double* G, double* h, int batch,
-                          hipStream_t stream, hipError_t* err);
+                          hipStream_t stream, hipError_t* err, const int32_t* h_itab);
 // preview.hip
 int launch_preview_direct(const PlanDev& p, const SrcTable& eff, const double* given,
                           const double* optim, double* out, int batch, int num_cus,
                           hipStream_t stream, hipError_t* err, const int32_t* h_itab = nullptr);
+int launch_preview_goals(const PlanDev& p, const SrcTable& eff, const double* given, const double* optim,
+                         const double* params, long long nparams, const int32_t* terms, int nterms,
+                         int ngoals, double* out, int batch, int num_cus, hipStream_t stream,
+                         hipError_t* err, const int32_t* h_itab);
 int launch_goal_distance(const double* preview, long long preview_stride, const double* params,
                          long long nparams, const int32_t* terms, int nterms, int ngoals,
                          double* out, int batch, hipStream_t stream, hipError_t* err);

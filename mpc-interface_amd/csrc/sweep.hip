@@ -42,16 +42,18 @@ constexpr int SW_WAVES = SW_BLOCK / 64;
 __device__ __forceinline__ double ldsd(const double* base, int i) { return base[i]; }
 
 // LDS of one workgroup (doubles): all steps' [A_k | B_k], the free responses, Psi_l B_l[:, j], lam_l, the
-// parameters, the combinations c, per line of G and axis the weights arrow * c (0: the line has nothing
-// on that axis), then the plan's small integer tables (terms, limits, the per-step lists, the axes) and
-// per line its row of G
+// parameters, the combinations c, the weights arrow * c of the lines of G -- per limit and axis when no
+// limit has an arrow of its own per line (`per_line` 0: 0.4 KB for C5, five workgroups per CU), else
+// per line and axis (19 KB) --, then small integer tables: the terms, the per-step list of G's lines
+// (one word per line: row of G | limit << 20), the axes
 struct SweepLds {
   int ab, xbar, gv, lam, par, cvec, lw, ints, total;
-  int i_term, i_lim, i_gptr, i_gent, i_axis, i_lrow, nints;
+  int i_term, i_gptr, i_axis, i_lword, nints;
 };
 constexpr int LIMW = SW_LIM_WORDS + SW_AXMAX * SW_LAX_WORDS;
 constexpr int SW_TERMS_REG = 8;   // cost terms the recursion waves keep in registers
-__host__ __device__ inline SweepLds sweep_lds(const PlanDev& p) {
+constexpr int SW_LINES_REG = 8;   // lines of G of one step whose words are fetched a step ahead
+__host__ __device__ inline SweepLds sweep_lds(const PlanDev& p, int per_line) {
   const int n = p.sw_n, m = p.sw_m, N = p.sw_horizon, naxes = p.sw_naxes;
   SweepLds x;
   x.ab = 0;
@@ -62,16 +64,13 @@ __host__ __device__ inline SweepLds sweep_lds(const PlanDev& p) {
   x.cvec = x.par + p.nparams + 1;
   x.cvec += x.cvec & 1;
   x.lw = x.cvec + p.sw_ncvec * SW_NMAX;
-  x.ints = x.lw + p.sw_ngent * naxes * n;
+  x.ints = x.lw + (per_line ? p.sw_ngent : p.sw_nlim) * naxes * n;
   x.ints += x.ints & 1;
   x.i_term = 0;
-  x.i_lim = x.i_term + p.sw_nterm * SW_TERM_WORDS;
-  x.i_gptr = x.i_lim + p.sw_nlim * LIMW;
-  x.i_gent = x.i_gptr + N + 1;
-  x.i_gent += x.i_gent & 1;
-  x.i_axis = x.i_gent + 2 * p.sw_ngent;
-  x.i_lrow = x.i_axis + naxes * SW_AXIS_WORDS;
-  x.nints = x.i_lrow + p.sw_ngent;
+  x.i_gptr = x.i_term + p.sw_nterm * SW_TERM_WORDS;
+  x.i_axis = x.i_gptr + N + 2;
+  x.i_lword = x.i_axis + naxes * SW_AXIS_WORDS;
+  x.nints = x.i_lword + p.sw_ngent + SW_LINES_REG;   // (read ahead behind the last line)
   x.total = x.ints + (x.nints + 1) / 2;
   x.total += x.total & 1;
   return x;
@@ -88,7 +87,7 @@ __global__ __launch_bounds__(SW_BLOCK) void ltv_sweep_kernel(
     PlanDev p, const double* __restrict__ sysA, long long strideA, const double* __restrict__ sysB,
     long long strideB, const double* __restrict__ params, const double* __restrict__ given,
     double* __restrict__ P, double* __restrict__ q, double* __restrict__ G, double* __restrict__ h,
-    int batch) {
+    int batch, int per_line) {
   extern __shared__ __attribute__((aligned(16))) double sw[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -97,21 +96,22 @@ __global__ __launch_bounds__(SW_BLOCK) void ltv_sweep_kernel(
   const int n = NS ? NS : p.sw_n, m = MS ? MS : p.sw_m, naxes = AS ? AS : p.sw_naxes;
   const int N = p.sw_horizon, no = p.no, nc = p.nc;
   const int nn = n * n, nm = n * m, abw = nn + nm;
-  const SweepLds L = sweep_lds(p);
+  const SweepLds L = sweep_lds(p, per_line);
   double* AB = sw + L.ab;       // [N][n n + n m]: A_k row major, then B_k
   double* xbar = sw + L.xbar;   // [naxes][N][n]
   double* gv = sw + L.gv;       // [naxes][m][N][n]
   double* lamT = sw + L.lam;    // [naxes][N][n]
   double* par = sw + L.par;     // [nparams + 1], the last 0.0
   double* cvec = sw + L.cvec;   // [ncvec][SW_NMAX]
-  double* lw = sw + L.lw;       // [lines][naxes][n]
+  double* lw = sw + L.lw;       // [lines or limits][naxes][n]
   int* itb = reinterpret_cast<int*>(sw + L.ints);
   const int* terms = itb + L.i_term;
-  const int* lims = itb + L.i_lim;
   const int* gptr = itb + L.i_gptr;
-  const int2* gent = reinterpret_cast<const int2*>(itb + L.i_gent);
   const int* axis = itb + L.i_axis;
-  int* lrow = itb + L.i_lrow;
+  int* lword = itb + L.i_lword;  // [lines + SW_LINES_REG] row of G | limit << 20
+  // (the limits' records and the list of lines are read where threads work side by side: from the plan)
+  const int32_t* lims = p.itab + p.off_sw_lim;
+  const int2* gent = reinterpret_cast<const int2*>(p.itab + p.off_sw_gent);
   const double* pb = params + (size_t)inst * p.nparams;
   const int nlines = p.sw_ngent;
 
@@ -127,9 +127,8 @@ __global__ __launch_bounds__(SW_BLOCK) void ltv_sweep_kernel(
       for (int e = tid; e < count; e += SW_BLOCK) itb[dst + e] = (p.itab + src_off)[e];
     };
     copy(L.i_term, p.off_sw_term, p.sw_nterm * SW_TERM_WORDS);
-    copy(L.i_lim, p.off_sw_lim, p.sw_nlim * LIMW);
     copy(L.i_gptr, p.off_sw_gptr, N + 1);
-    copy(L.i_gent, p.off_sw_gent, 2 * nlines);
+    if (tid == 0) itb[L.i_gptr + N + 1] = nlines;   // (read a step ahead)
     copy(L.i_axis, p.off_sw_axis, naxes * SW_AXIS_WORDS);
   }
   // this thread's columns: axis, input, step; the diagonal terms on them (a cost on the input itself)
@@ -323,21 +322,36 @@ __global__ __launch_bounds__(SW_BLOCK) void ltv_sweep_kernel(
     }
   }
   if (G != nullptr && wave >= 2) {
-    // lines of G, in the order of the steps: their rows, and per axis the weights arrow * c
+    // the lines of G in the order of the steps: a word each (row of G | limit << 20); the weights
+    // arrow * c per limit and axis -- or, where a limit's arrow changes from line to line, per line
     const int wt = tid - 128, WT = SW_BLOCK - 128;
-    for (int e = wt; e < nlines; e += WT) {
-      const int2 ge = gent[e];
+    for (int e = wt; e < nlines + SW_LINES_REG; e += WT) {
+      const int2 ge = gent[e < nlines ? e : nlines - 1];
       const int* rec = lims + ge.x * LIMW;
-      lrow[e] = rec[SL_OUT0] + ge.y;
-      for (int a = 0; a < naxes; ++a)
-        for (int s_ = 0; s_ < n; ++s_) lw[(e * naxes + a) * n + s_] = 0.0;
-      for (int ax = 0; ax < rec[SL_NAXES]; ++ax) {
-        const int* xr = rec + SW_LIM_WORDS + ax * SW_LAX_WORDS;
-        const double ar = par[xr[SX_ARROW] + ge.y * xr[SX_ARROW_STEP]];
-        const double* cv = cvec + xr[SX_CVEC];
-        for (int s_ = 0; s_ < n; ++s_) lw[(e * naxes + xr[SX_AXIS]) * n + s_] += ar * cv[s_];
+      lword[e] = (rec[SL_OUT0] + ge.y) | (ge.x << 20);
+      if (per_line && e < nlines) {
+        for (int a = 0; a < naxes; ++a)
+          for (int s_ = 0; s_ < n; ++s_) lw[(e * naxes + a) * n + s_] = 0.0;
+        for (int ax = 0; ax < rec[SL_NAXES]; ++ax) {
+          const int* xr = rec + SW_LIM_WORDS + ax * SW_LAX_WORDS;
+          const double ar = par[xr[SX_ARROW] + ge.y * xr[SX_ARROW_STEP]];
+          const double* cv = cvec + xr[SX_CVEC];
+          for (int s_ = 0; s_ < n; ++s_) lw[(e * naxes + xr[SX_AXIS]) * n + s_] += ar * cv[s_];
+        }
       }
     }
+    if (!per_line)
+      for (int li = wt; li < p.sw_nlim; li += WT) {
+        const int* rec = lims + li * LIMW;
+        for (int a = 0; a < naxes; ++a)
+          for (int s_ = 0; s_ < n; ++s_) lw[(li * naxes + a) * n + s_] = 0.0;
+        for (int ax = 0; ax < rec[SL_NAXES]; ++ax) {
+          const int* xr = rec + SW_LIM_WORDS + ax * SW_LAX_WORDS;
+          const double ar = par[xr[SX_ARROW]];
+          const double* cv = cvec + xr[SX_CVEC];
+          for (int s_ = 0; s_ < n; ++s_) lw[(li * naxes + xr[SX_AXIS]) * n + s_] += ar * cv[s_];
+        }
+      }
   }
   __syncthreads();
 
@@ -390,10 +404,15 @@ __global__ __launch_bounds__(SW_BLOCK) void ltv_sweep_kernel(
   for (int t = 0; t < CPT; ++t)
 #pragma unroll
     for (int i = 0; i < SW_NMAX; ++i) u[t][i] = 0.0;
+  constexpr int LR = CPT == 1 ? SW_LINES_REG : (CPT == 2 ? 4 : 2);   // lines of a step in registers
+  int wcur[LR];   // the words of the step's first lines (wave-uniform)
+#pragma unroll
+  for (int x = 0; x < LR; ++x) wcur[x] = G != nullptr ? __builtin_amdgcn_readfirstlane(lword[x]) : 0;
+  int e1 = G != nullptr ? __builtin_amdgcn_readfirstlane(gptr[1]) : 0, e0 = 0;
   for (int l = 0; l < N; ++l) {
     const double* Al = AB + l * abw;
     const double* Bl = Al + nn;
-    const int e0 = gptr[l], e1 = gptr[l + 1];   // (requested with the step's A: one trip)
+    const int e2 = gptr[l + 2];                 // (the end of the NEXT step's lines: a step ahead)
 #pragma unroll
     for (int t = 0; t < CPT; ++t) {
       double y[SW_NMAX];
@@ -436,37 +455,58 @@ __global__ __launch_bounds__(SW_BLOCK) void ltv_sweep_kernel(
       }
     }
     if (G != nullptr) {
-      // four lines at a time: their rows and this thread's weights requested together, then used
-      for (int e = e0; e < e1; e += 4) {
-        int row[4];
-        double w4[4][CPT][SW_NMAX];
+      // This step's lines: their words came in a step ahead (wcur); now the weights of this thread's axis
+      // are requested for all of them at once, and the NEXT step's words -- one trip through LDS per step.
+      const int cnt = e1 - e0;
+      const int first_next = e1;
+      double wv[LR][CPT][SW_NMAX];
 #pragma unroll
-        for (int x = 0; x < 4; ++x) {
-          const int ee = e + x < e1 ? e + x : e1 - 1;
-          row[x] = lrow[ee];
+      for (int x = 0; x < LR; ++x) {
+        const int word = wcur[x];
+        const int slot = per_line ? e0 + (x < cnt ? x : 0) : (word >> 20);
 #pragma unroll
-          for (int t = 0; t < CPT; ++t) {
-            const double* wv = lw + (ee * naxes + (ca[t] < 0 ? 0 : ca[t])) * n;
+        for (int t = 0; t < CPT; ++t) {
+          const double* wp = lw + (slot * naxes + (ca[t] < 0 ? 0 : ca[t])) * n;
 #pragma unroll
-            for (int s_ = 0; s_ < SW_NMAX; ++s_) w4[x][t][s_] = s_ < n ? wv[s_] : 0.0;
-          }
-        }
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {
-          if (e + x >= e1) break;
-          double* grow = Gb + (size_t)row[x] * no;
-#pragma unroll
-          for (int t = 0; t < CPT; ++t) {
-            const int c = tid + t * SW_BLOCK;
-            double v = 0.0;
-#pragma unroll
-            for (int s_ = 0; s_ < SW_NMAX; ++s_)
-              if (s_ < n) v = fma(w4[x][t][s_], u[t][s_], v);
-            if (CPT == 1 || c < no) grow[c] = v;
-          }
+          for (int s_ = 0; s_ < SW_NMAX; ++s_) wv[x][t][s_] = (x < cnt && s_ < n) ? wp[s_] : 0.0;
         }
       }
+      int wnext[LR];
+#pragma unroll
+      for (int x = 0; x < LR; ++x) wnext[x] = lword[first_next + x];
+#pragma unroll
+      for (int x = 0; x < LR; ++x) {
+        if (x >= cnt) break;
+        double* grow = Gb + (size_t)(wcur[x] & 0xFFFFF) * no;
+#pragma unroll
+        for (int t = 0; t < CPT; ++t) {
+          const int c = tid + t * SW_BLOCK;
+          double v = 0.0;
+#pragma unroll
+          for (int s_ = 0; s_ < SW_NMAX; ++s_)
+            if (s_ < n) v = fma(wv[x][t][s_], u[t][s_], v);
+          if (CPT == 1 || c < no) grow[c] = v;
+        }
+      }
+      // (a step with more lines than are kept in registers: the rest one by one)
+      for (int e = e0 + LR; e < e1; ++e) {
+        const int word = lword[e];
+        const int slot = per_line ? e : (word >> 20);
+        double* grow = Gb + (size_t)(word & 0xFFFFF) * no;
+#pragma unroll
+        for (int t = 0; t < CPT; ++t) {
+          const int c = tid + t * SW_BLOCK;
+          const double* wp = lw + (slot * naxes + (ca[t] < 0 ? 0 : ca[t])) * n;
+          double v = 0.0;
+          for (int s_ = 0; s_ < n; ++s_) v = fma(wp[s_], u[t][s_], v);
+          if (CPT == 1 || c < no) grow[c] = v;
+        }
+      }
+#pragma unroll
+      for (int x = 0; x < LR; ++x) wcur[x] = __builtin_amdgcn_readfirstlane(wnext[x]);
     }
+    e0 = e1;
+    e1 = __builtin_amdgcn_readfirstlane(e2);
   }
   if (P == nullptr) return;
 
@@ -524,12 +564,21 @@ bool sweep_eligible(const PlanDev& p) { return p.sw_ok != 0; }
 
 int launch_assemble_sweep(const PlanDev& p, const SrcTable& src, const double* params,
                           const double* given, double* P, double* q, double* G, double* h, int batch,
-                          hipStream_t stream, hipError_t* err) {
+                          hipStream_t stream, hipError_t* err, const int32_t* h_itab) {
   const int n = p.sw_n, m = p.sw_m, naxes = p.sw_naxes;
   if (n < 1 || n > SW_NMAX || m < 1 || m > SW_MMAX || naxes < 1 || naxes > SW_AXMAX ||
       naxes * n * n > 64 || p.no > SW_BLOCK * 4)
     return MPCASM_ERR_LIMIT;
-  const size_t lds = (size_t)sweep_lds(p).total * sizeof(double);
+  // weights per limit unless some limit has an arrow of its own per line (or more than 2^11 limits /
+  // 2^20 lines of G: the line word's fields)
+  int per_line = p.sw_nlim >= (1 << 11) || p.nc >= (1 << 20);
+  if (h_itab == nullptr) return MPCASM_ERR_ARG;
+  for (int li = 0; li < p.sw_nlim && !per_line; ++li) {
+    const int32_t* rec = h_itab + p.off_sw_lim + li * LIMW;
+    for (int ax = 0; ax < rec[SL_NAXES]; ++ax) per_line |= rec[SW_LIM_WORDS + ax * SW_LAX_WORDS + SX_ARROW_STEP] != 0;
+  }
+  if (p.nc >= (1 << 20)) return MPCASM_ERR_LIMIT;
+  const size_t lds = (size_t)sweep_lds(p, per_line).total * sizeof(double);
   if (lds > (size_t)RESIDENT_LDS_LIMIT) return MPCASM_ERR_LIMIT;
   const double* A = src.ptr[p.sw_src_a];
   const double* Bm = src.ptr[p.sw_src_b];
@@ -542,7 +591,7 @@ int launch_assemble_sweep(const PlanDev& p, const SrcTable& src, const double* p
       if (*err != hipSuccess) return MPCASM_ERR_HIP;                                                   \
     }                                                                                                  \
     hipLaunchKernelGGL(kernel, dim3((unsigned)batch), dim3(SW_BLOCK), lds, stream, p, A, sa, Bm, sb,   \
-                       params, given, P, q, G, h, batch);                                              \
+                       params, given, P, q, G, h, batch, per_line);                                    \
     *err = hipGetLastError();                                                                          \
     return *err == hipSuccess ? MPCASM_OK : MPCASM_ERR_HIP;                                            \
   }

@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MPCASM_LIB") or os.path.join(_HERE, "libmpcasm.so")
 
 OK = 0
+ERR_LIMIT = -5
 OPT_PATH = 1
 OPT_PHASE_MASK = 2
 OPT_RESIDENT_PER_CU = 3
@@ -69,6 +70,10 @@ SIGNATURES = {
     "mpcasm_goal_distance": (ctypes.c_int, [_void_p, ctypes.c_int64, _void_p, ctypes.c_int64,
                                             _void_p, ctypes.c_int, ctypes.c_int, _void_p,
                                             ctypes.c_int, _void_p]),
+    "mpcasm_preview_goal_distance": (ctypes.c_int, [_void_p, ctypes.POINTER(_void_p),
+                                                    ctypes.POINTER(ctypes.c_int64), _void_p, _void_p,
+                                                    _void_p, _void_p, ctypes.c_int, ctypes.c_int,
+                                                    _void_p, _void_p, ctypes.c_int, _void_p]),
     "mpcasm_gather": (ctypes.c_int, [_void_p, ctypes.c_int64, _void_p, ctypes.c_int, _void_p,
                                      ctypes.c_int, _void_p]),
     "mpcasm_box_transform": (ctypes.c_int, [_void_p, ctypes.c_int64, ctypes.c_int, _void_p,

@@ -594,6 +594,38 @@ class Assembler:
         capi.check(rc, "mpcasm_goal_distance")
         return out
 
+    def full_goal_distances(self, form, given, optim, out=None, stream=None, count=None):
+        """``goal_distance`` of every goal (body.py:221-234) straight from the sources, the rows
+        of the definitions never leaving the chip (``mpcasm_preview_goal_distance``): ``(B, n_goals)``;
+        the row sum is ``full_goal_distance``.  Falls back to :meth:`preview_rows` +
+        :meth:`goal_distance` where the plan does not run on the kernel that fuses the two."""
+        torch = self._torch
+        table, names = self.goal_terms(form)
+        n = self.batch if count is None else int(count)
+        if not 0 <= n <= self.batch:
+            raise ValueError("count must lie in 0 .. %d, got %d" % (self.batch, n))
+        g = _as_device(torch, given, self.device).reshape(-1, self.ng) if self.ng else None
+        x = _as_device(torch, optim, self.device).reshape(-1, self.no) if self.no else None
+        for t, name in ((g, "given"), (x, "optim")):
+            if t is not None and t.shape[0] < n:
+                raise ValueError("%s must have %d rows, got %d" % (name, n, t.shape[0]))
+        if out is None:
+            out = torch.empty((self.batch, len(names)), dtype=torch.float64, device=self.device)
+        else:
+            _checked_out(torch, out, (n, len(names)), self.device, "full_goal_distances")
+        ptrs, strides = self._src_args()
+        work = self._workspace()
+        with torch.cuda.device(self.device):
+            rc = capi.load().mpcasm_preview_goal_distance(
+                self._handle, ptrs, strides, g.data_ptr() if g is not None else None,
+                x.data_ptr() if x is not None else None, self.params.data_ptr(), table.data_ptr(),
+                table.shape[0], len(names), out.data_ptr(), work.data_ptr(), n, _stream_handle(torch, stream))
+        if rc == capi.ERR_LIMIT:
+            rows = self.preview_rows(given, optim, stream=stream, count=count)
+            return self.goal_distance(form, rows, out=out, stream=stream, count=count)
+        capi.check(rc, "mpcasm_preview_goal_distance")
+        return out
+
     def preview(self, PM, given, optim, stream=None):
         """``Mg @ given + Mo @ optim`` for every definition row (body.py:209-219):
         ``(B, preview_rows)``."""

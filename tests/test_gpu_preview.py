@@ -51,6 +51,13 @@ def test_batched_preview_and_goal_distances(gpu_api, lti):
     dist = asm.goal_distance(form, rows)
     names = asm.goal_terms(form)[1]
     assert dist.shape == (B, len(names)) and names == list(form.goals.keys())
+    # the same distances with the rows never leaving the chip (mpcasm_preview_goal_distance): the whole
+    # batch against the two-step path, an odd count (the last block of four is not full), a caller's buffer
+    fused = asm.full_goal_distances(form, gt, xt)
+    assert float((fused - dist).abs().max() / dist.abs().max()) <= 1e-13
+    part = torch.full((B, len(names)), float("nan"), dtype=torch.float64, device="cuda")
+    asm.full_goal_distances(form, gt, xt, out=part, count=B - 3)
+    assert torch.equal(part[:B - 3], fused[:B - 3]) and torch.isnan(part[B - 3:]).all()
     R, D = rows.cpu().numpy(), dist.cpu().numpy()
     goal = form.goals[vel]
     saved = np.array(goal.aim, copy=True)

@@ -179,6 +179,59 @@ def test_random_per_step_systems(gpu_api, torch_gpu, nx, nu, N, kw):
         assert_close(Gb, Ao, RTOL_TIGHT), assert_close(hb, ho.ravel(), RTOL_TIGHT)
 
 
+def test_arrows_of_their_own_per_line_and_many_lines_per_step(gpu_api, torch_gpu):
+    """A limit whose arrow changes from line to line (the weights of G's lines are then kept per line,
+    not per limit) and more lines at one step than the kernel fetches ahead (twelve limits on every
+    step), against the oracle."""
+    torch = torch_gpu
+    from mpcasm import engine
+
+    api = gpu_api
+    rng = np.random.default_rng(9)
+    nx, nu, N, B = 3, 2, 24, 5
+    A0, B0 = problems.random_lti_matrices(rng, nx, nu)
+    system = api.ControlSystem(["u0", "u1"], ["s0", "s1", "s2"], A0, B0, axes=["_x", "_y"])
+    ext = api.ExtendedSystem.from_cotrol_system(system, "x", N)
+    form = api.Formulation()
+    form.incorporate_dynamics("plant", ext)
+    form.incorporate_goal("track", api.Cost("s0", 0.7, aim=[0.3, -0.2], axes=["_x", "_y"]))
+    form.incorporate_goal("effort", api.Cost("u1", 0.2, axes=["_x", "_y"]))
+    limits = [api.Constraint("s%d" % (k % 3), 2.0 + k, axes=["_x", "_y"], arrow=[0.6 + 0.1 * k, 0.8 - 0.1 * k])
+              for k in range(12)]
+    limits.append(api.Constraint("s1", 3.0, axes=["_x", "_y"], arrow=rng.standard_normal((N, 2))))
+    form.incorporate_constraint("many", limits)
+    form.identify_qp_domain(["u0_x", "u1_x", "u0_y", "u1_y"])
+    form.make_preview_matrices()
+    A = np.stack([np.stack([problems.random_lti_matrices(rng, nx, nu)[0] for _ in range(N)]) for _ in range(B)])
+    Bm = np.stack([np.stack([problems.random_lti_matrices(rng, nx, nu)[1] for _ in range(N)]) for _ in range(B)])
+    given = torch.as_tensor(rng.normal(0, 0.3, [B, form.given_len]), device="cuda")
+    for drop_last in (False, True):           # (with and without the limit that has per-line arrows)
+        use = limits if not drop_last else limits[:-1]
+        asm = engine.Assembler(form, batch=B, ltv=["plant"], limits=use)
+        asm.bind_ltv("plant", torch.as_tensor(A, device="cuda"), torch.as_tensor(Bm, device="cuda"))
+        out = tuple(torch.full_like(t, float("nan")) for t in asm.assemble(given))
+        mine = tuple(t.clone() for t in asm.assemble(given, out=out))
+        assert "sweep" in asm.last_kernel() and not any(torch.isnan(t).any().item() for t in mine)
+        for b in (0, B - 1):
+            dyn = form.dynamics["plant"]
+            saved = list(dyn.matrices)
+            try:
+                So, Uo = orc.extend_matrices_ltv(N, A[b], Bm[b])
+                dyn.matrices = list(Uo) + [So]
+                dyn.update_definitions()
+                PM = orc.preview_matrices(form)
+                g = given[b].cpu().numpy().reshape(-1, 1)
+                parts = [orc.qp_constraint(PM, l, g) for l in use]
+                Ao, ho = np.vstack([x[0] for x in parts]), np.vstack([x[1] for x in parts])
+                Qo, qo = orc.qp_all_costs(form, PM, g)
+            finally:
+                dyn.matrices = saved
+                dyn.update_definitions()
+            Pb, qb, Gb, hb = (t[b].cpu().numpy() for t in mine)
+            assert_close(Pb, Qo, RTOL_TIGHT), assert_close(qb, qo.ravel(), RTOL_TIGHT)
+            assert_close(Gb, Ao, RTOL_TIGHT), assert_close(hb, ho.ravel(), RTOL_TIGHT)
+
+
 def test_what_the_sweep_kernel_does_not_take(gpu_api, torch_gpu):
     """ValueError when the formulation cannot be assembled step by step; the preview entry points have no
     horizon tables to read for such a plan."""
