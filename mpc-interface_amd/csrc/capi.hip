@@ -642,6 +642,18 @@ int validate_plan(const int32_t* it, const double* h_dtab, size_t n_itab, size_t
       if (ts[i] < 0 || ts[i] >= img || tg[i] < 0 || tg[i] >= img || td[i] < -1 ||
           (td[i] >= 0 && (td[i] & ~RS_DST_ACC) >= vsize))
         return MPCASM_ERR_PLAN;
+    {  // the packed copy of the program says what the four tables say
+      if (!in_range(it[H_OFF_RS_PROG], slots * 4, n, H_WORDS) || it[H_OFF_RS_PROG] % 4) return MPCASM_ERR_PLAN;
+      const int32_t* pr = it + it[H_OFF_RS_PROG];
+      const double* tc = h_dtab + it[H_DOFF_RS_COEF];
+      for (int64_t i = 0; i < slots; ++i) {
+        double c;
+        memcpy(&c, pr + 4 * i + 2, sizeof c);
+        if ((uint32_t)pr[4 * i] != ((uint32_t)ts[i] | ((uint32_t)tg[i] << 16)) || pr[4 * i + 1] != td[i] ||
+            memcmp(&c, &tc[i], sizeof c) != 0)
+          return MPCASM_ERR_PLAN;
+      }
+    }
     const int32_t* sp = it + it[H_OFF_RS_SPLIT];
     for (int i = 0; i < it[H_RS_NSPLIT]; ++i)
       if (sp[i] < 0 || sp[i] >= vsize) return MPCASM_ERR_PLAN;
@@ -1022,6 +1034,7 @@ void plan_dev_from_tables(const int32_t* it, PlanDev* out) {
   d.sw_doff_cvec = it[H_SW_DOFF_CVEC]; d.sw_ncvec = it[H_SW_NCVEC];
   d.off_sw_cptr = it[H_OFF_SW_CPTR]; d.off_sw_cent = it[H_OFF_SW_CENT]; d.sw_ncent = it[H_SW_NCENT];
   d.off_sw_gptr = it[H_OFF_SW_GPTR]; d.off_sw_gent = it[H_OFF_SW_GENT]; d.sw_ngent = it[H_SW_NGENT];
+  d.off_rs_prog = it[H_OFF_RS_PROG];
   d.t_nbrow = d.t_ci_ok ? it[d.off_t_brow0 + d.nbase] : 0;
   d.pm_nfd = it[H_PM_NFD]; d.off_pm_map = it[H_OFF_PM_MAP]; d.off_pm_fdptr = it[H_OFF_PM_FDPTR];
   d.off_pm_op = it[H_OFF_PM_OP]; d.doff_pm_pool = it[H_DOFF_PM_POOL];

@@ -29,7 +29,7 @@
 namespace mpcasm {
 
 constexpr int32_t PLAN_MAGIC = 0x4D504341;  // 'MPCA'
-constexpr int32_t PLAN_VERSION = 28;
+constexpr int32_t PLAN_VERSION = 29;
 
 enum HeaderWord : int {
   H_MAGIC = 0,
@@ -260,9 +260,11 @@ enum HeaderWord : int {
   H_OFF_SW_GPTR,      // [HORIZON + 1]
   H_OFF_SW_GENT,      // [NGENT][2]
   H_SW_NGENT,
+  H_OFF_RS_PROG,      // [JC][RS_NT][4] the compose program once more, one 16-byte record per op and thread:
+                      //    RS_SRC | RS_GIDX << 16, RS_DST, the two halves of RS_COEF (16-byte aligned)
   H_WORDS = 160
 };
-static_assert(H_SW_NGENT < H_WORDS, "plan header");
+static_assert(H_OFF_RS_PROG < H_WORDS, "plan header");
 constexpr int SW_NMAX = 4, SW_MMAX = 4, SW_AXMAX = 4, SW_AXIS_WORDS = 8, SW_TERM_WORDS = 8, SW_LIM_WORDS = 8,
               SW_LAX_WORDS = 8;
 // a cost term on one axis: rows i = 0 .. ST_COUNT-1 are c . x of step ST_K0 + i ST_KSTEP

@@ -577,16 +577,16 @@ __device__ __forceinline__ void resident_body(
   int c_sg[JC], c_dst[JC];  // c_sg: image offset of the source | of the given value << 16
   double c_coef[JC];
   {
-    const int32_t* tsrc = plan_itab + p.off_rs_src;
-    const int32_t* tg = plan_itab + p.off_rs_gidx;
-    const int32_t* tdst = plan_itab + p.off_rs_dst;
-    const double* tcoef = plan_dtab + p.doff_rs_coef;
+    // one 16-byte record per op (H_OFF_RS_PROG): a quarter of the load instructions of the four tables
+    // it is packed from -- the set-up of a launch is bound by how many loads 512 workgroups issue at once
+    const int4* prog = reinterpret_cast<const int4*>(plan_itab + p.off_rs_prog);
 #pragma unroll
     for (int j = 0; j < JC; ++j) {
       const bool have = j < p.rs_jc;
-      c_sg[j] = have ? (tsrc[j * NT + tid] | (tg[j * NT + tid] << 16)) : 0;
-      c_dst[j] = have ? tdst[j * NT + tid] : -1;
-      c_coef[j] = have ? tcoef[j * NT + tid] : 0.0;
+      const int4 w = have ? prog[j * NT + tid] : int4{0, -1, 0, 0};
+      c_sg[j] = w.x;
+      c_dst[j] = w.y;
+      c_coef[j] = __hiloint2double(w.w, w.z);
     }
   }
   SETUP_STAMP(2)

@@ -17,7 +17,7 @@ import numpy as np
 import scipy.sparse as sp
 
 PLAN_MAGIC = 0x4D504341
-PLAN_VERSION = 28
+PLAN_VERSION = 29
 
 # header words (csrc/plan_tables.h, enum HeaderWord)
 _H = {name: i for i, name in enumerate([
@@ -46,6 +46,7 @@ _H = {name: i for i, name in enumerate([
     "SW_OK", "SW_N", "SW_M", "SW_HORIZON", "SW_SRC_A", "SW_SRC_B", "SW_NAXES", "OFF_SW_AXIS", "SW_NTERM",
     "OFF_SW_TERM", "SW_NLIM", "OFF_SW_LIM", "OFF_SW_COL", "SW_DOFF_CVEC", "SW_NCVEC",
     "OFF_SW_CPTR", "OFF_SW_CENT", "SW_NCENT", "OFF_SW_GPTR", "OFF_SW_GENT", "SW_NGENT",
+    "OFF_RS_PROG",
 ])}
 H_WORDS = 160
 assert len(_H) <= H_WORDS
@@ -1067,6 +1068,24 @@ def is_causal(U):
     return not np.any(U[..., ll > kk, :])
 
 
+def _packed_program(resident):
+    """The persistent kernel's compose program once more, as ONE 16-byte record per op and thread --
+    image offset of the source | of the given value << 16, destination, the coefficient's two halves --
+    so that a thread's set-up is one load per op instead of four (plan_tables.h H_OFF_RS_PROG)."""
+    jc = int(resident.get("jc", 0)) if resident.get("ok") else 0
+    if jc == 0:
+        return np.zeros(0, dtype=np.int32)
+    src = np.asarray(resident["src"], dtype=np.int64).reshape(jc, RS_NT)
+    gidx = np.asarray(resident["gidx"], dtype=np.int64).reshape(jc, RS_NT)
+    dst = np.asarray(resident["dst"], dtype=np.int64).reshape(jc, RS_NT)
+    coef = np.ascontiguousarray(np.asarray(resident["coef"], dtype=np.float64).reshape(jc, RS_NT))
+    rec = np.zeros((jc, RS_NT, 4), dtype=np.int32)
+    rec[:, :, 0] = (src | (gidx << 16)).astype(np.uint32).view(np.int32)
+    rec[:, :, 1] = dst.astype(np.int32)
+    rec[:, :, 2:4] = coef.view(np.int32).reshape(jc, RS_NT, 2)
+    return rec.reshape(-1)
+
+
 def causal_sources(form, sources, groups=()):
     """Ids of the sources that are the ``U_j`` of an ExtendedSystem and hold exact zeros above
     the diagonal: ``U_j[k][l] = A^(k-l) B`` for ``l <= k``, else 0 (tools.py:27-31).  The tables
@@ -1799,6 +1818,7 @@ def compile_plan(form, costs=None, limits=None, lti=(), csc=None, workspace="aut
         ("OFF_FD_IDX", fused["fd_idx"]),
         ("OFF_FD_PTR", fused["fd_ptr"]),
         ("OFF_OP", fused["ops"]),
+        ("OFF_RS_PROG", _packed_program(resident)),
         ("OFF_RS_SRC", resident["src"]),
         ("OFF_RS_GIDX", resident["gidx"]),
         ("OFF_RS_DST", resident["dst"]),
@@ -2032,7 +2052,7 @@ def compile_plan(form, costs=None, limits=None, lti=(), csc=None, workspace="aut
         if name == "OFF_PM_OP" and off & 1:       # ... 8-byte pairs
             parts.append(np.zeros(1, dtype=np.int32))
             off += 1
-        if name in ("OFF_RS_RR", "OFF_RS_INMETA", "OFF_RS_ABMETA", "OFF_RS_DPAR",
+        if name in ("OFF_RS_RR", "OFF_RS_INMETA", "OFF_RS_ABMETA", "OFF_RS_DPAR", "OFF_RS_PROG",
                     "OFF_RS_GDESC", "OFF_RS_GFIX", "OFF_CSC_G", "OFF_T_CIG", "OFF_T_CIO", "OFF_T_P1ENT",
                     "OFF_T_STAGE", "OFF_T_GROW", "OFF_T_SROW", "OFF_T_PIG", "OFF_T_SCAN_BLK",
                     "OFF_T_SCAN_GT", "OFF_T_SCAN_GROW", "OFF_SW_AXIS", "OFF_SW_TERM", "OFF_SW_LIM") and off & 3:   # ... 16-byte quads
