@@ -207,6 +207,16 @@ int mpcasm_assemble(const mpcasm_plan* plan, const double* const* h_src,
                     const double* d_given, double* d_P, double* d_q, double* d_G,
                     double* d_h, void* d_work, int batch, void* stream);
 
+/* The same with the rows of d_given picked by an index: instance b reads d_given[d_given_index[b]]
+ * and row b of everything else (parameters, per-instance sources; results to row b).  What a walker
+ * fleet's structure bucket needs (biped_mpc_loop.py:41-56 for many walkers: the bucket's walkers are
+ * scattered over the fleet-wide `given`): no gather pass in front of the assembly.  Persistent kernel
+ * only: MPCASM_ERR_LIMIT for a plan that runs elsewhere (gather the rows and call mpcasm_assemble). */
+int mpcasm_assemble_indexed(const mpcasm_plan* plan, const double* const* h_src,
+                            const int64_t* h_src_stride, const double* d_params, const double* d_given,
+                            const int32_t* d_given_index, double* d_P, double* d_q, double* d_G,
+                            double* d_h, void* d_work, int batch, void* stream);
+
 /* Which kernels the latest successful mpcasm_assemble on this plan launched (a record for
  * benchmarks and tests; 0 before the first launch): the persistent kernel ahead of time / compiled
  * for the plan, the per-instance fused kernel, the staged K2 -> K3 -> K4 pipeline, the tiled

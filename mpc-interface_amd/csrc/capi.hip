@@ -1331,10 +1331,10 @@ int mpcasm_workspace_bytes(const mpcasm_plan* plan, int batch, size_t* out_bytes
   return MPCASM_OK;
 }
 
-int mpcasm_assemble(const mpcasm_plan* plan, const double* const* h_src,
-                    const int64_t* h_src_stride, const double* d_params, const double* d_given,
-                    double* d_P, double* d_q, double* d_G, double* d_h, void* d_work, int batch,
-                    void* stream) {
+static int assemble_impl(const mpcasm_plan* plan, const double* const* h_src,
+                         const int64_t* h_src_stride, const double* d_params, const double* d_given,
+                         const int32_t* d_given_index, double* d_P, double* d_q, double* d_G, double* d_h,
+                         void* d_work, int batch, void* stream) {
   if (!plan || batch < 0) return MPCASM_ERR_ARG;
   if (batch == 0) return MPCASM_OK;  // nothing to do (empty buffers may be null)
   const PlanDev& d = plan->dev;
@@ -1354,6 +1354,12 @@ int mpcasm_assemble(const mpcasm_plan* plan, const double* const* h_src,
   SrcTable src;
   int rc = make_src_table(plan, h_src, h_src_stride, &src);
   if (rc != MPCASM_OK) return rc;
+  if (d_given_index != nullptr) {
+    // the index of `given`'s rows rides in the last slot of the source table (resident.hip)
+    if (d.nsrc >= MAX_SOURCES || d.ng == 0) return MPCASM_ERR_LIMIT;
+    src.ptr[MAX_SOURCES - 1] = reinterpret_cast<const double*>(d_given_index);
+    src.stride[MAX_SOURCES - 1] = -1;
+  }
   hipError_t err;
   // what this launch runs on: the plan's own options where it has them, else the process-wide ones
   t_path = plan->opt_path >= 0 ? plan->opt_path : g_path;
@@ -1361,10 +1367,27 @@ int mpcasm_assemble(const mpcasm_plan* plan, const double* const* h_src,
   t_per_cu = plan->opt_per_cu >= 0 ? plan->opt_per_cu : g_resident_per_cu;
   rc = launch_assemble(d, src, d_params, d_given, d_P, d_q, d_G, d_h, d_work, batch,
                        plan->num_cus, static_cast<hipStream_t>(stream), &err, plan->h_itab.data(),
-                       plan->device);
+                       plan->device, d_given_index != nullptr);
   if (rc == MPCASM_ERR_HIP) g_last_hip = (int)err;
   if (rc == MPCASM_OK) plan->last_kernel = t_last_kernel;
   return rc;
+}
+
+int mpcasm_assemble(const mpcasm_plan* plan, const double* const* h_src,
+                    const int64_t* h_src_stride, const double* d_params, const double* d_given,
+                    double* d_P, double* d_q, double* d_G, double* d_h, void* d_work, int batch,
+                    void* stream) {
+  return assemble_impl(plan, h_src, h_src_stride, d_params, d_given, nullptr, d_P, d_q, d_G, d_h, d_work,
+                       batch, stream);
+}
+
+int mpcasm_assemble_indexed(const mpcasm_plan* plan, const double* const* h_src,
+                            const int64_t* h_src_stride, const double* d_params, const double* d_given,
+                            const int32_t* d_given_index, double* d_P, double* d_q, double* d_G,
+                            double* d_h, void* d_work, int batch, void* stream) {
+  if (!d_given_index) return MPCASM_ERR_ARG;
+  return assemble_impl(plan, h_src, h_src_stride, d_params, d_given, d_given_index, d_P, d_q, d_G, d_h,
+                       d_work, batch, stream);
 }
 
 int mpcasm_plan_last_kernel(const mpcasm_plan* plan) { return plan ? plan->last_kernel : MPCASM_ERR_ARG; }
@@ -1547,10 +1570,11 @@ thread_local int t_last_kernel = 0;
 int launch_assemble(const PlanDev& plan, const SrcTable& src, const double* params,
                     const double* given, double* P, double* q, double* G, double* h, void* work,
                     int batch, int num_cus, hipStream_t stream, hipError_t* err,
-                    const int32_t* h_itab, int device) {
+                    const int32_t* h_itab, int device, bool indexed) {
   // a dynamics compiled as ltv: the sweep kernel and nothing else (the other kernels' tables describe
   // the formulation's own horizon matrices, the source slots carry (A_k, B_k))
   if (sweep_eligible(plan)) {
+    if (indexed) return MPCASM_ERR_LIMIT;   // (rows of `given` by index: the persistent kernel only)
     t_last_kernel = MPCASM_KERNEL_SWEEP;
     return launch_assemble_sweep(plan, src, params, given, P, q, G, h, batch, stream, err, h_itab);
   }
@@ -1574,6 +1598,7 @@ int launch_assemble(const PlanDev& plan, const SrcTable& src, const double* para
     return launch_assemble_resident(p, src, params, given, P, q, G, h, work, batch, rs, num_cus,
                                     stream, err);
   }
+  if (indexed) return MPCASM_ERR_LIMIT;   // (rows of `given` by index: the persistent kernel only)
   // wide problems: one workgroup per block of P, rows composed straight into the LDS tiles
   if (tiled_eligible(p) && t_path != 2 && p.csc_pnnz == 0 && p.csc_gnnz == 0) {
     t_last_kernel = MPCASM_KERNEL_TILED;

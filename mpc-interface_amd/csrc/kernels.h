@@ -76,7 +76,7 @@ extern thread_local int t_last_kernel;  // MPCASM_KERNEL_*: what launch_assemble
 int launch_assemble(const PlanDev& p, const SrcTable& src, const double* params,
                     const double* given, double* P, double* q, double* G, double* h, void* work,
                     int batch, int num_cus, hipStream_t stream, hipError_t* err,
-                    const int32_t* h_itab = nullptr, int device = 0);
+                    const int32_t* h_itab = nullptr, int device = 0, bool indexed = false);
 int launch_preview_matrices(const PlanDev& p, const SrcTable& src, double* PM, int batch,
                             hipStream_t stream, hipError_t* err);
 int launch_box_transform(double* params, long long nparams, int batch, const int32_t* facets,

@@ -387,8 +387,15 @@ __device__ __forceinline__ void resident_body(
 #else
   constexpr int FK = 0;  // (the ahead-of-time kernel has no registers to spare: it looks the streams up)
 #endif
+  // The `given` rows of a launch may be picked by an index (mpcasm_assemble_indexed: a fleet's bucket takes
+  // its walkers' rows out of the fleet-wide array, no gather pass): the table travels in the last,
+  // unused slot of the source table, marked by a stride of -1; instance b reads row gix[b] of `given`
+  // and row b of everything else.
+  const int32_t* gix = src.stride[MAX_SOURCES - 1] == -1
+                           ? reinterpret_cast<const int32_t*>(src.ptr[MAX_SOURCES - 1]) : nullptr;
   const char* f_base[FK > 0 ? FK : 1];
   int f_stride[FK > 0 ? FK : 1];
+  bool f_isg[FK > 0 ? FK : 1];   // the lane's piece of the chunk comes out of `given`
   // A chunk whose every lane reads a stream shared by the whole batch (stride 0: one model
   // for all instances, the constants) holds the same bytes for every instance: once both
   // halves of the double buffer have it, it is not fetched again.
@@ -402,6 +409,7 @@ __device__ __forceinline__ void resident_body(
       const long long stride = reinterpret_cast<const long long*>(strm)[2 * m.x + 1];
       f_base[j] = reinterpret_cast<const char* const*>(strm)[2 * m.x] + m.y;
       f_stride[j] = (int)stride;
+      f_isg[j] = m.x == p.nsrc;
       f_shared[j] = __all(stride == 0);
       f_fast = f_fast && stride >= 0 && stride < (1ll << 31);
     }
@@ -410,13 +418,14 @@ __device__ __forceinline__ void resident_body(
   // `settled`: both image buffers have been filled once by this workgroup
   auto fetch_image = [&](long inst, int buf, bool settled) {
     const unsigned dst0 = img_lds + (unsigned)buf * (unsigned)p.rs_img * 8u;
+    const long ginst = gix != nullptr ? (long)gix[inst] : inst;   // (wave-uniform: one scalar load)
     int kfirst = wave;
     if (FK > 0 && f_fast) {
 #pragma unroll
       for (int j = 0; j < FK; ++j) {
         const int k = wave + j * MW;
         if (k < nchunk && !(settled && f_shared[j])) {
-          const char* a = f_base[j] + (unsigned long long)inst * (unsigned)f_stride[j];
+          const char* a = f_base[j] + (unsigned long long)(f_isg[j] ? ginst : inst) * (unsigned)f_stride[j];
           const unsigned dst = __builtin_amdgcn_readfirstlane(dst0 + (unsigned)(k * 64 * unit));
           if (unit == 16)
             dma16(a, dst);
@@ -431,7 +440,7 @@ __device__ __forceinline__ void resident_body(
       const char* base = reinterpret_cast<const char* const*>(strm)[2 * m.x];
       const long long stride = reinterpret_cast<const long long*>(strm)[2 * m.x + 1];
       if (settled && __all(stride == 0)) continue;
-      const char* a = base + inst * stride + m.y;
+      const char* a = base + (m.x == p.nsrc ? ginst : inst) * stride + m.y;
       const unsigned dst = __builtin_amdgcn_readfirstlane(dst0 + (unsigned)(k * 64 * unit));
       if (unit == 16)
         dma16(a, dst);

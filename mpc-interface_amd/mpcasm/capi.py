@@ -51,6 +51,10 @@ SIGNATURES = {
     "mpcasm_plan_sizes": (ctypes.c_int, [_void_p, ctypes.POINTER(ctypes.c_int64)]),
     "mpcasm_plan_csc_sizes": (ctypes.c_int, [_void_p, ctypes.POINTER(ctypes.c_int64)]),
     "mpcasm_plan_set_option": (ctypes.c_int, [_void_p, ctypes.c_int, ctypes.c_int]),
+    "mpcasm_assemble_indexed": (ctypes.c_int, [_void_p, ctypes.POINTER(_void_p),
+                                               ctypes.POINTER(ctypes.c_int64), _void_p, _void_p, _void_p,
+                                               _void_p, _void_p, _void_p, _void_p, _void_p, ctypes.c_int,
+                                               _void_p]),
     "mpcasm_plan_last_kernel": (ctypes.c_int, [_void_p]),
     "mpcasm_plan_prepare": (ctypes.c_int, [_void_p, ctypes.c_int]),
     "mpcasm_jit_stats": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int64)]),

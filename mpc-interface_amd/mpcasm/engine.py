@@ -424,16 +424,26 @@ class Assembler:
         return self._src_ctypes
 
     def assemble(self, given=None, out=None, stream=None, want_cost=True, want_constraints=True,
-                 count=None):
+                 count=None, index=None, params=None):
         """Assemble the batch; returns ``(P, q, G, h)`` device tensors (``None`` for a
         skipped half).  ``given``: ``(B, ng)`` or ``(ng,)``.  ``count`` < batch assembles
-        only the first ``count`` instances (buffers keep their full capacity)."""
+        only the first ``count`` instances (buffers keep their full capacity).
+        ``index`` (int32 device tensor, ``count`` entries): instance ``b`` reads row ``index[b]`` of
+        ``given`` -- which may then have any number of rows, e.g. a whole fleet's -- and row ``b`` of
+        everything else (``mpcasm_assemble_indexed``; a gather in front where the plan does not run
+        on the persistent kernel).  ``params``: a ``(B, n_params)`` tensor to read the parameters
+        from instead of :attr:`params` (a fleet keeps one per place in its step cycle)."""
         torch = self._torch
         B, ng, no, nc = self.batch, self.ng, self.no, self.nc
         n_run = B if count is None else int(count)
         if not 0 <= n_run <= B:
             raise ValueError("count must lie in [0, %d]" % B)
-        if ng:
+        if index is not None:
+            if (not torch.is_tensor(index) or index.dtype != torch.int32 or index.device != self.device
+                    or not index.is_contiguous() or index.numel() < n_run or not ng):
+                raise ValueError("index: a contiguous int32 tensor of %d entries on %s" % (n_run, self.device))
+            g = _as_device(torch, given, self.device).reshape(-1, ng)
+        elif ng:
             g = _as_device(torch, given, self.device).reshape(-1, ng)
             if g.shape[0] == 1 and B > 1:
                 g = g.repeat(B, 1)
@@ -441,6 +451,10 @@ class Assembler:
                 raise ValueError("given must have %d rows, got %d" % (n_run, g.shape[0]))
         else:
             g = None
+        if params is not None and (tuple(params.shape) != tuple(self.params.shape) or params.dtype != torch.float64
+                                   or params.device != self.device or not params.is_contiguous()):
+            raise ValueError("params: a contiguous float64 tensor of shape %s on %s"
+                             % (tuple(self.params.shape), self.device))
         if out is None:
             if self._out is None:
                 f = dict(dtype=torch.float64, device=self.device)
@@ -454,18 +468,27 @@ class Assembler:
             P = q = None
         if not want_constraints or nc == 0:
             G = h = None
-        self._launch(g, (P, q, G, h), n_run, stream)
+        self._launch(g, (P, q, G, h), n_run, stream, index, params)
         return P, q, G, h
 
-    def _launch(self, g, out, n_run, stream):
+    def _launch(self, g, out, n_run, stream, index=None, params=None):
         torch = self._torch
         ptrs, strides = self._src_args()
         ptr = lambda t: t.data_ptr() if t is not None else None
         work = self._workspace()
+        prm = self.params if params is None else params
         with torch.cuda.device(self.device):
-            rc = capi.load().mpcasm_assemble(
-                self._handle, ptrs, strides, self.params.data_ptr(), ptr(g), *(ptr(t) for t in out),
-                work.data_ptr(), n_run, _stream_handle(torch, stream))
+            if index is not None:
+                rc = capi.load().mpcasm_assemble_indexed(
+                    self._handle, ptrs, strides, prm.data_ptr(), ptr(g), index.data_ptr(),
+                    *(ptr(t) for t in out), work.data_ptr(), n_run, _stream_handle(torch, stream))
+                if rc == capi.ERR_LIMIT:     # (not on the persistent kernel: gather, then as ever)
+                    g = g.index_select(0, index[:n_run].long())
+                    index = None
+            if index is None:
+                rc = capi.load().mpcasm_assemble(
+                    self._handle, ptrs, strides, prm.data_ptr(), ptr(g), *(ptr(t) for t in out),
+                    work.data_ptr(), n_run, _stream_handle(torch, stream))
         capi.check(rc, "mpcasm_assemble")
 
     def last_kernel(self):

@@ -128,8 +128,9 @@ class WalkerFleet:
         ``2 * step_samples`` (the step cycle times the left/right alternation): each of those
         ticks is worked out once on the host (tools.plan_steps / find_step_centers semantics)
         and kept on the device in the shape the assembler takes as it is -- the indicator
-        matrices as a full source tensor (bound per tick, no copy), the centres of all facets
-        side by side (one indexed copy into the parameters)."""
+        matrices as a full source tensor (bound per tick, no copy), the parameters with this place's
+        centres of all facets in their columns (handed over per tick, no copy), the walkers' ids as the
+        index of their rows of ``given``."""
         key = self._ticks % (2 * self.conf.step_samples)
         if key not in self._cache:
             torch = self._torch
@@ -147,23 +148,28 @@ class WalkerFleet:
                 E[:idx.size, :, :, 0] = torch.as_tensor(step_indicator(kept, self.N), device=dev)
                 centers = stepping_centers(self.clock.step_count[idx], p, self.conf.stepping_center)
                 centers = torch.as_tensor(centers.reshape(idx.size, -1), device=dev)
-                entry.append(dict(p=p, idx=idx, index=torch.as_tensor(idx, device=dev), E=E,
-                                  centers=centers.repeat(1, len(bucket["facets"]))))
+                # the bucket's parameters at this place of the cycle: the assembler's own, with the centres
+                # of the stepping area of these walkers in their columns -- a tensor per place, so that a
+                # tick copies nothing (only the centres change with the place in the cycle)
+                params = asm.params.clone()
+                params[:idx.size].index_copy_(1, bucket["center_cols"], centers.repeat(1, len(bucket["facets"])))
+                entry.append(dict(p=p, idx=idx, index=torch.as_tensor(idx, dtype=torch.int32, device=dev), E=E,
+                                  params=params))
             self._cache[key] = entry
         return self._cache[key]
 
     def _launch(self, given):
-        """This tick's launches for ``given`` (a device tensor): per structure bucket the
-        parameter update, the gather of its walkers' rows and the assembly."""
+        """This tick's launches for ``given`` (a device tensor): ONE assembly per structure bucket
+        (its walkers' rows of ``given`` picked by index inside the kernel, the parameters of this place in
+        the step cycle kept ready)."""
         out = []
         for item in self._bucket_inputs():
             p, idx = item["p"], item["idx"]
             bucket = self.buckets[p]
             asm = bucket["asm"]
             asm.bind_source(("steps", 0), item["E"])
-            asm.params[:idx.size].index_copy_(1, bucket["center_cols"], item["centers"])
-            g = given.index_select(0, item["index"])
-            P, q, G, h = asm.assemble(g, count=idx.size)
+            # (no gather, no copy: the walkers' rows of `given` by index, the place's own parameters)
+            P, q, G, h = asm.assemble(given, count=idx.size, index=item["index"], params=item["params"])
             out.append({"p": p, "index": idx, "P": P[:idx.size], "q": q[:idx.size],
                         "G": G[:idx.size], "h": h[:idx.size]})
         return out

@@ -121,3 +121,66 @@ def test_fleet_ticks_replayed_from_graphs(gpu_api, jit):
                     assert torch.equal(ra[k], rb[k]), (tick, k)
     finally:
         lib.mpcasm_set_option(capi.OPT_JIT, 0)
+
+
+@pytest.mark.gpu
+def test_a_fleet_of_4096_walkers_against_the_oracle(gpu_api):
+    """4096 walkers (buckets of 512 and 3584: the kernels compiled per plan), a full step cycle and a
+    half: every tick 64 walkers -- the first and last of every bucket and random ones -- against the
+    oracle stepped walker by walker.  The buckets take their walkers' rows of `given` by index inside
+    the kernel (mpcasm_assemble_indexed) and the parameters of the place in the cycle as they are."""
+    import torch
+
+    conf = problems.BipedConfig(step_samples=8)
+    batch = 4096
+    phases = np.arange(batch) % 8
+    fleet = WalkerFleet(batch, phases=phases, conf=conf, api=gpu_api)
+    ref = problems.biped(gpu_api, conf)
+    clock = FleetClock(conf.step_samples, conf.num_steps, phases)
+    rng = np.random.default_rng(5)
+    for tick in range(12):
+        given = rng.normal(0, 0.1, [batch, fleet.given_len])
+        results = fleet.tick(torch.as_tensor(given, device="cuda"))
+        assert sorted(int(b) for res in results for b in res["index"]) == list(range(batch))
+        for res in results:
+            assert "persistent" in fleet.buckets[res["p"]]["asm"].last_kernel()
+            idx = res["index"]
+            rows = sorted({0, idx.size - 1} | set(int(x) for x in rng.integers(0, idx.size, 32)))
+            P, q, G, h = (res[k][rows].cpu().numpy() for k in ("P", "q", "G", "h"))
+            for at, row in enumerate(rows):
+                b = int(idx[row])
+                ref.update(step_times=clock.step_times[b], step_count=int(clock.step_count[b]))
+                A, hh, Q, qq = orc.assemble(ref, given[b].reshape(-1, 1))
+                assert Q.shape[0] == P.shape[1] == 32 + 2 * res["p"]
+                assert_close(P[at], Q, RTOL_TIGHT, "P"), assert_close(q[at], qq.ravel(), RTOL_TIGHT, "q")
+                assert_close(G[at], A, RTOL_TIGHT, "G"), assert_close(h[at], hh.ravel(), RTOL_TIGHT, "h")
+        clock.tick()
+
+
+@pytest.mark.gpu
+def test_rows_of_given_by_index(gpu_api):
+    """Assembler.assemble(index=...): instance b reads row index[b] of a larger `given` -- the same
+    numbers as gathering first; on a plan that is not on the persistent kernel the engine gathers."""
+    import torch
+
+    from mpcasm import capi, engine
+
+    conf = problems.BipedConfig(step_samples=8)
+    form = problems.biped(gpu_api, conf)
+    form.update(step_times=np.array([6, 14]), step_count=0)
+    rng = np.random.default_rng(6)
+    B, fleet = 700, 5000
+    given = torch.as_tensor(rng.normal(0, 0.1, [fleet, form.given_len]), device="cuda")
+    index = torch.as_tensor(rng.permutation(fleet)[:B].astype(np.int32), device="cuda")
+    for path in (0, 2):
+        asm = engine.Assembler(form, batch=B)
+        asm.set_option(capi.OPT_PATH, path)
+        want = tuple(t.clone() for t in asm.assemble(given.index_select(0, index.long())))
+        got = asm.assemble(given, index=index)
+        assert ("persistent" in asm.last_kernel()) == (path == 0)
+        for a, b in zip(got, want):
+            assert torch.equal(a, b)
+        part = asm.assemble(given, index=index, count=B - 5)
+        assert torch.equal(part[0][:B - 5], want[0][:B - 5])
+    with pytest.raises(ValueError):
+        asm.assemble(given, index=index.long())
