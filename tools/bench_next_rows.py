@@ -70,6 +70,9 @@ def main():
               "(algorithmic: given + optim%s read, rows written)"
               % (label + ":", B, a2.plan.pmrows, t * 1e3, B / t, algo * B / t / 1e9, " + A, B" if kw else ""))
         print("   goal distances (%d goals)   %8.3f ms" % (len(form.goals), td * 1e3))
+        tf = timed(lambda: a2.full_goal_distances(form, given, optim0), 100)
+        print("   goal distances straight from the sources, rows never stored: %8.3f ms  %10.0f instances/s"
+              % (tf * 1e3, B / tf))
         del a2
     # ... against round 2's two passes: the preview matrices through HBM, then a GEMV
     PM = asm.preview_matrices()
