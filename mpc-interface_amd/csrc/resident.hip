@@ -365,15 +365,21 @@ __device__ __forceinline__ void resident_body(
     for (int i = tid; i < nchunk * 64; i += NT) meta[i] = t2[i];
     for (int i = tid; i < p.rs_nlti * RS_LTI_WORDS; i += NT) lti[i] = (plan_itab + p.off_rs_lti)[i];
     // input streams: the sources, then given, params, the plan's constants
-    if (tid < p.nsrc + 3) {
-      const int s = tid - p.nsrc;
-      const double* base = s < 0 ? src.ptr[tid]
-                                 : (s == 0 ? given : (s == 1 ? params : plan_dtab + p.doff_rs_const));
-      const long long stride =
-          s < 0 ? src.stride[tid] : (s == 0 ? (long long)p.ng : (s == 1 ? (long long)p.nparams : 0));
-      reinterpret_cast<const double**>(strm)[2 * tid] = base;
-      reinterpret_cast<long long*>(strm)[2 * tid + 1] = stride * (long long)sizeof(double);
-    }
+    // (wave-uniform index into the kernel's arguments: scalar loads out of the argument segment, which
+    // the scalar cache already holds -- indexed by the lane, the table would be fetched by vector
+    // loads from wherever the runtime keeps kernel arguments, and the first barrier would wait for it)
+    if (wave == 0)
+      for (int t = 0; t < p.nsrc + 3; ++t) {
+        const int s = t - p.nsrc;
+        const double* base = s < 0 ? src.ptr[t]
+                                   : (s == 0 ? given : (s == 1 ? params : plan_dtab + p.doff_rs_const));
+        const long long stride =
+            s < 0 ? src.stride[t] : (s == 0 ? (long long)p.ng : (s == 1 ? (long long)p.nparams : 0));
+        if (lane == 0) {
+          reinterpret_cast<const double**>(strm)[2 * t] = base;
+          reinterpret_cast<long long*>(strm)[2 * t + 1] = stride * (long long)sizeof(double);
+        }
+      }
   }
   SETUP_STAMP(0)
   lds_barrier();
@@ -472,13 +478,16 @@ __device__ __forceinline__ void resident_body(
     double* im = lds + L.img + buf * p.rs_img;
     const double* ab = lds + L.ab + slot * p.rs_ab;
     for (int g = 0; g < p.rs_nlti; ++g) {
+      // (the record comes out of LDS: the same for every lane, and said so -- sizes and offsets the
+      // compiler takes for per-lane values turn every loop below into a masked one)
       const int* rec = lti + g * RS_LTI_WORDS;
-      const int n = rec[LT_N], m = rec[LT_M], N = rec[LT_HORIZON], nn = n * n, nm = n * m;
-      const double* Am = ab + rec[LT_A];
-      const double* Bm = ab + rec[LT_B];
-      double* TA = im + rec[LT_TA];
-      double* TB = im + rec[LT_TB];
-      double* TP = im + rec[LT_TP];
+      const int n = __builtin_amdgcn_readfirstlane(rec[LT_N]), m = __builtin_amdgcn_readfirstlane(rec[LT_M]);
+      const int N = __builtin_amdgcn_readfirstlane(rec[LT_HORIZON]), nn = n * n, nm = n * m;
+      const double* Am = ab + __builtin_amdgcn_readfirstlane(rec[LT_A]);
+      const double* Bm = ab + __builtin_amdgcn_readfirstlane(rec[LT_B]);
+      double* TA = im + __builtin_amdgcn_readfirstlane(rec[LT_TA]);
+      double* TB = im + __builtin_amdgcn_readfirstlane(rec[LT_TB]);
+      double* TP = im + __builtin_amdgcn_readfirstlane(rec[LT_TP]);
       if (n <= 4 && n + m <= 4) {
         // Small systems: the recurrence X_d = A X_{d-1}, X_0 = [B | A] (tools.py:21-30) in
         // registers.  Lane 4 c + i of a group of 16 holds element i of column c, so the n
@@ -615,9 +624,9 @@ __device__ __forceinline__ void resident_body(
     constexpr int RRK = 3;  // row-record words per thread in the first batch
     const int32_t* trr = plan_itab + p.off_rs_rr;  // row records of G, precomputed by the plan compiler
     const int nrr = p.rr_packed ? 0 : nc * RR_WORDS;  // (packed plans keep compact records, below)
-    int v_rr[RRK], v_wtrip = 0, v_split = 0;
-    int2 v_gd[GU];
-    int4 v_dpar = int4{0, 0, 0, 0};
+    int v_rr[RRK], v_wtrip = 0, v_split = 0, v_rrwin = 0;
+    int2 v_gd[GU], v_gfix = int2{0, 0};
+    int4 v_dpar = int4{0, 0, 0, 0}, v_rra = int4{0, 0, 0, 0}, v_rrb = int4{0, 0, 0, 0};
     double2 v_dcoef = double2{0.0, 0.0};
     const bool own_gd = resident_g_mode(p) == 2 && tid >= MW * 64;
     const bool own_diag = p.ndiag != 0 && ct >= 0 && ct < no;
@@ -627,6 +636,13 @@ __device__ __forceinline__ void resident_body(
       for (int k = 0; k < RRK; ++k) v_rr[k] = ct + k * CT < nrr ? trr[ct + k * CT] : 0;
       if (ct < RS_WAVES * 2) v_wtrip = (plan_itab + p.off_rs_wtrip)[ct];
       if (ct < p.rs_nsplit) v_split = (plan_itab + p.off_rs_split)[ct];
+      // (the compact row record of row ct of G: words 8 .. 15 of its 64-byte record, two 16-byte
+      // loads in this batch -- read word by word behind the LDS stores, they cost a second trip)
+      if (p.rr_packed && ct < nc) {
+        v_rra = reinterpret_cast<const int4*>(trr + ct * RR_WORDS)[2];
+        v_rrb = reinterpret_cast<const int4*>(trr + ct * RR_WORDS)[3];
+      }
+      if (p.rs_compact && ct < nc) v_rrwin = (plan_itab + p.off_rs_rrwin)[ct];
     }
     if (own_gd) {
       // the descriptors of this thread's pieces of G (made by the plan compiler): piece
@@ -634,6 +650,7 @@ __device__ __forceinline__ void resident_body(
       const int2* gd = reinterpret_cast<const int2*>(plan_itab + p.off_rs_gdesc);
 #pragma unroll
       for (int u = 0; u < GU; ++u) v_gd[u] = gd[u * WT + wt_];
+      if (p.rs_ngfix != 0) v_gfix = reinterpret_cast<const int2*>(plan_itab + p.off_rs_gfix)[wt_];
     }
     if (own_diag) {
       // the diagonal gterms on column ct; free slots read the 0.0 behind the parameters
@@ -652,14 +669,20 @@ __device__ __forceinline__ void resident_body(
       for (int k = 0; k < RRK; ++k)
         if (ct + k * CT < nrr) rr[ct + k * CT] = v_rr[k];
       for (int i = ct + RRK * CT; i < nrr; i += CT) rr[i] = trr[i];
-      if (p.rs_compact)
-        for (int R = ct; R < nc; R += CT) rrwin[R] = (plan_itab + p.off_rs_rrwin)[R];
-      if (p.rr_packed)
-        for (int R = ct; R < nc; R += CT) {
+      if (p.rs_compact) {
+        if (ct < nc) rrwin[ct] = v_rrwin;
+        for (int R = ct + CT; R < nc; R += CT) rrwin[R] = (plan_itab + p.off_rs_rrwin)[R];
+      }
+      if (p.rr_packed) {
+        static_assert(RR_CENTER == 8 && RR_EXTREME == 13 && RR_PACKED == 14, "the row record's second half");
+        if (ct < nc)
+          reinterpret_cast<int4*>(rr)[ct] = int4{v_rrb.z, v_rrb.w, v_rra.x | (v_rra.y << 16), v_rrb.y};
+        for (int R = ct + CT; R < nc; R += CT) {
           const int32_t* g = trr + R * RR_WORDS;
           reinterpret_cast<int4*>(rr)[R] =
               int4{g[RR_PACKED], g[RR_PACKED + 1], g[RR_CENTER] | (g[RR_CENTER + 1] << 16), g[RR_EXTREME]};
         }
+      }
       if (resident_g_mode(p) == 3) {  // CSC hand-off tables
         const int2* cg = reinterpret_cast<const int2*>(plan_itab + p.off_csc_g);
         for (int i = ct; i < p.csc_gnnz; i += CT) gdesc[i] = cg[i];
@@ -672,7 +695,7 @@ __device__ __forceinline__ void resident_body(
     if (own_gd) {
 #pragma unroll
       for (int u = 0; u < GU; ++u) gdesc[u * WT + wt_] = v_gd[u];
-      if (p.rs_ngfix != 0) gfix[wt_] = reinterpret_cast<const int2*>(plan_itab + p.off_rs_gfix)[wt_];
+      if (p.rs_ngfix != 0) gfix[wt_] = v_gfix;
     }
     if (own_diag) {
       dpar[ct] = v_dpar;

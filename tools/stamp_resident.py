@@ -31,6 +31,8 @@ def main():
     lib = capi.load()
     if os.environ.get("MPCASM_JIT"):
         lib.mpcasm_set_option(capi.OPT_JIT, int(os.environ["MPCASM_JIT"]))
+    if os.environ.get("MPCASM_PER_CU"):       # workgroups per CU (is the set-up bound by the CU's load path?)
+        lib.mpcasm_set_option(capi.OPT_RESIDENT_PER_CU, int(os.environ["MPCASM_PER_CU"]))
     for _ in range(3):
         asm.assemble(given)
     lib.mpcasm_set_option(capi.OPT_PHASE_MASK, capi.PHASE_DEFAULT | capi.PHASE_STAMPS)
