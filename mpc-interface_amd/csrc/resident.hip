@@ -1273,24 +1273,6 @@ __device__ __forceinline__ void resident_body(
     }
     MPCASM_STAMP(6)
   }
-  // ---- on the way out: the plan's tables once more, for the NEXT launch ------------------------------
-  // A launch's set-up is three dependent trips to the plan's tables, and after 140 MB of results have
-  // gone through the caches every one of them is a miss (~3 500 cycles each: tools/stamp_resident.py).
-  // A control loop launches the same plan again right away: every wavefront touches its 1 KB of the
-  // tables as its last instruction, the workgroups of one XCD (blockIdx mod 8) cover them all, and the
-  // next launch finds them in that XCD's L2.  (bit 15 of the phase mask, A/B aid: not.)
-  if (!(phases & 32768)) {
-    const long nbytes_i = (long)plan_itab[H_NITAB] * 4, nbytes_d = (long)plan_itab[H_NDTAB] * 8;
-    const long off = (((long)(blockIdx.x >> 3) * RS_WAVES + wave) * 64 + lane) * 16;
-    const char* src_i = reinterpret_cast<const char*>(plan_itab);
-    const char* src_d = reinterpret_cast<const char*>(plan_dtab);
-    int4 warm = int4{0, 0, 0, 0};
-    if (off + 16 <= nbytes_i)
-      warm = *reinterpret_cast<const int4*>(src_i + off);
-    else if (off - nbytes_i >= 0 && ((off - nbytes_i) & ~15L) + 16 <= nbytes_d)
-      warm = *reinterpret_cast<const int4*>(src_d + ((off - nbytes_i) & ~15L));
-    asm volatile("" ::"v"(warm.x), "v"(warm.y), "v"(warm.z), "v"(warm.w));   // (the load stays; nothing reads it)
-  }
   if (STAMPS && stamping && lane == 0) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) stamps[((size_t)blockIdx.x * (NT / 64) + wave) * 8 + i] = t_acc[i];
