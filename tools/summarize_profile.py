@@ -27,6 +27,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def short(name):
     for key in ("resident_spec_kernel", "resident_assemble_kernel", "fused_assemble_kernel",
+                "toeplitz_scan_kernel", "ltv_sweep_kernel", "preview_blocked_kernel", "preview_staged_kernel",
+                "lti_tables_small_kernel", "lti_tables_kernel", "compose_d_kernel",
                 "fill_lti_quad_kernel", "fill_ltv_row_kernel", "fill_lti_tiny_kernel",
                 "toeplitz_assemble_kernel", "tiled_assemble_kernel", "preview_direct_kernel", "goal_distance_kernel", "fill_lti_kernel", "fill_ltv_wave_kernel", "fill_ltv_kernel", "compose_rowsets_kernel", "hessian_kernel",
                 "constraints_kernel", "compose_preview_kernel", "preview_kernel"):
