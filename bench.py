@@ -1027,10 +1027,11 @@ def run_rank(args):
         full_dir = os.path.join(ROOT, "gpurun_out")
         try:
             os.makedirs(full_dir, exist_ok=True)
-            full_path = os.path.join(full_dir, "bench_full.json")
-            with open(full_path, "w") as f:
+            # (the complete run keeps its name; a run with --no-extras does not overwrite it)
+            name = "bench_full.json" if not args.no_extras else "bench_full_no_extras.json"
+            with open(os.path.join(full_dir, name), "w") as f:
                 json.dump(record, f, indent=1)
-            record["full_record"] = "gpurun_out/bench_full.json"
+            record["full_record"] = "gpurun_out/" + name
         except OSError:
             record["full_record"] = "stderr"
         print(json.dumps(record), file=sys.stderr, flush=True)
