@@ -60,7 +60,7 @@ const char* mpcasm_status_string(int status);
  * kernel's Toeplitz form instead of its scan form, which sums P along diagonals).  The parity
  * tests use it to exercise every path; all paths give the same results. */
 enum { MPCASM_OPT_PATH = 1, MPCASM_OPT_PHASE_MASK = 2, MPCASM_OPT_RESIDENT_PER_CU = 3, MPCASM_OPT_JIT = 4,
-       MPCASM_OPT_P_DIRECT = 5 };
+       MPCASM_OPT_P_DIRECT = 5, MPCASM_OPT_RESIDENT_GRID = 6 };
 /* MPCASM_OPT_PHASE_MASK is a profiling aid (timing-only ablation of the fused
  * kernels: bit 0 compose, 1 Hessian, 2 gradient, 3 constraints, 4 input staging
  * after the first instance, 5 P/q stores, 7 register prefetch of the next instance's
@@ -74,6 +74,10 @@ enum { MPCASM_OPT_PATH = 1, MPCASM_OPT_PHASE_MASK = 2, MPCASM_OPT_RESIDENT_PER_C
  * storing it (results WRONG).
  * MPCASM_OPT_RESIDENT_PER_CU (tuning aid): workgroups of the persistent kernel per CU;
  * 0 (default) = chosen from the batch size, never more than are resident at once.
+ * MPCASM_OPT_RESIDENT_GRID: at most this many workgroups of the persistent kernel per launch
+ * (0, the default: all that are resident at once).  For callers that run launches of several plans
+ * side by side on streams of their own (the structure buckets of a walker fleet): every launch gets
+ * its share of the chip's workgroup slots and none waits for another to drain.
  * MPCASM_OPT_JIT: the persistent kernel compiled for the very plan by hiprtc (its sizes and
  * matrix-core trip lists become constants; same source, same results as the ahead-of-time
  * kernel): 0 (default) = for batches of at least 512 instances, when libhiprtc.so is there
@@ -87,7 +91,8 @@ enum { MPCASM_OPT_PATH = 1, MPCASM_OPT_PHASE_MASK = 2, MPCASM_OPT_RESIDENT_PER_C
  * These options are process-wide test / tuning hooks, not part of a launch's state: set them
  * before other threads start launching. */
 int mpcasm_set_option(int option, int value);
-/* The same choice for ONE plan (MPCASM_OPT_PATH, MPCASM_OPT_JIT, MPCASM_OPT_RESIDENT_PER_CU; value
+/* The same choice for ONE plan (MPCASM_OPT_PATH, MPCASM_OPT_JIT, MPCASM_OPT_RESIDENT_PER_CU,
+ * MPCASM_OPT_RESIDENT_GRID; value
  * -1: back to the process-wide value): part of the plan's state, read by every mpcasm_assemble on
  * it -- what a caller with several plans on several threads uses instead of the hooks above. */
 int mpcasm_plan_set_option(mpcasm_plan* plan, int option, int value);

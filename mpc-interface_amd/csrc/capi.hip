@@ -20,7 +20,7 @@ namespace mpcasm {
 int g_p_direct = 0;  // MPCASM_OPT_P_DIRECT (read when a plan is created)
 extern int g_path;
 extern int g_phase_mask;
-extern int g_resident_per_cu;
+extern int g_resident_per_cu, g_resident_grid;
 }
 
 struct mpcasm_plan {
@@ -32,7 +32,7 @@ struct mpcasm_plan {
   std::vector<int32_t> h_itab;  // host copy: what a specialised kernel is generated from (jit.hip)
   // mpcasm_plan_set_option: this plan's own choice of path / per-plan compilation / workgroups
   // per CU (-1: the process-wide value of mpcasm_set_option)
-  int opt_path = -1, opt_jit = -1, opt_per_cu = -1;
+  int opt_path = -1, opt_jit = -1, opt_per_cu = -1, opt_grid = -1;
   mutable int last_kernel = 0;  // mpcasm_plan_last_kernel: what the latest mpcasm_assemble launched
 };
 
@@ -1116,6 +1116,11 @@ int mpcasm_set_option(int option, int value) {
     g_resident_per_cu = value;
     return MPCASM_OK;
   }
+  if (option == MPCASM_OPT_RESIDENT_GRID) {
+    if (value < 0 || value > (1 << 20)) return MPCASM_ERR_ARG;
+    g_resident_grid = value;
+    return MPCASM_OK;
+  }
   return MPCASM_ERR_ARG;
 }
 
@@ -1124,6 +1129,7 @@ int mpcasm_plan_set_option(mpcasm_plan* plan, int option, int value) {
   if (option == MPCASM_OPT_PATH && value >= -1 && value <= 4) plan->opt_path = value;
   else if (option == MPCASM_OPT_JIT && value >= -1 && value <= 2) plan->opt_jit = value;
   else if (option == MPCASM_OPT_RESIDENT_PER_CU && value >= -1 && value <= 16) plan->opt_per_cu = value;
+  else if (option == MPCASM_OPT_RESIDENT_GRID && value >= -1 && value <= (1 << 20)) plan->opt_grid = value;
   else return MPCASM_ERR_ARG;
   return MPCASM_OK;
 }
@@ -1365,6 +1371,7 @@ static int assemble_impl(const mpcasm_plan* plan, const double* const* h_src,
   t_path = plan->opt_path >= 0 ? plan->opt_path : g_path;
   t_jit = plan->opt_jit >= 0 ? plan->opt_jit : g_jit;
   t_per_cu = plan->opt_per_cu >= 0 ? plan->opt_per_cu : g_resident_per_cu;
+  t_grid = plan->opt_grid >= 0 ? plan->opt_grid : g_resident_grid;
   rc = launch_assemble(d, src, d_params, d_given, d_P, d_q, d_G, d_h, d_work, batch,
                        plan->num_cus, static_cast<hipStream_t>(stream), &err, plan->h_itab.data(),
                        plan->device, d_given_index != nullptr);
@@ -1562,8 +1569,9 @@ hipError_t allow_whole_lds(const void* fn) {
 
 int g_path = 0;  // test hook (MPCASM_OPT_PATH): 0 best, 1 no resident kernel, 2 staged only
 int g_resident_per_cu = 0;  // tuning aid (MPCASM_OPT_RESIDENT_PER_CU): 0 = automatic
+int g_resident_grid = 0;    // MPCASM_OPT_RESIDENT_GRID: 0 = every resident workgroup slot
 // the values in force for the launch this thread is making (mpcasm_assemble sets them)
-thread_local int t_path = 0, t_jit = 0, t_per_cu = 0;
+thread_local int t_path = 0, t_jit = 0, t_per_cu = 0, t_grid = 0;
 thread_local int t_last_kernel = 0;
 
 // dispatch: fused single launch when the problem fits on chip, else staged
@@ -1592,7 +1600,7 @@ int launch_assemble(const PlanDev& plan, const SrcTable& src, const double* para
       if (const void* k = jit_kernel_for(p, h_itab, device, batch, rs)) {
         t_last_kernel = MPCASM_KERNEL_RESIDENT_JIT;
         return jit_launch(k, p, src, params, given, P, q, G, h, batch, num_cus, t_per_cu,
-                          work, stream, err);
+                          t_grid, work, stream, err);
       }
     t_last_kernel = MPCASM_KERNEL_RESIDENT;
     return launch_assemble_resident(p, src, params, given, P, q, G, h, work, batch, rs, num_cus,

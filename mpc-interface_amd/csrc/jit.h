@@ -34,6 +34,6 @@ void jit_stats(long out[3]);
 void jit_forget(const void* itab);
 int jit_launch(const void* kernel, const PlanDev& p, const SrcTable& src, const double* params,
                const double* given, double* P, double* q, double* G, double* h, int batch,
-               int num_cus, int per_cu_limit, void* work, hipStream_t stream, hipError_t* err);
+               int num_cus, int per_cu_limit, int grid_limit, void* work, hipStream_t stream, hipError_t* err);
 
 }  // namespace mpcasm

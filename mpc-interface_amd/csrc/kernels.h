@@ -71,7 +71,7 @@ int launch_assemble_resident(const PlanDev& p, const SrcTable& src, const double
 // kernel (jit.hip); nullptr = ahead-of-time kernels only
 // options in force for the launch the calling thread is making (capi.hip: the plan's own where
 // mpcasm_plan_set_option gave it some, else the process-wide ones of mpcasm_set_option)
-extern thread_local int t_path, t_jit, t_per_cu;
+extern thread_local int t_path, t_jit, t_per_cu, t_grid;
 extern thread_local int t_last_kernel;  // MPCASM_KERNEL_*: what launch_assemble launched
 int launch_assemble(const PlanDev& p, const SrcTable& src, const double* params,
                     const double* given, double* P, double* q, double* G, double* h, void* work,

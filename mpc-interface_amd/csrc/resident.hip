@@ -1368,6 +1368,7 @@ int launch_jc(const PlanDev& p, const SrcTable& src, const double* params, const
   if (per_cu < 1) return MPCASM_ERR_LIMIT;
   if (t_per_cu > 0 && t_per_cu < per_cu) per_cu = t_per_cu;
   long grid = (long)num_cus * per_cu;
+  if (t_grid > 0 && t_grid < grid) grid = t_grid;
   if (grid > batch) grid = batch;
   hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(NT), lds_bytes, stream, p, src, params,
                      given, P, q, G, h, batch, g_phase_mask,

@@ -16,6 +16,7 @@ ERR_LIMIT = -5
 OPT_PATH = 1
 OPT_PHASE_MASK = 2
 OPT_RESIDENT_PER_CU = 3
+OPT_RESIDENT_GRID = 6
 OPT_P_DIRECT = 5     # the persistent kernel writes P 1: straight to HBM, 2: through LDS when it fits, 0: by the launch's size (read at plan creation)
 OPT_JIT = 4            # 0: specialise the persistent kernel for batches >= 512, 1: always, 2: never
 PHASE_DEFAULT = 0xBF   # every phase on, cycle stamps (bit 6) off

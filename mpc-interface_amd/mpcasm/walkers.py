@@ -70,7 +70,7 @@ class WalkerFleet:
     ``{"p": steps in preview, "index": walker ids, "P", "q", "G", "h": device tensors}``.
     """
 
-    def __init__(self, batch, phases=None, conf=None, api=None, device=None, graphs=False):
+    def __init__(self, batch, phases=None, conf=None, api=None, device=None, graphs=False, side_by_side=False):
         from .engine import Assembler, require_device
 
         self._torch = require_device()
@@ -88,6 +88,12 @@ class WalkerFleet:
         # comes round and replayed from then on -- the tick is a copy of `given` into a fixed
         # buffer and one graph launch instead of a dozen host-side calls
         self._use_graphs, self._graphs, self._given = bool(graphs), {}, None
+        # side_by_side=True: inside the graph every bucket on a branch of its own with its share of the chip's
+        # workgroup slots (capi.OPT_RESIDENT_GRID, by the number of its walkers).  Measured (round 4, 4 096
+        # walkers: buckets of 512 and 3 584): 64 us per tick against 48 one after the other -- this runtime
+        # replays a graph with parallel branches through signals between queues that cost more than the
+        # second set-up they would hide; off by default
+        self._side, self._side_by_side = [], bool(side_by_side)
 
         # one template formulation + assembler per structure bucket (steps in preview)
         self.buckets = {}
@@ -158,21 +164,55 @@ class WalkerFleet:
             self._cache[key] = entry
         return self._cache[key]
 
-    def _launch(self, given):
+    def _launch(self, given, side_by_side=False):
         """This tick's launches for ``given`` (a device tensor): ONE assembly per structure bucket
         (its walkers' rows of ``given`` picked by index inside the kernel, the parameters of this place in
-        the step cycle kept ready)."""
+        the step cycle kept ready).  ``side_by_side``: every bucket on a stream of its own with its share
+        of the workgroup slots (forked from and joined to the current stream: what a graph captures as
+        parallel branches)."""
+        from . import capi
+        torch = self._torch
+        items = self._bucket_inputs()
+        side_by_side = side_by_side and len(items) > 1
         out = []
-        for item in self._bucket_inputs():
+        if side_by_side:
+            dev = self.buckets[items[0]["p"]]["asm"].device
+            cur = torch.cuda.current_stream(dev)
+            while len(self._side) < len(items) - 1:
+                self._side.append(torch.cuda.Stream(device=dev))
+            total = sum(item["idx"].size for item in items)
+            slots = 2 * torch.cuda.get_device_properties(dev).multi_processor_count
+        for i, item in enumerate(items):
             p, idx = item["p"], item["idx"]
             bucket = self.buckets[p]
             asm = bucket["asm"]
             asm.bind_source(("steps", 0), item["E"])
+            stream = None
+            if side_by_side:
+                asm.set_option(capi.OPT_RESIDENT_GRID, max(1, int(round(slots * idx.size / total))))
+                if i:
+                    stream = self._side[i - 1]
+                    stream.wait_stream(cur)
+            elif self._side:
+                asm.set_option(capi.OPT_RESIDENT_GRID, -1)
             # (no gather, no copy: the walkers' rows of `given` by index, the place's own parameters)
-            P, q, G, h = asm.assemble(given, count=idx.size, index=item["index"], params=item["params"])
+            P, q, G, h = asm.assemble(given, count=idx.size, index=item["index"], params=item["params"],
+                                      stream=stream)
             out.append({"p": p, "index": idx, "P": P[:idx.size], "q": q[:idx.size],
                         "G": G[:idx.size], "h": h[:idx.size]})
+        if side_by_side:
+            for stream in self._side[:len(items) - 1]:
+                cur.wait_stream(stream)
         return out
+
+    def given_buffer(self):
+        """The fleet's own ``(batch, ng)`` buffer of ``given`` on the device: a caller that writes the
+        walkers' states straight into it and hands it to :meth:`tick` saves the copy a replayed graph needs
+        (its launches read fixed addresses)."""
+        if self._given is None:
+            dev = next(iter(self.buckets.values()))["asm"].device
+            self._given = self._torch.empty((self.batch, self.given_len), dtype=self._torch.float64, device=dev)
+        return self._given
 
     def tick(self, given):
         """Assemble this tick's QPs (``given``: ``(batch, ng)`` tensor or array), then
@@ -186,16 +226,15 @@ class WalkerFleet:
         if not self._use_graphs:
             out = self._launch(g)
         else:
-            if self._given is None:
-                self._given = torch.empty((self.batch, self.given_len), dtype=torch.float64, device=dev)
-            self._given.copy_(g, non_blocking=True)
+            if g is not self.given_buffer() and g.data_ptr() != self._given.data_ptr():
+                self._given.copy_(g, non_blocking=True)
             key = self._ticks % (2 * self.conf.step_samples)
             if key not in self._graphs:
                 self._launch(self._given)            # once as it is: kernels compiled, buffers there
                 torch.cuda.synchronize(dev)
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
-                    out = self._launch(self._given)
+                    out = self._launch(self._given, side_by_side=self._side_by_side)
                 self._graphs[key] = (graph, out)
             graph, out = self._graphs[key]
             graph.replay()

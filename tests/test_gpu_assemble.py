@@ -352,6 +352,27 @@ def test_workgroups_per_cu_option_changes_nothing_but_the_grid(gpu_api):
         lib.mpcasm_set_option(capi.OPT_RESIDENT_PER_CU, 0)
 
 
+def test_a_share_of_the_workgroup_slots_changes_nothing_but_the_grid(gpu_api):
+    """MPCASM_OPT_RESIDENT_GRID, per plan: a launch that may take 48 (or 3) workgroups walks more
+    instances with each; same bits out, on the compiled and the ahead-of-time kernel."""
+    from mpcasm import capi, engine
+
+    form = problems.biped(gpu_api, problems.BipedConfig(step_samples=8))
+    form.update(step_times=np.array([6, 14]), step_count=0)
+    batch = 700
+    asm = engine.Assembler(form, batch=batch)
+    given = np.random.default_rng(12).normal(0, 0.1, [batch, form.given_len])
+    ref = [t.cpu().numpy().copy() for t in asm.assemble(given)]
+    for jit in (1, 2):
+        asm.set_option(capi.OPT_JIT, jit)
+        for grid in (48, 3, 0):
+            asm.set_option(capi.OPT_RESIDENT_GRID, grid)
+            for mine, theirs in zip(asm.assemble(given), ref):
+                assert np.array_equal(mine.cpu().numpy(), theirs)
+    with pytest.raises(capi.MpcasmError):
+        asm.set_option(capi.OPT_RESIDENT_GRID, -2)
+
+
 def test_biped_long_horizon_persistent_kernel(gpu_api):
     """N = 24 (no = 52, nc = 108): more 16-byte pieces of G than the per-thread descriptor
     table of the persistent kernel holds, so G goes by the packed words of the row records

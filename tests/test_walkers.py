@@ -110,15 +110,21 @@ def test_fleet_ticks_replayed_from_graphs(gpu_api, jit):
     try:
         plain = WalkerFleet(batch, phases=phases, conf=conf, api=gpu_api)
         replayed = WalkerFleet(batch, phases=phases, conf=conf, api=gpu_api, graphs=True)
+        # ... the buckets as parallel branches of the graph, each with its share of the workgroup slots, and
+        # `given` written straight into the fleet's own buffer (no copy in front of the replay)
+        branches = WalkerFleet(batch, phases=phases, conf=conf, api=gpu_api, graphs=True, side_by_side=True)
+        own = branches.given_buffer()
         rng = np.random.default_rng(4)
         for tick in range(2 * 2 * conf.step_samples + 3):
             given = torch.as_tensor(rng.normal(0, 0.1, [batch, plain.given_len]), device="cuda")
-            a, b = plain.tick(given), replayed.tick(given)
-            assert [r["p"] for r in a] == [r["p"] for r in b]
-            for ra, rb in zip(a, b):
-                assert np.array_equal(ra["index"], rb["index"])
+            own.copy_(given)
+            a, b, c = plain.tick(given), replayed.tick(given), branches.tick(own)
+            assert [r["p"] for r in a] == [r["p"] for r in b] == [r["p"] for r in c]
+            for ra, rb, rc in zip(a, b, c):
+                assert np.array_equal(ra["index"], rb["index"]) and np.array_equal(ra["index"], rc["index"])
                 for k in ("P", "q", "G", "h"):
                     assert torch.equal(ra[k], rb[k]), (tick, k)
+                    assert torch.equal(ra[k], rc[k]), (tick, k, "branches")
     finally:
         lib.mpcasm_set_option(capi.OPT_JIT, 0)
 

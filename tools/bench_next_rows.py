@@ -54,6 +54,14 @@ def main():
     fleet = WalkerFleet(B, conf=problems.BipedConfig(step_samples=8), graphs=True)
     t = timed(lambda: fleet.tick(g_fleet), 64, warm=4 * fleet.conf.step_samples + 4)
     print("   from hipGraphs %6d walkers  %8.3f ms per tick  %10.0f walker-ticks/s" % (B, t * 1e3, B / t))
+    fleet1 = WalkerFleet(B, conf=problems.BipedConfig(step_samples=8), graphs=True, side_by_side=True)
+    t = timed(lambda: fleet1.tick(g_fleet), 64, warm=4 * fleet.conf.step_samples + 4)
+    print("   from hipGraphs, the buckets side by side (branches)  %8.3f ms per tick  %10.0f walker-ticks/s" % (t * 1e3, B / t))
+    del fleet1
+    # ... with the walkers' states written straight into the fleet's own buffer (no copy per tick)
+    g_own = fleet.given_buffer()
+    t = timed(lambda: fleet.tick(g_own), 64, warm=8)
+    print("   from hipGraphs, `given` in the fleet's buffer  %8.3f ms per tick  %10.0f walker-ticks/s" % (t * 1e3, B / t))
 
     # f2 (round 3): every row of every definition and every goal's distance straight from the
     # sources -- no preview matrix in memory (mpcasm_preview_direct, mpcasm_goal_distance)
