@@ -276,7 +276,7 @@ int validate_tiled(const int32_t* it, const double* h_dtab, int64_t n, int64_t n
   if (!it[H_T_OK]) return MPCASM_OK;
   // the tiled program
   const int64_t nstage = it[H_T_NSTAGE], rtot = it[H_RTOT];
-  if (no < T_BLOCK || (no & 1) || nstage < 0 ||
+  if (no < T_BLOCK || nstage < 0 ||
       !in_range(it[H_OFF_T_STAGE], nstage * T_STAGE_WORDS, n, H_WORDS) || it[H_OFF_T_STAGE] % 4 ||
       !in_range(it[H_OFF_T_GROW], nc * RS_AXMAX, n, H_WORDS) ||
       !in_range(it[H_OFF_RS_RR], nc * RS_RR_WORDS, n, H_WORDS) ||

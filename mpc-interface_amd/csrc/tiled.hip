@@ -248,6 +248,17 @@ __device__ __forceinline__ double2 colref_at(const ColRef& c, int k) {
   return v;
 }
 
+// two adjacent columns of a row of G leave as one 16-byte piece when the rows are 16-byte aligned (an even
+// width); an odd width shifts every other row by 8 bytes: two 8-byte stores there, the last column alone
+__device__ __forceinline__ void store_pair(double* row, int col, int no, bool odd, double2 v) {
+  if (!odd) {
+    if (col < no) store_result(reinterpret_cast<double2*>(row + col), v);
+  } else {
+    if (col < no) store_result(row + col, v.x);
+    if (col + 1 < no) store_result(row + col + 1, v.y);
+  }
+}
+
 struct RowTables {
   const int32_t* rowptr;
   const int32_t* entbase;
@@ -378,6 +389,7 @@ __global__ __launch_bounds__(BLOCK, 2) void tiled_assemble_kernel(
   const int scol = lane * 2;
   const int colA = bi * T_BLOCK + scol, colB = bj * T_BLOCK + scol;
   const bool want_g = G != nullptr && diag;
+  const bool odd = no & 1;
 
   f64x4 acc[4][4];
 #pragma unroll
@@ -482,13 +494,11 @@ __global__ __launch_bounds__(BLOCK, 2) void tiled_assemble_kernel(
         const int4 pg = cur.pig[rr];
         if (pg.x >= 0) {
           const double ar = pb[pg.y];
-          store_result(reinterpret_cast<double2*>(G + ((size_t)inst * p.nc + pg.x) * no + colA),
-                       double2{ar * a.x, ar * a.y});
+          store_pair(G + ((size_t)inst * p.nc + pg.x) * no, colA, no, odd, double2{ar * a.x, ar * a.y});
         }
         if (pg.z >= 0) {
           const double ar = pb[pg.w];
-          store_result(reinterpret_cast<double2*>(G + ((size_t)inst * p.nc + pg.z) * no + colA),
-                       double2{ar * a.x, ar * a.y});
+          store_pair(G + ((size_t)inst * p.nc + pg.z) * no, colA, no, odd, double2{ar * a.x, ar * a.y});
         }
       }
       if (!P) continue;
@@ -570,8 +580,7 @@ __global__ __launch_bounds__(BLOCK, 2) void tiled_assemble_kernel(
         out.x = fma(ar, v.x, out.x);
         out.y = fma(ar, v.y, out.y);
       }
-      if (colA < no)
-        store_result(reinterpret_cast<double2*>(G + ((size_t)inst * p.nc + R) * no + colA), out);
+      store_pair(G + ((size_t)inst * p.nc + R) * no, colA, no, odd, out);
     }
     if (bi == 0)  // h: (extreme + arrow . center) - arrow . d
       for (int R = tid; R < p.nc; R += BLOCK) {
@@ -1552,7 +1561,8 @@ int launch_assemble_tiled(const PlanDev& p, const SrcTable& src, const double* p
   const int sym = p.rs_sym_any;
   const int npairs = sym ? nb * (nb + 1) / 2 : nb * nb;
   const unsigned groups = ceil_div((unsigned)batch, 8u);
-  if (p.t_toeplitz && p.t_nlti == 1 && h_itab != nullptr && t_path != 3) {
+  // (the Toeplitz forms write rows of G in 16-byte pieces: an even width)
+  if (p.t_toeplitz && p.t_nlti == 1 && h_itab != nullptr && t_path != 3 && (p.no & 1) == 0) {
     // every stage is a window of the one generated group's table: operands straight out of LDS
     const int32_t* rec = h_itab + p.off_t_lti;
     const int tbn = rec[TL_N] * rec[TL_M] * 2 * rec[TL_HORIZON];

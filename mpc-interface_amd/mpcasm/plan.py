@@ -1294,7 +1294,7 @@ def _tiled_program(b, form, gterms, rowptr, entbase, entk, entcoef, rtot, groups
         lti.append([n, m, N, len(ids), work, work + N * n * n, 0, 0])
         work += N * n * n + n * m * 2 * N
         ids.extend(g["ids"])
-    ok = int(ci_ok and rr_ok and no >= T_BLOCK and no % 2 == 0 and len(b.base_rows) > 0
+    ok = int(ci_ok and rr_ok and no >= T_BLOCK and len(b.base_rows) > 0
              and len(b.sources) <= MAX_SOURCES and rtot < (1 << 24))
     toeplitz = int(bool(ok and stages and all((st[3] >> 8) & TS_FLAG_TOEPLITZ for st in stages)))
     return dict(ok=ok, toeplitz=toeplitz, ci_ok=int(ci_ok), nop=nop, ci=ci, delta=delta, masks=masks,

@@ -369,25 +369,53 @@ def test_two_plants_in_one_wide_problem(gpu_api, torch_gpu, lti, optim_second):
         assert_close(rows[3, r0:r0 + n], want, 1e-11, var)
 
 
-def test_odd_width_falls_back_to_the_staged_pipeline(gpu_api, torch_gpu):
-    """129 unknowns: rows of G are not 16-byte aligned, the tiled kernel does not take the plan
-    (T_OK = 0); the staged pipeline does, same numbers as the oracle."""
+@pytest.mark.parametrize("nx,nu,N", [(3, 3, 43), (2, 5, 27), (4, 1, 131)], ids=["129", "135", "131"])
+def test_odd_width_on_the_tiled_kernel(gpu_api, torch_gpu, nx, nu, N):
+    """An odd number of unknowns (129, 135, 131): every other row of G starts 8 bytes off a 16-byte
+    boundary, so the general form of the tiled kernel writes such rows with 8-byte stores and the last
+    column alone (round 3 sent these plans to the staged pipeline).  Every instance against the oracle and
+    against the staged pipeline; with the horizon tables generated from the system's own (A, B) the
+    general form reads them (the Toeplitz forms write 16-byte pieces: even widths only)."""
     torch = torch_gpu
-    from mpcasm import engine
+    from mpcasm import capi, engine
 
     rng = np.random.default_rng(5)
-    form = problems.random_lti(gpu_api, rng, nx=3, nu=3, N=43)
-    assert form.optim_len == 129
-    asm = engine.Assembler(form, batch=5)
-    assert asm.plan.itab[_H["T_OK"]] == 0 and asm.plan.itab[_H["T_CI_OK"]] == 1
-    given = rng.normal(0, 0.3, [5, form.given_len])
-    P, q, G, h = (t.cpu().numpy() for t in asm.assemble(given))
+    form = problems.random_lti(gpu_api, rng, nx=nx, nu=nu, N=N)
+    assert form.optim_len == nu * N and form.optim_len % 2 == 1
+    B = 5
+    asm = engine.Assembler(form, batch=B)
+    assert asm.plan.itab[_H["T_OK"]] == 1 and asm.plan.itab[_H["T_CI_OK"]] == 1
+    given = rng.normal(0, 0.3, [B, form.given_len])
+    out = [torch.full(shape, float("nan"), dtype=torch.float64, device="cuda")
+           for shape in ((B, asm.no, asm.no), (B, asm.no), (B, asm.nc, asm.no), (B, asm.nc))]
+    P, q, G, h = (t.cpu().numpy() for t in asm.assemble(given, out=tuple(out)))
+    assert asm.last_kernel() == "tiled_assemble_kernel", asm.last_kernel()
+    for b in range(B):
+        Ao, ho, Qo, qo = orc.assemble(form, given[b].reshape(-1, 1))
+        assert_close(P[b], Qo, RTOL_TIGHT), assert_close(q[b], qo.ravel(), RTOL_TIGHT)
+        assert_close(G[b], Ao, RTOL_TIGHT), assert_close(h[b], ho.ravel(), RTOL_TIGHT)
+    asm.set_option(capi.OPT_PATH, 2)
+    staged = [t.cpu().numpy() for t in asm.assemble(given)]
     assert "staged" in asm.last_kernel()
-    Ao, ho, Qo, qo = orc.assemble(form, given[2].reshape(-1, 1))
-    assert_close(P[2], Qo, RTOL_TIGHT), assert_close(q[2], qo.ravel(), RTOL_TIGHT)
-    assert_close(G[2], Ao, RTOL_TIGHT), assert_close(h[2], ho.ravel(), RTOL_TIGHT)
-    with pytest.raises(Exception):
-        engine.Assembler(form, batch=5, lti=["plant"]).assemble(given)   # nowhere to generate the tables
+    for mine, theirs in zip((P, q, G, h), staged):
+        assert_close(mine, theirs, RTOL_TIGHT)
+    # a system of its own per instance: tables from the pre-pass, read by the general form; against the staged
+    # pipeline on the horizon matrices mpcasm_fill_su writes for the same systems
+    As, Bs = zip(*(problems.random_lti_matrices(rng, nx, nu) for _ in range(B)))
+    At, Bt = torch.as_tensor(np.stack(As), device="cuda"), torch.as_tensor(np.stack(Bs), device="cuda")
+    lti = engine.Assembler(form, batch=B, lti=["plant"])
+    lti.bind_lti("plant", At, Bt)
+    res = [t.cpu().numpy() for t in lti.assemble(given)]
+    # (a narrow system with its tables on chip may fit the persistent kernel instead: nx = 2)
+    assert lti.last_kernel() == "tiled_assemble_kernel" or "persistent" in lti.last_kernel(), lti.last_kernel()
+    S, U = engine.fill_su(At, Bt, N)
+    for j in range(nu):
+        asm.bind_source(("plant", j), U[:, j])
+    asm.bind_source(("plant", nu), S)
+    ref = [t.cpu().numpy() for t in asm.assemble(given)]
+    assert "staged" in asm.last_kernel()
+    for mine, theirs in zip(res, ref):
+        assert_close(mine, theirs, RTOL_TIGHT)
 
 
 def test_a_non_causal_matrix_is_refused_where_the_masks_assume_causality(gpu_api, torch_gpu):

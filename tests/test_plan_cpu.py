@@ -753,3 +753,21 @@ def test_sweep_tables_are_validated(cpu_api):
         assert bad[word] != value, what
         bad[word] = value
         assert create(bad) == -2, what
+
+
+def test_an_odd_width_compiles_for_the_tiled_kernel(cpu_api):
+    """129 unknowns: the plan is one the tiled kernel takes (T_OK; round 3 required an even width because rows
+    of G leave in 16-byte pieces -- the general form now writes the rows of an odd width with 8-byte stores),
+    the library accepts its tables, and the tables give the oracle's numbers."""
+    from mpcasm import engine
+
+    rng = np.random.default_rng(5)
+    form = problems.random_lti(cpu_api, rng, nx=3, nu=3, N=43)
+    plan = compile_plan(form)
+    assert plan.no == 129 and plan.itab[_H["T_OK"]] == 1 and plan.itab[_H["T_NOP"]] == 256
+    assert engine.resident_lds_bytes(plan) == (0, 0)          # validated like mpcasm_plan_create does; not persistent
+    given = rng.normal(0, 0.3, [form.given_len, 1])
+    out = plan_emulator.run_tiled(plan, given)
+    A, h, Q, q = orc.assemble(form, given)
+    assert_close(out["P"], Q, 1e-12, "P"), assert_close(out["q"], q.ravel(), 1e-12, "q")
+    assert_close(out["G"], A, 1e-12, "G"), assert_close(out["h"], h.ravel(), 1e-12, "h")
