@@ -225,6 +225,38 @@ def cpu_baseline(work, budget_s=12.0):
     return done / elapsed, done, elapsed
 
 
+def cpu_baseline_compiled(work, threads, budget_s=4.0):
+    """The same per-instance path compiled: oracle/assemble_port.c (plain C restatement of
+    extend_matrices + make_preview_matrices + generate_all_qp_matrices, body.py:142-348, the dense
+    matrices and loop order of the numpy oracle) on ``threads`` host threads, every thread on its own
+    slice of the instances (the library call releases the GIL)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from oracle import c_port
+
+    form = work["form"]
+    recipe = c_port.Recipe(form, per_instance="LIP")
+    count = work["given"].shape[0]
+    consts = np.tile(recipe.consts, (count, 1))
+    # (the workload's per-instance aim of the velocity cost; a plain cost's cross_aim IS its aim, goal.py:67-86)
+    for field in ("aim", "cross_aim"):
+        consts[:, recipe.const_slice("cost", "track vel_x", field)] = np.asarray(work["aims"]).reshape(count, -1)[:, 0:1]
+    A, B, given = work["A"], work["B"], work["given"]
+    recipe.assemble(A[:8], B[:8], given[:8], consts[:8], keep=False)
+
+    def loop(t):
+        lo, hi = t * count // threads, (t + 1) * count // threads
+        done, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < budget_s:
+            recipe.assemble(A[lo:hi], B[lo:hi], given[lo:hi], consts[lo:hi], keep=False)
+            done += hi - lo
+        return done, time.perf_counter() - t0
+
+    with ThreadPoolExecutor(threads) as pool:
+        results = list(pool.map(loop, range(threads)))
+    return sum(d / t for d, t in results), sum(d for d, _ in results)
+
+
 def cpu_fill_compiled(budget_s=2.0):
     """K1 on one host core, compiled: oracle/extend_matrices.c (plain C restatement of
     tools.extend_matrices, reference twin cpp/src/tools.cc:83-144) on the C2 and C4 shapes."""
@@ -606,6 +638,9 @@ def compact_line(rec):
         b = rec["cpu_baseline"]
         out["cpu_baseline"] = {"value": b["value"], "unit": b["unit"], "cores": b["cores"], "kind": b["kind"],
                                "sample": b["sample_short"], "one_core": b["single_core_value"]}
+        if "numpy_oracle" in b:   # (the interpreted port beside the compiled one)
+            out["cpu_baseline"]["numpy"] = {"value": b["numpy_oracle"]["value"],
+                                            "one_core": b["numpy_oracle"]["single_core_value"]}
     out["devices"] = rec["devices"]
     if "gather" in rec:
         g = rec["gather"]
@@ -1001,27 +1036,39 @@ def run_rank(args):
             torch.cuda.empty_cache()
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        rate1, count1, secs1 = cpu_baseline(work, 6.0)
-        rate, count, procs = cpu_baseline_all_cores(10.0)
+        rate1, count1, secs1 = cpu_baseline(work, 5.0)
+        rate, count, procs = cpu_baseline_all_cores(8.0)
         try:
             compiled = cpu_fill_compiled()
         except (OSError, RuntimeError) as exc:       # (oracle/liboracle.so not built)
             compiled = "unavailable: %s" % exc
-        record["cpu_baseline"] = {
-            "value": rate,
-            "unit": "assemblies/s",
-            "cores": procs,
-            "kind": "port",
-            "single_core_value": rate1,
-            "sample_short": "oracle (numpy port of the path), %d assemblies in 10 s on %d procs; 1 proc: %d in %.0f s"
-                            % (count, procs, count1, secs1),
-            "compiled_fill_single_thread": compiled,
-            "sample": "%d assemblies of the same workload in 10 s on %d processes (one formulation "
-                      "each): oracle/qp_oracle.py (extend_matrices + preview matrices + all QP "
-                      "blocks per instance; the per-tick update() callback of the reference's "
-                      "979/s figure is not in it); one process alone: %d in %.1f s; host has %d cores"
-                      % (count, procs, count1, secs1, os.cpu_count() or 0),
-        }
+        numpy_line = {"value": rate, "cores": procs, "single_core_value": rate1,
+                      "sample": "%d assemblies of the same workload in 8 s on %d processes (one formulation "
+                                "each): oracle/qp_oracle.py (extend_matrices + preview matrices + all QP "
+                                "blocks per instance; the per-tick update() callback of the reference's "
+                                "979/s figure is not in it); one process alone: %d in %.1f s; host has %d cores"
+                                % (count, procs, count1, secs1, os.cpu_count() or 0)}
+        try:
+            # the stronger baseline: the same path compiled (oracle/assemble_port.c), one thread per core
+            c1, n1 = cpu_baseline_compiled(work, 1, 3.0)
+            cp, np_ = cpu_baseline_compiled(work, procs, 5.0)
+            record["cpu_baseline"] = {
+                "value": cp, "unit": "assemblies/s", "cores": procs, "kind": "port",
+                "single_core_value": c1,
+                "sample_short": "oracle/assemble_port.c (C port of the path, gcc -O3): %d assemblies in 5 s on %d threads"
+                                % (np_, procs),
+                "sample": "%d assemblies of the same workload (per-instance (A, B), given, aim) in 5 s on %d threads: "
+                          "extend_matrices + dense preview matrices + every limit and cost per instance, the loop "
+                          "structure of body.py:142-348" % (np_, procs),
+                "numpy_oracle": numpy_line, "compiled_fill_single_thread": compiled}
+        except (OSError, RuntimeError, AttributeError) as exc:   # (liboracle.so not built, or an old one)
+            record["cpu_baseline"] = {
+                "value": rate, "unit": "assemblies/s", "cores": procs, "kind": "port",
+                "single_core_value": rate1,
+                "sample_short": "oracle (numpy port of the path), %d assemblies in 8 s on %d procs; 1 proc: %d in %.0f s"
+                                % (count, procs, count1, secs1),
+                "sample": numpy_line["sample"], "compiled_port": "unavailable: %s" % exc,
+                "compiled_fill_single_thread": compiled}
     if rank == 0:
         # the long form beside the line: a file (gpurun_out/ travels back from a GPU box) and stderr
         full_dir = os.path.join(ROOT, "gpurun_out")

@@ -136,7 +136,68 @@ def check_snapshot(form, g, prefix):
     A, h, Q, q = orc.assemble(form, given, PM, maps)
     for mine, nm in ((A, "A"), (h, "h"), (Q, "Q"), (q, "q")):
         assert_close(mine, g[prefix + nm], RTOL, prefix + nm)
+    # the compiled port of the same path (oracle/assemble_port.c) against the same vectors of the reference
+    port = _c_port()
+    Gc, hc, Pc, qc = port.Recipe(form).assemble(None, None, np.asarray(given).reshape(1, -1))
+    for mine, nm in ((Gc[0], "A"), (hc[0][:, None], "h"), (Pc[0], "Q"), (qc[0][:, None], "q")):
+        assert_close(mine, g[prefix + nm], RTOL, prefix + nm + " (C port)")
     return A, h, Q, q
+
+
+def _c_port():
+    """oracle/c_port.py over oracle/liboracle.so; built here when it is not yet (or is an older one)."""
+    import os
+    import subprocess
+
+    from oracle import c_port
+    try:
+        c_port.load()
+    except (RuntimeError, AttributeError):
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        subprocess.check_call(["make", "-B", "-C", os.path.join(root, "oracle")], stdout=subprocess.DEVNULL)
+        c_port._lib = None
+        c_port.load()
+    return c_port
+
+
+def test_c_port_with_a_system_and_constants_of_its_own_per_instance(cpu_api):
+    """The compiled port on the bench's workload shape: every instance its own (A, B) (horizon matrices
+    extended per instance, tools.py:14-33; where they land in the preview matrices found by probing the
+    definitions), its own `given` and its own aim of the velocity cost -- against the numpy oracle run
+    instance by instance the way the reference re-plans (dynamics.py:222-231 + body.py:142-348)."""
+    port = _c_port()
+    conf = problems.BipedConfig(step_samples=8)
+    form = problems.biped(cpu_api, conf)
+    form.update(step_times=np.array([6, 14]), step_count=0)
+    N, B = conf.horizon_lenght, 6
+    rng = np.random.default_rng(21)
+    lip = form.dynamics["LIP"]
+    A0, B0 = np.array([[1, 0.1, 0.005], [0, 1, 0.1], [0, 0, 1]]), np.array([[0.1 ** 3 / 6], [0.005], [0.1]])
+    As = A0[None] + rng.normal(0, 0.01, [B, 3, 3])
+    Bs = B0[None] + rng.normal(0, 0.01, [B, 3, 1])
+    given = rng.normal(0, 0.2, [B, form.given_len])
+    aims = rng.normal(0.3, 0.1, [B, 1])
+    recipe = port.Recipe(form, per_instance="LIP")
+    consts = np.tile(recipe.consts, (B, 1))
+    for field in ("aim", "cross_aim"):
+        consts[:, recipe.const_slice("cost", "track vel_x", field)] = aims
+    G, h, P, q = recipe.assemble(As, Bs, given, consts)
+    saved, aim0 = list(lip.matrices), np.array(form.goals["track vel_x"].aim)
+    try:
+        for b in range(B):
+            S, U = orc.extend_matrices(N, As[b], Bs[b])
+            lip.matrices = U + [S]
+            lip.update_definitions()
+            form.goals["track vel_x"].update(aim=aims[b])
+            Ao, ho, Qo, qo = orc.assemble(form, given[b].reshape(-1, 1))
+            assert_close(G[b], Ao, 1e-13, "G"), assert_close(h[b], ho.ravel(), 1e-13, "h")
+            assert_close(P[b], Qo, 1e-13, "P"), assert_close(q[b], qo.ravel(), 1e-13, "q")
+    finally:
+        lip.matrices = saved
+        lip.update_definitions()
+        form.goals["track vel_x"].update(aim=aim0)
+    # the formulation's own matrices are back where the probing found them
+    assert all(np.array_equal(a, b) for a, b in zip(lip.matrices, saved))
 
 
 def test_body_case(cpu_api):
