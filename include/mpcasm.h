@@ -335,6 +335,28 @@ int mpcasm_box_transform_ss(double* d_params, int64_t n_params, int batch,
                             int lrows, int ss_dim, const double* d_arg, int64_t arg_stride,
                             void* stream);
 
+/* f3, the "or": the solve itself, batched ---------------------------------------------
+ * Replaces, for every instance of a batch at once, the solver call of the walking loop
+ *   self.optim = osqp_solve_qp(P=Q, q=q, G=A, h=h)
+ *   python/use_examples/simple_functional_example/biped_mpc_loop.py:60
+ * on the dense results of mpcasm_assemble where they lie:  min 1/2 x'Px + q'x  s.t.  Gx <= h  (no
+ * equalities on this path, body.py:331).  `iters` iterations of OSQP's ADMM (Stellato et al., Math.
+ * Prog. Comp. 12 (2020), Algorithm 1) with the steps rho, sigma, alpha (OSQP's defaults: 0.1, 1e-6,
+ * 1.6) and without its problem scaling, adaptive rho and polishing:
+ *   (P + sigma I + rho G'G) xt = sigma x - q + G'(rho z - y);  zt = G xt;  x+ = alpha xt + (1 - alpha) x
+ *   z+ = min(alpha zt + (1 - alpha) z + y / rho, h);  y+ = y + rho (alpha zt + (1 - alpha) z - z+)
+ * d_P [batch][no][no] (symmetric), d_q [batch][no], d_G [batch][nc][no], d_h [batch][nc].
+ * d_x [batch][no], d_y [batch][nc], d_z [batch][nc]: the iterates -- read when warm != 0 (a walking
+ * loop starts a tick from the last one's), else started from x = 0, y = 0, z = min(0, h); always
+ * written.  d_res (may be NULL) [batch][2]: OSQP's residuals |Gx - z|_inf and |Px + q + G'y|_inf after
+ * the last iteration -- the caller decides whether to iterate on.  An instance whose
+ * P + sigma I + rho G'G is not positive definite gets NaNs.  MPCASM_ERR_LIMIT when one instance's
+ * matrices do not fit on chip ((no + max(nc, no)) * (no | 1) + 4 no + 4 nc doubles in 156 KB of LDS:
+ * the biped up to N = 24 and beyond; not C3). */
+int mpcasm_admm(int no, int nc, const double* d_P, const double* d_q, const double* d_G,
+                const double* d_h, double* d_x, double* d_y, double* d_z, double* d_res, double rho,
+                double sigma, double alpha, int iters, int warm, int batch, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

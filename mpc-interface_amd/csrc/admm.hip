@@ -1,0 +1,224 @@
+// admm.hip -- K5: the step after the assembly, on the device (the "or"): a batch
+// of dense QPs  min 1/2 x'Px + q'x  s.t.  Gx <= h  straight out of mpcasm_assemble's buffers, iterated
+// with OSQP's ADMM -- the solve the reference's loop hands to qpsolvers.osqp_solve_qp
+// (use_examples/simple_functional_example/biped_mpc_loop.py:57-60).  osqp is a third-party dependency
+// of the example, absent from the reference tree; the iteration is the published one (Stellato,
+// Banjac, Goulart, Bemporad, Boyd, Math. Prog. Comp. 12 (2020), Algorithm 1, reduced KKT form):
+//     (P + sigma I + rho G'G) xt = sigma x - q + G'(rho z - y);   zt = G xt
+//     x+ = alpha xt + (1 - alpha) x
+//     z+ = min(alpha zt + (1 - alpha) z + y / rho, h);   y+ = y + rho (alpha zt + (1 - alpha) z - z+)
+// restated on the CPU by oracle/admm_oracle.py, which the tests hold this kernel to.
+//
+// One wavefront per instance, everything in LDS: the matrix K = P + sigma I + rho G'G is factored once
+// (Cholesky, in place), inverted once (L^-1 column by column, every lane its own right-hand side; then
+// K^-1 = L^-T L^-1), and an iteration is three matrix-vector products -- G'v (lanes over the unknowns),
+// K^-1 r (the same) and G xt (lanes over the rows) -- with no dependent chain longer than a row: the
+// two triangular solves per iteration that OSQP's LDL' does on the host would be 2 no dependent steps
+// of a wavefront each.  K is symmetric positive definite by construction (sigma > 0), well conditioned
+// for the steps OSQP uses; the explicit inverse changes the iterates by rounding only.
+// LDS per instance: no (no|1) doubles for K^-1, max(nc, no) (no|1) for G (and, before G is needed,
+// L^-1), nine vectors: 34 KB for the biped at N = 16 (no = 36, nc = 76): four instances per CU.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+
+#include "device_prims.h"
+#include "kernels.h"
+
+namespace mpcasm {
+
+namespace {
+
+constexpr int ADMM_BLOCK = 64;
+
+struct AdmmLds {
+  int mi, gs, x, xt, rhs, q, z, y, v, h, total, ld;
+};
+__host__ __device__ inline AdmmLds admm_lds(int no, int nc) {
+  AdmmLds L;
+  L.ld = no | 1;   // (an odd leading dimension: a column of a row-major matrix is conflict-free)
+  L.mi = 0;
+  L.gs = L.mi + no * L.ld;
+  L.x = L.gs + (nc > no ? nc : no) * L.ld;
+  L.xt = L.x + no;
+  L.rhs = L.xt + no;
+  L.q = L.rhs + no;
+  L.z = L.q + no;
+  L.y = L.z + nc;
+  L.v = L.y + nc;
+  L.h = L.v + nc;
+  L.total = L.h + nc;
+  L.total += L.total & 1;
+  return L;
+}
+
+__global__ __launch_bounds__(ADMM_BLOCK) void admm_kernel(
+    int no, int nc, const double* __restrict__ P, const double* __restrict__ q,
+    const double* __restrict__ G, const double* __restrict__ h, double* __restrict__ X,
+    double* __restrict__ Y, double* __restrict__ Z, double* __restrict__ res, double rho, double sigma,
+    double alpha, int iters, int warm, int batch) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int lane = threadIdx.x;
+  const long inst = blockIdx.x;
+  if (inst >= batch) return;
+  const AdmmLds L = admm_lds(no, nc);
+  const int ld = L.ld;
+  double* Mi = sm + L.mi;   // K, then its Cholesky factor (lower), then K^-1
+  double* Gs = sm + L.gs;   // G [nc][ld]; in between: T = L^-1 [no][ld]
+  double* xs = sm + L.x;
+  double* xt = sm + L.xt;
+  double* rhs = sm + L.rhs;
+  double* qs = sm + L.q;
+  double* zs = sm + L.z;
+  double* ys = sm + L.y;
+  double* vs = sm + L.v;
+  double* hs = sm + L.h;
+  const double* Pb = P + (size_t)inst * no * no;
+  const double* Gb = G + (size_t)inst * nc * no;
+  auto load_g = [&]() {
+    for (int e = lane; e < nc * no; e += ADMM_BLOCK) {
+      const int r = e / no, c = e - r * no;
+      Gs[r * ld + c] = Gb[e];
+    }
+  };
+
+  // ---- K = P + sigma I + rho G'G ------------------------------------------------------------------
+  load_g();
+  for (int e = lane; e < no; e += ADMM_BLOCK) {
+    qs[e] = q[(size_t)inst * no + e];
+    xs[e] = warm ? X[(size_t)inst * no + e] : 0.0;
+  }
+  for (int e = lane; e < nc; e += ADMM_BLOCK) {
+    hs[e] = h[(size_t)inst * nc + e];
+    ys[e] = warm ? Y[(size_t)inst * nc + e] : 0.0;
+    zs[e] = warm ? Z[(size_t)inst * nc + e] : 0.0;
+  }
+  __syncthreads();
+  for (int e = lane; e < no * no; e += ADMM_BLOCK) {
+    const int a = e / no, b = e - a * no;
+    double acc = 0.0;
+    for (int r = 0; r < nc; ++r) acc = fma(Gs[r * ld + a], Gs[r * ld + b], acc);
+    Mi[a * ld + b] = fma(rho, acc, Pb[e]) + (a == b ? sigma : 0.0);
+  }
+  if (!warm) {   // (a cold start: z = min(G x, h) with x = 0)
+    for (int e = lane; e < nc; e += ADMM_BLOCK) zs[e] = fmin(0.0, hs[e]);
+  }
+  __syncthreads();
+
+  // ---- Cholesky, in place (the lower triangle): K = L L' ------------------------------------------
+  bool ok = true;
+  for (int k = 0; k < no; ++k) {
+    const double dkk = Mi[k * ld + k];
+    ok = ok && dkk > 0.0;
+    const double d = sqrt(dkk > 0.0 ? dkk : 1.0);
+    __syncthreads();
+    for (int i = k + lane; i < no; i += ADMM_BLOCK) Mi[i * ld + k] = i == k ? d : Mi[i * ld + k] / d;
+    __syncthreads();
+    const int wdt = no - k - 1;
+    for (int e = lane; e < wdt * wdt; e += ADMM_BLOCK) {
+      const int i = k + 1 + e / wdt, j = k + 1 + e % wdt;
+      if (j <= i) Mi[i * ld + j] = fma(-Mi[i * ld + k], Mi[j * ld + k], Mi[i * ld + j]);
+    }
+    __syncthreads();
+  }
+  // ---- T = L^-1: lane c solves L t = e_c (rows above c stay zero) -----------------------------------
+  double* T = Gs;
+  for (int c = lane; c < no; c += ADMM_BLOCK)
+    for (int i = 0; i < no; ++i) {
+      double s = i == c ? 1.0 : 0.0;
+      for (int j = c; j < i; ++j) s = fma(-Mi[i * ld + j], T[j * ld + c], s);
+      T[i * ld + c] = i < c ? 0.0 : s / Mi[i * ld + i];
+    }
+  __syncthreads();
+  // ---- K^-1 = T' T ---------------------------------------------------------------------------------------
+  for (int e = lane; e < no * no; e += ADMM_BLOCK) {
+    const int a = e / no, b = e - a * no;
+    double acc = 0.0;
+    for (int i = a > b ? a : b; i < no; ++i) acc = fma(T[i * ld + a], T[i * ld + b], acc);
+    Mi[a * ld + b] = acc;
+  }
+  __syncthreads();
+  load_g();
+  __syncthreads();
+
+  // ---- the iterations -------------------------------------------------------------------------------------
+  const double inv_rho = 1.0 / rho;
+  for (int it = 0; it < iters; ++it) {
+    for (int r = lane; r < nc; r += ADMM_BLOCK) vs[r] = fma(rho, zs[r], -ys[r]);
+    __syncthreads();
+    for (int c = lane; c < no; c += ADMM_BLOCK) {
+      double acc = fma(sigma, xs[c], -qs[c]);
+      for (int r = 0; r < nc; ++r) acc = fma(Gs[r * ld + c], vs[r], acc);
+      rhs[c] = acc;
+    }
+    __syncthreads();
+    for (int c = lane; c < no; c += ADMM_BLOCK) {
+      double acc = 0.0;
+      for (int b = 0; b < no; ++b) acc = fma(Mi[c * ld + b], rhs[b], acc);
+      xt[c] = acc;
+    }
+    __syncthreads();
+    for (int r = lane; r < nc; r += ADMM_BLOCK) {
+      double acc = 0.0;
+      for (int c = 0; c < no; ++c) acc = fma(Gs[r * ld + c], xt[c], acc);
+      const double zr = fma(alpha, acc, (1.0 - alpha) * zs[r]);
+      const double zn = fmin(fma(ys[r], inv_rho, zr), hs[r]);
+      ys[r] = fma(rho, zr - zn, ys[r]);
+      zs[r] = zn;
+    }
+    for (int c = lane; c < no; c += ADMM_BLOCK) xs[c] = fma(alpha, xt[c], (1.0 - alpha) * xs[c]);
+    __syncthreads();
+  }
+
+  // ---- results; OSQP's residuals |Gx - z|_inf, |Px + q + G'y|_inf -------------------------------
+  const double bad = __builtin_nan("");
+  for (int c = lane; c < no; c += ADMM_BLOCK) X[(size_t)inst * no + c] = ok ? xs[c] : bad;
+  for (int r = lane; r < nc; r += ADMM_BLOCK) {
+    Y[(size_t)inst * nc + r] = ok ? ys[r] : bad;
+    Z[(size_t)inst * nc + r] = ok ? zs[r] : bad;
+  }
+  if (res != nullptr) {
+    double rp = 0.0, rd = 0.0;
+    for (int r = lane; r < nc; r += ADMM_BLOCK) {
+      double acc = 0.0;
+      for (int c = 0; c < no; ++c) acc = fma(Gs[r * ld + c], xs[c], acc);
+      rp = fmax(rp, fabs(acc - zs[r]));
+    }
+    for (int c = lane; c < no; c += ADMM_BLOCK) {
+      double acc = qs[c];
+      for (int b = 0; b < no; ++b) acc = fma(Pb[(size_t)c * no + b], xs[b], acc);
+      for (int r = 0; r < nc; ++r) acc = fma(Gs[r * ld + c], ys[r], acc);
+      rd = fmax(rd, fabs(acc));
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      rp = fmax(rp, __shfl_xor(rp, off, 64));
+      rd = fmax(rd, __shfl_xor(rd, off, 64));
+    }
+    if (lane == 0) {
+      res[inst * 2 + 0] = ok ? rp : bad;
+      res[inst * 2 + 1] = ok ? rd : bad;
+    }
+  }
+}
+
+}  // namespace
+
+size_t admm_lds_bytes(int no, int nc) { return (size_t)admm_lds(no, nc).total * sizeof(double); }
+
+int launch_admm(int no, int nc, const double* P, const double* q, const double* G, const double* h,
+                double* x, double* y, double* z, double* res, double rho, double sigma, double alpha,
+                int iters, int warm, int batch, hipStream_t stream, hipError_t* err) {
+  const size_t lds = admm_lds_bytes(no, nc);
+  if (lds > (size_t)RESIDENT_LDS_LIMIT) return MPCASM_ERR_LIMIT;
+  if (lds > 64 * 1024) {
+    *err = allow_whole_lds(reinterpret_cast<const void*>(admm_kernel));
+    if (*err != hipSuccess) return MPCASM_ERR_HIP;
+  }
+  hipLaunchKernelGGL(admm_kernel, dim3((unsigned)batch), dim3(ADMM_BLOCK), lds, stream, no, nc, P, q, G,
+                     h, x, y, z, res, rho, sigma, alpha, iters, warm, batch);
+  *err = hipGetLastError();
+  return *err == hipSuccess ? MPCASM_OK : MPCASM_ERR_HIP;
+}
+
+}  // namespace mpcasm

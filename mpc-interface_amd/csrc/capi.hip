@@ -1528,6 +1528,21 @@ int mpcasm_box_transform_ss(double* d_params, int64_t n_params, int batch,
   return rc;
 }
 
+int mpcasm_admm(int no, int nc, const double* d_P, const double* d_q, const double* d_G,
+                const double* d_h, double* d_x, double* d_y, double* d_z, double* d_res, double rho,
+                double sigma, double alpha, int iters, int warm, int batch, void* stream) {
+  if (no < 1 || nc < 0 || batch < 0 || iters < 0 || !(rho > 0.0) || !(sigma > 0.0) || !(alpha > 0.0) ||
+      !(alpha < 2.0) || no > (1 << 12) || nc > (1 << 16))
+    return MPCASM_ERR_ARG;
+  if (batch == 0) return MPCASM_OK;
+  if (!d_P || !d_q || !d_x || (nc > 0 && (!d_G || !d_h || !d_y || !d_z))) return MPCASM_ERR_ARG;
+  hipError_t err;
+  const int rc = launch_admm(no, nc, d_P, d_q, d_G, d_h, d_x, d_y, d_z, d_res, rho, sigma, alpha, iters,
+                             warm != 0, batch, static_cast<hipStream_t>(stream), &err);
+  if (rc == MPCASM_ERR_HIP) g_last_hip = (int)err;
+  return rc;
+}
+
 int mpcasm_gather(const double* d_src, int64_t src_stride, const int32_t* d_index, int nnz,
                   double* d_dst, int batch, void* stream) {
   if (nnz < 0 || batch < 0 || src_stride < 0) return MPCASM_ERR_ARG;

@@ -88,6 +88,9 @@ int launch_box_transform_ss(double* params, long long nparams, int batch, const 
                             hipError_t* err);
 int launch_gather(const double* src, long long src_stride, const int32_t* index, int nnz,
                   double* dst, int batch, hipStream_t stream, hipError_t* err);
+int launch_admm(int no, int nc, const double* P, const double* q, const double* G, const double* h,
+                double* x, double* y, double* z, double* res, double rho, double sigma, double alpha,
+                int iters, int warm, int batch, hipStream_t stream, hipError_t* err);
 int launch_preview(const double* PM, const double* given, const double* optim, double* out,
                    int batch, int rows, int ng, int no, hipStream_t stream, hipError_t* err);
 

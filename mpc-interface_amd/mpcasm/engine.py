@@ -99,6 +99,51 @@ def fill_su_numpy(A, B, N, ltv=False):
 
 
 # --------------------------------------------------------------------------
+# K5: the solve after the assembly (the "or")
+# --------------------------------------------------------------------------
+OSQP_RHO, OSQP_SIGMA, OSQP_ALPHA = 0.1, 1e-6, 1.6     # OSQP's default steps
+
+
+def admm(P, q, G, h, x=None, y=None, z=None, iters=50, rho=OSQP_RHO, sigma=OSQP_SIGMA, alpha=OSQP_ALPHA,
+         residuals=True, stream=None):
+    """``iters`` iterations of OSQP's ADMM on a batch of dense QPs ``min 1/2 x'Px + q'x s.t. Gx <= h``
+    (``mpcasm_admm``) -- the solver call of the walking loop, ``osqp_solve_qp(P=Q, q=q, G=A, h=h)``
+    (biped_mpc_loop.py:60), on the device tensors :meth:`Assembler.assemble` returns: ``P (B, no, no)``,
+    ``q (B, no)``, ``G (B, nc, no)``, ``h (B, nc)``.  ``x, y, z``: the iterates of a warm start (all three,
+    device tensors, updated IN PLACE) or None for a cold start.  Returns ``x, y, z, res`` with
+    ``res (B, 2)`` = OSQP's primal and dual residuals (None when ``residuals`` is off)."""
+    torch = require_device()
+    for t in (P, q, G, h):
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()):
+            raise ValueError("P, q, G, h: contiguous float64 device tensors")
+    if P.dim() != 3 or P.shape[1] != P.shape[2] or q.shape != P.shape[:2] or G.dim() != 3 or \
+            G.shape[0] != P.shape[0] or G.shape[2] != P.shape[1] or h.shape != G.shape[:2]:
+        raise ValueError("shapes: P (B, no, no), q (B, no), G (B, nc, no), h (B, nc)")
+    batch, no, nc = P.shape[0], P.shape[1], G.shape[1]
+    warm = x is not None or y is not None or z is not None
+    if warm:
+        if x is None or y is None or z is None:
+            raise ValueError("a warm start takes x, y and z")
+        for t, shape in ((x, (batch, no)), (y, (batch, nc)), (z, (batch, nc))):
+            if not (isinstance(t, torch.Tensor) and t.device == P.device and t.dtype == torch.float64
+                    and t.is_contiguous() and tuple(t.shape) == shape):
+                raise ValueError("x (B, no), y (B, nc), z (B, nc): contiguous float64 tensors on P's device")
+    else:
+        x = torch.empty((batch, no), dtype=torch.float64, device=P.device)
+        y = torch.empty((batch, nc), dtype=torch.float64, device=P.device)
+        z = torch.empty((batch, nc), dtype=torch.float64, device=P.device)
+    res = torch.empty((batch, 2), dtype=torch.float64, device=P.device) if residuals else None
+    with torch.cuda.device(P.device):
+        rc = capi.load().mpcasm_admm(no, nc, P.data_ptr(), q.data_ptr(), G.data_ptr(), h.data_ptr(),
+                                     x.data_ptr(), y.data_ptr(), z.data_ptr(),
+                                     res.data_ptr() if residuals else None, float(rho), float(sigma),
+                                     float(alpha), int(iters), 1 if warm else 0, batch,
+                                     _stream_handle(torch, stream))
+    capi.check(rc, "mpcasm_admm")
+    return x, y, z, res
+
+
+# --------------------------------------------------------------------------
 # K2 + K3 + K4
 # --------------------------------------------------------------------------
 HALF_CU_LDS = 80 * 1024      # two workgroups of the persistent kernel share a CU's 160 KB
