@@ -53,6 +53,36 @@ __host__ __device__ inline AdmmLds admm_lds(int no, int nc) {
   return L;
 }
 
+// sum_i a[i sa] b[i sb], i < n: four sums side by side -- one wavefront per SIMD has nothing to hide an LDS
+// read behind but its own other reads, so the loop must not be one dependent chain of read -> fma
+__device__ __forceinline__ double dot4(const double* a, int sa, const double* b, int sb, int n, double init) {
+  double s0 = init, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int i = 0;
+  for (; i + 8 <= n; i += 8) {   // (eight pairs of reads in flight)
+    double av[8], bv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) av[u] = a[(i + u) * sa], bv[u] = b[(i + u) * sb];
+    s0 = fma(av[0], bv[0], s0);
+    s1 = fma(av[1], bv[1], s1);
+    s2 = fma(av[2], bv[2], s2);
+    s3 = fma(av[3], bv[3], s3);
+    s0 = fma(av[4], bv[4], s0);
+    s1 = fma(av[5], bv[5], s1);
+    s2 = fma(av[6], bv[6], s2);
+    s3 = fma(av[7], bv[7], s3);
+  }
+  for (; i + 4 <= n; i += 4) {
+    const double a0 = a[i * sa], a1 = a[(i + 1) * sa], a2 = a[(i + 2) * sa], a3 = a[(i + 3) * sa];
+    const double b0 = b[i * sb], b1 = b[(i + 1) * sb], b2 = b[(i + 2) * sb], b3 = b[(i + 3) * sb];
+    s0 = fma(a0, b0, s0);
+    s1 = fma(a1, b1, s1);
+    s2 = fma(a2, b2, s2);
+    s3 = fma(a3, b3, s3);
+  }
+  for (; i < n; ++i) s0 = fma(a[i * sa], b[i * sb], s0);
+  return (s0 + s1) + (s2 + s3);
+}
+
 __global__ __launch_bounds__(ADMM_BLOCK) void admm_kernel(
     int no, int nc, const double* __restrict__ P, const double* __restrict__ q,
     const double* __restrict__ G, const double* __restrict__ h, double* __restrict__ X,
@@ -97,8 +127,7 @@ __global__ __launch_bounds__(ADMM_BLOCK) void admm_kernel(
   __syncthreads();
   for (int e = lane; e < no * no; e += ADMM_BLOCK) {
     const int a = e / no, b = e - a * no;
-    double acc = 0.0;
-    for (int r = 0; r < nc; ++r) acc = fma(Gs[r * ld + a], Gs[r * ld + b], acc);
+    const double acc = dot4(Gs + a, ld, Gs + b, ld, nc, 0.0);
     Mi[a * ld + b] = fma(rho, acc, Pb[e]) + (a == b ? sigma : 0.0);
   }
   if (!warm) {   // (a cold start: z = min(G x, h) with x = 0)
@@ -115,10 +144,11 @@ __global__ __launch_bounds__(ADMM_BLOCK) void admm_kernel(
     __syncthreads();
     for (int i = k + lane; i < no; i += ADMM_BLOCK) Mi[i * ld + k] = i == k ? d : Mi[i * ld + k] / d;
     __syncthreads();
-    const int wdt = no - k - 1;
-    for (int e = lane; e < wdt * wdt; e += ADMM_BLOCK) {
-      const int i = k + 1 + e / wdt, j = k + 1 + e % wdt;
-      if (j <= i) Mi[i * ld + j] = fma(-Mi[i * ld + k], Mi[j * ld + k], Mi[i * ld + j]);
+    // (rows of the trailing block in turn, lanes over the columns j <= i of a row: no division; a row
+    // of at most 64 columns is one step, and the rows do not depend on each other)
+    for (int i = k + 1; i < no; ++i) {
+      const double lik = Mi[i * ld + k];
+      for (int j = k + 1 + lane; j <= i; j += ADMM_BLOCK) Mi[i * ld + j] = fma(-lik, Mi[j * ld + k], Mi[i * ld + j]);
     }
     __syncthreads();
   }
@@ -126,17 +156,15 @@ __global__ __launch_bounds__(ADMM_BLOCK) void admm_kernel(
   double* T = Gs;
   for (int c = lane; c < no; c += ADMM_BLOCK)
     for (int i = 0; i < no; ++i) {
-      double s = i == c ? 1.0 : 0.0;
-      for (int j = c; j < i; ++j) s = fma(-Mi[i * ld + j], T[j * ld + c], s);
+      const double s = (i == c ? 1.0 : 0.0) - (i > c ? dot4(Mi + i * ld + c, 1, T + c * ld + c, ld, i - c, 0.0) : 0.0);
       T[i * ld + c] = i < c ? 0.0 : s / Mi[i * ld + i];
     }
   __syncthreads();
   // ---- K^-1 = T' T ---------------------------------------------------------------------------------------
   for (int e = lane; e < no * no; e += ADMM_BLOCK) {
     const int a = e / no, b = e - a * no;
-    double acc = 0.0;
-    for (int i = a > b ? a : b; i < no; ++i) acc = fma(T[i * ld + a], T[i * ld + b], acc);
-    Mi[a * ld + b] = acc;
+    const int i0 = a > b ? a : b;
+    Mi[a * ld + b] = dot4(T + i0 * ld + a, ld, T + i0 * ld + b, ld, no - i0, 0.0);
   }
   __syncthreads();
   load_g();
@@ -148,20 +176,15 @@ __global__ __launch_bounds__(ADMM_BLOCK) void admm_kernel(
     for (int r = lane; r < nc; r += ADMM_BLOCK) vs[r] = fma(rho, zs[r], -ys[r]);
     __syncthreads();
     for (int c = lane; c < no; c += ADMM_BLOCK) {
-      double acc = fma(sigma, xs[c], -qs[c]);
-      for (int r = 0; r < nc; ++r) acc = fma(Gs[r * ld + c], vs[r], acc);
-      rhs[c] = acc;
+      rhs[c] = dot4(Gs + c, ld, vs, 1, nc, fma(sigma, xs[c], -qs[c]));
     }
     __syncthreads();
     for (int c = lane; c < no; c += ADMM_BLOCK) {
-      double acc = 0.0;
-      for (int b = 0; b < no; ++b) acc = fma(Mi[c * ld + b], rhs[b], acc);
-      xt[c] = acc;
+      xt[c] = dot4(Mi + c * ld, 1, rhs, 1, no, 0.0);
     }
     __syncthreads();
     for (int r = lane; r < nc; r += ADMM_BLOCK) {
-      double acc = 0.0;
-      for (int c = 0; c < no; ++c) acc = fma(Gs[r * ld + c], xt[c], acc);
+      const double acc = dot4(Gs + r * ld, 1, xt, 1, no, 0.0);
       const double zr = fma(alpha, acc, (1.0 - alpha) * zs[r]);
       const double zn = fmin(fma(ys[r], inv_rho, zr), hs[r]);
       ys[r] = fma(rho, zr - zn, ys[r]);

@@ -121,6 +121,18 @@ def main():
     print("   dense assembly + 2 gathers %8.3f ms  %10.0f QPs/s;  CSC from the kernel %8.3f ms  %10.0f QPs/s  (%.0f GB/s written)"
           % (t2 * 1e3, B / t2, t1 * 1e3, B / t1, B * out_bytes / t1 / 1e9))
 
+    # f3, the "or": the solve itself on the assembled QPs (mpcasm_admm: OSQP's ADMM iteration)
+    Pd, qd, Gd, hd = asm.assemble(given)
+    Pd, qd, Gd, hd = (t.clone() for t in (Pd, qd, Gd, hd))
+    for iters in (0, 25, 100):
+        t = timed(lambda: engine.admm(Pd, qd, Gd, hd, iters=iters, rho=1.0, residuals=False), 20)
+        print("f3 admm %3d iterations, cold  %6d QPs (no %d nc %d)  %8.3f ms  %10.0f QPs/s"
+              % (iters, B, asm.no, asm.nc, t * 1e3, B / t))
+    xs, ys, zs, _ = engine.admm(Pd, qd, Gd, hd, iters=50, rho=1.0)
+    t = timed(lambda: engine.admm(Pd, qd, Gd, hd, xs, ys, zs, iters=25, rho=1.0, residuals=False), 20)
+    print("   warm, 25 iterations                       %8.3f ms  %10.0f QPs/s   (factor + inverse per call: the 0-iteration line)"
+          % (t * 1e3, B / t))
+
     # f4: box transforms on the per-instance parameters
     box = BoxBatch(asm, form, "support_polygon")
     rot = torch.eye(2, dtype=torch.float64, device="cuda").repeat(B, 1, 1)
