@@ -1000,10 +1000,13 @@ def run_rank(args):
         except Exception as exc:        # (never at the cost of the main line)
             record["f2"] = {"error": repr(exc)}
         # the other BASELINE configurations: C1 (the drop-in tick of one instance), C3, C4, C5 at their
-        # per-GPU batches (never at the cost of the main line)
+        # per-GPU batches (never at the cost of the main line).  They are figures of ONE GPU: a run on
+        # several ranks does not repeat them on every rank (tens of GB of results each, minutes of
+        # wall clock between the timed region and the line the driver waits for)
+        single = world == 1
         for key, make in (("c1", lambda: c1_record()), ("c3", lambda: c3_record(torch, dev)),
                           ("c4", lambda: c4_record(torch, dev)), ("c5", lambda: c5_record(torch, dev))):
-            if rank != 0 and key == "c1":
+            if not single:
                 continue
             try:
                 record[key] = make()
@@ -1012,7 +1015,7 @@ def run_rank(args):
         # the same step at B=65536: 2.2 GB of outputs per step, no cache can hold it
         big = 65536
         times = (big + B - 1) // B
-        if big > B:
+        if big > B and single:
             Ab = torch.as_tensor(tiled(work["A"], times)[:big], device=dev)
             Bb = torch.as_tensor(tiled(work["B"], times)[:big], device=dev)
             gb = torch.as_tensor(tiled(work["given"], times)[:big], device=dev)
