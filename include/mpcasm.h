@@ -229,7 +229,9 @@ int mpcasm_assemble_indexed(const mpcasm_plan* plan, const double* const* h_src,
 enum { MPCASM_KERNEL_NONE = 0, MPCASM_KERNEL_RESIDENT = 1, MPCASM_KERNEL_RESIDENT_JIT = 2,
        MPCASM_KERNEL_FUSED = 3, MPCASM_KERNEL_STAGED = 4, MPCASM_KERNEL_TILED = 5,
        MPCASM_KERNEL_TILED_SCAN = 6 /* the tiled kernel's scan form: P summed along diagonals */,
-       MPCASM_KERNEL_SWEEP = 7 /* per-step dynamics (a plan compiled with ltv): no horizon matrix */ };
+       MPCASM_KERNEL_SWEEP = 7 /* per-step dynamics (a plan compiled with ltv): no horizon matrix */,
+       MPCASM_KERNEL_TILED_SHARED = 8 /* wide problem, every source shared by the batch: P and G as
+                                         weighted sums of matrices computed once per launch */ };
 int mpcasm_plan_last_kernel(const mpcasm_plan* plan);
 
 /* K2 alone  preview matrices ------------------------------------------------

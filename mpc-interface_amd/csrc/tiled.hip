@@ -1410,6 +1410,268 @@ __global__ __launch_bounds__(BLOCK, 2) void toeplitz_scan_kernel(
 }
 
 inline unsigned ceil_div(unsigned a, unsigned b) { return (a + b - 1) / b; }
+inline long ceil_div(long a, long b) { return (a + b - 1) / b; }
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+
+// ---------------------------------------------------------------------------
+// Shared-model form (round 4): every source of the launch is ONE tensor for the whole batch (stride 0:
+// one model, many states -- a fleet on the same robot; C4 with its S, U read from memory).  Then
+//   * the composed rows V[r][c] are the same for every instance: composed ONCE (shared_rows_kernel);
+//   * P is linear in the weights, P_b = sum_g w_b[g] K_g with K_g the Hessian of the plan at "weight g
+//     = 1, all others 0": the T <= SH_TMAX matrices K_g come out of the general kernel itself, run on T
+//     pseudo-instances whose parameters are those unit vectors -- the same arithmetic, once per launch
+//     instead of once per instance;
+//   * a row of G is sum_ax arrow_b[ax] V[row_ax]: a scaled copy.
+// What is left per instance is streaming: 8 no^2 + 8 nc no bytes of weighted sums written in flat
+// chunks of 1024 doubles (whole lines, nontemporal), the operands of a chunk in registers for all the
+// instances a workgroup walks -- and q, h (a GEMV with the rows of V against w s (d - aim)).
+// The general kernel multiplies the same tiles again for every instance: 29 ms per 8192 C4 instances.
+// ---------------------------------------------------------------------------
+constexpr int SH_TMAX = 32;     // weight parameters with a Hessian term
+constexpr int SH_QB = 4;        // instances a workgroup of the q / h kernel takes together
+
+struct SharedSlots {
+  int n;
+  int slot[SH_TMAX];
+};
+
+// scratch behind the per-instance part of the workspace (doubles)
+struct SharedScratch {
+  size_t v, k, pseudo, zero, qdummy, total;
+};
+__host__ __device__ inline SharedScratch shared_scratch(const PlanDev& p) {
+  SharedScratch x;
+  x.v = 0;
+  x.k = x.v + (size_t)p.rtot * p.t_nop;
+  x.pseudo = x.k + (size_t)SH_TMAX * p.no * p.no;
+  x.zero = x.pseudo + (size_t)SH_TMAX * (p.nparams + 2);
+  x.qdummy = x.zero + (size_t)p.rtot + 2;
+  x.total = x.qdummy + (size_t)SH_TMAX * p.no + 2;
+  x.total += x.total & 1;
+  return x;
+}
+
+// pseudo-instance g: weight slot[g] = 1, every other parameter 0; the zero d vector
+__global__ __launch_bounds__(BLOCK) void shared_pseudo_kernel(SharedSlots sl, int nparams, int rtot,
+                                                             double* __restrict__ pseudo,
+                                                             double* __restrict__ zero) {
+  const int i = blockIdx.x * BLOCK + threadIdx.x;
+  if (i < sl.n * nparams) {
+    const int g = i / nparams, k = i - g * nparams;
+    pseudo[i] = k == sl.slot[g] ? 1.0 : 0.0;
+  }
+  if (i < rtot) zero[i] = 0.0;
+}
+
+// V[r][c], c < nop: every workspace row once, through the column tables (the sources are shared)
+__global__ __launch_bounds__(BLOCK) void shared_rows_kernel(PlanDev p, SrcTable src,
+                                                           double* __restrict__ V) {
+  __shared__ const double* s_base[NSTREAM];
+  const int tid = threadIdx.x;
+  stream_bases(p, src, 0, s_base, tid);
+  __syncthreads();
+  const int pairs = p.t_nop / 2;
+  const long e = (long)blockIdx.x * BLOCK + tid;
+  if (e >= (long)p.rtot * pairs) return;
+  const int r = (int)(e / pairs), col = (int)(e - (long)r * pairs) * 2;
+  RowTables rt;
+  rt.rowptr = p.itab + p.off_rowptr;
+  rt.entbase = p.itab + p.off_entbase;
+  rt.entk = p.itab + p.off_entk;
+  rt.coef = p.dtab + p.doff_entcoef;
+  rt.cio = p.itab + p.off_t_cio;
+  rt.nop = p.t_nop;
+  int cur = -1;
+  ColRef cr;
+  cr.p0 = cr.p1 = p.dtab;
+  cr.rs0 = cr.rs1 = 0;
+  const double2 v = compose_row2(rt, r, col, s_base, cur, cr);
+  *reinterpret_cast<double2*>(V + (size_t)r * p.t_nop + col) = v;
+}
+
+// P_b = sum_g w_b[g] K_g.  A workgroup takes a flat range of SH_PRANGE elements of P for SH_PIB instances and
+// walks it from front to back (every instance's stream of stores consecutive in memory, as for G below);
+// per step a thread reads its 16 bytes of every K_g out of L2 -- TG / SH_PIB bytes read per byte written --
+// and the weights of its instances out of LDS.
+constexpr int SH_PIB = 16;           // instances of a workgroup
+constexpr int SH_PRANGE = 4096;      // elements of P per instance and workgroup: 8 steps of 512
+
+template <int TG>
+__global__ __launch_bounds__(BLOCK) void shared_p_kernel(SharedSlots sl, long nn,
+                                                        const double* __restrict__ K,
+                                                        const double* __restrict__ params, int nparams,
+                                                        double* __restrict__ P, int batch) {
+  // (the weights in LDS before the first store: a load in the loop waits for the stores in flight in front
+  // of it -- one counter counts both)
+  __shared__ double sh_w[TG][SH_PIB];
+  const long r0 = (long)blockIdx.x * SH_PRANGE;
+  const long r1 = r0 + SH_PRANGE < nn ? r0 + SH_PRANGE : nn;
+  const long b0 = (long)blockIdx.y * SH_PIB;
+  const int nb = (int)(b0 + SH_PIB <= batch ? SH_PIB : batch - b0);
+  for (int i = threadIdx.x; i < TG * SH_PIB; i += BLOCK) {
+    const int g = i / SH_PIB, bb = i - g * SH_PIB;
+    sh_w[g][bb] = (g < sl.n && bb < nb) ? params[(size_t)(b0 + bb) * nparams + sl.slot[g]] : 0.0;
+  }
+  __syncthreads();
+  for (long e = r0 + threadIdx.x * 2; e < r1; e += BLOCK * 2) {   // (nn is even: pairs never straddle the end)
+    double2 k[TG];
+#pragma unroll
+    for (int g = 0; g < TG; ++g)
+      k[g] = g < sl.n ? *reinterpret_cast<const double2*>(K + (size_t)g * nn + e) : double2{0.0, 0.0};
+#pragma unroll 4
+    for (int bb = 0; bb < SH_PIB; ++bb) {
+      if (bb >= nb) break;
+      double2 acc{0.0, 0.0};
+#pragma unroll
+      for (int g = 0; g < TG; ++g) {
+        const double w = sh_w[g][bb];
+        acc.x = fma(w, k[g].x, acc.x);
+        acc.y = fma(w, k[g].y, acc.y);
+      }
+      store_result(reinterpret_cast<double2*>(P + (size_t)(b0 + bb) * nn + e), acc);
+    }
+  }
+}
+
+// G_b[R][c] = sum_ax arrow_b[R][ax] V[row(R, ax)][c].  A workgroup takes a flat range of SH_GRANGE elements of
+// G for SH_GIB instances and walks it from front to back: every instance's stream of stores is
+// consecutive in memory (a first version kept a chunk's operands in registers and walked the instances --
+// every store of a workgroup 4.7 MB from the one before: 2.2 TB/s, however few loads the loop held), and
+// the rows of V come out of L2 once per SH_GIB instances, requested a step ahead.
+constexpr int SH_GIB = 8;            // instances of a workgroup
+constexpr int SH_GRANGE = 8192;      // elements of G per instance and workgroup: 16 steps of 512
+constexpr int SH_GSTEP = BLOCK * 2;  // a thread's 16 bytes per step
+constexpr int SH_GRMAX = SH_GRANGE / T_BLOCK + 2;   // rows a range can touch (no >= T_BLOCK)
+
+__global__ __launch_bounds__(BLOCK) void shared_g_kernel(PlanDev p, const double* __restrict__ V,
+                                                        const double* __restrict__ params,
+                                                        double* __restrict__ G, int batch) {
+  __shared__ double sh_ar[SH_GIB][SH_GRMAX][2];   // the arrows of the range's rows (a free axis: 0)
+  const long total = (long)p.nc * p.no;
+  const long r0 = (long)blockIdx.x * SH_GRANGE;
+  const long r1 = r0 + SH_GRANGE < total ? r0 + SH_GRANGE : total;
+  const long b0 = (long)blockIdx.y * SH_GIB;
+  const int nb = (int)(b0 + SH_GIB <= batch ? SH_GIB : batch - b0);
+  const int32_t* grow = p.itab + p.off_t_grow;
+  const int32_t* rrw = p.itab + p.off_rs_rr;
+  const int R0 = (int)(r0 / p.no), nrl = (int)((r1 - 1) / p.no) - R0 + 1;
+  for (int i = threadIdx.x; i < SH_GIB * nrl * 2; i += BLOCK) {
+    const int bb = i / (nrl * 2), rem = i - bb * (nrl * 2), rl = rem >> 1, ax = rem & 1;
+    const int32_t* rec = rrw + (size_t)(R0 + rl) * RS_RR_WORDS;
+    sh_ar[bb][rl][ax] = (bb < nb && ax < rec[RR_NAXES])
+                            ? params[(size_t)(b0 + bb) * p.nparams + rec[RR_ARROW + ax]] : 0.0;
+  }
+  __syncthreads();
+  // (rows of one axis only -- wave-uniform, told by the plan's records -- skip the second operand)
+  bool two = false;
+  for (int rl = 0; rl < nrl; ++rl) two = two || rrw[(size_t)(R0 + rl) * RS_RR_WORDS + RR_NAXES] > 1;
+  auto fetch = [&](long e, double2& a, double2& c, int& rl) {
+    // the two elements e, e + 1 lie in one row (an even width); a thread behind the range reads the
+    // range's first pair and stores nothing
+    const long ee = e < r1 ? e : r0;
+    const int R = (int)(ee / p.no), col = (int)(ee - (long)R * p.no);
+    rl = R - R0;
+    const int naxes = rrw[(size_t)R * RS_RR_WORDS + RR_NAXES];
+    a = naxes > 0 ? *reinterpret_cast<const double2*>(V + (size_t)grow[R * RS_AXMAX + 0] * p.t_nop + col)
+                  : double2{0.0, 0.0};
+    c = (two && naxes > 1) ? *reinterpret_cast<const double2*>(V + (size_t)grow[R * RS_AXMAX + 1] * p.t_nop + col)
+                           : double2{0.0, 0.0};
+  };
+  long e = r0 + threadIdx.x * 2;
+  double2 va, vc;
+  int rl;
+  fetch(e, va, vc, rl);
+  for (; e - threadIdx.x * 2 < r1; e += SH_GSTEP) {
+    double2 na, nc2;
+    int nrl2;
+    fetch(e + SH_GSTEP, na, nc2, nrl2);       // the next step's operands: in flight behind this step's stores
+    if (e < r1) {
+#pragma unroll
+      for (int bb = 0; bb < SH_GIB; ++bb) {
+        if (bb >= nb) break;
+        const double a0 = sh_ar[bb][rl][0], a1 = sh_ar[bb][rl][1];
+        store_result(reinterpret_cast<double2*>(G + (size_t)(b0 + bb) * total + e),
+                     double2{fma(a1, vc.x, a0 * va.x), fma(a1, vc.y, a0 * va.y)});
+      }
+    }
+    va = na, vc = nc2, rl = nrl2;
+  }
+}
+
+// q_b[c] = sum over the stages' rows of V[row][c] w s (d_b[drow] - aim) + the diagonal terms;
+// h_b[R] = (extreme + arrow . center) - arrow . d_b: SH_QB instances per workgroup, their residuals
+// rho_b[k] = w s (d - aim) in LDS, a thread per column
+__global__ __launch_bounds__(BLOCK) void shared_qh_kernel(PlanDev p, const double* __restrict__ V,
+                                                         const double* __restrict__ params,
+                                                         const double* __restrict__ work,
+                                                         long long work_stride, double* __restrict__ q,
+                                                         double* __restrict__ h, int batch, int nrho) {
+  extern __shared__ __attribute__((aligned(16))) double sh_rho[];   // [nrho][SH_QB]
+  int* sh_row = reinterpret_cast<int*>(sh_rho + (size_t)nrho * SH_QB);   // [nrho] row of V
+  const int tid = threadIdx.x;
+  const long b0 = (long)blockIdx.x * SH_QB;
+  const int32_t* stages = p.itab + p.off_t_stage;
+  for (int k = tid; k < nrho; k += BLOCK) {
+    const int st = k / TK, i = k - st * TK;
+    const int32_t* rec = stages + st * T_STAGE_WORDS;
+    const int info = rec[TS_INFO], nrows = info & 255, fl = (info >> 8) & 255;
+    const bool live = i < nrows;
+    sh_row[k] = live ? rec[TS_AROW] + i : 0;
+    const double scale = (fl & TS_FLAG_HALF) ? 0.5 : 1.0;
+#pragma unroll
+    for (int x = 0; x < SH_QB; ++x) {
+      const long b = b0 + x;
+      double r = 0.0;
+      if (live && b < batch) {
+        const double* pb = params + (size_t)b * p.nparams;
+        const double d = work[b * work_stride + rec[TS_DROW] + i];
+        r = pb[rec[TS_WPARAM]] * (scale * (d - pb[rec[TS_AIMPARAM]]));
+      }
+      sh_rho[(size_t)k * SH_QB + x] = r;
+    }
+  }
+  __syncthreads();
+  if (q != nullptr)
+    for (int c = tid; c < p.no; c += BLOCK) {
+      double acc[SH_QB];
+#pragma unroll
+      for (int x = 0; x < SH_QB; ++x) acc[x] = 0.0;
+      for (int k = 0; k < nrho; ++k) {
+        const double v = V[(size_t)sh_row[k] * p.t_nop + c];
+#pragma unroll
+        for (int x = 0; x < SH_QB; ++x) acc[x] = fma(v, sh_rho[(size_t)k * SH_QB + x], acc[x]);
+      }
+#pragma unroll
+      for (int x = 0; x < SH_QB; ++x) {
+        const long b = b0 + x;
+        if (b >= batch) break;
+        double dP, dq;
+        diagonal_of_column(p, params + (size_t)b * p.nparams, c, dP, dq);
+        q[(size_t)b * p.no + c] = acc[x] + dq;
+      }
+    }
+  if (h != nullptr) {
+    const int32_t* grow = p.itab + p.off_t_grow;
+    const int32_t* rrw = p.itab + p.off_rs_rr;
+    for (int R = tid; R < p.nc; R += BLOCK) {
+      const int32_t* x = rrw + (size_t)R * RS_RR_WORDS;
+      for (int y = 0; y < SH_QB; ++y) {
+        const long b = b0 + y;
+        if (b >= batch) break;
+        const double* pb = params + (size_t)b * p.nparams;
+        const double* dvec = work + b * work_stride;
+        double ac = 0.0, ad = 0.0;
+        for (int ax = 0; ax < x[RR_NAXES]; ++ax) {
+          const double ar = pb[x[RR_ARROW + ax]];
+          ac += ar * pb[x[RR_CENTER + ax]];
+          ad = fma(ar, dvec[grow[R * RS_AXMAX + ax]], ad);
+        }
+        h[(size_t)b * p.nc + R] = (pb[x[RR_EXTREME]] + ac) - ad;
+      }
+    }
+  }
+}
 
 }  // namespace
 
@@ -1417,8 +1679,12 @@ extern int g_phase_mask;  // fused.hip (MPCASM_OPT_PHASE_MASK)
 
 bool tiled_eligible(const PlanDev& p) { return p.t_ok != 0 && p.no >= T_BLOCK; }
 
+// the shared-model form may run on plans without generated groups and with rows of G in 16-byte pieces
+static bool shared_form_plan(const PlanDev& p) { return p.t_nlti == 0 && (p.no & 1) == 0 && p.t_nop % 2 == 0; }
+
 size_t tiled_workspace_bytes(const PlanDev& p, int batch) {
-  return (size_t)batch * p.t_work * sizeof(double);
+  // per instance: d and the generated tables; behind them, once: the scratch of the shared-model form
+  return ((size_t)batch * p.t_work + (shared_form_plan(p) ? shared_scratch(p).total : 0)) * sizeof(double);
 }
 
 // The horizon tables of the plan's generated groups, from the (A, B) in the slots of each group's
@@ -1476,6 +1742,89 @@ int launch_lti_tables(const PlanDev& p, const SrcTable& src, double* w, int batc
 }
 
 namespace {
+
+// The shared-model form; MPCASM_ERR_LIMIT when the launch is not one (a source of an instance's own, more
+// weights than SH_TMAX, a row of G with more than two axes, an odd width): the general kernel then.
+int launch_shared_form(const PlanDev& p, const SrcTable& eff, const double* params, double* w,
+                       long long stride, double* P, double* q, double* G, double* h, int batch, int nb,
+                       int npairs, int sym, const int32_t* h_itab, hipStream_t stream, hipError_t* err) {
+  if (!shared_form_plan(p) || w == nullptr) return MPCASM_ERR_LIMIT;
+  for (int i = 0; i < p.nsrc; ++i)
+    if (eff.stride[i] != 0) return MPCASM_ERR_LIMIT;
+  // the weight parameters: of every stage and of every diagonal term
+  SharedSlots sl;
+  sl.n = 0;
+  for (int g = 0; g < SH_TMAX; ++g) sl.slot[g] = 0;
+  auto add = [&](int slot) {
+    for (int g = 0; g < sl.n; ++g)
+      if (sl.slot[g] == slot) return true;
+    if (sl.n == SH_TMAX) return false;
+    sl.slot[sl.n++] = slot;
+    return true;
+  };
+  for (int st = 0; st < p.t_nstage; ++st)
+    if (!add(h_itab[p.off_t_stage + st * T_STAGE_WORDS + TS_WPARAM])) return MPCASM_ERR_LIMIT;
+  for (int g = 0; g < p.ngterm; ++g) {
+    const int32_t* rec = h_itab + p.off_gterm + g * GT_WORDS;
+    if ((rec[GT_FLAGS] & GT_FLAG_DIAG) && !add(rec[GT_WPARAM])) return MPCASM_ERR_LIMIT;
+  }
+  if (batch < 2 * sl.n) return MPCASM_ERR_LIMIT;   // (the K_g cost a launch of sl.n instances themselves)
+  if (G != nullptr)
+    for (int R = 0; R < p.nc; ++R)
+      if (h_itab[p.off_rs_rr + R * RS_RR_WORDS + RR_NAXES] > 2) return MPCASM_ERR_LIMIT;
+  const int nrho = p.t_nstage * TK;
+  const size_t qh_lds = (size_t)nrho * SH_QB * sizeof(double) + (size_t)nrho * sizeof(int);
+  if (qh_lds > 64 * 1024) return MPCASM_ERR_LIMIT;
+  const SharedScratch S = shared_scratch(p);
+  double* base = w + (size_t)batch * stride;
+  double* V = base + S.v;
+  double* K = base + S.k;
+  double* pseudo = base + S.pseudo;
+  double* zero = base + S.zero;
+  double* qdummy = base + S.qdummy;
+  const long pairs = (long)p.rtot * (p.t_nop / 2);
+  hipLaunchKernelGGL(shared_rows_kernel, dim3((unsigned)ceil_div(pairs, (long)BLOCK)), dim3(BLOCK), 0, stream, p,
+                     eff, V);
+  const long nn = (long)p.no * p.no;
+  if (P != nullptr && sl.n > 0) {
+    const int fill = std::max(sl.n * p.nparams, p.rtot);
+    hipLaunchKernelGGL(shared_pseudo_kernel, dim3((unsigned)ceil_div(fill, BLOCK)), dim3(BLOCK), 0, stream, sl,
+                       p.nparams, p.rtot, pseudo, zero);
+    // K_g: the Hessian of pseudo-instance g, by the general kernel (d = 0, no constraints)
+    const unsigned groups = ceil_div((unsigned)sl.n, 8u);
+    hipLaunchKernelGGL(tiled_assemble_kernel, dim3(groups * 8 * (unsigned)npairs), dim3(BLOCK), 0, stream, p,
+                       eff, pseudo, zero, 0ll, K, qdummy, static_cast<double*>(nullptr),
+                       static_cast<double*>(nullptr), nb, npairs, sym, sl.n);
+  }
+  if (P != nullptr) {
+    const dim3 pgrid((unsigned)ceil_div(nn, (long)SH_PRANGE), (unsigned)ceil_div(batch, SH_PIB));
+    // (the kernel multiplies by every one of its TG matrices, the ones behind the last being zeros: the
+    // instantiation just above the number of weights -- at 32 for C4's 18 the kernel was bound by its FMAs)
+#define MPCASM_SHARED_P(TG)                                                                                \
+  hipLaunchKernelGGL((shared_p_kernel<TG>), pgrid, dim3(BLOCK), 0, stream, sl, nn, K, params, p.nparams, P, batch)
+    if (sl.n > 24) MPCASM_SHARED_P(32);
+    else if (sl.n > 20) MPCASM_SHARED_P(24);
+    else if (sl.n > 16) MPCASM_SHARED_P(20);
+    else if (sl.n > 12) MPCASM_SHARED_P(16);
+    else if (sl.n > 8) MPCASM_SHARED_P(12);
+    else if (sl.n > 4) MPCASM_SHARED_P(8);
+    else if (sl.n > 0) MPCASM_SHARED_P(4);
+#undef MPCASM_SHARED_P
+    else
+      (void)hipMemsetAsync(P, 0, sizeof(double) * (size_t)batch * nn, stream);
+  }
+  if (G != nullptr && p.nc > 0)
+    hipLaunchKernelGGL(shared_g_kernel,
+                       dim3((unsigned)ceil_div((long)p.nc * p.no, (long)SH_GRANGE), (unsigned)ceil_div(batch, SH_GIB)),
+                       dim3(BLOCK), 0, stream, p, V, params, G, batch);
+  if (P != nullptr || (G != nullptr && p.nc > 0))
+    hipLaunchKernelGGL(shared_qh_kernel, dim3((unsigned)ceil_div(batch, SH_QB)), dim3(BLOCK), qh_lds, stream, p,
+                       V, params, w, stride, P != nullptr ? q : nullptr,
+                       (G != nullptr && p.nc > 0) ? h : nullptr, batch, nrho);
+  *err = hipGetLastError();
+  t_last_kernel = MPCASM_KERNEL_TILED_SHARED;
+  return *err == hipSuccess ? MPCASM_OK : MPCASM_ERR_HIP;
+}
 
 template <int KP, int CB>
 int launch_scan_as(const PlanDev& p, const SrcTable& eff, const double* A, long long strideA,
@@ -1585,6 +1934,14 @@ int launch_assemble_tiled(const PlanDev& p, const SrcTable& src, const double* p
       return *err == hipSuccess ? MPCASM_OK : MPCASM_ERR_HIP;
     }
   }
+  // one model for the whole batch (every source shared): P and G are weighted sums of matrices that are
+  // the same for every instance -- the shared-model form (MPCASM_OPT_PATH 3 keeps the general kernel)
+  if (t_path != 3 && h_itab != nullptr && batch >= 8) {
+    const int rc = launch_shared_form(p, eff, params, w, stride, P, q, G, h, batch, nb, npairs, sym, h_itab,
+                                      stream, err);
+    if (rc != MPCASM_ERR_LIMIT) return rc;
+  }
+  t_last_kernel = MPCASM_KERNEL_TILED;
   hipLaunchKernelGGL(tiled_assemble_kernel, dim3(groups * 8 * (unsigned)npairs), dim3(BLOCK), 0,
                      stream, p, eff, params, w, stride, P, q, G, h, nb, npairs, sym, batch);
   *err = hipGetLastError();

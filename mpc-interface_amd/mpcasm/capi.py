@@ -95,7 +95,8 @@ KERNEL_NAMES = {0: "none", 1: "resident_assemble_kernel (persistent, ahead of ti
                 3: "fused_assemble_kernel", 4: "staged pipeline (compose_rowsets / hessian / constraints)",
                 5: "tiled_assemble_kernel",
                 6: "toeplitz_scan_kernel (tiled, scan form: P summed along diagonals)",
-                7: "ltv_sweep_kernel (per-step dynamics, no horizon matrix)"}
+                7: "ltv_sweep_kernel (per-step dynamics, no horizon matrix)",
+                8: "shared_p_kernel / shared_g_kernel (tiled, shared-model form: weighted sums of per-term matrices)"}
 BOX_RECENTER, BOX_TRANSLATE, BOX_ROTATE, BOX_SCALE, BOX_MARGIN = range(5)
 
 

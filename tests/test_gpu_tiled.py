@@ -73,6 +73,71 @@ def test_tiled_against_staged_and_oracle(gpu_api, torch_gpu, nx, nu, N, B, seed)
     assert torch.equal(G2, Gt) and torch.equal(h2, ht)
 
 
+@pytest.mark.parametrize("nx,nu,N,B,kw", [
+    (5, 3, 48, 67, {}),                                              # no = 144; a ragged last group of instances
+    (12, 6, 64, 40, {}),                                             # the C4 shape
+    (4, 6, 40, 33, dict(scaled=True, two_axis_limit=True)),          # a derived variable; a row of G over two rows of V
+    (3, 4, 40, 300, dict(extra_unknown=True, scheduled_cost=True)),  # a diagonal term with a weight of its own; a cost on part of the horizon
+    (3, 3, 100, 35, dict(given_input=True)),                         # d = Mg given from a given input (200 unknowns)
+])
+def test_one_model_for_the_whole_batch_is_the_shared_form(gpu_api, torch_gpu, nx, nu, N, B, kw):
+    """Every source shared by the batch (a fleet on one model): P_b = sum_g w_b[g] K_g with the K_g of the
+    general kernel on unit weights, rows of G as scaled copies of the rows composed once, q and h from
+    them -- with EVERY parameter an instance's own (weights, aims, arrows, centers, extremes), against
+    the general kernel on the same launch (MPCASM_OPT_PATH 3), against the oracle for sampled instances,
+    one half at a time, and with NaNs in the result buffers first."""
+    torch = torch_gpu
+    from mpcasm import capi, engine
+
+    rng = np.random.default_rng(nx * 100 + nu)
+    form, _, _ = lti_tracking_problem(gpu_api, rng, nx, nu, N, **kw)
+    asm = engine.Assembler(form, batch=B)
+    assert asm.plan.itab[_H["T_OK"]] == 1
+    given = torch.as_tensor(rng.normal(0, 0.3, [B, form.given_len]), device="cuda")
+    # every field of every cost and limit differs from instance to instance
+    host = asm.params.cpu().numpy().copy()
+    for (kind, name, field), (start, rows, cols) in asm.plan.param_slots.items():
+        block = host[:, start:start + rows * cols]
+        if field == "weight":
+            block *= rng.uniform(0.5, 2.0, [B, 1])
+        elif field == "arrow":
+            block *= rng.uniform(0.5, 1.5, [B, 1])     # (no sign change: Constraint.update would renormalise the host object)
+        else:
+            block += rng.normal(0, 0.2, block.shape)
+    asm.params.copy_(torch.as_tensor(host, device="cuda"))
+    out = tuple(torch.full_like(t, float("nan")) for t in asm.assemble(given))
+    Ps, qs, Gs, hs = (t.clone() for t in asm.assemble(given, out=out))
+    assert "shared" in asm.last_kernel(), asm.last_kernel()
+    assert not any(torch.isnan(t).any().item() for t in (Ps, qs, Gs, hs))
+    asm.set_option(capi.OPT_PATH, 3)
+    Pg, qg, Gg, hg = (t.clone() for t in asm.assemble(given))
+    assert asm.last_kernel() == "tiled_assemble_kernel", asm.last_kernel()
+    assert max(_rel(Ps, Pg), _rel(qs, qg), _rel(Gs, Gg), _rel(hs, hg)) <= RTOL_TIGHT
+    asm.set_option(capi.OPT_PATH, -1)
+    P2, q2, _, _ = asm.assemble(given, want_constraints=False)
+    assert torch.equal(P2, Ps) and torch.equal(q2, qs)
+    out = tuple(torch.full_like(t, float("nan")) for t in (Ps, qs, Gs, hs))
+    _, _, G2, h2 = asm.assemble(given, out=out, want_cost=False)
+    assert torch.equal(G2, Gs) and torch.equal(h2, hs)
+    # the oracle, with the instance's own numbers in the formulation's objects
+    limits = orc.all_limits(form)
+    saved = {(k, n, f): np.array(getattr(form.goals[n] if k == "cost" else limits[n], f))
+             for (k, n, f) in asm.plan.param_slots}
+    try:
+        for b in (0, B // 2, B - 1):
+            for (kind, name, field), (start, rows, cols) in asm.plan.param_slots.items():
+                obj = form.goals[name] if kind == "cost" else limits[name]
+                value = host[b, start:start + rows * cols].reshape(rows, cols)
+                obj.update(**{field: float(value[0, 0]) if field == "weight" else value})
+            Ao, ho, Qo, qo = orc.assemble(form, given[b].cpu().numpy().reshape(-1, 1))
+            assert_close(Ps[b].cpu().numpy(), Qo, RTOL_TIGHT), assert_close(qs[b].cpu().numpy(), qo.ravel(), RTOL_TIGHT)
+            assert_close(Gs[b].cpu().numpy(), Ao, RTOL_TIGHT), assert_close(hs[b].cpu().numpy(), ho.ravel(), RTOL_TIGHT)
+    finally:
+        for (kind, name, field), value in saved.items():
+            obj = form.goals[name] if kind == "cost" else limits[name]
+            obj.update(**{field: float(value.ravel()[0]) if field == "weight" else value})
+
+
 @pytest.mark.parametrize("path", [0, 4, 3], ids=["scan", "toeplitz", "general"])
 @pytest.mark.parametrize("nx,nu,N,B,seed", [(5, 3, 48, 19, 11), (12, 6, 64, 24, 12), (3, 4, 40, 9, 13),
                                             (3, 2, 100, 7, 14)])
