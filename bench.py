@@ -507,7 +507,22 @@ def c4_record(torch, dev, batch=8192, reps=3):
                             "hbm_frac": (out_bytes + in_bytes) * batch / (ms4 * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                             "executed_mfma_per_assembly": mfma, "mfma_TFLOPs": tflops,
                             "mfma_frac": tflops / F64_MFMA_PEAK_TFLOPS}
-    del asm, given
+    del asm
+    torch.cuda.empty_cache()
+    # one model for the whole batch (S, U of the formulation's own system read from memory, shared; weights and
+    # `given` per instance): the shared-model form -- P as a weighted sum of per-weight Hessians computed once per
+    # launch -- and, beside it, the general form on the same launch (every instance's tiles multiplied anew)
+    shared = engine.Assembler(form, batch=batch, device=dev)
+    shared.set_param("cost", "track s0", "weight", rng.uniform(0.1, 1.0, [batch, 1, 1]))
+    ms_s = _event_ms(torch, lambda: shared.assemble(given), 2, warm=1, settle_ms=0.0)
+    rec["shared_model"] = {"kernel": shared.last_kernel(), "ms_per_call": ms_s,
+                           "assemblies_per_s": batch / (ms_s * 1e-3),
+                           "hbm_frac": out_bytes * batch / (ms_s * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+    shared.set_option(capi.OPT_PATH, 3)
+    ms_g = _event_ms(torch, lambda: shared.assemble(given), 1, warm=1, settle_ms=0.0)
+    rec["general_form"] = {"kernel": shared.last_kernel(), "ms_per_call": ms_g,
+                           "hbm_frac": out_bytes * batch / (ms_g * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+    del shared, given
     torch.cuda.empty_cache()
     return rec
 
@@ -667,6 +682,9 @@ def compact_line(rec):
                         "per_s": v["assemblies_per_s"], "frac": v["hbm"]["frac"],
                         "mfma_form": {"ms": v["toeplitz_form"]["ms_per_call"],
                                       "mfma_frac": v["toeplitz_form"]["mfma_frac"]}}
+            if "shared_model" in v:     # (S, U shared by the batch: the shared-model form, the general form)
+                out[key]["shared_ms"] = v["shared_model"]["ms_per_call"]
+                out[key]["general_ms"] = v["general_form"]["ms_per_call"]
         elif key == "c5":
             out[key] = {"B": v["batch_per_gpu"], "kernel": short_kernel(v["kernel"]), "ms": v["ms_per_call"],
                         "per_s": v["assemblies_per_s"], "frac": v["hbm"]["frac"]}

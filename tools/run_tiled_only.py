@@ -2,7 +2,8 @@
 """C4 (random LTI nx=12 nu=6, N=64) on the tiled kernel with horizon tables generated from
 per-instance (A, B): the program the profiling scripts wrap.
    python tools/run_tiled_only.py [batch] [reps] [lti: 1 | 0] [what: all | cost | constraints] [MPCASM_OPT_PATH]
-(path 0: the scan form where the plan has one, 4: the Toeplitz form on the matrix core, 3: the general form)"""
+(path 0: the scan form where the plan has one -- with lti=0 the shared-model form --, 4: the Toeplitz form on the
+matrix core, 3: the general form)"""
 import os
 import sys
 
