@@ -452,6 +452,26 @@ def f2_records(torch, dev, seed, batches=(4096, 65536)):
     return out
 
 
+def admm_record(torch, dev, seed, batch=4096):
+    """SURVEY.md 8 row f3, the "or": the solve itself on the assembled QPs (mpcasm_admm: OSQP's ADMM iteration,
+    biped_mpc_loop.py:60) -- a fleet of C2 walkers near their nominal state, factor + inverse per call and the
+    time of one iteration of the whole batch."""
+    from mpcasm import engine
+
+    work = build_workload(batch, seed)
+    asm = engine.Assembler(work["form"], batch=batch, device=dev)
+    given = torch.as_tensor(work["given"] * 1e-2, device=dev)
+    P, q, G, h = (t.clone() for t in asm.assemble(given))
+    ms0 = _event_ms(torch, lambda: engine.admm(P, q, G, h, iters=0, rho=1.0, residuals=False), 10)
+    ms100 = _event_ms(torch, lambda: engine.admm(P, q, G, h, iters=100, rho=1.0, residuals=False), 5)
+    x, y, z, res = engine.admm(P, q, G, h, iters=400, rho=1.0)
+    return {"workload": "C2 biped N=16 QPs (no=%d, nc=%d) from mpcasm_assemble, OSQP's ADMM iteration, rho = 1"
+                        % (asm.no, asm.nc),
+            "batch_per_gpu": batch, "factor_ms": ms0, "us_per_iteration": (ms100 - ms0) * 10.0,
+            "qp_iterations_per_s": batch * 100 / ((ms100 - ms0) * 1e-3),
+            "residuals_after_400": [float(res[:, 0].max()), float(res[:, 1].max())]}
+
+
 F64_MFMA_PEAK_TFLOPS = 78.6    # dense fp64 matrix peak of gfx950 (v_mfma_f64_16x16x4_f64: 32 flop/clk/SIMD)
 
 
@@ -666,7 +686,7 @@ def compact_line(rec):
     if "variants" in rec:    # the other C2 shapes: fraction of HBM
         out["variants"] = {("w%d%s" % (v["no"], "r" if "reduced" in v["workload"] else "")): v["frac"]
                            for v in rec["variants"]}
-    for key in ("c1", "c3", "c4", "c5", "f2", "extra"):
+    for key in ("c1", "c3", "c4", "c5", "admm", "f2", "extra"):
         v = rec.get(key)
         if v is None:
             continue
@@ -688,6 +708,8 @@ def compact_line(rec):
         elif key == "c5":
             out[key] = {"B": v["batch_per_gpu"], "kernel": short_kernel(v["kernel"]), "ms": v["ms_per_call"],
                         "per_s": v["assemblies_per_s"], "frac": v["hbm"]["frac"]}
+        elif key == "admm":
+            out[key] = {"B": v["batch_per_gpu"], "factor_ms": v["factor_ms"], "iter_us": v["us_per_iteration"]}
         elif key == "f2":
             out[key] = {"B%d" % f["batch_per_gpu"]: {"ms": f["avg_launch_ms"], "frac": f["frac"]} for f in v}
         elif key == "extra":
@@ -1023,7 +1045,8 @@ def run_rank(args):
         # wall clock between the timed region and the line the driver waits for)
         single = world == 1
         for key, make in (("c1", lambda: c1_record()), ("c3", lambda: c3_record(torch, dev)),
-                          ("c4", lambda: c4_record(torch, dev)), ("c5", lambda: c5_record(torch, dev))):
+                          ("c4", lambda: c4_record(torch, dev)), ("c5", lambda: c5_record(torch, dev)),
+                          ("admm", lambda: admm_record(torch, dev, 20260))):
             if not single:
                 continue
             try:

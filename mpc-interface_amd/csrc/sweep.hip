@@ -53,18 +53,21 @@ struct SweepLds {
 constexpr int LIMW = SW_LIM_WORDS + SW_AXMAX * SW_LAX_WORDS;
 constexpr int SW_TERMS_REG = 8;   // cost terms the recursion waves keep in registers
 constexpr int SW_LINES_REG = 8;   // lines of G of one step whose words are fetched a step ahead
+// [A_k | B_k] of a step: n n + n m doubles, rounded up to whole 16-byte pieces; the vectors the sweeps read
+// per step (Psi_l B_l[:, j], the weights of a line of G) are padded to SW_NMAX = 4 doubles: two 16-byte reads
+__host__ __device__ inline int sweep_abw(int n, int m) { return (n * n + n * m + 1) & ~1; }
 __host__ __device__ inline SweepLds sweep_lds(const PlanDev& p, int per_line) {
   const int n = p.sw_n, m = p.sw_m, N = p.sw_horizon, naxes = p.sw_naxes;
   SweepLds x;
   x.ab = 0;
-  x.xbar = x.ab + N * (n * n + n * m);
-  x.gv = x.xbar + naxes * N * n;
-  x.lam = x.gv + naxes * m * N * n;
+  x.gv = x.ab + N * sweep_abw(n, m);
+  x.lw = x.gv + naxes * m * N * SW_NMAX;
+  x.xbar = x.lw + (per_line ? p.sw_ngent : p.sw_nlim) * naxes * SW_NMAX;
+  x.lam = x.xbar + naxes * N * n;
   x.par = x.lam + naxes * N * n;
   x.cvec = x.par + p.nparams + 1;
   x.cvec += x.cvec & 1;
-  x.lw = x.cvec + p.sw_ncvec * SW_NMAX;
-  x.ints = x.lw + (per_line ? p.sw_ngent : p.sw_nlim) * naxes * n;
+  x.ints = x.cvec + p.sw_ncvec * SW_NMAX;
   x.ints += x.ints & 1;
   x.i_term = 0;
   x.i_gptr = x.i_term + p.sw_nterm * SW_TERM_WORDS;
@@ -95,15 +98,15 @@ __global__ __launch_bounds__(SW_BLOCK) void ltv_sweep_kernel(
   if (inst >= batch) return;
   const int n = NS ? NS : p.sw_n, m = MS ? MS : p.sw_m, naxes = AS ? AS : p.sw_naxes;
   const int N = p.sw_horizon, no = p.no, nc = p.nc;
-  const int nn = n * n, nm = n * m, abw = nn + nm;
+  const int nn = n * n, nm = n * m, abw = sweep_abw(n, m);
   const SweepLds L = sweep_lds(p, per_line);
   double* AB = sw + L.ab;       // [N][n n + n m]: A_k row major, then B_k
   double* xbar = sw + L.xbar;   // [naxes][N][n]
-  double* gv = sw + L.gv;       // [naxes][m][N][n]
+  double* gv = sw + L.gv;       // [N][naxes][m][SW_NMAX]: what a step's sweeps read lies side by side
   double* lamT = sw + L.lam;    // [naxes][N][n]
   double* par = sw + L.par;     // [nparams + 1], the last 0.0
   double* cvec = sw + L.cvec;   // [ncvec][SW_NMAX]
-  double* lw = sw + L.lw;       // [lines or limits][naxes][n]
+  double* lw = sw + L.lw;       // [lines or limits][naxes][SW_NMAX]
   int* itb = reinterpret_cast<int*>(sw + L.ints);
   const int* terms = itb + L.i_term;
   const int* gptr = itb + L.i_gptr;
@@ -251,7 +254,7 @@ __global__ __launch_bounds__(SW_BLOCK) void ltv_sweep_kernel(
           if (n > 1) gsum = fma(p1, Bl[m + j], gsum);
           if (n > 2) gsum = fma(p2, Bl[2 * m + j], gsum);
           if (n > 3) gsum = fma(p3, Bl[3 * m + j], gsum);
-          gv[((ra * m + j) * N + l) * n + ri] = gsum;
+          gv[((l * naxes + ra) * m + j) * SW_NMAX + ri] = gsum;
         }
     }
   } else if (wave == 1) {
@@ -331,12 +334,12 @@ __global__ __launch_bounds__(SW_BLOCK) void ltv_sweep_kernel(
       lword[e] = (rec[SL_OUT0] + ge.y) | (ge.x << 20);
       if (per_line && e < nlines) {
         for (int a = 0; a < naxes; ++a)
-          for (int s_ = 0; s_ < n; ++s_) lw[(e * naxes + a) * n + s_] = 0.0;
+          for (int s_ = 0; s_ < SW_NMAX; ++s_) lw[(e * naxes + a) * SW_NMAX + s_] = 0.0;
         for (int ax = 0; ax < rec[SL_NAXES]; ++ax) {
           const int* xr = rec + SW_LIM_WORDS + ax * SW_LAX_WORDS;
           const double ar = par[xr[SX_ARROW] + ge.y * xr[SX_ARROW_STEP]];
           const double* cv = cvec + xr[SX_CVEC];
-          for (int s_ = 0; s_ < n; ++s_) lw[(e * naxes + xr[SX_AXIS]) * n + s_] += ar * cv[s_];
+          for (int s_ = 0; s_ < n; ++s_) lw[(e * naxes + xr[SX_AXIS]) * SW_NMAX + s_] += ar * cv[s_];
         }
       }
     }
@@ -344,12 +347,12 @@ __global__ __launch_bounds__(SW_BLOCK) void ltv_sweep_kernel(
       for (int li = wt; li < p.sw_nlim; li += WT) {
         const int* rec = lims + li * LIMW;
         for (int a = 0; a < naxes; ++a)
-          for (int s_ = 0; s_ < n; ++s_) lw[(li * naxes + a) * n + s_] = 0.0;
+          for (int s_ = 0; s_ < SW_NMAX; ++s_) lw[(li * naxes + a) * SW_NMAX + s_] = 0.0;
         for (int ax = 0; ax < rec[SL_NAXES]; ++ax) {
           const int* xr = rec + SW_LIM_WORDS + ax * SW_LAX_WORDS;
           const double ar = par[xr[SX_ARROW]];
           const double* cv = cvec + xr[SX_CVEC];
-          for (int s_ = 0; s_ < n; ++s_) lw[(li * naxes + xr[SX_AXIS]) * n + s_] += ar * cv[s_];
+          for (int s_ = 0; s_ < n; ++s_) lw[(li * naxes + xr[SX_AXIS]) * SW_NMAX + s_] += ar * cv[s_];
         }
       }
   }
@@ -387,23 +390,54 @@ __global__ __launch_bounds__(SW_BLOCK) void ltv_sweep_kernel(
       }
     }
 
-  // ---- forward sweep: u = Phi(l, l'+1) B_l' per column; rows of G of step l, P at and below the diagonal ----
-  // (branch-free per step: a thread's column is "not yet" (u = 0), "now" (u = B_l[:, j]) or "running"
-  // (u = A_l u) by selects; threads without a column leave here)
-  if (CPT == 1 && tid >= no) return;
   double* Pb = P + (size_t)inst * no * no;
   double* Gb = G + (size_t)inst * nc * no;
-  // first unknown of every (axis, input): wave-uniform, kept in registers
-  int c0[SW_AXMAX][SW_MMAX];
-#pragma unroll
-  for (int a = 0; a < SW_AXMAX; ++a)
-#pragma unroll
-    for (int j = 0; j < SW_MMAX; ++j) c0[a][j] = (a < naxes && j < m) ? axis[a * SW_AXIS_WORDS + 1 + j] : 0;
+  // ---- the blocks of P between different axes: zeros (no cost couples two axes here), written as such --
+  // 16 bytes per store, no arithmetic -- instead of being "computed" element by element in the sweeps
+  if (P != nullptr && naxes > 1) {
+    const bool wide = (N & 1) == 0 && (no & 1) == 0;   // (pairs of columns stay inside a row, 16-byte aligned)
+    for (int a = 0; a < naxes; ++a)
+      for (int j = 0; j < m; ++j)
+        for (int a2 = 0; a2 < naxes; ++a2) {
+          if (a2 == a) continue;
+          for (int j2 = 0; j2 < m; ++j2) {
+            const int col0 = axis[a2 * SW_AXIS_WORDS + 1 + j2];
+            double* blk = Pb + (size_t)axis[a * SW_AXIS_WORDS + 1 + j] * no + col0;
+            // (plain stores: a block's rows end inside cache lines the neighbouring block completes)
+            if (wide && (col0 & 1) == 0)
+              for (int e = tid * 2; e < N * N; e += SW_BLOCK * 2) {
+                const int r = e / N, c = e - r * N;
+                *reinterpret_cast<double2*>(blk + (size_t)r * no + c) = double2{0.0, 0.0};
+              }
+            else
+              for (int e = tid; e < N * N; e += SW_BLOCK) {
+                const int r = e / N, c = e - r * N;
+                blk[(size_t)r * no + c] = 0.0;
+              }
+          }
+        }
+  }
+
+  // ---- forward sweep: u = Phi(l, l'+1) B_l' per column; rows of G of step l, P at and below the diagonal ----
+  // (branch-free per step: a thread's column is "not yet" (u = 0), "now" (u = B_l[:, j]) or "running"
+  // (u = A_l u) by selects; threads without a column leave here).  Everything a step needs comes out of
+  // LDS in 16-byte pieces up front -- the step's [A | B] (the same for every lane), the lane's own axis'
+  // Psi_l B_l[:, j] and the weights of the step's lines of G -- and a thread writes the row of its OWN axis.
+  if (CPT == 1 && tid >= no) return;
   double u[CPT][SW_NMAX];
+  double* prow[CPT][SW_MMAX];      // P[(own axis, j, step l)][own column], stepping down a row per step
+  int goff[CPT];                   // the lane's axis' slice of a step of gv, of a slot of lw (doubles)
 #pragma unroll
-  for (int t = 0; t < CPT; ++t)
+  for (int t = 0; t < CPT; ++t) {
+    const int c = tid + t * SW_BLOCK;
+    const int cat = ca[t] < 0 ? 0 : ca[t];
+    goff[t] = cat * m * SW_NMAX;
 #pragma unroll
     for (int i = 0; i < SW_NMAX; ++i) u[t][i] = 0.0;
+#pragma unroll
+    for (int j = 0; j < SW_MMAX; ++j)
+      prow[t][j] = Pb + (size_t)(j < m ? axis[cat * SW_AXIS_WORDS + 1 + j] : 0) * no + (c < no ? c : 0);
+  }
   constexpr int LR = CPT == 1 ? SW_LINES_REG : (CPT == 2 ? 4 : 2);   // lines of a step in registers
   int wcur[LR];   // the words of the step's first lines (wave-uniform)
 #pragma unroll
@@ -413,18 +447,27 @@ __global__ __launch_bounds__(SW_BLOCK) void ltv_sweep_kernel(
     const double* Al = AB + l * abw;
     const double* Bl = Al + nn;
     const int e2 = gptr[l + 2];                 // (the end of the NEXT step's lines: a step ahead)
+    double am[SW_NMAX][SW_NMAX];
+#pragma unroll
+    for (int i = 0; i < SW_NMAX; ++i)
+#pragma unroll
+      for (int s_ = 0; s_ < SW_NMAX; ++s_) am[i][s_] = (i < n && s_ < n) ? Al[i * n + s_] : 0.0;
 #pragma unroll
     for (int t = 0; t < CPT; ++t) {
-      double y[SW_NMAX];
+      double bnow[SW_NMAX], y[SW_NMAX];
+#pragma unroll
+      for (int i = 0; i < SW_NMAX; ++i) {
+        bnow[i] = i < n ? Bl[i * m + cj[t]] : 0.0;
+        asm volatile("" : "+v"(bnow[i]));       // (read by every lane, not only by the ones that start now)
+      }
 #pragma unroll
       for (int i = 0; i < SW_NMAX; ++i) {
         y[i] = 0.0;
         if (i < n) {
 #pragma unroll
           for (int s_ = 0; s_ < SW_NMAX; ++s_)
-            if (s_ < n) y[i] = fma(Al[i * n + s_], u[t][s_], y[i]);
-          const double bnow = Bl[i * m + cj[t]];
-          y[i] = cl[t] == l ? bnow : y[i];       // (u is 0 before its step: A_l 0 = 0)
+            if (s_ < n) y[i] = fma(am[i][s_], u[t][s_], y[i]);
+          y[i] = cl[t] == l ? bnow[i] : y[i];   // (u is 0 before its step: A_l 0 = 0)
         }
       }
 #pragma unroll
@@ -432,25 +475,19 @@ __global__ __launch_bounds__(SW_BLOCK) void ltv_sweep_kernel(
     }
     if (P != nullptr) {
 #pragma unroll
-      for (int a = 0; a < SW_AXMAX; ++a) {
-        if (a >= naxes) break;
+      for (int t = 0; t < CPT; ++t) {
+        const int c = tid + t * SW_BLOCK;
+        const double* gl = gv + (size_t)l * naxes * m * SW_NMAX + goff[t];
 #pragma unroll
         for (int j = 0; j < SW_MMAX; ++j) {
           if (j >= m) break;
-          const double* g = gv + ((a * m + j) * N + l) * n;
-          const int r = c0[a][j] + l;
-          double* prow = Pb + (size_t)r * no;
+          double v = (cl[t] == l && cj[t] == j) ? dPc[t] : 0.0;
 #pragma unroll
-          for (int t = 0; t < CPT; ++t) {
-            const int c = tid + t * SW_BLOCK;
-            double v = c == r ? dPc[t] : 0.0;
-#pragma unroll
-            for (int s_ = 0; s_ < SW_NMAX; ++s_)
-              if (s_ < n) v = fma(g[s_], u[t][s_], v);
-            // another axis: a zero; this axis: at and below the diagonal now, above it in the backward sweep
-            const bool other = ca[t] != a;
-            if ((CPT == 1 || c < no) && (other || cl[t] <= l)) prow[c] = other ? 0.0 : v;
-          }
+          for (int s_ = 0; s_ < SW_NMAX; ++s_)
+            if (s_ < n) v = fma(gl[j * SW_NMAX + s_], u[t][s_], v);
+          // this axis: at and below the diagonal now, above it in the backward sweep
+          if ((CPT == 1 || c < no) && cl[t] <= l) *prow[t][j] = v;   // (plain: the backward sweep completes the line)
+          prow[t][j] += no;
         }
       }
     }
@@ -466,9 +503,9 @@ __global__ __launch_bounds__(SW_BLOCK) void ltv_sweep_kernel(
         const int slot = per_line ? e0 + (x < cnt ? x : 0) : (word >> 20);
 #pragma unroll
         for (int t = 0; t < CPT; ++t) {
-          const double* wp = lw + (slot * naxes + (ca[t] < 0 ? 0 : ca[t])) * n;
+          const double* wp = lw + (size_t)slot * naxes * SW_NMAX + (goff[t] / m);
 #pragma unroll
-          for (int s_ = 0; s_ < SW_NMAX; ++s_) wv[x][t][s_] = (x < cnt && s_ < n) ? wp[s_] : 0.0;
+          for (int s_ = 0; s_ < SW_NMAX; ++s_) wv[x][t][s_] = s_ < n ? wp[s_] : 0.0;
         }
       }
       int wnext[LR];
@@ -485,7 +522,7 @@ __global__ __launch_bounds__(SW_BLOCK) void ltv_sweep_kernel(
 #pragma unroll
           for (int s_ = 0; s_ < SW_NMAX; ++s_)
             if (s_ < n) v = fma(wv[x][t][s_], u[t][s_], v);
-          if (CPT == 1 || c < no) grow[c] = v;
+          if (CPT == 1 || c < no) store_result(grow + c, v);
         }
       }
       // (a step with more lines than are kept in registers: the rest one by one)
@@ -496,10 +533,10 @@ __global__ __launch_bounds__(SW_BLOCK) void ltv_sweep_kernel(
 #pragma unroll
         for (int t = 0; t < CPT; ++t) {
           const int c = tid + t * SW_BLOCK;
-          const double* wp = lw + (slot * naxes + (ca[t] < 0 ? 0 : ca[t])) * n;
+          const double* wp = lw + (size_t)slot * naxes * SW_NMAX + (goff[t] / m);
           double v = 0.0;
           for (int s_ = 0; s_ < n; ++s_) v = fma(wp[s_], u[t][s_], v);
-          if (CPT == 1 || c < no) grow[c] = v;
+          if (CPT == 1 || c < no) store_result(grow + c, v);
         }
       }
 #pragma unroll
@@ -510,7 +547,7 @@ __global__ __launch_bounds__(SW_BLOCK) void ltv_sweep_kernel(
   }
   if (P == nullptr) return;
 
-  // ---- backward sweep: z = Phi(l', l+1)^T Psi_l' B_l' per column; P above the diagonal ---------------
+  // ---- backward sweep: z = Phi(l', l+1)^T Psi_l' B_l' per column; P above the diagonal (the own axis' rows) ----
   double z[CPT][SW_NMAX];
 #pragma unroll
   for (int t = 0; t < CPT; ++t)
@@ -519,40 +556,46 @@ __global__ __launch_bounds__(SW_BLOCK) void ltv_sweep_kernel(
   for (int l = N - 1; l >= 0; --l) {
     const double* An = AB + (l + 1 < N ? l + 1 : l) * abw;
     const double* Bl = AB + l * abw + nn;
+    double at[SW_NMAX][SW_NMAX], bm[SW_NMAX][SW_MMAX];
+#pragma unroll
+    for (int i = 0; i < SW_NMAX; ++i)
+#pragma unroll
+      for (int s_ = 0; s_ < SW_NMAX; ++s_) at[s_][i] = (i < n && s_ < n) ? An[s_ * n + i] : 0.0;
+#pragma unroll
+    for (int s_ = 0; s_ < SW_NMAX; ++s_)
+#pragma unroll
+      for (int j = 0; j < SW_MMAX; ++j) bm[s_][j] = (s_ < n && j < m) ? Bl[s_ * m + j] : 0.0;
 #pragma unroll
     for (int t = 0; t < CPT; ++t) {
-      const int cat = ca[t] < 0 ? 0 : ca[t];
-      const double* g = gv + ((cat * m + cj[t]) * N + l) * n;
-      double y[SW_NMAX];
+      const int c = tid + t * SW_BLOCK;
+      const double* gl = gv + (size_t)l * naxes * m * SW_NMAX + goff[t] + cj[t] * SW_NMAX;
+      double gnow[SW_NMAX], y[SW_NMAX];
+#pragma unroll
+      for (int i = 0; i < SW_NMAX; ++i) {
+        gnow[i] = i < n ? gl[i] : 0.0;
+        asm volatile("" : "+v"(gnow[i]));
+      }
 #pragma unroll
       for (int i = 0; i < SW_NMAX; ++i) {
         y[i] = 0.0;
         if (i < n) {
 #pragma unroll
           for (int s_ = 0; s_ < SW_NMAX; ++s_)
-            if (s_ < n) y[i] = fma(An[s_ * n + i], z[t][s_], y[i]);
-          y[i] = cl[t] == l ? g[i] : y[i];       // (z is 0 behind its step: A^T 0 = 0)
+            if (s_ < n) y[i] = fma(at[s_][i], z[t][s_], y[i]);
+          y[i] = cl[t] == l ? gnow[i] : y[i];    // (z is 0 behind its step: A^T 0 = 0)
         }
       }
 #pragma unroll
       for (int i = 0; i < SW_NMAX; ++i) z[t][i] = y[i];
-    }
-#pragma unroll
-    for (int a = 0; a < SW_AXMAX; ++a) {
-      if (a >= naxes) break;
 #pragma unroll
       for (int j = 0; j < SW_MMAX; ++j) {
         if (j >= m) break;
-        double* prow = Pb + (size_t)(c0[a][j] + l) * no;
+        prow[t][j] -= no;                       // (the forward sweep left it one row behind the last)
+        double v = 0.0;
 #pragma unroll
-        for (int t = 0; t < CPT; ++t) {
-          const int c = tid + t * SW_BLOCK;
-          double v = 0.0;
-#pragma unroll
-          for (int s_ = 0; s_ < SW_NMAX; ++s_)
-            if (s_ < n) v = fma(Bl[s_ * m + j], z[t][s_], v);
-          if (ca[t] == a && cl[t] > l) prow[c] = v;
-        }
+        for (int s_ = 0; s_ < SW_NMAX; ++s_)
+          if (s_ < n) v = fma(bm[s_][j], z[t][s_], v);
+        if ((CPT == 1 || c < no) && cl[t] > l) *prow[t][j] = v;
       }
     }
   }
