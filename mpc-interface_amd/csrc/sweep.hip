@@ -63,7 +63,7 @@ __host__ __device__ inline SweepLds sweep_lds(const PlanDev& p, int per_line) {
   x.gv = x.ab + N * sweep_abw(n, m);
   x.lw = x.gv + naxes * m * N * SW_NMAX;
   x.xbar = x.lw + (per_line ? p.sw_ngent : p.sw_nlim) * naxes * SW_NMAX;
-  x.lam = x.xbar + naxes * N * n;
+  x.lam = x.xbar;   // (rho_l, then lam_l, take x_l's place once h has been written: one wavefront does all three)
   x.par = x.lam + naxes * N * n;
   x.cvec = x.par + p.nparams + 1;
   x.cvec += x.cvec & 1;
@@ -275,9 +275,32 @@ __global__ __launch_bounds__(SW_BLOCK) void ltv_sweep_kernel(
       x = xl ? y : 0.0;
       if (xl) xbar[(ra * N + k) * n + ri] = x;
     }
+    asm volatile("" ::: "memory");   // (a wavefront's LDS operations complete in order: xbar is there)
+    // h: (extreme + arrow . center) - arrow . (c . x of the line's step) -- here, by this wavefront, because
+    // rho and lam below overwrite x (one buffer for the three: 4.8 KB of LDS less for C5, a sixth workgroup
+    // per CU)
+    if (G != nullptr)
+      for (int e = lane; e < nlines; e += 64) {
+        const int2 ge = gent[e];
+        const int* rec = lims + ge.x * LIMW;
+        const int i = ge.y, nax = rec[SL_NAXES];
+        double ac = 0.0, ad = 0.0;
+        for (int ax = 0; ax < nax; ++ax) {
+          const int* xr = rec + SW_LIM_WORDS + ax * SW_LAX_WORDS;
+          const double ar = par[xr[SX_ARROW] + i * xr[SX_ARROW_STEP]];
+          ac += ar * par[xr[SX_CENTER] + i * xr[SX_CENTER_STEP]];
+          const double* xb = xbar + (xr[SX_AXIS] * N + xr[SX_K0] + i * xr[SX_KSTEP]) * n;
+          const double* cv = cvec + xr[SX_CVEC];
+          double d = 0.0;
+          for (int s_ = 0; s_ < n; ++s_) d = fma(cv[s_], xb[s_], d);
+          ad = fma(ar, d, ad);
+        }
+        h[(size_t)inst * nc + rec[SL_OUT0] + i] = (par[rec[SL_EXTREME] + i * rec[SL_EXTREME_STEP]] + ac) - ad;
+      }
     if (P != nullptr) {
-      asm volatile("" ::: "memory");   // (a wavefront's LDS operations complete in order: xbar is there)
-      // rho_l[i] = sum over the cost rows of step l on the axis of w (c . x_l - aim) c[i] -> lamT
+      asm volatile("" ::: "memory");
+      // rho_l[i] = sum over the cost rows of step l on the axis of w (c . x_l - aim) c[i] -> lamT, in x_l's place
+      // (a lane reads the x of its own (axis, step) and nothing else's)
       for (int e = lane; e < naxes * N; e += 64) {
         const int a = e / N, l = e - a * N;
         const double* xb = xbar + e * n;
@@ -358,25 +381,7 @@ __global__ __launch_bounds__(SW_BLOCK) void ltv_sweep_kernel(
   }
   __syncthreads();
 
-  // ---- h: (extreme + arrow . center) - arrow . (c . x of the line's step);  q = B_l[:, j] . lam_l ---------
-  if (G != nullptr)
-    for (int e = tid; e < nlines; e += SW_BLOCK) {
-      const int2 ge = gent[e];
-      const int* rec = lims + ge.x * LIMW;
-      const int i = ge.y, nax = rec[SL_NAXES];
-      double ac = 0.0, ad = 0.0;
-      for (int ax = 0; ax < nax; ++ax) {
-        const int* xr = rec + SW_LIM_WORDS + ax * SW_LAX_WORDS;
-        const double ar = par[xr[SX_ARROW] + i * xr[SX_ARROW_STEP]];
-        ac += ar * par[xr[SX_CENTER] + i * xr[SX_CENTER_STEP]];
-        const double* xb = xbar + (xr[SX_AXIS] * N + xr[SX_K0] + i * xr[SX_KSTEP]) * n;
-        const double* cv = cvec + xr[SX_CVEC];
-        double d = 0.0;
-        for (int s_ = 0; s_ < n; ++s_) d = fma(cv[s_], xb[s_], d);
-        ad = fma(ar, d, ad);
-      }
-      h[(size_t)inst * nc + rec[SL_OUT0] + i] = (par[rec[SL_EXTREME] + i * rec[SL_EXTREME_STEP]] + ac) - ad;
-    }
+  // ---- q = B_l[:, j] . lam_l (h: written by the wavefront that ran the free response, above) ---------
   if (P != nullptr)
 #pragma unroll
     for (int t = 0; t < CPT; ++t) {

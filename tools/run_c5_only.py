@@ -32,8 +32,11 @@ if route == "sweep":
     asm = engine.Assembler(form, batch=batch, ltv=["LIP"])
     asm.bind_ltv("LIP", A, Bm)
 
+    what = os.environ.get("MPCASM_C5_WHAT", "all")       # all | cost | constraints (timing-only ablation)
+    kw = dict(want_cost=what != "constraints", want_constraints=what != "cost")
+
     def step():
-        asm.assemble(given)
+        asm.assemble(given, **kw)
 else:
     asm = engine.Assembler(form, batch=batch)
     S, U = engine.fill_su(A, Bm, N, ltv=True)
