@@ -40,6 +40,10 @@ import sys
 import time
 
 # the CPU baseline is quoted for one core per process: keep BLAS single-threaded
+# kernel arguments in device memory (a documented setting of the HIP runtime, read when it initialises):
+# by default they live in host memory, and the first loads of EVERY launch -- the kernel's own arguments --
+# cross PCIe: 2.5 us of a 27 us launch ("set-up")
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 os.environ.setdefault("OMP_NUM_THREADS", "1")
 os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
 
@@ -677,6 +681,8 @@ def compact_line(rec):
             out["cpu_baseline"]["numpy"] = {"value": b["numpy_oracle"]["value"],
                                             "one_core": b["numpy_oracle"]["single_core_value"]}
     out["devices"] = rec["devices"]
+    if "runtime_settings" in rec:
+        out["kernarg_dev"] = rec["runtime_settings"]["HIP_FORCE_DEV_KERNARG"]
     if "gather" in rec:
         g = rec["gather"]
         out["gather"] = {"backend": g["backend"], "ms": g["ms"], "GBps": g["GBps_received_per_gpu"],
@@ -949,6 +955,7 @@ def run_rank(args):
         "n_gpus": world,
         "n_ranks_seen": ranks_seen,
         "devices": devices,
+        "runtime_settings": {"HIP_FORCE_DEV_KERNARG": os.environ.get("HIP_FORCE_DEV_KERNARG")},
         "steps": args.steps,
         "warmup": args.warmup,
         "timed_region_ms": timed_ms,

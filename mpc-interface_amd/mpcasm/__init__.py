@@ -8,3 +8,13 @@ torch nor the GPU):
 * ``mpcasm.engine``   batched assembler on torch-ROCm buffers, sharding helpers
 * ``mpcasm.problems`` builders of the BASELINE configurations
 """
+
+import os as _os
+
+# Kernel arguments in device memory.  The HIP runtime keeps them in host memory unless told otherwise, and
+# then the first thing every launch does -- read its own arguments -- is a trip across PCIe: 2.5 us of the 27 us
+# of a C2 launch at B = 4096 (measured both ways, DESIGN.md section 2).  The runtime reads the setting once, when
+# it initialises (the first HIP call of the process, e.g. torch's first use of the GPU): importing this package
+# before that is enough; a process that has already initialised HIP keeps what it had.  An explicit setting of
+# the user's wins.
+_os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
