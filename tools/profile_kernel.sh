@@ -7,6 +7,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 out=$R/gpurun_out/$tag
 rm -rf $out && mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
+export HIP_FORCE_DEV_KERNARG=${HIP_FORCE_DEV_KERNARG:-1}   # (as the package sets it; under rocprofv3 the runtime starts before python)
 rocprofv3 --kernel-trace --stats -d $out/stats -o p --output-format csv -- "$@" > $out/stats.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAIT_INST_ANY -d $out/sq -o p --output-format csv -- "$@" > $out/sq.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_VALU -d $out/lds -o p --output-format csv -- "$@" > $out/lds.log 2>&1 || exit 1

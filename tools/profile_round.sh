@@ -8,6 +8,7 @@ R=$GRAFT_REPO_ROOT
 out=$R/gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
+export HIP_FORCE_DEV_KERNARG=${HIP_FORCE_DEV_KERNARG:-1}   # (as the package sets it; under rocprofv3 the runtime starts before python)
 rocprofv3 --kernel-trace --stats -d $out/stats -o p --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-extras --streams 1 > $out/bench_stats.json 2> $out/stats.log || exit 1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/fetch -o p --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-extras --streams 1 --steps 20 > $out/bench_fetch.json 2> $out/fetch.log || exit 1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out/write -o p --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-extras --streams 1 --steps 20 > $out/bench_write.json 2> $out/write.log || exit 1
