@@ -146,9 +146,26 @@ __global__ __launch_bounds__(ADMM_BLOCK) void admm_kernel(
     __syncthreads();
     // (rows of the trailing block in turn, lanes over the columns j <= i of a row: no division; a row
     // of at most 64 columns is one step, and the rows do not depend on each other)
-    for (int i = k + 1; i < no; ++i) {
-      const double lik = Mi[i * ld + k];
-      for (int j = k + 1 + lane; j <= i; j += ADMM_BLOCK) Mi[i * ld + j] = fma(-lik, Mi[j * ld + k], Mi[i * ld + j]);
+    // (the lane's own L[j][k] once per column k, for the first 64 columns behind k; four rows on their way at a time)
+    const int j0 = k + 1 + lane;
+    const double ljk = j0 < no ? Mi[j0 * ld + k] : 0.0;
+    int i = k + 1;
+    for (; i + 4 <= no; i += 4) {
+      double lik[4], mij[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        lik[u] = Mi[(i + u) * ld + k];
+        mij[u] = j0 <= i + u ? Mi[(i + u) * ld + j0] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (j0 <= i + u) Mi[(i + u) * ld + j0] = fma(-lik[u], ljk, mij[u]);
+    }
+    for (; i < no; ++i)
+      if (j0 <= i) Mi[i * ld + j0] = fma(-Mi[i * ld + k], ljk, Mi[i * ld + j0]);
+    for (int ii = k + 1; ii < no; ++ii) {   // (columns beyond the first 64: more unknowns than lanes)
+      const double lik = Mi[ii * ld + k];
+      for (int j = j0 + ADMM_BLOCK; j <= ii; j += ADMM_BLOCK) Mi[ii * ld + j] = fma(-lik, Mi[j * ld + k], Mi[ii * ld + j]);
     }
     __syncthreads();
   }
