@@ -34,8 +34,11 @@ def test_rccl_with_one_rank():
     # the ONE line of the contract survives a 2000-character tail, sub-records included
     line = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")][0]
     assert len(line) < 2000, len(line)
-    for key in ("roofline", "fill", "variants", "c3", "c4", "c5", "f2", "B65536"):
+    for key in ("roofline", "fill", "variants", "c3", "c4", "c5", "admm", "f2", "B65536"):
         assert key in rec, key
+    assert "error" not in rec["c4"] and rec["c4"]["shared_ms"] < rec["c4"]["general_ms"]
+    assert "error" not in rec["c5"] and "error" not in rec["admm"] and rec["admm"]["iter_us"] > 0
+    assert rec["kernarg_dev"] == "1"          # (kernel arguments in device memory: set by bench.py itself)
     assert rec["roofline"]["bound"] == "hbm" and 0 < rec["roofline"]["frac"] < 1
 
 
