@@ -771,3 +771,44 @@ def test_an_odd_width_compiles_for_the_tiled_kernel(cpu_api):
     A, h, Q, q = orc.assemble(form, given)
     assert_close(out["P"], Q, 1e-12, "P"), assert_close(out["q"], q.ravel(), 1e-12, "q")
     assert_close(out["G"], A, 1e-12, "G"), assert_close(out["h"], h.ravel(), 1e-12, "h")
+
+
+@pytest.mark.parametrize("kw", [{}, dict(scaled=True, two_axis_limit=True), dict(extra_unknown=True, scheduled_cost=True),
+                                dict(given_input=True)], ids=["plain", "scaled+two-axis", "slack+schedule", "given input"])
+def test_what_the_shared_model_form_relies_on(cpu_api, kw):
+    """The shared-model form of the tiled kernel (csrc/tiled.hip launch_shared_form) writes P_b = sum_g w_b[g] K_g
+    with K_g the Hessian at "weight slot g = 1, every other parameter 0", and takes aims, arrows, centers and
+    extremes for irrelevant to P.  On the plan's own tables (the emulator of the general form): P is exactly that
+    sum over the weight slots of the stages and of the diagonal terms -- with every parameter random -- and G is
+    linear in the arrows alone."""
+    from helpers import lti_tracking_problem
+    from mpcasm.plan import GT_WORDS
+
+    rng = np.random.default_rng(31)
+    form, _, _ = lti_tracking_problem(cpu_api, rng, 4, 5 if kw.get("given_input") else 4, 32, **kw)
+    plan = compile_plan(form)
+    it = plan.itab
+    assert it[_H["T_OK"]] == 1
+    given = rng.normal(0, 0.3, [plan.ng])
+    params = np.array(plan.params, dtype=float) * rng.uniform(0.5, 1.5, plan.params.shape) + rng.normal(0, 0.1, plan.params.shape)
+    full = plan_emulator.run_tiled(plan, given, params=params)
+    # the weight slots as the launcher collects them: every stage's, every diagonal term's
+    nstage, off = int(it[_H["T_NSTAGE"]]), int(it[_H["OFF_T_STAGE"]])
+    slots = {int(it[off + s * 16 + 4]) for s in range(nstage)}                   # TS_WPARAM of T_STAGE_WORDS = 16
+    ngt, goff = int(it[_H["NGTERM"]]), int(it[_H["OFF_GTERM"]])
+    slots |= {int(it[goff + g * GT_WORDS + 3]) for g in range(ngt) if it[goff + g * GT_WORDS + 6] & 4}   # GT_WPARAM of DIAG terms
+    assert 0 < len(slots) <= 32
+    P = np.zeros_like(full["P"])
+    for slot in sorted(slots):
+        unit = np.zeros_like(params)
+        unit[slot] = 1.0
+        P += params[slot] * plan_emulator.run_tiled(plan, np.zeros(plan.ng), params=unit)["P"]
+    assert_close(P, full["P"], 1e-13, "P as the weighted sum of the per-weight Hessians")
+    # G: no weight, aim, center or extreme in it
+    others = params.copy()
+    arrow_cols = np.zeros(len(params), dtype=bool)
+    for (kind, name, field), (start, rows, cols) in plan.param_slots.items():
+        if field == "arrow":
+            arrow_cols[start:start + rows * cols] = True
+    others[~arrow_cols] = rng.normal(0, 1, (~arrow_cols).sum())
+    assert_close(plan_emulator.run_tiled(plan, given, params=others)["G"], full["G"], 1e-14, "G depends on the arrows alone")
