@@ -90,7 +90,7 @@ __global__ __launch_bounds__(SW_BLOCK) void ltv_sweep_kernel(
     PlanDev p, const double* __restrict__ sysA, long long strideA, const double* __restrict__ sysB,
     long long strideB, const double* __restrict__ params, const double* __restrict__ given,
     double* __restrict__ P, double* __restrict__ q, double* __restrict__ G, double* __restrict__ h,
-    int batch, int per_line) {
+    int batch, int per_line, int reg_lines) {
   extern __shared__ __attribute__((aligned(16))) double sw[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -443,6 +443,24 @@ __global__ __launch_bounds__(SW_BLOCK) void ltv_sweep_kernel(
     for (int j = 0; j < SW_MMAX; ++j)
       prow[t][j] = Pb + (size_t)(j < m ? axis[cat * SW_AXIS_WORDS + 1 + j] : 0) * no + (c < no ? c : 0);
   }
+  // Regular lines (the launcher finds them in the plan's tables): the first `reg_lines` lines of EVERY step belong
+  // to the same limits in the same order and sit one row further down G per step -- limits on every step of the
+  // horizon, C5's 4 per step.  Their weights (per limit and axis) are the same at every step: in registers for
+  // the whole sweep; their rows: pointers stepped by one row -- no word, no weight, no multiplication per step.
+  constexpr int RLMAX = 4;
+  double wreg[RLMAX][CPT][SW_NMAX];
+  double* gp[RLMAX];
+#pragma unroll
+  for (int x = 0; x < RLMAX; ++x) {
+    const int word = (G != nullptr && x < reg_lines) ? __builtin_amdgcn_readfirstlane(lword[x]) : 0;
+    gp[x] = Gb + (size_t)(word & 0xFFFFF) * no;
+#pragma unroll
+    for (int t = 0; t < CPT; ++t) {
+      const double* wp = lw + (size_t)(word >> 20) * naxes * SW_NMAX + (goff[t] / m);
+#pragma unroll
+      for (int s_ = 0; s_ < SW_NMAX; ++s_) wreg[x][t][s_] = (x < reg_lines && s_ < n) ? wp[s_] : 0.0;
+    }
+  }
   constexpr int LR = CPT == 1 ? SW_LINES_REG : (CPT == 2 ? 4 : 2);   // lines of a step in registers
   int wcur[LR];   // the words of the step's first lines (wave-uniform)
 #pragma unroll
@@ -496,7 +514,35 @@ __global__ __launch_bounds__(SW_BLOCK) void ltv_sweep_kernel(
         }
       }
     }
-    if (G != nullptr) {
+    if (G != nullptr && reg_lines > 0) {
+#pragma unroll
+      for (int x = 0; x < RLMAX; ++x) {
+        if (x >= reg_lines) break;
+#pragma unroll
+        for (int t = 0; t < CPT; ++t) {
+          const int c = tid + t * SW_BLOCK;
+          double v = 0.0;
+#pragma unroll
+          for (int s_ = 0; s_ < SW_NMAX; ++s_)
+            if (s_ < n) v = fma(wreg[x][t][s_], u[t][s_], v);
+          if (CPT == 1 || c < no) store_result(gp[x] + c, v);
+        }
+        gp[x] += no;
+      }
+      // (what a step holds beyond its regular lines: one by one)
+      for (int e = e0 + reg_lines; e < e1; ++e) {
+        const int word = lword[e];
+        double* grow = Gb + (size_t)(word & 0xFFFFF) * no;
+#pragma unroll
+        for (int t = 0; t < CPT; ++t) {
+          const int c = tid + t * SW_BLOCK;
+          const double* wp = lw + (size_t)(word >> 20) * naxes * SW_NMAX + (goff[t] / m);
+          double v = 0.0;
+          for (int s_ = 0; s_ < n; ++s_) v = fma(wp[s_], u[t][s_], v);
+          if (CPT == 1 || c < no) store_result(grow + c, v);
+        }
+      }
+    } else if (G != nullptr) {
       // This step's lines: their words came in a step ahead (wcur); now the weights of this thread's axis
       // are requested for all of them at once, and the NEXT step's words -- one trip through LDS per step.
       const int cnt = e1 - e0;
@@ -626,6 +672,28 @@ int launch_assemble_sweep(const PlanDev& p, const SrcTable& src, const double* p
     for (int ax = 0; ax < rec[SL_NAXES]; ++ax) per_line |= rec[SW_LIM_WORDS + ax * SW_LAX_WORDS + SX_ARROW_STEP] != 0;
   }
   if (p.nc >= (1 << 20)) return MPCASM_ERR_LIMIT;
+  // regular lines: the first R lines of every step are lines of the same R limits, a row further down per step
+  int reg_lines = 0;
+  if (!per_line && p.sw_ngent > 0) {
+    const int32_t* gptr = h_itab + p.off_sw_gptr;
+    const int32_t* gent = h_itab + p.off_sw_gent;
+    const int N = p.sw_horizon;
+    int R = 4;
+    for (int l = 0; l < N; ++l) R = std::min(R, gptr[l + 1] - gptr[l]);
+    for (int x = 0; x < R; ++x) {
+      const int lim0 = gent[2 * (gptr[0] + x)], i0 = gent[2 * (gptr[0] + x) + 1];
+      bool ok = true;
+      for (int l = 1; l < N && ok; ++l) {
+        const int e = gptr[l] + x;
+        ok = gent[2 * e] == lim0 && gent[2 * e + 1] == i0 + l;
+      }
+      if (!ok) {
+        R = x;
+        break;
+      }
+    }
+    reg_lines = R;
+  }
   const size_t lds = (size_t)sweep_lds(p, per_line).total * sizeof(double);
   if (lds > (size_t)RESIDENT_LDS_LIMIT) return MPCASM_ERR_LIMIT;
   const double* A = src.ptr[p.sw_src_a];
@@ -639,7 +707,7 @@ int launch_assemble_sweep(const PlanDev& p, const SrcTable& src, const double* p
       if (*err != hipSuccess) return MPCASM_ERR_HIP;                                                   \
     }                                                                                                  \
     hipLaunchKernelGGL(kernel, dim3((unsigned)batch), dim3(SW_BLOCK), lds, stream, p, A, sa, Bm, sb,   \
-                       params, given, P, q, G, h, batch, per_line);                                    \
+                       params, given, P, q, G, h, batch, per_line, reg_lines);                         \
     *err = hipGetLastError();                                                                          \
     return *err == hipSuccess ? MPCASM_OK : MPCASM_ERR_HIP;                                            \
   }
