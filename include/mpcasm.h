@@ -52,7 +52,8 @@ int mpcasm_last_hip(void);
 const char* mpcasm_status_string(int status);
 /* Process-wide options.  MPCASM_OPT_PATH selects the assembly kernels: 0 = best
  * available (persistent fused kernel when one instance fits on chip), 1 = never
- * the persistent kernel (per-instance fused kernel if it fits), 2 = always the
+ * the persistent kernel (per-instance fused kernel if it fits; the tiled kernel's scan form with its
+ * pre-passes instead of the set-up fused into it), 2 = always the
  * staged K2 -> K3 -> K4 pipeline with the workspace in HBM, 3 = as 1, and a wide problem whose
  * rows are windows of generated horizon tables still composes its tiles (the tiled kernel's
  * general form instead of its Toeplitz form), 4 = as 1, and such a problem multiplies its windows

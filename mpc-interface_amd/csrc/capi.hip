@@ -471,6 +471,21 @@ int validate_tiled(const int32_t* it, const double* h_dtab, int64_t n, int64_t n
           return MPCASM_ERR_PLAN;
       }
       if (r != nrest) return MPCASM_ERR_PLAN;
+      // fused set-up: `given` is the initial state, the K terms' rows tile the workspace (the kernel writes
+      // d[first row + k] for every term and reads nothing else), no row of G through the column tables,
+      // every input an unknown
+      if (it[H_T_SCAN_FUSED] != 0) {
+        if (it[H_T_SCAN_FUSED] != 1 || it[H_NG] != gn || nrest != 0 || rtot != K * gN || nblk != gm)
+          return MPCASM_ERR_PLAN;
+        std::vector<char> seen((size_t)K, 0);
+        for (int64_t k = 0; k < K; ++k) {
+          const int64_t dr = gt[k * T_SCAN_GT_WORDS + SG_DROW];
+          if (dr % gN || seen[(size_t)(dr / gN)]) return MPCASM_ERR_PLAN;
+          seen[(size_t)(dr / gN)] = 1;
+        }
+      }
+    } else if (it[H_T_SCAN_FUSED] != 0) {
+      return MPCASM_ERR_PLAN;
     }
   }
   {  // every row of G is written exactly once: riding on a stage or listed in the rest
@@ -1035,6 +1050,7 @@ void plan_dev_from_tables(const int32_t* it, PlanDev* out) {
   d.off_sw_cptr = it[H_OFF_SW_CPTR]; d.off_sw_cent = it[H_OFF_SW_CENT]; d.sw_ncent = it[H_SW_NCENT];
   d.off_sw_gptr = it[H_OFF_SW_GPTR]; d.off_sw_gent = it[H_OFF_SW_GENT]; d.sw_ngent = it[H_SW_NGENT];
   d.off_rs_prog = it[H_OFF_RS_PROG];
+  d.t_scan_fused = it[H_T_SCAN_FUSED];
   d.t_nbrow = d.t_ci_ok ? it[d.off_t_brow0 + d.nbase] : 0;
   d.pm_nfd = it[H_PM_NFD]; d.off_pm_map = it[H_OFF_PM_MAP]; d.off_pm_fdptr = it[H_OFF_PM_FDPTR];
   d.off_pm_op = it[H_OFF_PM_OP]; d.doff_pm_pool = it[H_DOFF_PM_POOL];

@@ -34,7 +34,7 @@ namespace mpcasm {
   X(t_doff_scan_gcoef) X(t_scan_ngrest) X(off_t_scan_grest) X(off_t_scan_colblk) X(t_scan_nother) \
   X(sw_ok) X(sw_n) X(sw_m) X(sw_horizon) X(sw_src_a) X(sw_src_b) X(sw_naxes) X(off_sw_axis) X(sw_nterm)  \
   X(off_sw_term) X(sw_nlim) X(off_sw_lim) X(off_sw_col) X(sw_doff_cvec) X(sw_ncvec) \
-  X(off_sw_cptr) X(off_sw_cent) X(sw_ncent) X(off_sw_gptr) X(off_sw_gent) X(sw_ngent) X(off_rs_prog)
+  X(off_sw_cptr) X(off_sw_cent) X(sw_ncent) X(off_sw_gptr) X(off_sw_gent) X(sw_ngent) X(off_rs_prog) X(t_scan_fused)
 
 // device-side view of a plan (pointers into the device copies of the tables).
 //   rs_p_direct: the persistent kernel sends the blocks of P straight to HBM (set by

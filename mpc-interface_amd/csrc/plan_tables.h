@@ -29,7 +29,7 @@
 namespace mpcasm {
 
 constexpr int32_t PLAN_MAGIC = 0x4D504341;  // 'MPCA'
-constexpr int32_t PLAN_VERSION = 29;
+constexpr int32_t PLAN_VERSION = 30;
 
 enum HeaderWord : int {
   H_MAGIC = 0,
@@ -262,9 +262,12 @@ enum HeaderWord : int {
   H_SW_NGENT,
   H_OFF_RS_PROG,      // [JC][RS_NT][4] the compose program once more, one 16-byte record per op and thread:
                       //    RS_SRC | RS_GIDX << 16, RS_DST, the two halves of RS_COEF (16-byte aligned)
+  H_T_SCAN_FUSED,     // 1: the scan kernel makes its own table and its own d (no pre-pass, no scratch): `given` is the
+                      // group's initial state in order, every workspace row a row of one of the K terms, no
+                      // row of G through the column tables
   H_WORDS = 160
 };
-static_assert(H_OFF_RS_PROG < H_WORDS, "plan header");
+static_assert(H_T_SCAN_FUSED < H_WORDS, "plan header");
 constexpr int SW_NMAX = 4, SW_MMAX = 4, SW_AXMAX = 4, SW_AXIS_WORDS = 8, SW_TERM_WORDS = 8, SW_LIM_WORDS = 8,
               SW_LAX_WORDS = 8;
 // a cost term on one axis: rows i = 0 .. ST_COUNT-1 are c . x of step ST_K0 + i ST_KSTEP

@@ -1106,7 +1106,7 @@ __global__ __launch_bounds__(BLOCK, 2) void toeplitz_scan_kernel(
     const double* __restrict__ sysB, long long strideB, const double* __restrict__ params,
     const double* __restrict__ work, long long work_stride, double* __restrict__ P,
     double* __restrict__ q, double* __restrict__ G, double* __restrict__ h, int batch, int dlen,
-    int whole_lines, int group, int rows_in_lds, int phases) {
+    int whole_lines, int group, int rows_in_lds, int phases, const double* __restrict__ given, int fused) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1125,7 +1125,72 @@ __global__ __launch_bounds__(BLOCK, 2) void toeplitz_scan_kernel(
   const ScanLds L = scan_lds(dlen, p.nparams, n, m, N, nc, rows_in_lds != 0);
   int* ticket = reinterpret_cast<int*>(lds + L.ticket);
   // ---- set-up: the table (the value halves of TB's rows), d, the parameters into LDS -------------
-  {
+  if (fused) {
+    // Fused set-up (H_T_SCAN_FUSED): no pre-pass has run.  Wavefront 1 makes the table where it is needed --
+    // X_0 = B, X_d = A X_{d-1} (the reference's recurrence, tools.py:24-29), Tc[(i m + j) N + d] = X_d[i][j],
+    // lanes over the n m elements in up to two passes, a row of A in registers, the column of X_{d-1} out
+    // of LDS (a wavefront's LDS operations complete in order: no barrier between the steps) -- while
+    // wavefront 0 runs the free response x_k = A x_{k-1} from x_{-1} = given and writes
+    // d[first row of the term + k] = c x_k[state] for every term: what compose_d_kernel computes through the
+    // column tables when every workspace row is such a row.
+    const double* A = sysA + inst * strideA;
+    const double* Bm = sysB + inst * strideB;
+    double* Tc = reinterpret_cast<double*>(lds + L.tb);
+    if (wave == 1) {
+      const int nm = n * m;
+      double arow[2][SCAN_AREG];
+      int ej[2];
+      bool live[2];
+#pragma unroll
+      for (int ps = 0; ps < 2; ++ps) {
+        const int e = lane + 64 * ps;
+        live[ps] = e < nm;
+        const int i = live[ps] ? e / m : 0;
+        ej[ps] = live[ps] ? e - i * m : 0;
+#pragma unroll
+        for (int t = 0; t < SCAN_AREG; ++t) arow[ps][t] = (live[ps] && t < n) ? A[i * n + t] : 0.0;
+        if (live[ps]) Tc[e * N] = Bm[e];
+      }
+      for (int d = 1; d < N; ++d) {
+        asm volatile("" ::: "memory");
+        double acc[2] = {0.0, 0.0};
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps)
+#pragma unroll
+          for (int t = 0; t < SCAN_AREG; ++t)
+            if (t < n) acc[ps] = fma(arow[ps][t], Tc[(t * m + ej[ps]) * N + d - 1], acc[ps]);
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps)
+          if (live[ps]) Tc[(lane + 64 * ps) * N + d] = acc[ps];
+      }
+    } else if (wave == 0) {
+      double* dl = reinterpret_cast<double*>(lds + L.d);
+      double* xs = reinterpret_cast<double*>(lds + L.lam);   // (the gradient's buffer, not yet in use: two copies of x)
+      double arow[SCAN_AREG];
+#pragma unroll
+      for (int t = 0; t < SCAN_AREG; ++t) arow[t] = (lane < n && t < n) ? A[lane * n + t] : 0.0;
+      double x = lane < n ? given[inst * p.ng + lane] : 0.0;
+      // lane g < K also looks after term g: its state, its first row of d, its coefficient -- read once
+      const unsigned per_state = (unsigned)(m * N);
+      const int4 tg = gts[lane < K ? lane : 0];
+      const int st = (int)((unsigned)tg.x / per_state), drow = tg.w;
+      const double cg = gcs[lane < K ? lane : 0];
+      if (lane < n) xs[lane] = x;
+      for (int k = 0; k < N; ++k) {
+        const double* xk = xs + (k & 1) * n;              // x_{k-1}
+        double* xn = xs + ((k + 1) & 1) * n;              // x_k = A^{k+1} x_{-1}
+        asm volatile("" ::: "memory");
+        double acc = 0.0;
+#pragma unroll
+        for (int t = 0; t < SCAN_AREG; ++t)
+          if (t < n) acc = fma(arow[t], xk[t], acc);
+        if (lane < n) xn[lane] = acc;
+        asm volatile("" ::: "memory");
+        if (lane < K) dl[drow + k] = cg * xn[st];
+      }
+      if (lane == 0 && (dlen & 1) == 0 && dlen > p.rtot) dl[p.rtot] = 0.0;
+    }
+  } else {
     const char* tb = reinterpret_cast<const char*>(src.ptr[first_u] + inst * src.stride[first_u]);
     const unsigned lds0 = (unsigned)(uintptr_t)lds;
     const unsigned half = (unsigned)N >> 1;                    // 16-byte pieces of a row (N is even)
@@ -1143,6 +1208,8 @@ __global__ __launch_bounds__(BLOCK, 2) void toeplitz_scan_kernel(
       const unsigned off = c0 + (unsigned)lane * 16u;
       if (off < d_bytes) lds_dma16(dsrc + off, __builtin_amdgcn_readfirstlane(lds0 + L.d + c0));
     }
+  }
+  {
     double* par = reinterpret_cast<double*>(lds + L.par);
     for (int e = tid; e <= p.nparams; e += BLOCK) par[e] = e < p.nparams ? pb[e] : 0.0;  // ([nparams] reads 0.0)
     if (tid < 2) ticket[tid] = 0;  // (row blocks of P, groups of rows of G)
@@ -1830,7 +1897,8 @@ template <int KP, int CB>
 int launch_scan_as(const PlanDev& p, const SrcTable& eff, const double* A, long long strideA,
                    const double* Bm, long long strideB, const double* params, const double* w,
                    long long stride, double* P, double* q, double* G, double* h, int batch, int dlen,
-                   int whole_lines, int rows_in_lds, size_t lds, hipStream_t stream, hipError_t* err) {
+                   int whole_lines, int rows_in_lds, size_t lds, const double* given, int fused,
+                   hipStream_t stream, hipError_t* err) {
   auto kernel = toeplitz_scan_kernel<KP, CB>;
   if (lds > 64 * 1024) {
     *err = allow_whole_lds(reinterpret_cast<const void*>(kernel));
@@ -1844,7 +1912,8 @@ int launch_scan_as(const PlanDev& p, const SrcTable& eff, const double* A, long 
     return v < 1 ? 1 : (v > SCAN_GROUP ? SCAN_GROUP : v);
   }();
   hipLaunchKernelGGL(kernel, dim3((unsigned)batch), dim3(BLOCK), lds, stream, p, eff, A, strideA, Bm, strideB,
-                     params, w, stride, P, q, G, h, batch, dlen, whole_lines, group, rows_in_lds, g_phase_mask);
+                     params, w, stride, P, q, G, h, batch, dlen, whole_lines, group, rows_in_lds, g_phase_mask,
+                     given, fused);
   *err = hipGetLastError();
   if (*err == hipSuccess) t_last_kernel = MPCASM_KERNEL_TILED_SCAN;
   return *err == hipSuccess ? MPCASM_OK : MPCASM_ERR_HIP;
@@ -1854,13 +1923,16 @@ int launch_scan_as(const PlanDev& p, const SrcTable& eff, const double* A, long 
 // blocks in registers, or an instance does not fit in LDS (the Toeplitz form takes it then).
 // `src`: the launch's own sources (the group's (A, B) in the slots of its first two), `eff`: with the
 // generated tables in the places of the group's U_j and S.
+// `fused`: no pre-pass has run -- the kernel makes its table and d itself (H_T_SCAN_FUSED); `eff` and `w` unused.
 int launch_scan(const PlanDev& p, const SrcTable& src, const SrcTable& eff, const double* params,
                 const double* w, long long stride, double* P, double* q, double* G, double* h, int batch,
-                const int32_t* h_itab, hipStream_t stream, hipError_t* err) {
+                const int32_t* h_itab, hipStream_t stream, hipError_t* err, const double* given = nullptr,
+                int fused = 0) {
   const int K = p.t_scan, nblk = p.t_scan_nblk;
   const int32_t* rec = h_itab + p.off_t_lti;
   const int n = rec[TL_N], m = rec[TL_M], N = rec[TL_HORIZON];
   if (p.no > 128 * SCAN_GCH_MAX || n > 64 || (N & 1)) return MPCASM_ERR_LIMIT;
+  if (fused && (n > SCAN_AREG || n * m > 128 || given == nullptr)) return MPCASM_ERR_LIMIT;
   const int dlen = p.rtot + (p.rtot & 1);
   // the records of G's rows in LDS while that leaves room for two workgroups per CU
   const int rows_in_lds = scan_lds(dlen, p.nparams, n, m, N, p.nc, true).total + NSTREAM * sizeof(double*) <= SCAN_HALF_CU;
@@ -1875,7 +1947,7 @@ int launch_scan(const PlanDev& p, const SrcTable& src, const SrcTable& eff, cons
   if (K <= KP && nblk <= CB)                                                                             \
     return launch_scan_as<KP, CB>(p, eff, src.ptr[ids[0]], src.stride[ids[0]], src.ptr[ids[1]],           \
                                   src.stride[ids[1]], params, w, stride, P, q, G, h, batch, dlen, whole, \
-                                  rows_in_lds, lds, stream, err);
+                                  rows_in_lds, lds, given, fused, stream, err);
   MPCASM_SCAN_CASE(4, 4)
   MPCASM_SCAN_CASE(8, 4)
   MPCASM_SCAN_CASE(4, 8)
@@ -1895,6 +1967,13 @@ int launch_assemble_tiled(const PlanDev& p, const SrcTable& src, const double* p
                           const int32_t* h_itab) {
   double* w = static_cast<double*>(work);
   const long long stride = p.t_work;
+  // the scan form with its set-up fused (H_T_SCAN_FUSED): one kernel, no scratch (MPCASM_OPT_PATH 1 keeps the
+  // pre-passes: the A/B of the two)
+  if (p.t_scan_fused && p.t_scan > 0 && p.t_toeplitz && p.t_nlti == 1 && h_itab != nullptr && t_path == 0 &&
+      (p.no & 1) == 0) {
+    const int rc = launch_scan(p, src, src, params, nullptr, 0, P, q, G, h, batch, h_itab, stream, err, given, 1);
+    if (rc != MPCASM_ERR_LIMIT) return rc;
+  }
   SrcTable eff;
   {
     const int rc = launch_lti_tables(p, src, w, batch, h_itab, &eff, stream);

@@ -17,7 +17,7 @@ import numpy as np
 import scipy.sparse as sp
 
 PLAN_MAGIC = 0x4D504341
-PLAN_VERSION = 29
+PLAN_VERSION = 30
 
 # header words (csrc/plan_tables.h, enum HeaderWord)
 _H = {name: i for i, name in enumerate([
@@ -46,7 +46,7 @@ _H = {name: i for i, name in enumerate([
     "SW_OK", "SW_N", "SW_M", "SW_HORIZON", "SW_SRC_A", "SW_SRC_B", "SW_NAXES", "OFF_SW_AXIS", "SW_NTERM",
     "OFF_SW_TERM", "SW_NLIM", "OFF_SW_LIM", "OFF_SW_COL", "SW_DOFF_CVEC", "SW_NCVEC",
     "OFF_SW_CPTR", "OFF_SW_CENT", "SW_NCENT", "OFF_SW_GPTR", "OFF_SW_GENT", "SW_NGENT",
-    "OFF_RS_PROG",
+    "OFF_RS_PROG", "T_SCAN_FUSED",
 ])}
 H_WORDS = 160
 assert len(_H) <= H_WORDS
@@ -1326,7 +1326,7 @@ def _scan_tables(b, gterms, rowptr, entbase, entk, entcoef, groups, g_rows, tile
     nc, no, ng = len(g_rows), b.no, b.ng
     off = dict(ok=0, K=0, blk=np.zeros((0, 2), np.int64), gt=np.zeros((0, T_SCAN_GT_WORDS), np.int64),
                gc=np.zeros(0), grow=np.zeros((0, 2), np.int64), gcoef=np.zeros(0),
-               grest=np.zeros(0, np.int64), colblk=np.zeros(0, np.int64), nother=0)
+               grest=np.zeros(0, np.int64), colblk=np.zeros(0, np.int64), nother=0, fused=0)
     if not tiled["toeplitz"] or len(groups) != 1:
         return off
     g0 = groups[0]
@@ -1388,10 +1388,21 @@ def _scan_tables(b, gterms, rowptr, entbase, entk, entcoef, groups, g_rows, tile
             continue
         grow[R] = (x[0] * m * N + x[1], axes[0][1])
         gcoef[R] = x[2]
+    # Fused set-up (H_T_SCAN_FUSED): the kernel can make its own table and its own d = Mg given -- no pre-pass, no
+    # scratch -- when `given` is exactly the group's initial state in order (every state reads S at
+    # S[k][j][i], j = the given column), every input of the group is an unknown, every workspace row is a row
+    # of one of the K terms (d[first row + k] = c (A^{k+1} x0)[state]) and no row of G needs the column tables.
+    rtot = len(rowptr) - 1
+    sS = g0["ids"][m]
+    s_spans = {(seg[1] % n, seg[2], seg[3], seg[4], seg[5]) for seg in b.segments if seg[6] == SEG_GATHER and seg[0] == sS}
+    s_ok = bool(s_spans) and all(sp[1:] == (n * n, n, 0, n) for sp in s_spans) and all(
+        seg[1] < n for seg in b.segments if seg[6] == SEG_GATHER and seg[0] == sS)
+    fused = int(ng == n and s_ok and len(blk) == m and not grest and rtot == len(gt) * N
+                and sorted(x[3] for x in gt) == [k * N for k in range(len(gt))])
     return dict(ok=1, K=len(gt), blk=np.asarray(blk, dtype=np.int64),
                 gt=np.asarray(gt, dtype=np.int64), gc=np.asarray(gc, dtype=np.float64), grow=grow,
                 gcoef=gcoef, grest=np.asarray(grest, dtype=np.int64), colblk=colblk,
-                nother=int((colblk < 0).sum()))
+                nother=int((colblk < 0).sum()), fused=fused)
 
 
 def _sweep_tables(b, gterms, limit_recs, lax_recs, rowptr, entbase, entk, entcoef, group, nparams):
@@ -2104,6 +2115,7 @@ def compile_plan(form, costs=None, limits=None, lti=(), csc=None, workspace="aut
     header[_H["T_SCAN"]] = scan["K"] if scan["ok"] else 0
     header[_H["T_SCAN_NBLK"]], header[_H["T_SCAN_NGREST"]] = scan["blk"].shape[0], scan["grest"].size
     header[_H["T_SCAN_NOTHER"]] = scan["nother"]
+    header[_H["T_SCAN_FUSED"]] = scan["fused"]
     header[_H["T_NGREST"]] = tiled["grest"].size
     header[_H["T_CI_OK"]], header[_H["T_NOP"]] = tiled["ci_ok"], tiled["nop"]
     header[_H["T_OK"]], header[_H["T_NSTAGE"]] = tiled["ok"], tiled["stages"].shape[0]

@@ -138,7 +138,7 @@ def test_one_model_for_the_whole_batch_is_the_shared_form(gpu_api, torch_gpu, nx
             obj.update(**{field: float(value.ravel()[0]) if field == "weight" else value})
 
 
-@pytest.mark.parametrize("path", [0, 4, 3], ids=["scan", "toeplitz", "general"])
+@pytest.mark.parametrize("path", [0, 1, 4, 3], ids=["scan", "scan with pre-passes", "toeplitz", "general"])
 @pytest.mark.parametrize("nx,nu,N,B,seed", [(5, 3, 48, 19, 11), (12, 6, 64, 24, 12), (3, 4, 40, 9, 13),
                                             (3, 2, 100, 7, 14)])
 def test_horizon_tables_from_the_systems_own_matrices(gpu_api, torch_gpu, nx, nu, N, B, seed, path):
@@ -165,7 +165,8 @@ def test_horizon_tables_from_the_systems_own_matrices(gpu_api, torch_gpu, nx, nu
     Pl, ql, Gl, hl = (t.clone() for t in lti.assemble(given, out=out))
     assert not any(torch.isnan(t).any().item() for t in (Pl, ql, Gl, hl))
     assert "tiled" in lti.last_kernel()
-    assert ("scan" in lti.last_kernel()) == (path == 0 and N <= 64), lti.last_kernel()
+    assert ("scan" in lti.last_kernel()) == (path in (0, 1) and N <= 64), lti.last_kernel()
+    assert lti.plan.itab[_H["T_SCAN_FUSED"]] == (1 if N <= 64 else 0)      # (path 0: the kernel makes its own table and d; 1: pre-passes)
     # one half at a time: the same numbers
     P2, q2, _, _ = lti.assemble(given, want_constraints=False)
     assert torch.equal(P2, Pl) and torch.equal(q2, ql)

@@ -559,6 +559,22 @@ def test_scan_form_tables_against_the_oracle(cpu_api, nx, nu, N, kw):
     A, B = problems.random_lti_matrices(rng, nx, nu)
     given = rng.normal(0, 0.3, form.given_len)
     out = plan_emulator.run_scan(plan, given, ab=[(A, B)])
+    # the set-up fused into the kernel (H_T_SCAN_FUSED): `given` is the initial state and nothing else, every
+    # workspace row a row of one of the terms, no row of G through the column tables -- then
+    # d[first row of the term + k] = c (A^{k+1} x0)[state], which is what the kernel writes instead of reading d
+    fused = int(it[_H["T_SCAN_FUSED"]])
+    assert fused == (1 if not kw else 0)      # (the others: a given input; a limit on rows no cost has; a row of G over two rows)
+    if fused:
+        K = int(it[_H["T_SCAN"]])
+        gt = it[it[_H["OFF_T_SCAN_GT"]]:it[_H["OFF_T_SCAN_GT"]] + 4 * K].reshape(K, 4)
+        gc = plan.dtab[it[_H["T_DOFF_SCAN_GC"]]:it[_H["T_DOFF_SCAN_GC"]] + K]
+        d, x = np.zeros(K * N), np.array(given, dtype=float)
+        for k in range(N):
+            x = A @ x
+            for g in range(K):
+                d[gt[g, 3] + k] = gc[g] * x[gt[g, 0] // (nu * N)]
+        assert_close(d, out["ref"]["d"][:K * N], 1e-13, "d from the free response")
+        assert plan.itab[_H["RTOT"]] == K * N
     dyn = form.dynamics["plant"]
     saved = list(dyn.matrices)
     try:
