@@ -1079,8 +1079,8 @@ __device__ __forceinline__ double lane_from_next(double v) {
 
 // where things sit in the scan kernel's dynamic LDS (bytes); the table last, at least N doubles in:
 // a window that starts before its row's first step reads what lies in front (and is masked)
-struct ScanLds {
-  unsigned d, par, lam, ticket, rows, tb, total;
+struct ScanLds {  // (byte offsets)
+  unsigned d, par, lam, ticket, rows, tb, pw, total;
 };
 // `rows_in_lds`: the records of the rows of G (16 bytes each: table row, arrow slot, coefficient) ride
 // along -- read per row out of LDS, in order with the table's own reads, instead of through the scalar
@@ -1094,7 +1094,8 @@ __host__ __device__ inline ScanLds scan_lds(int dlen, int nparams, int n, int m,
   x.rows = x.ticket + 16u;
   x.tb = x.rows + (rows_in_lds ? (unsigned)nc * 16u : 0u);
   if (x.tb < (unsigned)N * 8u) x.tb = (unsigned)((N + 1) & ~1) * 8u;
-  x.total = x.tb + (unsigned)(n * m * N) * 8u;
+  x.pw = x.tb + (unsigned)(n * m * N) * 8u;                   // two n x n powers of A (fused set-up)
+  x.total = x.pw + (unsigned)(2 * n * n) * 8u;
   return x;
 }
 // two workgroups per CU as long as an instance stays below this
@@ -1126,70 +1127,62 @@ __global__ __launch_bounds__(BLOCK, 2) void toeplitz_scan_kernel(
   int* ticket = reinterpret_cast<int*>(lds + L.ticket);
   // ---- set-up: the table (the value halves of TB's rows), d, the parameters into LDS -------------
   if (fused) {
-    // Fused set-up (H_T_SCAN_FUSED): no pre-pass has run.  Wavefront 1 makes the table where it is needed --
-    // X_0 = B, X_d = A X_{d-1} (the reference's recurrence, tools.py:24-29), Tc[(i m + j) N + d] = X_d[i][j],
-    // lanes over the n m elements in up to two passes, a row of A in registers, the column of X_{d-1} out
-    // of LDS (a wavefront's LDS operations complete in order: no barrier between the steps) -- while
-    // wavefront 0 runs the free response x_k = A x_{k-1} from x_{-1} = given and writes
-    // d[first row of the term + k] = c x_k[state] for every term: what compose_d_kernel computes through the
-    // column tables when every workspace row is such a row.
+    // Fused set-up (H_T_SCAN_FUSED): no pre-pass has run.  The whole workgroup makes the table where it is needed,
+    // Tc[(i m + j) N + d] = (A^d B)[i][j], and the free response x_k = A^{k+1} given, by DOUBLING: with A^h at
+    // hand, X_{d+h} = A^h X_d for every d < h at once -- log2(N) rounds of independent 12-term products
+    // instead of N dependent steps (the reference's recurrence X_d = A X_{d-1}, tools.py:24-29, as one
+    // wavefront's chain of LDS round trips took 85 us per instance; the association differs from it by a few
+    // ulp, as in the persistent kernel's on-chip tables).  Then d[first row of the term + k] = c x_k[state]
+    // for every term: what compose_d_kernel computes through the column tables when every workspace row
+    // is such a row.
     const double* A = sysA + inst * strideA;
     const double* Bm = sysB + inst * strideB;
     double* Tc = reinterpret_cast<double*>(lds + L.tb);
-    if (wave == 1) {
-      const int nm = n * m;
-      double arow[2][SCAN_AREG];
-      int ej[2];
-      bool live[2];
-#pragma unroll
-      for (int ps = 0; ps < 2; ++ps) {
-        const int e = lane + 64 * ps;
-        live[ps] = e < nm;
-        const int i = live[ps] ? e / m : 0;
-        ej[ps] = live[ps] ? e - i * m : 0;
-#pragma unroll
-        for (int t = 0; t < SCAN_AREG; ++t) arow[ps][t] = (live[ps] && t < n) ? A[i * n + t] : 0.0;
-        if (live[ps]) Tc[e * N] = Bm[e];
-      }
-      for (int d = 1; d < N; ++d) {
-        asm volatile("" ::: "memory");
-        double acc[2] = {0.0, 0.0};
-#pragma unroll
-        for (int ps = 0; ps < 2; ++ps)
-#pragma unroll
-          for (int t = 0; t < SCAN_AREG; ++t)
-            if (t < n) acc[ps] = fma(arow[ps][t], Tc[(t * m + ej[ps]) * N + d - 1], acc[ps]);
-#pragma unroll
-        for (int ps = 0; ps < 2; ++ps)
-          if (live[ps]) Tc[(lane + 64 * ps) * N + d] = acc[ps];
-      }
-    } else if (wave == 0) {
-      double* dl = reinterpret_cast<double*>(lds + L.d);
-      double* xs = reinterpret_cast<double*>(lds + L.lam);   // (the gradient's buffer, not yet in use: two copies of x)
-      double arow[SCAN_AREG];
-#pragma unroll
-      for (int t = 0; t < SCAN_AREG; ++t) arow[t] = (lane < n && t < n) ? A[lane * n + t] : 0.0;
-      double x = lane < n ? given[inst * p.ng + lane] : 0.0;
-      // lane g < K also looks after term g: its state, its first row of d, its coefficient -- read once
-      const unsigned per_state = (unsigned)(m * N);
-      const int4 tg = gts[lane < K ? lane : 0];
-      const int st = (int)((unsigned)tg.x / per_state), drow = tg.w;
-      const double cg = gcs[lane < K ? lane : 0];
-      if (lane < n) xs[lane] = x;
-      for (int k = 0; k < N; ++k) {
-        const double* xk = xs + (k & 1) * n;              // x_{k-1}
-        double* xn = xs + ((k + 1) & 1) * n;              // x_k = A^{k+1} x_{-1}
-        asm volatile("" ::: "memory");
-        double acc = 0.0;
-#pragma unroll
-        for (int t = 0; t < SCAN_AREG; ++t)
-          if (t < n) acc = fma(arow[t], xk[t], acc);
-        if (lane < n) xn[lane] = acc;
-        asm volatile("" ::: "memory");
-        if (lane < K) dl[drow + k] = cg * xn[st];
-      }
-      if (lane == 0 && (dlen & 1) == 0 && dlen > p.rtot) dl[p.rtot] = 0.0;
+    double* dl = reinterpret_cast<double*>(lds + L.d);
+    double* xb = reinterpret_cast<double*>(lds + L.lam);   // [N][n] (the gradient's buffer, not yet in use)
+    double* pw = reinterpret_cast<double*>(lds + L.pw);    // A^have, and the next power beside it
+    const int nn = n * n, nm = n * m;
+    for (int e = tid; e < nn; e += BLOCK) pw[e] = A[e];
+    for (int e = tid; e < nm; e += BLOCK) Tc[e * N] = Bm[e];
+    if (tid < n) {
+      double acc = 0.0;
+      for (int t = 0; t < n; ++t) acc = fma(A[tid * n + t], given[inst * p.ng + t], acc);
+      xb[tid] = acc;                                       // x_0 = A given
     }
+    __syncthreads();
+    int cur = 0;
+    for (int have = 1; have < N;) {
+      const int cnt = have < N - have ? have : N - have;
+      const double* Ph = pw + cur * nn;
+      double* Pn = pw + (cur ^ 1) * nn;
+      const int e1 = cnt * nm, e2 = e1 + cnt * n, e3 = e2 + (have + cnt < N ? nn : 0);
+      for (int e = tid; e < e3; e += BLOCK) {
+        double acc = 0.0;
+        if (e < e1) {                    // X_{have + d} = A^have X_d: element (i, j), d fastest
+          const int r = e / cnt, d = e - r * cnt, i = r / m, j = r - i * m;
+          for (int t = 0; t < n; ++t) acc = fma(Ph[i * n + t], Tc[(t * m + j) * N + d], acc);
+          Tc[r * N + have + d] = acc;
+        } else if (e < e2) {             // x_{have + d} = A^have x_d
+          const int f = e - e1, i = f / cnt, d = f - i * cnt;
+          for (int t = 0; t < n; ++t) acc = fma(Ph[i * n + t], xb[d * n + t], acc);
+          xb[(have + d) * n + i] = acc;
+        } else {                         // A^{2 have}
+          const int f = e - e2, i = f / n, c = f - i * n;
+          for (int t = 0; t < n; ++t) acc = fma(Ph[i * n + t], Ph[t * n + c], acc);
+          Pn[f] = acc;
+        }
+      }
+      __syncthreads();
+      have += cnt;
+      cur ^= 1;
+    }
+    const unsigned per_state = (unsigned)(m * N);
+    for (int e = tid; e < K * N; e += BLOCK) {
+      const int g = e / N, k = e - g * N;
+      const int4 tg = gts[g];
+      dl[tg.w + k] = gcs[g] * xb[k * n + (int)((unsigned)tg.x / per_state)];
+    }
+    if (tid == 0 && dlen > p.rtot) dl[p.rtot] = 0.0;
   } else {
     const char* tb = reinterpret_cast<const char*>(src.ptr[first_u] + inst * src.stride[first_u]);
     const unsigned lds0 = (unsigned)(uintptr_t)lds;
@@ -1932,7 +1925,7 @@ int launch_scan(const PlanDev& p, const SrcTable& src, const SrcTable& eff, cons
   const int32_t* rec = h_itab + p.off_t_lti;
   const int n = rec[TL_N], m = rec[TL_M], N = rec[TL_HORIZON];
   if (p.no > 128 * SCAN_GCH_MAX || n > 64 || (N & 1)) return MPCASM_ERR_LIMIT;
-  if (fused && (n > SCAN_AREG || n * m > 128 || given == nullptr)) return MPCASM_ERR_LIMIT;
+  if (fused && given == nullptr) return MPCASM_ERR_LIMIT;
   const int dlen = p.rtot + (p.rtot & 1);
   // the records of G's rows in LDS while that leaves room for two workgroups per CU
   const int rows_in_lds = scan_lds(dlen, p.nparams, n, m, N, p.nc, true).total + NSTREAM * sizeof(double*) <= SCAN_HALF_CU;
