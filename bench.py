@@ -516,6 +516,10 @@ def c4_record(torch, dev, batch=8192, reps=3):
            "algorithmic_bytes_per_assembly": out_bytes + in_bytes, "bound": "hbm",
            "hbm": {"achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS},
            "workspace_bytes_per_instance": 8 * int(asm.plan.tiled["work"])}
+    # the same form with its set-up as pre-pass kernels and scratch in HBM (MPCASM_OPT_PATH 1: round 4's first version)
+    asm.set_option(capi.OPT_PATH, 1)
+    ms1 = _event_ms(torch, lambda: asm.assemble(given), reps, warm=1, settle_ms=0.0)
+    rec["with_pre_passes"] = {"kernel": asm.last_kernel(), "ms_per_call": ms1}
     # the same plan with its windows multiplied on the matrix core (MPCASM_OPT_PATH 4)
     asm.set_option(capi.OPT_PATH, 4)
     ms4 = _event_ms(torch, lambda: asm.assemble(given), 2, warm=1, settle_ms=0.0)
@@ -666,7 +670,7 @@ def compact_line(rec):
     out = {k: rec[k] for k in ("metric", "value", "unit", "n_gpus", "n_ranks_seen", "steps", "warmup",
                                "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
     c = rec["config"]
-    out["config"] = {"workload": "C2 biped LIPM N=16 2 axes no=%d nc=%d, per-instance (A,B)/given/aim, %s"
+    out["config"] = {"workload": "C2 biped LIPM N=16 no=%d nc=%d, per-instance (A,B)/given/aim, %s"
                                  % (c["no"], c["nc"], "K1 on chip" if c["fused"] else "fill+assemble"),
                      "batch_per_gpu": c["batch_per_gpu"], "global_batch": c["global_batch"],
                      "streams": c["launch_streams"]}
@@ -708,6 +712,8 @@ def compact_line(rec):
                         "per_s": v["assemblies_per_s"], "frac": v["hbm"]["frac"],
                         "mfma_form": {"ms": v["toeplitz_form"]["ms_per_call"],
                                       "mfma_frac": v["toeplitz_form"]["mfma_frac"]}}
+            if "with_pre_passes" in v:
+                out[key]["prepass_ms"] = v["with_pre_passes"]["ms_per_call"]
             if "shared_model" in v:     # (S, U shared by the batch: the shared-model form, the general form)
                 out[key]["shared_ms"] = v["shared_model"]["ms_per_call"]
                 out[key]["general_ms"] = v["general_form"]["ms_per_call"]
@@ -1106,7 +1112,7 @@ def run_rank(args):
             record["cpu_baseline"] = {
                 "value": cp, "unit": "assemblies/s", "cores": procs, "kind": "port",
                 "single_core_value": c1,
-                "sample_short": "oracle/assemble_port.c (C port of the path, gcc -O3): %d assemblies in 5 s on %d threads"
+                "sample_short": "oracle/assemble_port.c (C port, gcc -O3): %d assemblies in 5 s on %d threads"
                                 % (np_, procs),
                 "sample": "%d assemblies of the same workload (per-instance (A, B), given, aim) in 5 s on %d threads: "
                           "extend_matrices + dense preview matrices + every limit and cost per instance, the loop "
