@@ -85,7 +85,9 @@ __device__ __forceinline__ double lane_value(double v, int src) { return __shfl(
 // CPT: columns per thread (no <= SW_BLOCK * CPT); NS, MS, AS: the system's states, inputs and the axes
 // as constants (0: read from the plan) -- the loops over them unroll without guards, which is a
 // third of the instructions of a step for the LIPM family (n = 3, m = 1, two axes: C5)
-template <int CPT, int NS, int MS, int AS>
+// PAIR (with CPT = 2): a thread's two columns are NEIGHBOURS (2 tid, 2 tid + 1) instead of SW_BLOCK apart: the two
+// elements it computes of a row of G or P leave as ONE 16-byte store.
+template <int CPT, int NS, int MS, int AS, bool PAIR = false>
 __global__ __launch_bounds__(SW_BLOCK) void ltv_sweep_kernel(
     PlanDev p, const double* __restrict__ sysA, long long strideA, const double* __restrict__ sysB,
     long long strideB, const double* __restrict__ params, const double* __restrict__ given,
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(SW_BLOCK) void ltv_sweep_kernel(
   const int32_t* colw = p.itab + p.off_sw_col;
 #pragma unroll
   for (int t = 0; t < CPT; ++t) {
-    const int c = tid + t * SW_BLOCK;
+    const int c = PAIR ? tid * CPT + t : tid + t * SW_BLOCK;
     ca[t] = -1;
     cj[t] = cl[t] = 0;
     dPc[t] = dqc[t] = 0.0;
@@ -385,7 +387,7 @@ __global__ __launch_bounds__(SW_BLOCK) void ltv_sweep_kernel(
   if (P != nullptr)
 #pragma unroll
     for (int t = 0; t < CPT; ++t) {
-      const int c = tid + t * SW_BLOCK;
+      const int c = PAIR ? tid * CPT + t : tid + t * SW_BLOCK;
       if (c < no) {
         const double* Bl = AB + cl[t] * abw + nn;
         const double* lm = lamT + (ca[t] * N + cl[t]) * n;
@@ -428,13 +430,13 @@ __global__ __launch_bounds__(SW_BLOCK) void ltv_sweep_kernel(
   // (u = A_l u) by selects; threads without a column leave here).  Everything a step needs comes out of
   // LDS in 16-byte pieces up front -- the step's [A | B] (the same for every lane), the lane's own axis'
   // Psi_l B_l[:, j] and the weights of the step's lines of G -- and a thread writes the row of its OWN axis.
-  if (CPT == 1 && tid >= no) return;
+  if ((CPT == 1 && tid >= no) || (PAIR && tid * CPT >= no)) return;
   double u[CPT][SW_NMAX];
   double* prow[CPT][SW_MMAX];      // P[(own axis, j, step l)][own column], stepping down a row per step
   int goff[CPT];                   // the lane's axis' slice of a step of gv, of a slot of lw (doubles)
 #pragma unroll
   for (int t = 0; t < CPT; ++t) {
-    const int c = tid + t * SW_BLOCK;
+    const int c = PAIR ? tid * CPT + t : tid + t * SW_BLOCK;
     const int cat = ca[t] < 0 ? 0 : ca[t];
     goff[t] = cat * m * SW_NMAX;
 #pragma unroll
@@ -497,35 +499,64 @@ __global__ __launch_bounds__(SW_BLOCK) void ltv_sweep_kernel(
       for (int i = 0; i < SW_NMAX; ++i) u[t][i] = y[i];
     }
     if (P != nullptr) {
+      double pv[CPT][SW_MMAX];
 #pragma unroll
       for (int t = 0; t < CPT; ++t) {
-        const int c = tid + t * SW_BLOCK;
         const double* gl = gv + (size_t)l * naxes * m * SW_NMAX + goff[t];
 #pragma unroll
         for (int j = 0; j < SW_MMAX; ++j) {
-          if (j >= m) break;
           double v = (cl[t] == l && cj[t] == j) ? dPc[t] : 0.0;
 #pragma unroll
           for (int s_ = 0; s_ < SW_NMAX; ++s_)
-            if (s_ < n) v = fma(gl[j * SW_NMAX + s_], u[t][s_], v);
-          // this axis: at and below the diagonal now, above it in the backward sweep
-          if ((CPT == 1 || c < no) && cl[t] <= l) *prow[t][j] = v;   // (plain: the backward sweep completes the line)
-          prow[t][j] += no;
+            if (s_ < n && j < m) v = fma(gl[j * SW_NMAX + s_], u[t][s_], v);
+          pv[t][j] = v;
         }
+      }
+      // this axis: at and below the diagonal now, above it in the backward sweep (plain stores: the
+      // backward sweep completes the line)
+#pragma unroll
+      for (int j = 0; j < SW_MMAX; ++j) {
+        if (j >= m) break;
+        if constexpr (PAIR) {
+          const bool m0 = cl[0] <= l, m1 = cl[1] <= l;
+          if (m0 && m1 && prow[1][j] == prow[0][j] + 1) {
+            *reinterpret_cast<double2*>(prow[0][j]) = double2{pv[0][j], pv[1][j]};
+          } else {
+            if (m0) *prow[0][j] = pv[0][j];
+            if (m1) *prow[1][j] = pv[1][j];
+          }
+        } else {
+#pragma unroll
+          for (int t = 0; t < CPT; ++t) {
+            const int c = tid + t * SW_BLOCK;
+            if ((CPT == 1 || c < no) && cl[t] <= l) *prow[t][j] = pv[t][j];
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < CPT; ++t) prow[t][j] += no;
       }
     }
     if (G != nullptr && reg_lines > 0) {
 #pragma unroll
       for (int x = 0; x < RLMAX; ++x) {
         if (x >= reg_lines) break;
+        double vv[CPT];
 #pragma unroll
         for (int t = 0; t < CPT; ++t) {
-          const int c = tid + t * SW_BLOCK;
-          double v = 0.0;
+          vv[t] = 0.0;
 #pragma unroll
           for (int s_ = 0; s_ < SW_NMAX; ++s_)
-            if (s_ < n) v = fma(wreg[x][t][s_], u[t][s_], v);
-          if (CPT == 1 || c < no) store_result(gp[x] + c, v);
+            if (s_ < n) vv[t] = fma(wreg[x][t][s_], u[t][s_], vv[t]);
+        }
+        if constexpr (PAIR) {
+          // (an even width: the pair lies in the row or not at all, 16-byte aligned)
+          store_result(reinterpret_cast<double2*>(gp[x] + tid * 2), double2{vv[0], vv[1]});
+        } else {
+#pragma unroll
+          for (int t = 0; t < CPT; ++t) {
+            const int c = tid + t * SW_BLOCK;
+            if (CPT == 1 || c < no) store_result(gp[x] + c, vv[t]);
+          }
         }
         gp[x] += no;
       }
@@ -535,7 +566,7 @@ __global__ __launch_bounds__(SW_BLOCK) void ltv_sweep_kernel(
         double* grow = Gb + (size_t)(word & 0xFFFFF) * no;
 #pragma unroll
         for (int t = 0; t < CPT; ++t) {
-          const int c = tid + t * SW_BLOCK;
+          const int c = PAIR ? tid * CPT + t : tid + t * SW_BLOCK;
           const double* wp = lw + (size_t)(word >> 20) * naxes * SW_NMAX + (goff[t] / m);
           double v = 0.0;
           for (int s_ = 0; s_ < n; ++s_) v = fma(wp[s_], u[t][s_], v);
@@ -568,7 +599,7 @@ __global__ __launch_bounds__(SW_BLOCK) void ltv_sweep_kernel(
         double* grow = Gb + (size_t)(wcur[x] & 0xFFFFF) * no;
 #pragma unroll
         for (int t = 0; t < CPT; ++t) {
-          const int c = tid + t * SW_BLOCK;
+          const int c = PAIR ? tid * CPT + t : tid + t * SW_BLOCK;
           double v = 0.0;
 #pragma unroll
           for (int s_ = 0; s_ < SW_NMAX; ++s_)
@@ -583,7 +614,7 @@ __global__ __launch_bounds__(SW_BLOCK) void ltv_sweep_kernel(
         double* grow = Gb + (size_t)(word & 0xFFFFF) * no;
 #pragma unroll
         for (int t = 0; t < CPT; ++t) {
-          const int c = tid + t * SW_BLOCK;
+          const int c = PAIR ? tid * CPT + t : tid + t * SW_BLOCK;
           const double* wp = lw + (size_t)slot * naxes * SW_NMAX + (goff[t] / m);
           double v = 0.0;
           for (int s_ = 0; s_ < n; ++s_) v = fma(wp[s_], u[t][s_], v);
@@ -607,7 +638,7 @@ __global__ __launch_bounds__(SW_BLOCK) void ltv_sweep_kernel(
   for (int l = N - 1; l >= 0; --l) {
     const double* An = AB + (l + 1 < N ? l + 1 : l) * abw;
     const double* Bl = AB + l * abw + nn;
-    double at[SW_NMAX][SW_NMAX], bm[SW_NMAX][SW_MMAX];
+    double at[SW_NMAX][SW_NMAX], bm[SW_NMAX][SW_MMAX], bv[CPT][SW_MMAX];
 #pragma unroll
     for (int i = 0; i < SW_NMAX; ++i)
 #pragma unroll
@@ -618,7 +649,7 @@ __global__ __launch_bounds__(SW_BLOCK) void ltv_sweep_kernel(
       for (int j = 0; j < SW_MMAX; ++j) bm[s_][j] = (s_ < n && j < m) ? Bl[s_ * m + j] : 0.0;
 #pragma unroll
     for (int t = 0; t < CPT; ++t) {
-      const int c = tid + t * SW_BLOCK;
+      const int c = PAIR ? tid * CPT + t : tid + t * SW_BLOCK;
       const double* gl = gv + (size_t)l * naxes * m * SW_NMAX + goff[t] + cj[t] * SW_NMAX;
       double gnow[SW_NMAX], y[SW_NMAX];
 #pragma unroll
@@ -646,7 +677,22 @@ __global__ __launch_bounds__(SW_BLOCK) void ltv_sweep_kernel(
 #pragma unroll
         for (int s_ = 0; s_ < SW_NMAX; ++s_)
           if (s_ < n) v = fma(bm[s_][j], z[t][s_], v);
-        if ((CPT == 1 || c < no) && cl[t] > l) *prow[t][j] = v;
+        bv[t][j] = v;
+        if constexpr (!PAIR)
+          if ((CPT == 1 || c < no) && cl[t] > l) *prow[t][j] = v;
+      }
+    }
+    if constexpr (PAIR) {
+#pragma unroll
+      for (int j = 0; j < SW_MMAX; ++j) {
+        if (j >= m) break;
+        const bool m0 = cl[0] > l, m1 = cl[1] > l;
+        if (m0 && m1 && prow[1][j] == prow[0][j] + 1) {
+          *reinterpret_cast<double2*>(prow[0][j]) = double2{bv[0][j], bv[1][j]};
+        } else {
+          if (m0) *prow[0][j] = bv[0][j];
+          if (m1) *prow[1][j] = bv[1][j];
+        }
       }
     }
   }
@@ -699,9 +745,10 @@ int launch_assemble_sweep(const PlanDev& p, const SrcTable& src, const double* p
   const double* A = src.ptr[p.sw_src_a];
   const double* Bm = src.ptr[p.sw_src_b];
   const long long sa = src.stride[p.sw_src_a], sb = src.stride[p.sw_src_b];
-#define MPCASM_SWEEP_CASE(CPT, NS, MS, AS)                                                             \
+#define MPCASM_SWEEP_CASE(CPT, NS, MS, AS) MPCASM_SWEEP_CASE_P(CPT, NS, MS, AS, false)
+#define MPCASM_SWEEP_CASE_P(CPT, NS, MS, AS, PAIR)                                                     \
   if (p.no <= SW_BLOCK * CPT && (NS == 0 || (n == NS && m == MS && naxes == AS))) {                    \
-    auto kernel = ltv_sweep_kernel<CPT, NS, MS, AS>;                                                   \
+    auto kernel = ltv_sweep_kernel<CPT, NS, MS, AS, PAIR>;                                             \
     if (lds > 64 * 1024) {                                                                             \
       *err = allow_whole_lds(reinterpret_cast<const void*>(kernel));                                   \
       if (*err != hipSuccess) return MPCASM_ERR_HIP;                                                   \
@@ -711,11 +758,14 @@ int launch_assemble_sweep(const PlanDev& p, const SrcTable& src, const double* p
     *err = hipGetLastError();                                                                          \
     return *err == hipSuccess ? MPCASM_OK : MPCASM_ERR_HIP;                                            \
   }
+  if ((p.no & 1) == 0 && (p.sw_horizon & 1) == 0) { MPCASM_SWEEP_CASE_P(2, 3, 1, 2, true) }
   MPCASM_SWEEP_CASE(1, 3, 1, 2)
+  if ((p.no & 1) == 0 && (p.sw_horizon & 1) == 0) { MPCASM_SWEEP_CASE_P(2, 0, 0, 0, true) }
   MPCASM_SWEEP_CASE(1, 0, 0, 0)
   MPCASM_SWEEP_CASE(2, 0, 0, 0)
   MPCASM_SWEEP_CASE(4, 0, 0, 0)
 #undef MPCASM_SWEEP_CASE
+#undef MPCASM_SWEEP_CASE_P
   return MPCASM_ERR_LIMIT;
 }
 
