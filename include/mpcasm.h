@@ -353,12 +353,17 @@ int mpcasm_box_transform_ss(double* d_params, int64_t n_params, int batch,
  * loop starts a tick from the last one's), else started from x = 0, y = 0, z = min(0, h); always
  * written.  d_res (may be NULL) [batch][2]: OSQP's residuals |Gx - z|_inf and |Px + q + G'y|_inf after
  * the last iteration -- the caller decides whether to iterate on.  An instance whose
- * P + sigma I + rho G'G is not positive definite gets NaNs.  MPCASM_ERR_LIMIT when one instance's
+ * P + sigma I + rho G'G is not positive definite gets NaNs.
+ * d_kinv (may be NULL) [batch][no][no]: the inverse of P + sigma I + rho G'G.  kinv_valid == 0: written by this
+ * call; != 0: READ instead of factoring -- for a caller whose P and G (and rho, sigma) did not change since the call
+ * that wrote it: the same model and structure with a new `given` changes q and h only (body.py:236-302), and the
+ * factorisation is the larger part of a call of a few dozen iterations.  MPCASM_ERR_LIMIT when one instance's
  * matrices do not fit on chip ((no + max(nc, no)) * (no | 1) + 4 no + 4 nc doubles in 156 KB of LDS:
  * the biped up to N = 24 and beyond; not C3). */
 int mpcasm_admm(int no, int nc, const double* d_P, const double* d_q, const double* d_G,
                 const double* d_h, double* d_x, double* d_y, double* d_z, double* d_res, double rho,
-                double sigma, double alpha, int iters, int warm, int batch, void* stream);
+                double sigma, double alpha, int iters, int warm, int batch, double* d_kinv, int kinv_valid,
+                void* stream);
 
 #ifdef __cplusplus
 }

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(ADMM_BLOCK) void admm_kernel(
     int no, int nc, const double* __restrict__ P, const double* __restrict__ q,
     const double* __restrict__ G, const double* __restrict__ h, double* __restrict__ X,
     double* __restrict__ Y, double* __restrict__ Z, double* __restrict__ res, double rho, double sigma,
-    double alpha, int iters, int warm, int batch) {
+    double alpha, int iters, int warm, int batch, double* __restrict__ Kinv, int kinv_valid) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int lane = threadIdx.x;
   const long inst = blockIdx.x;
@@ -114,6 +114,9 @@ __global__ __launch_bounds__(ADMM_BLOCK) void admm_kernel(
   };
 
   // ---- K = P + sigma I + rho G'G ------------------------------------------------------------------
+  // (a caller whose P and G did not change since the last call -- the same model and structure, a new
+  // `given` -- hands K^-1 back in: no factorisation, the larger part of a call of 25 iterations)
+  const bool reuse = Kinv != nullptr && kinv_valid != 0;
   load_g();
   for (int e = lane; e < no; e += ADMM_BLOCK) {
     qs[e] = q[(size_t)inst * no + e];
@@ -127,6 +130,10 @@ __global__ __launch_bounds__(ADMM_BLOCK) void admm_kernel(
   __syncthreads();
   for (int e = lane; e < no * no; e += ADMM_BLOCK) {
     const int a = e / no, b = e - a * no;
+    if (reuse) {
+      Mi[a * ld + b] = Kinv[(size_t)inst * no * no + e];
+      continue;
+    }
     const double acc = dot4(Gs + a, ld, Gs + b, ld, nc, 0.0);
     Mi[a * ld + b] = fma(rho, acc, Pb[e]) + (a == b ? sigma : 0.0);
   }
@@ -137,6 +144,7 @@ __global__ __launch_bounds__(ADMM_BLOCK) void admm_kernel(
 
   // ---- Cholesky, in place (the lower triangle): K = L L' ------------------------------------------
   bool ok = true;
+  if (!reuse) {
   for (int k = 0; k < no; ++k) {
     const double dkk = Mi[k * ld + k];
     ok = ok && dkk > 0.0;
@@ -184,7 +192,10 @@ __global__ __launch_bounds__(ADMM_BLOCK) void admm_kernel(
     Mi[a * ld + b] = dot4(T + i0 * ld + a, ld, T + i0 * ld + b, ld, no - i0, 0.0);
   }
   __syncthreads();
-  load_g();
+  if (Kinv != nullptr)
+    for (int e = lane; e < no * no; e += ADMM_BLOCK) Kinv[(size_t)inst * no * no + e] = ok ? Mi[(e / no) * ld + e % no] : __builtin_nan("");
+  }
+  if (!reuse) load_g();   // (the factorisation used G's place for L^-1)
   __syncthreads();
 
   // ---- the iterations -------------------------------------------------------------------------------------
@@ -248,7 +259,8 @@ size_t admm_lds_bytes(int no, int nc) { return (size_t)admm_lds(no, nc).total * 
 
 int launch_admm(int no, int nc, const double* P, const double* q, const double* G, const double* h,
                 double* x, double* y, double* z, double* res, double rho, double sigma, double alpha,
-                int iters, int warm, int batch, hipStream_t stream, hipError_t* err) {
+                int iters, int warm, int batch, double* kinv, int kinv_valid, hipStream_t stream,
+                hipError_t* err) {
   const size_t lds = admm_lds_bytes(no, nc);
   if (lds > (size_t)RESIDENT_LDS_LIMIT) return MPCASM_ERR_LIMIT;
   if (lds > 64 * 1024) {
@@ -256,7 +268,7 @@ int launch_admm(int no, int nc, const double* P, const double* q, const double* 
     if (*err != hipSuccess) return MPCASM_ERR_HIP;
   }
   hipLaunchKernelGGL(admm_kernel, dim3((unsigned)batch), dim3(ADMM_BLOCK), lds, stream, no, nc, P, q, G,
-                     h, x, y, z, res, rho, sigma, alpha, iters, warm, batch);
+                     h, x, y, z, res, rho, sigma, alpha, iters, warm, batch, kinv, kinv_valid);
   *err = hipGetLastError();
   return *err == hipSuccess ? MPCASM_OK : MPCASM_ERR_HIP;
 }

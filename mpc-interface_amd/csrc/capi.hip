@@ -1546,15 +1546,17 @@ int mpcasm_box_transform_ss(double* d_params, int64_t n_params, int batch,
 
 int mpcasm_admm(int no, int nc, const double* d_P, const double* d_q, const double* d_G,
                 const double* d_h, double* d_x, double* d_y, double* d_z, double* d_res, double rho,
-                double sigma, double alpha, int iters, int warm, int batch, void* stream) {
+                double sigma, double alpha, int iters, int warm, int batch, double* d_kinv, int kinv_valid,
+                void* stream) {
   if (no < 1 || nc < 0 || batch < 0 || iters < 0 || !(rho > 0.0) || !(sigma > 0.0) || !(alpha > 0.0) ||
       !(alpha < 2.0) || no > (1 << 12) || nc > (1 << 16))
     return MPCASM_ERR_ARG;
   if (batch == 0) return MPCASM_OK;
   if (!d_P || !d_q || !d_x || (nc > 0 && (!d_G || !d_h || !d_y || !d_z))) return MPCASM_ERR_ARG;
   hipError_t err;
+  if (kinv_valid != 0 && d_kinv == nullptr) return MPCASM_ERR_ARG;
   const int rc = launch_admm(no, nc, d_P, d_q, d_G, d_h, d_x, d_y, d_z, d_res, rho, sigma, alpha, iters,
-                             warm != 0, batch, static_cast<hipStream_t>(stream), &err);
+                             warm != 0, batch, d_kinv, kinv_valid != 0, static_cast<hipStream_t>(stream), &err);
   if (rc == MPCASM_ERR_HIP) g_last_hip = (int)err;
   return rc;
 }

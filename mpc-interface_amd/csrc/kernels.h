@@ -90,7 +90,8 @@ int launch_gather(const double* src, long long src_stride, const int32_t* index,
                   double* dst, int batch, hipStream_t stream, hipError_t* err);
 int launch_admm(int no, int nc, const double* P, const double* q, const double* G, const double* h,
                 double* x, double* y, double* z, double* res, double rho, double sigma, double alpha,
-                int iters, int warm, int batch, hipStream_t stream, hipError_t* err);
+                int iters, int warm, int batch, double* kinv, int kinv_valid, hipStream_t stream,
+                hipError_t* err);
 int launch_preview(const double* PM, const double* given, const double* optim, double* out,
                    int batch, int rows, int ng, int no, hipStream_t stream, hipError_t* err);
 

@@ -80,7 +80,7 @@ SIGNATURES = {
                                                     _void_p, _void_p, ctypes.c_int, ctypes.c_int,
                                                     _void_p, _void_p, ctypes.c_int, _void_p]),
     "mpcasm_admm": (ctypes.c_int, [ctypes.c_int, ctypes.c_int] + [_void_p] * 8 + [ctypes.c_double] * 3 +
-                    [ctypes.c_int, ctypes.c_int, ctypes.c_int, _void_p]),
+                    [ctypes.c_int, ctypes.c_int, ctypes.c_int, _void_p, ctypes.c_int, _void_p]),
     "mpcasm_gather": (ctypes.c_int, [_void_p, ctypes.c_int64, _void_p, ctypes.c_int, _void_p,
                                      ctypes.c_int, _void_p]),
     "mpcasm_box_transform": (ctypes.c_int, [_void_p, ctypes.c_int64, ctypes.c_int, _void_p,

@@ -105,13 +105,16 @@ OSQP_RHO, OSQP_SIGMA, OSQP_ALPHA = 0.1, 1e-6, 1.6     # OSQP's default steps
 
 
 def admm(P, q, G, h, x=None, y=None, z=None, iters=50, rho=OSQP_RHO, sigma=OSQP_SIGMA, alpha=OSQP_ALPHA,
-         residuals=True, stream=None):
+         residuals=True, stream=None, kinv=None, kinv_valid=False):
     """``iters`` iterations of OSQP's ADMM on a batch of dense QPs ``min 1/2 x'Px + q'x s.t. Gx <= h``
     (``mpcasm_admm``) -- the solver call of the walking loop, ``osqp_solve_qp(P=Q, q=q, G=A, h=h)``
     (biped_mpc_loop.py:60), on the device tensors :meth:`Assembler.assemble` returns: ``P (B, no, no)``,
     ``q (B, no)``, ``G (B, nc, no)``, ``h (B, nc)``.  ``x, y, z``: the iterates of a warm start (all three,
     device tensors, updated IN PLACE) or None for a cold start.  Returns ``x, y, z, res`` with
-    ``res (B, 2)`` = OSQP's primal and dual residuals (None when ``residuals`` is off)."""
+    ``res (B, 2)`` = OSQP's primal and dual residuals (None when ``residuals`` is off).
+    ``kinv``: a ``(B, no, no)`` device tensor for the inverse of ``P + sigma I + rho G'G`` -- written by this call,
+    or, with ``kinv_valid``, read instead of factoring (``P``, ``G``, ``rho``, ``sigma`` unchanged since the call that
+    wrote it: a new ``given`` on the same model changes ``q`` and ``h`` only)."""
     torch = require_device()
     for t in (P, q, G, h):
         if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()):
@@ -133,11 +136,17 @@ def admm(P, q, G, h, x=None, y=None, z=None, iters=50, rho=OSQP_RHO, sigma=OSQP_
         y = torch.empty((batch, nc), dtype=torch.float64, device=P.device)
         z = torch.empty((batch, nc), dtype=torch.float64, device=P.device)
     res = torch.empty((batch, 2), dtype=torch.float64, device=P.device) if residuals else None
+    if kinv is not None and not (isinstance(kinv, torch.Tensor) and kinv.device == P.device and kinv.dtype == torch.float64
+                                 and kinv.is_contiguous() and tuple(kinv.shape) == (batch, no, no)):
+        raise ValueError("kinv: a contiguous float64 (B, no, no) tensor on P's device")
+    if kinv_valid and kinv is None:
+        raise ValueError("kinv_valid without kinv")
     with torch.cuda.device(P.device):
         rc = capi.load().mpcasm_admm(no, nc, P.data_ptr(), q.data_ptr(), G.data_ptr(), h.data_ptr(),
                                      x.data_ptr(), y.data_ptr(), z.data_ptr(),
                                      res.data_ptr() if residuals else None, float(rho), float(sigma),
                                      float(alpha), int(iters), 1 if warm else 0, batch,
+                                     kinv.data_ptr() if kinv is not None else None, 1 if kinv_valid else 0,
                                      _stream_handle(torch, stream))
     capi.check(rc, "mpcasm_admm")
     return x, y, z, res

@@ -98,6 +98,33 @@ def test_from_the_assembly_to_the_solution_for_a_fleet_of_bipeds(gpu_api, torch_
     assert int((y > 1e-9).sum(dim=1).min()) >= 1          # (limits bind for every walker)
 
 
+def test_the_inverse_kept_from_one_call_to_the_next(gpu_api, torch_gpu):
+    """The same model with a new `given`: P and G as before, q and h new (body.py:236-302).  A call that is handed
+    the K^-1 an earlier call wrote gives the iterates of a call that factors again, bit for bit -- and does not
+    look at P any more."""
+    torch = torch_gpu
+    from mpcasm import engine
+
+    rng = np.random.default_rng(5)
+    B, no, nc = 33, 36, 76
+    P, q, G, h = to_dev(torch, *random_qps(rng, B, no, nc))
+    kinv = torch.full((B, no, no), float("nan"), dtype=torch.float64, device="cuda")
+    x0, y0, z0, _ = engine.admm(P, q, G, h, iters=20, rho=1.0, kinv=kinv)
+    assert not bool(torch.isnan(kinv).any())
+    Kref = np.linalg.inv(P[3].cpu().numpy() + 1e-6 * np.eye(no) + G[3].cpu().numpy().T @ G[3].cpu().numpy())
+    assert_close(kinv[3].cpu().numpy(), Kref, 1e-9, "K^-1")
+    q2, h2 = to_dev(torch, rng.standard_normal((B, no)), rng.uniform(0.1, 1.0, (B, nc)))
+    fresh = engine.admm(P, q2, G, h2, iters=30, rho=1.0)
+    garbage = torch.full_like(P, float("nan"))                 # (not read with a valid inverse and no residuals)
+    kept = engine.admm(garbage, q2, G, h2, iters=30, rho=1.0, kinv=kinv, kinv_valid=True, residuals=False)
+    for a, b in zip(fresh[:3], kept[:3]):
+        assert torch.equal(a, b)
+    with pytest.raises(ValueError):
+        engine.admm(P, q2, G, h2, kinv_valid=True)
+    with pytest.raises(ValueError):
+        engine.admm(P, q2, G, h2, kinv=kinv[:, :5].contiguous())
+
+
 def test_what_the_kernel_refuses(gpu_api, torch_gpu):
     torch = torch_gpu
     from mpcasm import capi, engine
