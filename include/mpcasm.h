@@ -174,7 +174,9 @@ int mpcasm_plan_sizes(const mpcasm_plan* plan, int64_t out[8]);
 int mpcasm_plan_csc_sizes(const mpcasm_plan* plan, int64_t out[2]);
 
 /* Bytes of scratch the assembly of `batch` instances needs (device memory,
- * caller-allocated, 16-byte aligned). */
+ * caller-allocated, 16-byte aligned): a part per instance and, for wide problems, a part per launch
+ * behind it (the shared-model form's tables) -- a buffer sized for a larger batch serves every
+ * smaller one. */
 int mpcasm_workspace_bytes(const mpcasm_plan* plan, int batch, size_t* out_bytes);
 
 /* K2+K3+K4  batched QP assembly --------------------------------------------
