@@ -360,7 +360,7 @@ int mpcasm_box_transform_ss(double* d_params, int64_t n_params, int batch,
  * call; != 0: READ instead of factoring -- for a caller whose P and G (and rho, sigma) did not change since the call
  * that wrote it: the same model and structure with a new `given` changes q and h only (body.py:236-302), and the
  * factorisation is the larger part of a call of a few dozen iterations.  MPCASM_ERR_LIMIT when one instance's
- * matrices do not fit on chip ((no + max(nc, no)) * (no | 1) + 4 no + 4 nc doubles in 156 KB of LDS:
+ * matrices do not fit on chip ((no + max(nc, no)) * (no | 1) + 8 no + 4 nc + 4 max(nc, no) doubles in 156 KB of LDS:
  * the biped up to N = 24 and beyond; not C3). */
 int mpcasm_admm(int no, int nc, const double* d_P, const double* d_q, const double* d_G,
                 const double* d_h, double* d_x, double* d_y, double* d_z, double* d_res, double rho,
