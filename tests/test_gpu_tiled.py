@@ -368,6 +368,64 @@ def test_c4_at_its_per_gpu_batch_in_one_call(gpu_api, torch_gpu):
     assert _rel(q0 + q1, qs + qz) <= 1e-12 and _rel(h0 + h1, hs + hz) <= 1e-12
 
 
+def test_c4_with_one_system_for_the_batch_in_one_call(gpu_api, torch_gpu):
+    """C4 at 8192 instances in ONE call with S, U of ONE system read from memory (the shared-model form): every
+    weight an instance's own, `given` per instance.  P symmetric and exactly the weighted sum it claims to be
+    (affine in each instance's weights: three launches with scaled weights), G the same for all instances
+    (no arrow differs here), q and h affine in `given`, sampled instances against the oracle and the whole
+    launch against the general form on a slice."""
+    torch = torch_gpu
+    from mpcasm import capi, engine
+
+    nx, nu, N, B = 12, 6, 64, 8192
+    if torch.cuda.get_device_properties(0).total_memory < 120e9:
+        pytest.skip("needs 60 GB of device memory")
+    rng = np.random.default_rng(20263)
+    form = problems.random_lti(gpu_api, rng, nx=nx, nu=nu, N=N)
+    asm = engine.Assembler(form, batch=B)
+    names = [n for n in form.goals if n.startswith("track")]
+    ws = {n: rng.uniform(0.1, 1.0, [B, 1, 1]) for n in names}
+    for n in names:
+        asm.set_param("cost", n, "weight", ws[n])
+    g0 = torch.as_tensor(rng.normal(0, 0.3, [B, form.given_len]), device="cuda")
+    g1 = torch.as_tensor(rng.normal(0, 0.3, [B, form.given_len]), device="cuda")
+    P, q, G, h = asm.assemble(g0)
+    assert "shared" in asm.last_kernel(), asm.last_kernel()
+    q0, h0 = q.clone(), h.clone()
+    for lo in range(0, B, 512):
+        blk = P[lo:lo + 512]
+        assert _rel(blk.transpose(1, 2), blk) <= RTOL_TIGHT
+    for lo in range(0, B, 256):
+        assert torch.equal(G[lo:lo + 256], G[:1].expand(min(256, B - lo), -1, -1))
+    goals = {n: form.goals[n] for n in names}
+    saved = {n: goals[n].weight for n in names}
+    try:
+        for b in (0, 15, 16, 4097, B - 1):                            # (first / last instances of the workgroups' groups)
+            for n in names:
+                goals[n].update(weight=float(ws[n][b, 0, 0]))
+            Ao, ho, Qo, qo = orc.assemble(form, g0[b].cpu().numpy().reshape(-1, 1))
+            assert_close(P[b].cpu().numpy(), Qo, RTOL), assert_close(q[b].cpu().numpy(), qo.ravel(), RTOL)
+            assert_close(G[b].cpu().numpy(), Ao, RTOL), assert_close(h[b].cpu().numpy(), ho.ravel(), RTOL)
+    finally:
+        for n in names:
+            goals[n].update(weight=saved[n])
+    # the general form on the first 40 instances of the same launch
+    small = engine.Assembler(form, batch=40)
+    for n in names:
+        small.set_param("cost", n, "weight", ws[n][:40])
+    small.set_option(capi.OPT_PATH, 3)
+    Pg, qg, Gg, hg = small.assemble(g0[:40])
+    assert small.last_kernel() == "tiled_assemble_kernel"
+    assert max(_rel(P[:40], Pg), _rel(q[:40], qg), _rel(G[:40], Gg), _rel(h[:40], hg)) <= RTOL_TIGHT
+    # q, h affine in given; P does not depend on it
+    Pa = P[::1024].clone()
+    _, q1, _, h1 = (t.clone() for t in asm.assemble(g1))
+    _, qz, _, hz = (t.clone() for t in asm.assemble(torch.zeros_like(g0)))
+    Pb, qs, _, hs = asm.assemble(g0 + g1)
+    assert torch.equal(Pb[::1024], Pa)
+    assert _rel(q0 + q1, qs + qz) <= 1e-12 and _rel(h0 + h1, hs + hz) <= 1e-12
+
+
 def _two_systems(api, rng, N, nx1, nu1, nx2, nu2, optim_second=True):
     """Two independent LTI plants in one formulation (inputs u*, v*), tracking + bounds on states of
     both; with ``optim_second`` False the second plant's inputs are GIVEN (they enter d, h, q only)."""
