@@ -19,7 +19,10 @@
 //     G[line of step l][(j',l')] = arrow (c . u)                                         (forward sweep)
 // -- O(n) multiply-adds per element of P and G, every element written once, nothing but the results
 // and 8 N (n^2 + n m) bytes of (A_k, B_k) crosses HBM.  One workgroup per instance; a thread owns a
-// column (an axis, an input, a step) and carries its u, then its z, in registers; all steps'
+// column (an axis, an input, a step) -- two neighbouring ones where the width allows (PAIR: its two elements
+// of a row leave as one 16-byte store, which is what this kernel's time follows: the width of a store and
+// where the results lie, not its instruction count) -- and carries its u, then its z, in registers; it
+// writes the rows of its OWN axis (the blocks of P between axes are zeros, written as such); all steps'
 // (A_k, B_k) sit in LDS (the "per-step reload" is an LDS read).  The plan states what lets a
 // formulation run here (plan.py _sweep_tables): one system shared by up to four axes, every unknown
 // one of its inputs, every given value an initial state, every row of a cost or a limit a fixed
@@ -43,8 +46,8 @@ __device__ __forceinline__ double ldsd(const double* base, int i) { return base[
 
 // LDS of one workgroup (doubles): all steps' [A_k | B_k], the free responses, Psi_l B_l[:, j], lam_l, the
 // parameters, the combinations c, the weights arrow * c of the lines of G -- per limit and axis when no
-// limit has an arrow of its own per line (`per_line` 0: 0.4 KB for C5, five workgroups per CU), else
-// per line and axis (19 KB) --, then small integer tables: the terms, the per-step list of G's lines
+// limit has an arrow of its own per line (`per_line` 0: 0.5 KB for C5; 24 KB in all, six workgroups per CU), else
+// per line and axis (26 KB) --, then small integer tables: the terms, the per-step list of G's lines
 // (one word per line: row of G | limit << 20), the axes
 struct SweepLds {
   int ab, xbar, gv, lam, par, cvec, lw, ints, total;
