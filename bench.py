@@ -873,11 +873,21 @@ def run_rank(args):
         step(k, streams[k % nstreams])
     sync_all()
 
-    # timed region: exactly K steps, dealt to the launch streams in turn.  One pair of hipEvents
-    # brackets it: the first on stream 0 (the others wait for it), the second on stream 0 after
-    # it has waited for the others.
-    e_begin, e_end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # timed region: exactly K steps, dealt to the launch streams in turn, between two barrier +
+    # synchronize pairs and nothing else -- no event, no wait between the streams (the device is idle
+    # at its start and synchronised as a whole at its end): with the driver's 20 steps the two event
+    # records and the two cross-stream waits of rounds 2-3 were a seventh of the region.
     t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(k, streams[k % nstreams])
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        elapsed = mdist.max_over_ranks(elapsed, device=dev)
+    # the same K steps once more with a pair of hipEvents around them (the first on stream 0, the
+    # others wait for it; the second on stream 0 after it has waited for the others): the device's own
+    # clock beside the wall clock, `timed_region.ms_per_step_hipEvents`; not what `value` comes from
+    e_begin, e_end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e_begin.record(streams[0])
     for s in streams[1:]:
         s.wait_event(e_begin)
@@ -887,9 +897,6 @@ def run_rank(args):
         streams[0].wait_stream(s)
     e_end.record(streams[0])
     sync_all()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        elapsed = mdist.max_over_ranks(elapsed, device=dev)
     region_ms = e_begin.elapsed_time(e_end) / args.steps
 
     # the dominant kernel by itself, for the roofline record: the same steps once more on ONE
@@ -897,7 +904,7 @@ def run_rank(args):
     # launch gaps included -- the conservative reading; rocprofv3's kernel time of the same
     # command with --streams 1 is what it is compared with); --two-kernels adds a pair of events
     # around the fill of every 8th step.
-    k_steps = min(args.steps, 1000)
+    k_steps = max(min(args.steps, 1000), 200)      # (a short run of the driver's: still 200 launches behind the kernel's figure)
     k_begin, k_end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     fill_ev = []
     k_begin.record()
