@@ -856,9 +856,9 @@ def run_rank(args):
 
     def sync_all():
         torch.cuda.synchronize()
-        if dist is not None:
+        if dist is not None:       # (one rank alone: nothing to wait for behind the first synchronize)
             dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
 
     # clocks first (tools/launch_series.py), then the W warm-up steps of the contract
     step(0)                       # (the first call compiles the kernel for the plan)
